@@ -1,0 +1,102 @@
+/*
+ * te_msm.h -- C-ABI of the MI355X-native Twisted-Edwards-BLS12 MSM engine (libtemsm.so).
+ *
+ * This is the drop-in boundary for the reference's hot path.  Nothing like it exists in the
+ * reference (a browser program); each entry point names the reference interface it stands behind
+ * (paths relative to /root/reference/src).  INTEGRATION.md shows the N-API binding that keeps
+ * `compute_msm(bufferPoints, bufferScalars)` (submission/submission.ts:73-78) intact.
+ *
+ * Wire format (README.md:297-299; encoder reference/webgpu/utils.ts:90-99):
+ *   points : n x (x[32 B little-endian] || y[32 B little-endian]), canonical affine, NOT Montgomery
+ *   scalars: n x 32 B little-endian integers (< p; anything < 2^255 is accepted)
+ *   result : x[32 B LE] || y[32 B LE], canonical affine  ( == result.toAffine(), submission.ts:412 )
+ *
+ * All functions return 0 on success or a negative TE_MSM_E* code; te_msm_last_error() gives text.
+ * A context is not thread-safe; use one context per host thread / device.
+ * There is NO CPU fallback: without a usable HIP device te_msm_init fails.
+ */
+#ifndef TE_MSM_H
+#define TE_MSM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct te_ctx te_ctx;
+
+#define TE_MSM_OK            0
+#define TE_MSM_EINVAL      (-1)   /* bad argument */
+#define TE_MSM_EDEVICE     (-2)   /* HIP error (no device, out of memory, launch failure) */
+#define TE_MSM_ESCALAR     (-3)   /* a scalar left a final carry: the reference's "final carry is 1"
+                                     (submission/miscellaneous/utils.ts:80-83) */
+#define TE_MSM_ESTATE      (-4)   /* call order / capacity */
+
+#define TE_MSM_POINT_BYTES   64
+#define TE_MSM_SCALAR_BYTES  32
+#define TE_MSM_PARTIAL_BYTES 384  /* per window: 3 extended points x 128 B (see te_msm_partial_device) */
+
+/* Replaces get_device() + per-call buffer/pipeline creation (implementation/cuzk/gpu.ts:14-25,
+ * submission.ts:96-97).  The context is persistent: buffers and streams live across calls.
+ * n_dev == 1: one GPU.  n_dev > 1: the windows of every MSM are sharded over the listed devices
+ * inside this process (device ids may repeat).  For one-process-per-GPU deployments use n_dev == 1
+ * plus te_msm_set_window_shard / te_msm_partial_device / te_msm_finalize and exchange the partial
+ * sums yourself (bench.py does it with an RCCL all-gather). */
+int te_msm_init(const int* device_ids, int n_dev, te_ctx** out);
+void te_msm_destroy(te_ctx* ctx);
+const char* te_msm_last_error(const te_ctx* ctx);   /* ctx may be NULL: last init error */
+
+/* compute_msm(bufferPoints, bufferScalars) -- submission.ts:73-413.  Host buffers; the callee copies
+ * them to the device and does not retain them.  out_xy_le receives 64 bytes. */
+int te_msm_run(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars_le, uint64_t n,
+               uint8_t out_xy_le[64]);
+
+/* Same with inputs already resident in device memory of the context's (first) device. */
+int te_msm_run_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_scalars_le, uint64_t n,
+                      uint8_t out_xy_le[64]);
+
+/* Options (the reference hard-codes these: chunk_size submission.ts:80, dispatch table :109-142).
+ *   "window_bits"   c in [4,16]; 0 = choose from n (default)
+ *   "sort_buckets"  1 = schedule buckets by descending size (default), 0 = natural order
+ *   "profile"       1 = record per-stage HIP events (te_msm_stage_ms)                      */
+int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value);
+int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value);
+
+/* ---- window-sharded building blocks (multi-GPU: one process per GPU) --------------------------
+ * This context computes windows w = first + k*step (k >= 0) of every MSM.  Default: first 0, step 1. */
+int te_msm_set_window_shard(te_ctx* ctx, int first, int step);
+/* Geometry for n points under the current options: window bits c and total number of windows W. */
+int te_msm_plan(te_ctx* ctx, uint64_t n, int* window_bits, int* num_windows);
+/* Runs every device stage for this context's windows and leaves the partial sums in DEVICE memory:
+ * d_partials is W x TE_MSM_PARTIAL_BYTES; only the rows of this context's windows are written
+ * (others untouched -- zero the buffer first; an all-zero row means "window not present").
+ * Row w = [ sum_j B_j | sum_hi hi*R_hi | sum_lo lo*C_lo ] as extended points (x|y|z|t, 8x32-bit limbs,
+ * Montgomery form R = 2^256, lazily reduced).  Asynchronous on `stream` (a hipStream_t, may be NULL
+ * for the context's own stream); returns after enqueueing. */
+int te_msm_partial_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_scalars_le, uint64_t n,
+                          void* d_partials, void* stream);
+/* Host tail (replaces submission.ts:362-412: de-Montgomery, sum, Horner, toAffine): folds the W rows
+ * (host memory; rows of absent windows all-zero are skipped as identity) into the affine result.
+ * Also reports a pending TE_MSM_ESCALAR of the last te_msm_partial_device call of this context. */
+int te_msm_finalize(te_ctx* ctx, const uint8_t* partials, int window_bits, int num_windows,
+                    uint8_t out_xy_le[64]);
+
+/* The same tail without a context (pure host code, no device needed): used when the rows were produced
+ * elsewhere, e.g. gathered from other ranks.  Does not know about scalar-range errors. */
+int te_msm_finalize_host(const uint8_t* partials, int window_bits, int num_windows, uint8_t out_xy_le[64]);
+
+/* ---- measurement / stage verification (the reference's `debug` flags, submission.ts:892-1363) --- */
+/* Per-stage device time of the last run in ms (needs option "profile" = 1).  Returns the number of
+ * stages written; names[i] points to static strings. */
+int te_msm_stage_ms(te_ctx* ctx, float* ms, const char** names, int max_stages);
+/* Copies an intermediate buffer of the last run to host memory.  stage is one of
+ * "records" (n x 96 B), "digits" (nw x n u16), "bucket_count" / "bucket_start" (nw x B u32),
+ * "sorted" (nw x n u32), "buckets" (nw x B x 128 B), "partials" (nw x 384 B).  Returns bytes copied
+ * (<= cap) or a negative error. */
+int64_t te_msm_debug_read(te_ctx* ctx, const char* stage, void* dst, uint64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TE_MSM_H */

@@ -1,0 +1,93 @@
+"""Generates tests/golden/msm_wasm_golden.json by running the reference's CPU MSM (Aleo WASM
+Address.msm, reference/reference.ts:29-39) on deterministic synthetic inputs.  BUILD CONTAINER ONLY
+(needs /root/reference and node); the fixture it writes holds data only: {name, seed, n, mode, x, y}.
+
+Inputs are regenerated in tests from (seed, n, mode) by oracle.gen_points / gen_scalars /
+edge_scalars, so no input data is stored.  y is recovered from the WASM's x exactly as the reference
+does (FieldMath.getPointFromX, reference/utils/FieldMath.ts:31-55).
+
+usage: python -m oracle.gen_golden [--max-n 65536]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import tempfile
+
+from . import model, oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "..", "tests", "golden", "msm_wasm_golden.json")
+
+CASES = [  # (name, seed, n, mode)
+    ("chain_n1", 0x5EED0001, 1, "chain"),
+    ("chain_n2", 0x5EED0002, 2, "chain"),
+    ("chain_n3", 0x5EED0003, 3, "chain"),
+    ("chain_n16", 0x5EED0010, 16, "chain"),
+    ("chain_n255", 0x5EED00FF, 255, "chain"),
+    ("chain_n256", 0x5EED0100, 256, "chain"),
+    ("chain_n1000", 0x5EED03E8, 1000, "chain"),
+    ("chain_n4096", 0x5EED1000, 4096, "chain"),
+    ("fixed_n256", 0x5EED0101, 256, "fixed"),      # harness mode: one point replicated
+    ("edge_n64", 0x5EED0040, 64, "edge"),          # scalars 0, 1, p-1, l, l-1, 2^k boundaries ...
+    ("chain_n65536", 0x5EED0010000, 65536, "chain"),
+    ("fixed_n65536", 0x5EED0010001, 65536, "fixed"),
+]
+
+
+def make_inputs(seed: int, n: int, mode: str):
+    pts = oracle.gen_points_fixed(n) if mode == "fixed" else oracle.gen_points(seed, n)
+    sc = oracle.gen_scalars(seed, n)
+    if mode == "edge":
+        sc = model.scalars_to_bytes(edge_scalars(seed, n))
+    return pts, sc
+
+
+def edge_scalars(seed: int, n: int):
+    p, l = model.P, model.L
+    special = [0, 1, p - 1, l, l - 1, l + 1, 2, (1 << 15), (1 << 15) - 1, (1 << 16) - 1, (1 << 16),
+               0x8000800080008000800080008000800080008000800080008000800080008000 % p,
+               0x7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF % p,
+               (1 << 252), (1 << 253) % p, p - 2, p // 2, 0xFFFF0000FFFF0000FFFF, 3 * l, 4 * l - 1]
+    rnd = model.gen_scalars(seed, n)
+    return [special[i] if i < len(special) else rnd[i] for i in range(n)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--max-n", type=int, default=65536)
+    args = ap.parse_args()
+    cases, meta = [], []
+    for name, seed, n, mode in CASES:
+        if n > args.max_n:
+            continue
+        pts, sc = make_inputs(seed, n, mode)
+        xs = [str(int.from_bytes(pts[64 * i:64 * i + 32], "little")) for i in range(n)]
+        ks = [str(int.from_bytes(sc[32 * i:32 * i + 32], "little")) for i in range(n)]
+        cases.append({"name": name, "xs": xs, "ks": ks})
+        meta.append((name, seed, n, mode))
+    with tempfile.TemporaryDirectory() as td:
+        cin, cout = os.path.join(td, "cases.json"), os.path.join(td, "out.json")
+        json.dump(cases, open(cin, "w"))
+        subprocess.check_call(["node", os.path.join(HERE, "wasm_msm.js"), cin, cout])
+        res = {r["name"]: r for r in json.load(open(cout))}
+    golden = []
+    for name, seed, n, mode in meta:
+        x = int(res[name]["x"])
+        if x == 0:
+            y = 1
+        else:
+            _, y = model.point_from_x(x)
+        golden.append({"name": name, "seed": seed, "n": n, "mode": mode, "x": str(x), "y": str(y),
+                       "source": "aleo-wasm Address.msm (reference/reference.ts:29-39), node " +
+                                 subprocess.check_output(["node", "--version"]).decode().strip(),
+                       "wasm_ms": res[name]["ms"]})
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    json.dump(golden, open(OUT, "w"), indent=1)
+    print("wrote", OUT, len(golden), "cases")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,22 @@
+"""MI355X-native Twisted-Edwards-BLS12 MSM engine: host-side mirror of the reference's entry point.
+
+The product is `libtemsm.so` (hand-written HIP kernels for gfx950 + the C-ABI of include/te_msm.h).
+This package is the thin Python host layer over that C-ABI used by tests, bench.py and
+multi-process (one rank per GPU) deployments; the JavaScript host layer that keeps the reference's
+`compute_msm(bufferPoints, bufferScalars)` signature lives in js/ (see INTEGRATION.md).
+
+The directory name contains hyphens (it is the reference's name + `_amd`), so import it with
+    importlib.import_module("webgpu-msm-twisted-edwards_amd")
+There is no CPU fallback anywhere in this package: without libtemsm.so and a HIP device every entry
+point raises.
+"""
+from .binding import (  # noqa: F401
+    MsmContext,
+    MsmError,
+    compute_msm,
+    finalize_host,
+    build_library,
+    library_path,
+    PARTIAL_BYTES,
+)
+from .sharding import compute_msm_sharded, exchange_partials, merge_partials, window_shard_for_rank  # noqa: F401

@@ -1,0 +1,193 @@
+"""ctypes binding of include/te_msm.h.
+
+Mirrors the reference's operator for this path -- `compute_msm(bufferPoints, bufferScalars, log_result,
+force_recompile) -> {x, y}` (submission/submission.ts:73-78) -- with the same argument meaning and
+error behaviour (errors raise; the reference rejects its promise).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+PARTIAL_BYTES = 384
+
+
+class MsmError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"te_msm error {code}: {msg}")
+        self.code = code
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "libtemsm.so")
+
+
+def build_library(force: bool = False) -> str:
+    """Compiles csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
+    so = library_path()
+    csrc = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(_HERE, "..", "include", "te_msm.h")]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.isfile(s))
+    if force or stale:
+        subprocess.check_call(["make", "-C", csrc, "-s"])
+    return so
+
+
+def _lib() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        so = library_path()
+        if not os.path.exists(so):
+            raise MsmError(-2, f"{so} is missing: build it with __graft_entry__.build() (there is no CPU fallback)")
+        L = ctypes.CDLL(so)
+        vp, u64, ci, cp = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_char_p
+        L.te_msm_init.argtypes = [ctypes.POINTER(ci), ci, ctypes.POINTER(vp)]
+        L.te_msm_init.restype = ci
+        L.te_msm_destroy.argtypes = [vp]
+        L.te_msm_destroy.restype = None
+        L.te_msm_last_error.argtypes = [vp]
+        L.te_msm_last_error.restype = cp
+        L.te_msm_run.argtypes = [vp, cp, cp, u64, cp]
+        L.te_msm_run.restype = ci
+        L.te_msm_run_device.argtypes = [vp, vp, vp, u64, cp]
+        L.te_msm_run_device.restype = ci
+        L.te_msm_set_option.argtypes = [vp, cp, ctypes.c_int64]
+        L.te_msm_set_option.restype = ci
+        L.te_msm_get_option.argtypes = [vp, cp, ctypes.POINTER(ctypes.c_int64)]
+        L.te_msm_get_option.restype = ci
+        L.te_msm_set_window_shard.argtypes = [vp, ci, ci]
+        L.te_msm_set_window_shard.restype = ci
+        L.te_msm_plan.argtypes = [vp, u64, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+        L.te_msm_plan.restype = ci
+        L.te_msm_partial_device.argtypes = [vp, vp, vp, u64, vp, vp]
+        L.te_msm_partial_device.restype = ci
+        L.te_msm_finalize.argtypes = [vp, cp, ci, ci, cp]
+        L.te_msm_finalize.restype = ci
+        L.te_msm_finalize_host.argtypes = [cp, ci, ci, cp]
+        L.te_msm_finalize_host.restype = ci
+        L.te_msm_stage_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(cp), ci]
+        L.te_msm_stage_ms.restype = ci
+        L.te_msm_debug_read.argtypes = [vp, cp, vp, u64]
+        L.te_msm_debug_read.restype = ctypes.c_int64
+        _LIB = L
+    return _LIB
+
+
+class MsmContext:
+    """Persistent engine context (device buffers, stream) -- te_msm_init / te_msm_destroy."""
+
+    def __init__(self, device_ids=(0,)):
+        L = _lib()
+        ids = (ctypes.c_int * len(device_ids))(*device_ids)
+        h = ctypes.c_void_p()
+        rc = L.te_msm_init(ids, len(device_ids), ctypes.byref(h))
+        if rc:
+            raise MsmError(rc, L.te_msm_last_error(None).decode())
+        self._h = h
+        self._L = L
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.te_msm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc < 0:
+            raise MsmError(rc, self._L.te_msm_last_error(self._h).decode())
+        return rc
+
+    # ---- options
+    def set_option(self, key: str, value: int):
+        self._check(self._L.te_msm_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key: str) -> int:
+        v = ctypes.c_int64()
+        self._check(self._L.te_msm_get_option(self._h, key.encode(), ctypes.byref(v)))
+        return v.value
+
+    def set_window_shard(self, first: int, step: int):
+        self._check(self._L.te_msm_set_window_shard(self._h, first, step))
+
+    def plan(self, n: int):
+        c, w = ctypes.c_int(), ctypes.c_int()
+        self._check(self._L.te_msm_plan(self._h, n, ctypes.byref(c), ctypes.byref(w)))
+        return c.value, w.value
+
+    # ---- whole MSM
+    def run(self, points: bytes, scalars: bytes) -> bytes:
+        """Host buffers in the reference's wire format -> 64-byte affine result (x || y, LE)."""
+        n = len(scalars) // 32
+        if len(scalars) != 32 * n or len(points) != 64 * n:
+            raise MsmError(-1, "points must be 64*n bytes and scalars 32*n bytes")
+        out = ctypes.create_string_buffer(64)
+        self._check(self._L.te_msm_run(self._h, bytes(points), bytes(scalars), n, out))
+        return out.raw
+
+    def run_device(self, d_points: int, d_scalars: int, n: int) -> bytes:
+        out = ctypes.create_string_buffer(64)
+        self._check(self._L.te_msm_run_device(self._h, d_points, d_scalars, n, out))
+        return out.raw
+
+    # ---- window-sharded building blocks
+    def partial_device(self, d_points: int, d_scalars: int, n: int, d_partials: int, stream: int = 0):
+        self._check(self._L.te_msm_partial_device(self._h, d_points, d_scalars, n, d_partials, stream))
+
+    def finalize(self, partials: bytes, window_bits: int, num_windows: int) -> bytes:
+        out = ctypes.create_string_buffer(64)
+        self._check(self._L.te_msm_finalize(self._h, bytes(partials), window_bits, num_windows, out))
+        return out.raw
+
+    # ---- measurement / stage verification
+    def stage_ms(self):
+        ms = (ctypes.c_float * 16)()
+        names = (ctypes.c_char_p * 16)()
+        k = self._check(self._L.te_msm_stage_ms(self._h, ms, names, 16))
+        return {names[i].decode(): float(ms[i]) for i in range(k)}
+
+    def debug_read(self, stage: str, nbytes: int) -> bytes:
+        buf = ctypes.create_string_buffer(max(nbytes, 1))
+        got = self._check(self._L.te_msm_debug_read(self._h, stage.encode(), buf, nbytes))
+        return buf.raw[:got]
+
+
+def finalize_host(partials: bytes, window_bits: int, num_windows: int) -> bytes:
+    """Context-free host tail (te_msm_finalize_host): Horner + affine over W rows of 384 bytes."""
+    out = ctypes.create_string_buffer(64)
+    rc = _lib().te_msm_finalize_host(bytes(partials), window_bits, num_windows, out)
+    if rc:
+        raise MsmError(rc, "te_msm_finalize_host failed")
+    return out.raw
+
+
+_DEFAULT_CTX = None
+
+
+def compute_msm(bufferPoints, bufferScalars, log_result: bool = True, force_recompile: bool = False):
+    """Python mirror of `compute_msm` (submission/submission.ts:73-78).
+
+    bufferPoints: n x (x || y), 32-byte little-endian each; bufferScalars: n x 32-byte little-endian.
+    Returns {"x": int, "y": int} (the reference resolves to {x: bigint, y: bigint}).  `force_recompile`
+    only exists to defeat WGSL pipeline caching (shader_manager.ts:85-92); here it drops the cached context.
+    """
+    global _DEFAULT_CTX
+    if force_recompile and _DEFAULT_CTX is not None:
+        _DEFAULT_CTX.close()
+        _DEFAULT_CTX = None
+    if _DEFAULT_CTX is None:
+        _DEFAULT_CTX = MsmContext((0,))
+    out = _DEFAULT_CTX.run(bytes(bufferPoints), bytes(bufferScalars))
+    res = {"x": int.from_bytes(out[:32], "little"), "y": int.from_bytes(out[32:], "little")}
+    if log_result:
+        print(res)
+    return res

@@ -1,0 +1,130 @@
+// host_tail.hpp -- the CPU tail of compute_msm (submission.ts:362-412): fold the per-window partial
+// sums with Horner's rule and convert to affine.  The reference does this with @noble/curves bigints
+// over up to 4096 points; here the device has already reduced every window to three points, so the
+// host executes ~256 doublings, ~50 additions and one inversion (tens of microseconds).
+// 4 x 64-bit limbs, Montgomery form R = 2^256 (the same bytes the device writes as 8 x 32-bit limbs).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+namespace te_host {
+
+typedef unsigned __int128 u128;
+struct Fe { uint64_t l[4]; };
+struct Pt { Fe x, y, z, t; };   // device layout: x | y | z | t
+
+static const uint64_t MOD[4] = {0x0a11800000000001ULL, 0x59aa76fed0000001ULL, 0x60b44d1e5c37b001ULL, 0x12ab655e9a2ca556ULL};
+static const uint64_t MOD_NEG_INV = 0x0a117fffffffffffULL;   // -p^-1 mod 2^64 (checked in tail_selftest)
+static const Fe ONE_M = {{0x7d1c7ffffffffff3ULL, 0x7257f50f6ffffff2ULL, 0x16d81575512c0feeULL, 0x0d4bda322bbb9a9dULL}};   // R mod p
+
+static inline bool ge_mod(const Fe& a) {
+  for (int i = 3; i >= 0; i--) { if (a.l[i] != MOD[i]) return a.l[i] > MOD[i]; }
+  return true;
+}
+static inline void sub_mod_raw(Fe& a) {
+  uint64_t br = 0;
+  for (int i = 0; i < 4; i++) { u128 d = (u128)a.l[i] - MOD[i] - br; a.l[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
+}
+static inline Fe canon(Fe a) { while (ge_mod(a)) sub_mod_raw(a); return a; }   // any 256-bit value -> [0, p)
+
+static inline Fe add(const Fe& a, const Fe& b) {
+  Fe r; u128 c = 0;
+  for (int i = 0; i < 4; i++) { c += (u128)a.l[i] + b.l[i]; r.l[i] = (uint64_t)c; c >>= 64; }
+  if (ge_mod(r)) sub_mod_raw(r);     // a, b < p < 2^253: no carry out
+  return r;
+}
+static inline Fe sub(const Fe& a, const Fe& b) {
+  Fe r; uint64_t br = 0;
+  for (int i = 0; i < 4; i++) { u128 d = (u128)a.l[i] - b.l[i] - br; r.l[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
+  if (br) { u128 c = 0; for (int i = 0; i < 4; i++) { c += (u128)r.l[i] + MOD[i]; r.l[i] = (uint64_t)c; c >>= 64; } }
+  return r;
+}
+static inline Fe mul(const Fe& a, const Fe& b) {
+  uint64_t t[5] = {0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) { c += (u128)a.l[j] * b.l[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+    c += t[4]; t[4] = (uint64_t)c; const uint64_t t5 = (uint64_t)(c >> 64);
+    const uint64_t m = t[0] * MOD_NEG_INV;
+    c = ((u128)m * MOD[0] + t[0]) >> 64;
+    for (int j = 1; j < 4; j++) { c += (u128)m * MOD[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+    c += t[4]; t[3] = (uint64_t)c; t[4] = t5 + (uint64_t)(c >> 64);
+  }
+  Fe r = {{t[0], t[1], t[2], t[3]}};
+  if (t[4] || ge_mod(r)) sub_mod_raw(r);
+  return r;
+}
+static inline Fe inv(const Fe& a) {            // a^(p-2)
+  uint64_t e[4] = {MOD[0] - 2, MOD[1], MOD[2], MOD[3]};
+  Fe acc = ONE_M, base = a;
+  for (int i = 0; i < 253; i++) {
+    if ((e[i >> 6] >> (i & 63)) & 1) acc = mul(acc, base);
+    base = mul(base, base);
+  }
+  return acc;
+}
+static inline bool is_zero(const Fe& a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0; }
+
+static inline Pt identity() { Pt r; memset(&r, 0, sizeof r); r.y = ONE_M; r.z = ONE_M; return r; }
+static inline bool all_zero_bytes(const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) if (p[i]) return false; return true; }
+
+static inline Pt load_point(const uint8_t* src) {      // 128 B device extended point, lazily reduced
+  Pt r; memcpy(&r, src, 128);
+  r.x = canon(r.x); r.y = canon(r.y); r.z = canon(r.z); r.t = canon(r.t);
+  return r;
+}
+// unified addition, a = -1, k = 2d (add-2008-hwcd-3)
+static inline Pt padd(const Pt& a, const Pt& b, const Fe& k2d) {
+  const Fe A = mul(sub(a.y, a.x), sub(b.y, b.x));
+  const Fe B = mul(add(a.y, a.x), add(b.y, b.x));
+  const Fe C = mul(mul(a.t, b.t), k2d);
+  const Fe zz = mul(a.z, b.z);
+  const Fe D = add(zz, zz);
+  const Fe E = sub(B, A), F = sub(D, C), G = add(D, C), H = add(B, A);
+  Pt r; r.x = mul(E, F); r.y = mul(G, H); r.t = mul(E, H); r.z = mul(F, G);
+  return r;
+}
+// dbl-2008-hwcd, a = -1
+static inline Pt pdbl(const Pt& a) {
+  const Fe A = mul(a.x, a.x), B = mul(a.y, a.y);
+  Fe C = mul(a.z, a.z); C = add(C, C);
+  const Fe zero = {{0, 0, 0, 0}};
+  const Fe D = sub(zero, A);
+  const Fe xy = add(a.x, a.y);
+  const Fe E = sub(sub(mul(xy, xy), A), B);
+  const Fe G = add(D, B), F = sub(G, C), H = sub(D, B);
+  Pt r; r.x = mul(E, F); r.y = mul(G, H); r.t = mul(E, H); r.z = mul(F, G);
+  return r;
+}
+
+// partials: W rows of 384 B = [T | WR | WC]; window value = T + WC + 2^lo_bits * WR, lo_bits = ceil((c-1)/2).
+// result = sum_w 2^(c*w) * window_w, evaluated top-down with c doublings per window, split as
+// (c - lo_bits) doublings -> + WR -> lo_bits doublings -> + (T + WC): no doubling is added by the split.
+static inline void horner_to_affine(const uint8_t* partials, int c, int W, uint8_t out_xy_le[64]) {
+  const Fe d2 = {{2 * 3021, 0, 0, 0}};
+  const Fe R2 = {{0x25d577bab861857bULL, 0xcc2c27b58860591fULL, 0xa7cc008fe5dc8593ULL, 0x011fdae7eff1c939ULL}};
+  const Fe k2d = mul(d2, R2);
+  const int lo_bits = (c - 1 + 1) / 2;
+  Pt acc = identity();
+  for (int w = W - 1; w >= 0; w--) {
+    const uint8_t* row = partials + (size_t)w * 384;
+    const bool present = !all_zero_bytes(row, 384);
+    for (int k = 0; k < c - lo_bits; k++) acc = pdbl(acc);
+    if (present) acc = padd(acc, load_point(row + 128), k2d);
+    for (int k = 0; k < lo_bits; k++) acc = pdbl(acc);
+    if (present) { acc = padd(acc, load_point(row), k2d); acc = padd(acc, load_point(row + 256), k2d); }
+  }
+  const Fe zi = inv(acc.z);
+  const Fe one_raw = {{1, 0, 0, 0}};
+  const Fe x = mul(mul(acc.x, zi), one_raw), y = mul(mul(acc.y, zi), one_raw);
+  memcpy(out_xy_le, x.l, 32); memcpy(out_xy_le + 32, y.l, 32);
+}
+
+static inline bool tail_selftest() {
+  if ((uint64_t)(MOD[0] * MOD_NEG_INV) != ~0ULL) return false;     // p * (-p^-1) = -1 mod 2^64
+  const Fe one_raw = {{1, 0, 0, 0}};
+  const Fe t = mul(ONE_M, one_raw);                                // R * 1 / R = 1
+  return t.l[0] == 1 && !t.l[1] && !t.l[2] && !t.l[3];
+}
+
+}  // namespace te_host

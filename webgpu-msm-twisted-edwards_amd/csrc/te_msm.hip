@@ -1,0 +1,466 @@
+// te_msm.hip -- context, stage orchestration and the C-ABI of libtemsm.so (include/te_msm.h).
+//
+// Host-side counterpart of compute_msm's orchestration (submission/submission.ts:73-413) and of the
+// WebGPU wrapper it drives (implementation/cuzk/gpu.ts:14-229).  Differences that matter:
+//   * the context is persistent -- device buffers, streams and kernels survive across calls (the
+//     reference re-creates device, buffers and pipelines on every call, submission.ts:96-97,360);
+//   * every stage is enqueued on one HIP stream with no host synchronisation in between, like the
+//     reference's single command-encoder submit (gpu.ts:118);
+//   * windows can be sharded over contexts / devices; the reference is single-device.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/te_msm.h"
+#include "host_tail.hpp"
+#include "kernels.hip.hpp"
+
+namespace {
+
+thread_local std::string g_init_error;
+
+enum { ST_PREP = 0, ST_DIGITS, ST_HIST, ST_SCAN, ST_SCATTER, ST_ORDER, ST_ACCUM, ST_TREE, ST_WEIGHTED, ST_COUNT };
+const char* const kStageNames[ST_COUNT] = {"prep_points", "digits", "hist", "scan", "scatter", "order",
+                                           "accumulate", "tree_sum", "weighted_sum"};
+
+struct plan_t {
+  int c = 0, W = 0, nw = 0;           // window bits, total windows, windows of this shard
+  uint32_t B = 0, logB = 0;           // buckets per window = 2^(c-1)
+  uint32_t RL = 0, RH = 0, lo_bits = 0;
+  uint32_t CH = 0, chunk_len = 0;     // histogram chunks per window
+  uint32_t nseg = 0, seg_threads = 0; // scan segments per window
+};
+
+struct gpu_t {
+  int device = 0;
+  int w_first = 0, w_step = 1;
+  hipStream_t stream = nullptr;
+  size_t cap[16] = {};                // per-buffer capacity in bytes (ensure())
+  int cap_W = 0;
+  te::pnt* d_recs = nullptr;
+  uint16_t* d_digits = nullptr;
+  uint32_t *d_counts = nullptr, *d_bucket_count = nullptr, *d_bucket_start = nullptr, *d_local_excl = nullptr;
+  uint32_t *d_seg_total = nullptr, *d_sorted = nullptr, *d_order = nullptr, *d_size_hist = nullptr, *d_size_cursor = nullptr;
+  te::ete *d_buckets = nullptr, *d_rowsum = nullptr, *d_colsum = nullptr;
+  uint8_t* d_partials = nullptr;      // W x 384
+  uint32_t* d_err = nullptr;
+  uint32_t* h_err = nullptr;          // pinned
+  uint8_t* h_partials = nullptr;      // pinned, W x 384
+  void *d_in_points = nullptr, *d_in_scalars = nullptr; uint64_t cap_in = 0;
+  hipEvent_t ev_done = nullptr;
+  hipEvent_t ev[ST_COUNT + 1] = {};
+  plan_t last_plan; uint64_t last_n = 0; bool have_last = false;
+};
+
+}  // namespace
+
+struct te_ctx {
+  std::vector<gpu_t> devs;
+  std::string err;
+  int opt_window_bits = 0;
+  int opt_sort = 1;
+  int opt_profile = 0;
+  float stage_ms[ST_COUNT] = {};
+  bool have_stage_ms = false;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                                                       \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess) {                                                                      \
+      char buf_[512];                                                                            \
+      snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      (ctx)->err = buf_;                                                                         \
+      return TE_MSM_EDEVICE;                                                                     \
+    }                                                                                            \
+  } while (0)
+
+int set_err(te_ctx* ctx, int code, const char* msg) { ctx->err = msg; return code; }
+
+uint32_t ilog2(uint32_t v) { uint32_t l = 0; while ((1u << l) < v) l++; return l; }
+
+int auto_window_bits(uint64_t n) {
+  // field products: accumulation 7 per point and window; bucket reduction ~ 2 full additions (9) per bucket
+  double best = 0; int bc = 16;
+  for (int c = 8; c <= 16; c++) {
+    const double W = (256 + c - 1) / c, B = (double)(1u << (c - 1));
+    const double cost = W * (7.0 * (double)n + 18.0 * B + 4000.0);
+    if (c == 8 || cost < best) { best = cost; bc = c; }
+  }
+  return bc;
+}
+
+void make_plan(const te_ctx* ctx, const gpu_t& d, uint64_t n, plan_t& p) {
+  p.c = ctx->opt_window_bits ? ctx->opt_window_bits : auto_window_bits(n);
+  p.W = (256 + p.c - 1) / p.c;
+  p.nw = 0;
+  for (int w = d.w_first; w < p.W; w += d.w_step) p.nw++;
+  p.B = 1u << (p.c - 1); p.logB = p.c - 1;
+  p.lo_bits = (p.c - 1 + 1) / 2; p.RL = 1u << p.lo_bits; p.RH = p.B / p.RL;
+  uint32_t ch = p.nw > 0 ? 256u / (uint32_t)p.nw : 1u;
+  if (ch < 1) ch = 1;
+  if (ch > 64) ch = 64;
+  const uint32_t by_n = (uint32_t)((n + 8191) / 8192);      // at least ~8k digits per chunk
+  if (ch > by_n) ch = by_n ? by_n : 1;
+  p.CH = ch;
+  p.chunk_len = (uint32_t)((n + ch - 1) / ch);
+  p.seg_threads = p.B < 1024u ? p.B : 1024u;
+  p.nseg = p.B / p.seg_threads;
+}
+
+template <typename T> int ensure(te_ctx* ctx, T*& ptr, size_t& cap_bytes, size_t need_elems) {
+  const size_t need = need_elems * sizeof(T);
+  if (ptr && need <= cap_bytes) return 0;
+  if (ptr) HIP_TRY(ctx, hipFree(ptr));
+  ptr = nullptr; cap_bytes = 0;
+  HIP_TRY(ctx, hipMalloc((void**)&ptr, need ? need : 16));
+  cap_bytes = need;
+  return 0;
+}
+
+int ensure_buffers(te_ctx* ctx, gpu_t& d, uint64_t n, const plan_t& p) {
+  HIP_TRY(ctx, hipSetDevice(d.device));
+  const size_t nd = (size_t)p.nw * n, wb = (size_t)p.nw * p.B;
+  int rc = 0;
+  if ((rc = ensure(ctx, d.d_recs, d.cap[0], (size_t)n))) return rc;
+  if ((rc = ensure(ctx, d.d_digits, d.cap[1], nd))) return rc;
+  if ((rc = ensure(ctx, d.d_sorted, d.cap[2], nd))) return rc;
+  if ((rc = ensure(ctx, d.d_counts, d.cap[3], (size_t)p.nw * p.CH * p.B))) return rc;
+  if ((rc = ensure(ctx, d.d_bucket_count, d.cap[4], wb))) return rc;
+  if ((rc = ensure(ctx, d.d_bucket_start, d.cap[5], wb))) return rc;
+  if ((rc = ensure(ctx, d.d_local_excl, d.cap[6], wb))) return rc;
+  if ((rc = ensure(ctx, d.d_order, d.cap[7], wb))) return rc;
+  if ((rc = ensure(ctx, d.d_buckets, d.cap[8], wb))) return rc;
+  if ((rc = ensure(ctx, d.d_seg_total, d.cap[9], (size_t)p.nw * p.nseg))) return rc;
+  if ((rc = ensure(ctx, d.d_rowsum, d.cap[10], (size_t)p.nw * p.RH))) return rc;
+  if ((rc = ensure(ctx, d.d_colsum, d.cap[11], (size_t)p.nw * p.RL))) return rc;
+  if (p.W > d.cap_W) {
+    if (d.d_partials) HIP_TRY(ctx, hipFree(d.d_partials));
+    if (d.h_partials) HIP_TRY(ctx, hipHostFree(d.h_partials));
+    d.d_partials = nullptr; d.h_partials = nullptr; d.cap_W = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&d.d_partials, (size_t)p.W * TE_MSM_PARTIAL_BYTES));
+    HIP_TRY(ctx, hipHostMalloc((void**)&d.h_partials, (size_t)p.W * TE_MSM_PARTIAL_BYTES, hipHostMallocDefault));
+    d.cap_W = p.W;
+  }
+  return 0;
+}
+
+template <int C> void launch_digits(const uint4* sc, uint16_t* dg, const te::digits_params& prm, uint32_t* err, hipStream_t s) {
+  hipLaunchKernelGGL(te::k_digits<C>, dim3((prm.n + 255) / 256), dim3(256), 0, s, sc, dg, prm, err);
+}
+
+int enqueue_partial(te_ctx* ctx, gpu_t& d, const void* d_points, const void* d_scalars, uint64_t n,
+                    void* d_partials_out, hipStream_t stream) {
+  plan_t p; make_plan(ctx, d, n, p);
+  if (int rc = ensure_buffers(ctx, d, n, p)) return rc;
+  d.last_plan = p; d.last_n = n; d.have_last = true;
+  HIP_TRY(ctx, hipSetDevice(d.device));
+  const bool prof = ctx->opt_profile != 0;
+  auto mark = [&](int i) { if (prof) (void)hipEventRecord(d.ev[i], stream); };
+  const uint32_t n32 = (uint32_t)n;
+
+  HIP_TRY(ctx, hipMemsetAsync(d.d_err, 0, sizeof(uint32_t), stream));
+  mark(ST_PREP);
+  hipLaunchKernelGGL(te::k_prep_points, dim3((n32 + 255) / 256), dim3(256), 0, stream,
+                     (const uint4*)d_points, d.d_recs, n32);
+  mark(ST_DIGITS);
+  if (p.nw > 0) {
+    te::digits_params prm; memset(&prm, 0, sizeof prm);
+    for (int w = 0; w < p.W; w++) { const int bit = w * p.c + p.c - 1; if (bit < 320) prm.half[bit >> 5] |= 1u << (bit & 31); }
+    prm.n = n32; prm.num_windows = p.W; prm.w_first = d.w_first; prm.w_step = d.w_step; prm.nw_local = p.nw;
+    const uint4* sc = (const uint4*)d_scalars;
+    switch (p.c) {
+      case 4: launch_digits<4>(sc, d.d_digits, prm, d.d_err, stream); break;
+      case 5: launch_digits<5>(sc, d.d_digits, prm, d.d_err, stream); break;
+      case 6: launch_digits<6>(sc, d.d_digits, prm, d.d_err, stream); break;
+      case 7: launch_digits<7>(sc, d.d_digits, prm, d.d_err, stream); break;
+      case 8: launch_digits<8>(sc, d.d_digits, prm, d.d_err, stream); break;
+      case 9: launch_digits<9>(sc, d.d_digits, prm, d.d_err, stream); break;
+      case 10: launch_digits<10>(sc, d.d_digits, prm, d.d_err, stream); break;
+      case 11: launch_digits<11>(sc, d.d_digits, prm, d.d_err, stream); break;
+      case 12: launch_digits<12>(sc, d.d_digits, prm, d.d_err, stream); break;
+      case 13: launch_digits<13>(sc, d.d_digits, prm, d.d_err, stream); break;
+      case 14: launch_digits<14>(sc, d.d_digits, prm, d.d_err, stream); break;
+      case 15: launch_digits<15>(sc, d.d_digits, prm, d.d_err, stream); break;
+      default: launch_digits<16>(sc, d.d_digits, prm, d.d_err, stream); break;
+    }
+  }
+  const uint32_t total = (uint32_t)p.nw * p.B;
+  const size_t lds_hist = (size_t)p.B * 4;
+  mark(ST_HIST);
+  if (p.nw > 0)
+    hipLaunchKernelGGL(te::k_hist, dim3(p.CH, p.nw), dim3(1024), lds_hist, stream, d.d_digits, d.d_counts, n32, p.B, p.chunk_len);
+  mark(ST_SCAN);
+  if (p.nw > 0) {
+    hipLaunchKernelGGL(te::k_scan_a, dim3(p.nseg, p.nw), dim3(p.seg_threads), 0, stream, d.d_counts, d.d_bucket_count,
+                       d.d_local_excl, d.d_seg_total, p.B, p.CH);
+    hipLaunchKernelGGL(te::k_scan_b, dim3(p.nseg, p.nw), dim3(p.seg_threads), 0, stream, d.d_local_excl, d.d_seg_total,
+                       d.d_bucket_start, p.B);
+  }
+  mark(ST_SCATTER);
+  if (p.nw > 0)
+    hipLaunchKernelGGL(te::k_scatter, dim3(p.CH, p.nw), dim3(1024), lds_hist, stream, d.d_digits, d.d_counts,
+                       d.d_bucket_start, d.d_sorted, n32, p.B, p.chunk_len);
+  mark(ST_ORDER);
+  const uint32_t* order = nullptr;
+  if (p.nw > 0 && ctx->opt_sort) {
+    HIP_TRY(ctx, hipMemsetAsync(d.d_size_hist, 0, 1024 * sizeof(uint32_t), stream));
+    uint32_t ob = (total + 4095) / 4096; if (ob > 512) ob = 512; if (ob < 1) ob = 1;
+    hipLaunchKernelGGL(te::k_order_hist, dim3(ob), dim3(256), 0, stream, d.d_bucket_count, total, d.d_size_hist);
+    hipLaunchKernelGGL(te::k_order_scan, dim3(1), dim3(1024), 0, stream, d.d_size_hist, d.d_size_cursor);
+    hipLaunchKernelGGL(te::k_order_scatter, dim3(ob), dim3(256), 0, stream, d.d_bucket_count, total, d.d_size_cursor, d.d_order);
+    order = d.d_order;
+  }
+  mark(ST_ACCUM);
+  if (p.nw > 0)
+    hipLaunchKernelGGL(te::k_accumulate, dim3((total + 255) / 256), dim3(256), 0, stream, d.d_recs, d.d_sorted,
+                       d.d_bucket_start, d.d_bucket_count, order, d.d_buckets, n32, p.logB, total);
+  mark(ST_TREE);
+  if (p.nw > 0) {
+    hipLaunchKernelGGL(te::k_tree_sum, dim3(p.RH, p.nw), dim3(p.RL), (size_t)p.RL * 128, stream, d.d_buckets, d.d_rowsum, p.B, p.RL, 1u);
+    hipLaunchKernelGGL(te::k_tree_sum, dim3(p.RL, p.nw), dim3(p.RH), (size_t)p.RH * 128, stream, d.d_buckets, d.d_colsum, p.B, 1u, p.RL);
+  }
+  mark(ST_WEIGHTED);
+  if (p.nw > 0) {
+    te::ete* rows = reinterpret_cast<te::ete*>(d_partials_out) + (size_t)d.w_first * 3;
+    const uint32_t stride = (uint32_t)d.w_step * 3u;
+    hipLaunchKernelGGL(te::k_weighted_sum, dim3(1, p.nw), dim3(p.RH), (size_t)p.RH * 128, stream, d.d_rowsum, rows, rows + 1, stride);
+    hipLaunchKernelGGL(te::k_weighted_sum, dim3(1, p.nw), dim3(p.RL), (size_t)p.RL * 128, stream, d.d_colsum, (te::ete*)nullptr, rows + 2, stride);
+  }
+  mark(ST_COUNT);
+  HIP_TRY(ctx, hipMemcpyAsync(d.h_err, d.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(ctx, hipEventRecord(d.ev_done, stream));
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+int collect_stage_ms(te_ctx* ctx, gpu_t& d) {
+  if (!ctx->opt_profile) return 0;
+  for (int i = 0; i < ST_COUNT; i++) {
+    float ms = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, d.ev[i], d.ev[i + 1]));
+    ctx->stage_ms[i] = ms;
+  }
+  ctx->have_stage_ms = true;
+  return 0;
+}
+
+void free_dev(gpu_t& d) {
+  (void)hipSetDevice(d.device);
+  void* ptrs[] = {d.d_recs, d.d_digits, d.d_counts, d.d_bucket_count, d.d_bucket_start, d.d_local_excl, d.d_seg_total,
+                  d.d_sorted, d.d_order, d.d_size_hist, d.d_size_cursor, d.d_buckets, d.d_rowsum, d.d_colsum, d.d_partials,
+                  d.d_err, d.d_in_points, d.d_in_scalars};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (d.h_err) (void)hipHostFree(d.h_err);
+  if (d.h_partials) (void)hipHostFree(d.h_partials);
+  if (d.ev_done) (void)hipEventDestroy(d.ev_done);
+  for (auto& e : d.ev) if (e) (void)hipEventDestroy(e);
+  if (d.stream) (void)hipStreamDestroy(d.stream);
+}
+
+int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, bool src_is_host, uint64_t n, uint8_t out[64]) {
+  if (!ctx || !out) return TE_MSM_EINVAL;
+  if (n >= (1ull << 31)) return set_err(ctx, TE_MSM_EINVAL, "n must be < 2^31");
+  if (n == 0) { memset(out, 0, 64); out[32] = 1; return 0; }       // empty sum = identity (0, 1)
+  if (!src_points || !src_scalars) return set_err(ctx, TE_MSM_EINVAL, "null input buffer");
+  const size_t nd = ctx->devs.size();
+  plan_t p0; make_plan(ctx, ctx->devs[0], n, p0);
+  // stage inputs on every device
+  for (size_t i = 0; i < nd; i++) {
+    gpu_t& d = ctx->devs[i];
+    HIP_TRY(ctx, hipSetDevice(d.device));
+    const void *dp = src_points, *ds = src_scalars;
+    if (src_is_host || i > 0) {
+      if (n > d.cap_in) {
+        if (d.d_in_points) HIP_TRY(ctx, hipFree(d.d_in_points));
+        if (d.d_in_scalars) HIP_TRY(ctx, hipFree(d.d_in_scalars));
+        d.d_in_points = d.d_in_scalars = nullptr;
+        HIP_TRY(ctx, hipMalloc(&d.d_in_points, n * TE_MSM_POINT_BYTES));
+        HIP_TRY(ctx, hipMalloc(&d.d_in_scalars, n * TE_MSM_SCALAR_BYTES));
+        d.cap_in = n;
+      }
+      if (src_is_host) {
+        HIP_TRY(ctx, hipMemcpyAsync(d.d_in_points, src_points, n * TE_MSM_POINT_BYTES, hipMemcpyHostToDevice, d.stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d.d_in_scalars, src_scalars, n * TE_MSM_SCALAR_BYTES, hipMemcpyHostToDevice, d.stream));
+      } else {
+        // inputs live on device 0's memory: wait for nothing (caller's data is ready), copy peer-to-peer
+        HIP_TRY(ctx, hipMemcpyPeerAsync(d.d_in_points, d.device, src_points, ctx->devs[0].device, n * TE_MSM_POINT_BYTES, d.stream));
+        HIP_TRY(ctx, hipMemcpyPeerAsync(d.d_in_scalars, d.device, src_scalars, ctx->devs[0].device, n * TE_MSM_SCALAR_BYTES, d.stream));
+      }
+      dp = d.d_in_points; ds = d.d_in_scalars;
+    }
+    if (int rc = ensure_buffers(ctx, d, n, p0)) return rc;     // sizes d_partials before the memset below
+    HIP_TRY(ctx, hipMemsetAsync(d.d_partials, 0, (size_t)p0.W * TE_MSM_PARTIAL_BYTES, d.stream));
+    if (int rc = enqueue_partial(ctx, d, dp, ds, n, d.d_partials, d.stream)) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(d.h_partials, d.d_partials, (size_t)p0.W * TE_MSM_PARTIAL_BYTES, hipMemcpyDeviceToHost, d.stream));
+  }
+  std::vector<uint8_t> merged((size_t)p0.W * TE_MSM_PARTIAL_BYTES, 0);
+  for (size_t i = 0; i < nd; i++) {
+    gpu_t& d = ctx->devs[i];
+    HIP_TRY(ctx, hipSetDevice(d.device));
+    HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+    if (*d.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
+    for (int w = d.w_first; w < p0.W; w += d.w_step)
+      memcpy(&merged[(size_t)w * TE_MSM_PARTIAL_BYTES], d.h_partials + (size_t)w * TE_MSM_PARTIAL_BYTES, TE_MSM_PARTIAL_BYTES);
+  }
+  if (int rc = collect_stage_ms(ctx, ctx->devs[0])) return rc;
+  te_host::horner_to_affine(merged.data(), p0.c, p0.W, out);
+  return 0;
+}
+
+}  // namespace
+
+// ================================================================================================ C-ABI
+extern "C" {
+
+int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
+  if (!out || n_dev < 1 || n_dev > 64) { g_init_error = "te_msm_init: bad arguments"; return TE_MSM_EINVAL; }
+  *out = nullptr;
+  if (!te_host::tail_selftest()) { g_init_error = "te_msm_init: host tail constants self-test failed"; return TE_MSM_ESTATE; }
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count < 1) {
+    g_init_error = std::string("te_msm_init: no usable HIP device (") + hipGetErrorString(e) + "); this library has no CPU fallback";
+    return TE_MSM_EDEVICE;
+  }
+  te_ctx* ctx = new te_ctx();
+  ctx->devs.resize(n_dev);
+  for (int i = 0; i < n_dev; i++) {
+    gpu_t& d = ctx->devs[i];
+    d.device = device_ids ? device_ids[i] : i;
+    d.w_first = i; d.w_step = n_dev;
+    if (d.device < 0 || d.device >= count) { g_init_error = "te_msm_init: device id out of range"; delete ctx; return TE_MSM_EINVAL; }
+    hipError_t er = hipSetDevice(d.device);
+    if (er == hipSuccess) er = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
+    if (er == hipSuccess) er = hipMalloc((void**)&d.d_err, sizeof(uint32_t));
+    if (er == hipSuccess) er = hipMalloc((void**)&d.d_size_hist, 1024 * sizeof(uint32_t));
+    if (er == hipSuccess) er = hipMalloc((void**)&d.d_size_cursor, 1024 * sizeof(uint32_t));
+    if (er == hipSuccess) er = hipHostMalloc((void**)&d.h_err, sizeof(uint32_t), hipHostMallocDefault);
+    if (er == hipSuccess) er = hipEventCreateWithFlags(&d.ev_done, hipEventDisableTiming);
+    for (auto& evn : d.ev) if (er == hipSuccess) er = hipEventCreate(&evn);
+    // the per-window histogram (up to 128 KB for c = 16) lives in LDS: raise the dynamic-LDS limit
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)te::k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)te::k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    if (er != hipSuccess) {
+      g_init_error = std::string("te_msm_init: ") + hipGetErrorString(er);
+      for (auto& dd : ctx->devs) free_dev(dd);
+      delete ctx; return TE_MSM_EDEVICE;
+    }
+    *d.h_err = 0;
+  }
+  *out = ctx;
+  return 0;
+}
+
+void te_msm_destroy(te_ctx* ctx) {
+  if (!ctx) return;
+  for (auto& d : ctx->devs) { (void)hipSetDevice(d.device); if (d.stream) (void)hipStreamSynchronize(d.stream); free_dev(d); }
+  delete ctx;
+}
+
+const char* te_msm_last_error(const te_ctx* ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
+
+int te_msm_run(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars_le, uint64_t n, uint8_t out_xy_le[64]) {
+  return run_common(ctx, points_xy_le, scalars_le, true, n, out_xy_le);
+}
+
+int te_msm_run_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_scalars_le, uint64_t n, uint8_t out_xy_le[64]) {
+  return run_common(ctx, d_points_xy_le, d_scalars_le, false, n, out_xy_le);
+}
+
+int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
+  if (!ctx || !key) return TE_MSM_EINVAL;
+  if (!strcmp(key, "window_bits")) { if (value != 0 && (value < 4 || value > 16)) return set_err(ctx, TE_MSM_EINVAL, "window_bits must be 0 or in [4,16]"); ctx->opt_window_bits = (int)value; return 0; }
+  if (!strcmp(key, "sort_buckets")) { ctx->opt_sort = value ? 1 : 0; return 0; }
+  if (!strcmp(key, "profile")) { ctx->opt_profile = value ? 1 : 0; return 0; }
+  return set_err(ctx, TE_MSM_EINVAL, "unknown option");
+}
+
+int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value) {
+  if (!ctx || !key || !value) return TE_MSM_EINVAL;
+  if (!strcmp(key, "window_bits")) { *value = ctx->opt_window_bits; return 0; }
+  if (!strcmp(key, "sort_buckets")) { *value = ctx->opt_sort; return 0; }
+  if (!strcmp(key, "profile")) { *value = ctx->opt_profile; return 0; }
+  if (!strcmp(key, "num_devices")) { *value = (int64_t)ctx->devs.size(); return 0; }
+  return set_err(ctx, TE_MSM_EINVAL, "unknown option");
+}
+
+int te_msm_set_window_shard(te_ctx* ctx, int first, int step) {
+  if (!ctx) return TE_MSM_EINVAL;
+  if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "window shards are set automatically for multi-device contexts");
+  if (first < 0 || step < 1) return set_err(ctx, TE_MSM_EINVAL, "need first >= 0 and step >= 1");
+  ctx->devs[0].w_first = first; ctx->devs[0].w_step = step;
+  return 0;
+}
+
+int te_msm_plan(te_ctx* ctx, uint64_t n, int* window_bits, int* num_windows) {
+  if (!ctx) return TE_MSM_EINVAL;
+  plan_t p; make_plan(ctx, ctx->devs[0], n ? n : 1, p);
+  if (window_bits) *window_bits = p.c;
+  if (num_windows) *num_windows = p.W;
+  return 0;
+}
+
+int te_msm_partial_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_scalars_le, uint64_t n, void* d_partials, void* stream) {
+  if (!ctx) return TE_MSM_EINVAL;
+  if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_partial_device needs a single-device context");
+  if (!d_points_xy_le || !d_scalars_le || !d_partials || n == 0 || n >= (1ull << 31)) return set_err(ctx, TE_MSM_EINVAL, "bad arguments");
+  gpu_t& d = ctx->devs[0];
+  return enqueue_partial(ctx, d, d_points_xy_le, d_scalars_le, n, d_partials, stream ? (hipStream_t)stream : d.stream);
+}
+
+int te_msm_finalize(te_ctx* ctx, const uint8_t* partials, int window_bits, int num_windows, uint8_t out_xy_le[64]) {
+  if (!ctx || !partials || !out_xy_le || window_bits < 2 || window_bits > 16 || num_windows < 1 || num_windows > 128) return TE_MSM_EINVAL;
+  gpu_t& d = ctx->devs[0];
+  if (d.have_last) {
+    HIP_TRY(ctx, hipEventSynchronize(d.ev_done));
+    if (*d.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
+    if (int rc = collect_stage_ms(ctx, d)) return rc;
+  }
+  te_host::horner_to_affine(partials, window_bits, num_windows, out_xy_le);
+  return 0;
+}
+
+int te_msm_finalize_host(const uint8_t* partials, int window_bits, int num_windows, uint8_t out_xy_le[64]) {
+  if (!partials || !out_xy_le || window_bits < 2 || window_bits > 16 || num_windows < 1 || num_windows > 128) return TE_MSM_EINVAL;
+  if (!te_host::tail_selftest()) return TE_MSM_ESTATE;
+  te_host::horner_to_affine(partials, window_bits, num_windows, out_xy_le);
+  return 0;
+}
+
+int te_msm_stage_ms(te_ctx* ctx, float* ms, const char** names, int max_stages) {
+  if (!ctx || !ms) return TE_MSM_EINVAL;
+  if (!ctx->have_stage_ms) return set_err(ctx, TE_MSM_ESTATE, "no profiled run yet (set option profile=1)");
+  int k = 0;
+  for (; k < ST_COUNT && k < max_stages; k++) { ms[k] = ctx->stage_ms[k]; if (names) names[k] = kStageNames[k]; }
+  return k;
+}
+
+int64_t te_msm_debug_read(te_ctx* ctx, const char* stage, void* dst, uint64_t cap) {
+  if (!ctx || !stage || !dst) return TE_MSM_EINVAL;
+  gpu_t& d = ctx->devs[0];
+  if (!d.have_last) return set_err(ctx, TE_MSM_ESTATE, "no run yet");
+  const plan_t& p = d.last_plan; const uint64_t n = d.last_n;
+  const void* src = nullptr; uint64_t bytes = 0;
+  if (!strcmp(stage, "records")) { src = d.d_recs; bytes = n * sizeof(te::pnt); }
+  else if (!strcmp(stage, "digits")) { src = d.d_digits; bytes = (uint64_t)p.nw * n * 2; }
+  else if (!strcmp(stage, "bucket_count")) { src = d.d_bucket_count; bytes = (uint64_t)p.nw * p.B * 4; }
+  else if (!strcmp(stage, "bucket_start")) { src = d.d_bucket_start; bytes = (uint64_t)p.nw * p.B * 4; }
+  else if (!strcmp(stage, "sorted")) { src = d.d_sorted; bytes = (uint64_t)p.nw * n * 4; }
+  else if (!strcmp(stage, "order")) { src = d.d_order; bytes = (uint64_t)p.nw * p.B * 4; }
+  else if (!strcmp(stage, "buckets")) { src = d.d_buckets; bytes = (uint64_t)p.nw * p.B * sizeof(te::ete); }
+  else if (!strcmp(stage, "partials")) { src = d.d_partials; bytes = (uint64_t)p.W * TE_MSM_PARTIAL_BYTES; }
+  else return set_err(ctx, TE_MSM_EINVAL, "unknown stage");
+  if (bytes > cap) bytes = cap;
+  HIP_TRY(ctx, hipSetDevice(d.device));
+  HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+  HIP_TRY(ctx, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return (int64_t)bytes;
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+"""Window sharding of one MSM over ranks (one process per GPU).
+
+The W windows of the signed-digit decomposition are independent until Horner's rule
+(submission.ts:369-407).  Rank r of D owns windows {w : w mod D == r}; every rank converts all n points
+and decomposes only its own windows, reduces them on its GPU to W/D rows of 384 bytes, and the rows are
+exchanged with ONE all-gather of W*384 bytes (6 KB for c = 16) -- RCCL over xGMI when the tensors are
+on GPUs, gloo in the CPU tests.  Group addition is exact, so the result is bit-identical for every D.
+"""
+from __future__ import annotations
+
+PARTIAL_BYTES = 384
+
+
+def window_shard_for_rank(rank: int, world: int):
+    """(first, step) such that the rank owns windows first, first+step, ..."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    return rank, world
+
+
+def merge_partials(rows_per_rank, num_windows: int, world: int) -> bytes:
+    """rows_per_rank[r] is rank r's full W x 384 B buffer (only its own rows non-zero)."""
+    out = bytearray(num_windows * PARTIAL_BYTES)
+    for w in range(num_windows):
+        r = w % world
+        out[w * PARTIAL_BYTES:(w + 1) * PARTIAL_BYTES] = rows_per_rank[r][w * PARTIAL_BYTES:(w + 1) * PARTIAL_BYTES]
+    return bytes(out)
+
+
+def exchange_partials(partials, num_windows: int, dist=None, group=None, gather_list=None) -> bytes:
+    """All-gathers every rank's W x 384 B tensor (CUDA tensor -> RCCL, CPU tensor -> gloo) and returns
+    the merged rows as bytes.  `partials` must be complete on the current stream when called."""
+    import torch
+
+    if dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1:
+        world = dist.get_world_size(group)
+        if gather_list is None:
+            gather_list = [torch.empty_like(partials) for _ in range(world)]
+        dist.all_gather(gather_list, partials, group=group)
+        if partials.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        return merge_partials([g.cpu().numpy().tobytes() for g in gather_list], num_windows, world)
+    if partials.is_cuda:
+        torch.cuda.current_stream().synchronize()
+    return partials.cpu().numpy().tobytes()
+
+
+def compute_msm_sharded(ctx, d_points, d_scalars, n: int, partials, dist=None, group=None, gather_list=None) -> bytes:
+    """One window-sharded MSM on this rank's GPU.
+
+    ctx        MsmContext whose window shard is (rank, world)
+    d_points / d_scalars   torch uint8 CUDA tensors holding the FULL inputs on this rank's GPU
+    partials   torch uint8 CUDA tensor of W*384 bytes (scratch, overwritten)
+    dist       torch.distributed (initialised) or None for a single rank
+    Returns the 64-byte affine result (identical on every rank).  All device work is enqueued on
+    torch's current stream so that the collective is ordered behind it.
+    """
+    import torch
+
+    c, W = ctx.plan(n)
+    partials.zero_()
+    ctx.partial_device(d_points.data_ptr(), d_scalars.data_ptr(), n, partials.data_ptr(),
+                       torch.cuda.current_stream().cuda_stream)
+    merged = exchange_partials(partials, W, dist, group, gather_list)
+    return ctx.finalize(merged, c, W)
