@@ -1,0 +1,163 @@
+"""bench.py -- MSM throughput / latency of the HIP path on N GPUs of one node.
+
+A "step" is one full MSM (n = 2^20 Twisted-Edwards BLS12 points, 16-bit signed windows) over
+synthetic inputs already resident in HBM.  N = 1: te_msm_run_device (device stages + host tail).
+N > 1: the MSM's 16 windows are sharded over the ranks (one process per GPU), the 6 KB of partial
+sums are exchanged with one RCCL all-gather, and every rank runs the host tail ("scaling": "strong").
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "webgpu-msm-twisted-edwards_amd"
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def algorithmic_bytes(n, W, B):
+    """whole MSM, and the share of the dominant kernel (bucket accumulation)."""
+    whole = 96 * n + W * n * (64 + 4) + 2 * W * B * 128 + 64
+    accumulate = W * n * (64 + 4) + W * B * 128          # gather each point + its 4-B index once, write each bucket once
+    return whole, accumulate
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log2n", type=int, default=20)
+    ap.add_argument("--window-bits", type=int, default=16)
+    ap.add_argument("--points", choices=["chain", "fixed"], default="chain", help="chain: distinct points (a+i*b)G; fixed: harness mode")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = local_rank if world > 1 else 0
+    torch.cuda.set_device(dev)
+
+    pkg = importlib.import_module(PKG)
+    from oracle import oracle          # input generator + checker + cpu_baseline leg only
+
+    n = 1 << args.log2n
+    seed = 0x5EED0000 + args.log2n
+    t0 = time.time()
+    pts = oracle.gen_points(seed, n) if args.points == "chain" else oracle.gen_points_fixed(n)
+    sc = oracle.gen_scalars(seed, n)
+    gen_s = time.time() - t0
+    d_pts = torch.frombuffer(bytearray(pts), dtype=torch.uint8).cuda()
+    d_sc = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+
+    ctx = pkg.MsmContext((dev,))
+    ctx.set_option("window_bits", args.window_bits)
+    ctx.set_option("profile", 1)
+    c, W = ctx.plan(n)
+    B = 1 << (c - 1)
+    if world > 1:
+        ctx.set_window_shard(*pkg.window_shard_for_rank(rank, world))
+        partials = torch.zeros(W * pkg.PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
+        gather_list = [torch.empty_like(partials) for _ in range(world)]
+
+    def step():
+        if world > 1:
+            return pkg.compute_msm_sharded(ctx, d_pts, d_sc, n, partials, dist, None, gather_list)
+        return ctx.run_device(d_pts.data_ptr(), d_sc.data_ptr(), n)
+
+    result = None
+    for _ in range(args.warmup):
+        result = step()
+    stage_acc = {}
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = step()
+        for k, v in ctx.stage_ms().items():          # HIP events recorded on the engine's own stream
+            stage_acc[k] = stage_acc.get(k, 0.0) + v
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    stage_ms = {k: v / args.steps for k, v in stage_acc.items()}
+    whole_bytes, acc_bytes = algorithmic_bytes(n, W, B)
+    acc_bytes_rank = acc_bytes / world                    # windows are sharded
+    acc_ms = stage_ms.get("accumulate", 0.0)
+    achieved = acc_bytes_rank / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
+
+    out = {
+        "metric": "MSMs/sec at n=2^%d Twisted-Edwards BLS12 (latency in ms_per_step)" % args.log2n,
+        "value": args.steps / elapsed,
+        "unit": "MSM/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {"workload": "n=2^%d TE-BLS12 MSM, %d-bit signed windows (%d windows x %d buckets), points=%s, inputs resident in HBM"
+                               % (args.log2n, c, W, B, args.points),
+                   "parallelism": "windows sharded over %d GPU(s), RCCL all-gather of %d B partial sums" % (world, W * 384) if world > 1 else "single GPU"},
+        "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "algorithmic_bytes_per_launch": acc_bytes_rank, "kernel_ms": acc_ms,
+                     "note": "integer-multiply bound (about 1.2e8 field products per launch), see DESIGN.md"},
+        "msm_algorithmic_bytes": whole_bytes,
+        "msm_algorithmic_gbps": whole_bytes / (ms_per_step * 1e-3) / 1e9,
+        "stage_ms": stage_ms,
+        "result_x": str(int.from_bytes(result[:32], "little")),
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+        t0 = time.perf_counter()
+        exp = oracle.msm(pts, sc, c=16 if n >= 65536 else 4, bpr_mode=1, threads=threads)
+        cpu_s = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "MSM/s", "cores": threads, "kind": "port",
+                               "sample": "1 full MSM at n=2^%d (C restatement of the reference pipeline, oracle/te_oracle.c), %.1f s"
+                                         % (args.log2n, cpu_s)}
+        out["parity"] = "bit-exact vs oracle" if exp == result else "MISMATCH vs oracle"
+        if exp != result:
+            print(json.dumps(out))
+            raise SystemExit("GPU result differs from the oracle")
+    if rank == 0:
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -255,3 +255,31 @@ def compute_misc_params(p: int, word_size: int):
     n0 = (-pow(p, -1, r)) % r % (1 << word_size)
     return {"num_words": num_words, "max_terms": max_terms, "k": k, "nsafe": nsafe,
             "r": r % p, "rinv": rinv, "n0": n0, "edwards_d": D * r % p}
+
+
+# ------------------------------------------------------------------ harness codecs (reference/webgpu/utils.ts)
+def bigint_to_u32_array(v: int):
+    """bigIntToU32Array, reference/webgpu/utils.ts:47-62: 8 words, most significant first."""
+    return [(v >> (32 * (7 - i))) & 0xFFFFFFFF for i in range(8)]
+
+
+def u32_array_to_bigints(words):
+    """u32ArrayToBigInts, reference/webgpu/utils.ts:64-79"""
+    out = []
+    for i in range(0, len(words), 8):
+        v = 0
+        for j, w in enumerate(words[i:i + 8]):
+            v |= int(w) << (32 * (7 - j))
+        out.append(v)
+    return out
+
+
+def bigints_to_buffer_le(vals, bits: int = 256) -> bytes:
+    """bigIntsToBufferLE, reference/webgpu/utils.ts:90-99 -- the wire format of compute_msm's Buffers."""
+    return b"".join(int(v).to_bytes(bits // 8, "little") for v in vals)
+
+
+def read_bigints_from_buffer_le(buf: bytes, bits: int = 256):
+    """readBigIntsFromBufferLE, reference/webgpu/utils.ts:101-112"""
+    step = bits // 8
+    return [int.from_bytes(buf[i:i + step], "little") for i in range(0, len(buf), step)]

@@ -1,0 +1,231 @@
+"""CPU-side tests of the product's host logic and of the device arithmetic headers compiled for the
+host (tests/csrc/fpcheck.cpp).  No GPU, no compute calls into libtemsm.so beyond the host tail."""
+import ctypes
+import os
+import random
+import re
+import subprocess
+import sys
+
+import pytest
+
+from oracle.gen_golden import edge_scalars
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = 1 << 256
+
+
+def limbs(v):
+    return (ctypes.c_uint32 * 8)(*[(v >> (32 * i)) & 0xFFFFFFFF for i in range(8)])
+
+
+def val(a):
+    return sum(int(a[i]) << (32 * i) for i in range(8))
+
+
+def test_field_constants(fpcheck, model):
+    out = (ctypes.c_uint32 * 40)()
+    fpcheck.fpc_constants(out)
+    got = [sum(int(out[8 * k + i]) << (32 * i) for i in range(8)) for k in range(5)]
+    P = model.P
+    assert got == [R % P, R * R % P, model.D * R % P, 2 * model.D * R % P, 1]
+
+
+def test_mont_mul_and_lazy_bounds(fpcheck, model):
+    P, rnd = model.P, random.Random(11)
+    rinv = pow(R, -1, P)
+    cases = [(8 * P - 1, R - 1), (0, 0), (1, 1), (P, P), (8 * P - 1, 0)]
+    cases += [(rnd.randrange(8 * P), rnd.randrange(R)) for _ in range(3000)]
+    for a, b in cases:
+        out = (ctypes.c_uint32 * 8)()
+        fpcheck.fpc_mont_mul(limbs(a), limbs(b), out)
+        r = val(out)
+        assert r % P == a * b * rinv % P
+        assert r < a * b // R + P + 1            # the bound every caller relies on: a*b/R + p
+
+
+def test_field_helpers(fpcheck, model):
+    P, rnd = model.P, random.Random(12)
+    for _ in range(500):
+        a = rnd.randrange(R)
+        out = (ctypes.c_uint32 * 8)()
+        fpcheck.fpc_reduce_full(limbs(a), out)
+        assert val(out) == a % P
+        c = rnd.randrange(P)
+        fpcheck.fpc_half(limbs(c), out)
+        assert val(out) * 2 % P == c and val(out) < P
+        x, y = rnd.randrange(2 * P), rnd.randrange(2 * P)
+        fpcheck.fpc_sub2(limbs(x), limbs(y), out)
+        assert val(out) == x - y + 2 * P
+
+
+def _ete_affine(model, b):
+    P = model.P
+    rinv = pow(R, -1, P)
+    x, y, z, t = [int.from_bytes(b[32 * i:32 * i + 32], "little") * rinv % P for i in range(4)]
+    zi = pow(z, -1, P)
+    assert t * z % P == x * y % P           # T = XY/Z stays consistent
+    return (x * zi % P, y * zi % P)
+
+
+def test_point_formulas(fpcheck, model, ora):
+    pts = [model.xy_from_bytes(ora.gen_points(21, 12)[64 * i:64 * i + 64]) for i in range(12)]
+    ident = ctypes.create_string_buffer(128)
+    fpcheck.fpc_identity(ident)
+    acc, exp = ident.raw, model.ZERO
+    recs = []
+    for p in pts:
+        rec = ctypes.create_string_buffer(96)
+        fpcheck.fpc_prep_point(model.points_to_bytes([p]), rec)
+        recs.append(rec.raw)
+    for i, p in enumerate(pts + pts[:3]):             # the last three re-add points: P + P through the unified law
+        neg = i % 3 == 1
+        out = ctypes.create_string_buffer(128)
+        fpcheck.fpc_madd(acc, recs[i % 12], int(neg), out)
+        acc = out.raw
+        exp = model.add(exp, model.neg(p) if neg else p)
+        assert _ete_affine(model, acc) == exp
+    out = ctypes.create_string_buffer(128)
+    fpcheck.fpc_add(acc, acc, out)                    # doubling through ete_add
+    assert _ete_affine(model, out.raw) == model.add(exp, exp)
+    fpcheck.fpc_add(out.raw, ident.raw, out)
+    assert _ete_affine(model, out.raw) == model.add(exp, exp)
+    assert fpcheck.fpc_bound_violations() == 0
+
+
+@pytest.mark.parametrize("n,c,mode", [(1, 4, "chain"), (2, 16, "chain"), (33, 5, "chain"), (64, 16, "edge"),
+                                       (300, 8, "chain"), (1000, 13, "chain"), (257, 16, "fixed"), (100, 7, "edge"),
+                                       (500, 12, "fixed"), (4096, 11, "chain")])
+def test_emulated_stages_plus_host_tail(fpcheck, pkg, model, ora, n, c, mode):
+    """device-stage emulation (same limb code as the kernels) -> partial rows -> the product's host tail
+    == oracle.  Covers the row format, the row/column weighting and Horner's split."""
+    seed = 1000 + n + c
+    pts = ora.gen_points_fixed(n) if mode == "fixed" else ora.gen_points(seed, n)
+    sc = model.scalars_to_bytes(edge_scalars(seed, n)) if mode == "edge" else ora.gen_scalars(seed, n)
+    W = (256 + c - 1) // c
+    buf = ctypes.create_string_buffer(W * 384)
+    assert fpcheck.fpc_partial_rows(pts, sc, n, c, 0, 1, buf) == 0
+    assert pkg.finalize_host(buf.raw, c, W) == ora.msm(pts, sc, threads=4)
+    assert fpcheck.fpc_bound_violations() == 0
+
+
+def test_window_shards_merge(fpcheck, pkg, ora):
+    n, c = 200, 9
+    pts, sc = ora.gen_points(9, n), ora.gen_scalars(9, n)
+    W = (256 + c - 1) // c
+    exp = ora.msm(pts, sc)
+    for world in (1, 2, 3, 8, 40):                    # 40 > W: some ranks own no window
+        bufs = []
+        for r in range(world):
+            first, step = pkg.window_shard_for_rank(r, world)
+            b = ctypes.create_string_buffer(W * 384)
+            assert fpcheck.fpc_partial_rows(pts, sc, n, c, first, step, b) == 0
+            bufs.append(b.raw)
+        assert pkg.finalize_host(pkg.merge_partials(bufs, W, world), c, W) == exp
+
+
+def test_final_carry_detected_by_emulation(fpcheck, model, ora):
+    pts = ora.gen_points(1, 2)
+    sc = model.scalars_to_bytes([5, (1 << 256) - 1])
+    buf = ctypes.create_string_buffer(16 * 384)
+    assert fpcheck.fpc_partial_rows(pts, sc, 2, 16, 0, 1, buf) == -3
+
+
+def test_host_tail_identity_and_args(pkg):
+    ident = bytes(32) + (1).to_bytes(32, "little")
+    assert pkg.finalize_host(bytes(16 * 384), 16, 16) == ident
+    with pytest.raises(pkg.MsmError):
+        pkg.finalize_host(bytes(384), 99, 1)
+
+
+# ---------------------------------------------------------------- C-ABI surface
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "te_msm.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(te_msm_\w+)\s*\(", hdr)))
+
+
+def test_abi_exports_every_declared_symbol(pkg):
+    L = ctypes.CDLL(pkg.library_path())
+    syms = _declared_symbols()
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/te_msm.h but not exported"
+
+
+def test_library_has_gfx950_code_object(pkg):
+    data = open(pkg.library_path(), "rb").read()
+    assert b"gfx950" in data and b"k_accumulate" in data
+
+
+def test_no_cpu_fallback_without_device(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the loud-failure path is not reachable")
+    with pytest.raises(pkg.MsmError) as e:
+        pkg.MsmContext((0,))
+    assert "no CPU fallback" in str(e.value)
+    with pytest.raises(pkg.MsmError):
+        pkg.compute_msm(bytes(64), bytes(32), log_result=False)
+
+
+def test_product_does_not_touch_the_oracle():
+    """The oracle is test infrastructure: nothing under the package or include/ may reference it."""
+    bad = []
+    for base in ("webgpu-msm-twisted-edwards_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".hpp", ".hip", ".h", ".inc", ".js", ".cc", ".cpp", "Makefile")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"te_oracle|oracle/|from oracle|import oracle|ora_msm", txt):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+def test_zprize_ingestion_format(pkg, model, tmp_path):
+    import importlib
+    td = importlib.import_module("webgpu-msm-twisted-edwards_amd.testdata")
+    pts = [(model.GX, model.GY), (model.HX, model.HY)]
+    ptxt = "\n".join('{"x": "%d", "y": "%d", "t": "%d", "z": "1"}' % (x, y, x * y % model.P) for x, y in pts) + "\n"
+    stxt = "5\n%d\n" % (model.P - 1)
+    (tmp_path / "p.txt").write_text(ptxt)
+    (tmp_path / "s.txt").write_text(stxt)
+    bp, bs = td.load_test_case(str(tmp_path / "p.txt"), str(tmp_path / "s.txt"))
+    assert bp == model.points_to_bytes(pts) and bs == model.scalars_to_bytes([5, model.P - 1])
+
+
+# ---------------------------------------------------------------- N > 1 path on CPU (gloo, world_size 2)
+_WORKER = r"""
+import ctypes, importlib, os, sys
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from oracle import oracle as o
+pkg = importlib.import_module("webgpu-msm-twisted-edwards_amd")
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
+rank, world = dist.get_rank(), dist.get_world_size()
+L = ctypes.CDLL(os.path.join({root!r}, "tests", "csrc", "libfpcheck.so"))
+L.fpc_partial_rows.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+n, c = 300, 10
+W = (256 + c - 1) // c
+pts, sc = o.gen_points(77, n), o.gen_scalars(77, n)
+first, step = pkg.window_shard_for_rank(rank, world)
+buf = ctypes.create_string_buffer(W * 384)
+assert L.fpc_partial_rows(pts, sc, n, c, first, step, buf) == 0       # stands in for the GPU stage
+t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
+merged = pkg.exchange_partials(t, W, dist)
+res = pkg.finalize_host(merged, c, W)
+assert res == o.msm(pts, sc), "rank %d mismatch" % rank
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_gloo_two_rank_window_sharding(fpcheck, pkg, tmp_path):
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o

@@ -52,8 +52,8 @@ template <int K> TE_HD uint32_t kp_limb(int i) {
   return (uint32_t)acc;
 }
 
-// Constants in Montgomery form (R = 2^256); values are checked against oracle/model.py in
-// tests/test_field_host.py.
+// Constants in Montgomery form (R = 2^256); values are re-derived from bigint arithmetic in
+// tests/test_host_logic.py::test_field_constants.
 //   R mod p, R^2 mod p, d*R mod p (d = 3021, AleoConstants.ts:2-4)
 TE_HD fp fp_const(const uint32_t (&w)[8]) { fp r; for (int i = 0; i < 8; i++) r.v[i] = w[i]; return r; }
 
@@ -158,7 +158,7 @@ TE_HD bool fp_is_zero_canonical(const fp& a) {
 
 // ---------------------------------------------------------------------------------------------
 // Constants (Montgomery form, R = 2^256), generated by tools/gen_constants.py and re-derived in
-// tests/test_field_host.py from oracle/model.py.
+// tests/test_host_logic.py::test_field_constants.
 #include "fp_constants.inc"
 
 }  // namespace te
