@@ -64,6 +64,9 @@ KERNEL32(k_mul_u32_u24, "v_mul_u32_u24 %0, %0, %1")
 KERNEL32(k_mul_hi_u32_u24, "v_mul_hi_u32_u24 %0, %0, %1")
 KERNEL32(k_fma_f32, "v_fma_f32 %0, %0, %1, %2")
 KERNEL32(k_cndmask, "v_cndmask_b32 %0, %0, %1, vcc")
+KERNEL32(k_cndmask_e64, "v_cndmask_b32_e64 %0, %0, %1, s[10:11]")
+KERNEL32(k_cmp_cndmask, "v_cmp_gt_u32 vcc, %0, %2\n\tv_cndmask_b32 %0, %0, %1, vcc")
+KERNEL32(k_sub_co_chain, "v_sub_co_u32 %0, vcc, %0, %1\n\tv_subb_co_u32 %0, vcc, %0, %2, vcc")
 KERNEL32(k_addc_pair, "v_add_co_u32 %0, vcc, %0, %1\n\tv_addc_co_u32 %0, vcc, %0, %2, vcc")
 KERNEL32(k_alignbit, "v_alignbit_b32 %0, %0, %1, 13")
 KERNEL32(k_and_or, "v_and_or_b32 %0, %0, %1, %2")
@@ -81,7 +84,7 @@ struct entry { const char* name; kern_t k; int instrs_per_slot; };
 int main() {
   std::vector<entry> es = {
     {"v_add_u32", k_add_u32, 1}, {"v_mov_b32", k_mov_b32, 1}, {"v_add3_u32", k_add3_u32, 1}, {"v_fma_f32", k_fma_f32, 1},
-    {"v_cndmask_b32", k_cndmask, 1}, {"v_alignbit_b32", k_alignbit, 1}, {"v_and_or_b32", k_and_or, 1},
+    {"v_cndmask_b32", k_cndmask, 1}, {"v_cndmask_b32_e64 (sgpr)", k_cndmask_e64, 1}, {"v_cmp+v_cndmask (pair)", k_cmp_cndmask, 2}, {"v_sub_co+v_subb_co (pair)", k_sub_co_chain, 2}, {"v_alignbit_b32", k_alignbit, 1}, {"v_and_or_b32", k_and_or, 1},
     {"v_add_co+v_addc_co (pair)", k_addc_pair, 2},
     {"v_mul_lo_u32", k_mul_lo_u32, 1}, {"v_mul_hi_u32", k_mul_hi_u32, 1}, {"v_mad_u64_u32", k_mad_u64_u32, 1},
     {"v_mad_u64_u32+v_addc_co (pair)", k_mad_u64_u32_addc, 2},

@@ -36,12 +36,34 @@ def build_library(force: bool = False) -> str:
     return so
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """A process must hold ONE HIP runtime: two copies of libamdhip64 (PyTorch wheels bundle their own)
+    cannot both open the GPU -- whichever initialises second reports "no ROCm-capable device".  Both copies
+    carry the SONAME libamdhip64.so.7, so loading torch's copy first (by path, without importing torch) makes
+    libtemsm.so's DT_NEEDED resolve to it, and a later `import torch` finds the same file already mapped.
+    Without torch in the environment libtemsm.so simply uses the system ROCm runtime (its RUNPATH)."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def _lib() -> ctypes.CDLL:
     global _LIB
     if _LIB is None:
         so = library_path()
         if not os.path.exists(so):
             raise MsmError(-2, f"{so} is missing: build it with __graft_entry__.build() (there is no CPU fallback)")
+        _share_hip_runtime_with_torch()
         L = ctypes.CDLL(so)
         vp, u64, ci, cp = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_char_p
         L.te_msm_init.argtypes = [ctypes.POINTER(ci), ci, ctypes.POINTER(vp)]
