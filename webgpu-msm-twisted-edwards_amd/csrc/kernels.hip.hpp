@@ -8,7 +8,7 @@
 //                                                   (whole-window histogram held in LDS, one pass)
 //   K3 smvp (wgsl/cuzk/smvp.template.wgsl:58-152) -> k_accumulate (7-product mixed additions)
 //   K4/K5 bpr stage_1/2 (wgsl/cuzk/bpr.template.wgsl:73-171) + the CPU sum of 4096 points
-//      (submission.ts:362-393)                   -> k_tree_sum (row / column marginals) + k_weighted_sum
+//      (submission.ts:362-393)                   -> k_sum_groups (row / column marginals) + k_weighted_sum
 // Window w of this context is  w = w_first + k * w_step  for local index k (multi-GPU window sharding).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -296,51 +296,59 @@ __global__ void __launch_bounds__(256) k_accumulate(const pnt* __restrict__ recs
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4a: tree sums of bucket rows / columns.  A window's B buckets form an RH x RL grid, bucket
+// K4a: marginal sums of the bucket grid.  A window's B buckets form an RH x RL grid, bucket
 // j = hi * RL + lo, weight j + 1.  With R_hi = sum_lo B[hi,lo] and C_lo = sum_hi B[hi,lo]:
 //     sum_j (j+1) B_j = sum_hi R_hi + RL * sum_hi hi R_hi + sum_lo lo C_lo.
-// This kernel computes one marginal: out[k*groups + g] = sum_{t < count} in[k*B + g*gstride + t*tstride].
-//   rows: groups = RH, count = RL, gstride = RL, tstride = 1;   cols: groups = RL, count = RH, gstride = 1, tstride = RL.
-// grid (groups, nw_local), block = count (power of two), dynamic LDS = count * 128 B.
-__global__ void __launch_bounds__(256) k_tree_sum(const ete* __restrict__ in, ete* __restrict__ out, uint32_t B,
-                                                   uint32_t gstride, uint32_t tstride) {
-  extern __shared__ uint4 lds_u4[];
-  ete* sm = reinterpret_cast<ete*>(lds_u4);
-  const uint32_t g = blockIdx.x, k = blockIdx.y, t = threadIdx.x, count = blockDim.x;
-  ete mine = load_ete(in + (size_t)k * B + (size_t)g * gstride + (size_t)t * tstride);
-  for (uint32_t s = count >> 1; s > 0; s >>= 1) {
-    if (t >= s && t < 2 * s) store_ete(&sm[t], mine);
-    __syncthreads();
-    if (t < s) mine = ete_add(mine, load_ete(&sm[t + s]));
-    __syncthreads();
+// Each level of k_sum_groups folds K (2 or 4) elements per thread with full additions, so every lane
+// of every wave does the same amount of work (the earlier LDS tree left 3/4 of the lanes idle):
+//     out[o] = sum_{k<K} in[(outer*K + k)*inner + q],   o = outer*inner + q.
+// rows fold the contiguous (lo) dimension: inner = 1;  columns fold hi: inner = RL.
+// Two independent jobs (rows, columns) share one launch: blockIdx.y selects the job.
+struct sum_job {
+  const ete* in; ete* out;
+  uint32_t n_out;      // outputs per window
+  uint32_t K, inner;
+  uint32_t in_per_window, out_per_window;
+};
+__global__ void __launch_bounds__(256) k_sum_groups(sum_job j0, sum_job j1, uint32_t nw) {
+  const sum_job& j = blockIdx.y == 0 ? j0 : j1;
+  const uint32_t total = j.n_out * nw;
+  for (uint32_t g = blockIdx.x * 256u + threadIdx.x; g < total; g += gridDim.x * 256u) {
+    const uint32_t k = g / j.n_out, o = g - k * j.n_out;
+    const uint32_t outer = o / j.inner, q = o - outer * j.inner;
+    const ete* src = j.in + (size_t)k * j.in_per_window + (size_t)outer * j.K * j.inner + q;
+    ete acc = load_ete(src);
+    for (uint32_t t = 1; t < j.K; t++) acc = ete_add(acc, load_ete(src + (size_t)t * j.inner));
+    store_ete(j.out + (size_t)k * j.out_per_window + o, acc);
   }
-  if (t == 0) store_ete(out + (size_t)k * gridDim.x + g, mine);
 }
 
-// K4b: weighted sum over N = blockDim.x points E_0..E_{N-1} (N a power of two):
-//   out_total = sum_v E_v,  out_weighted = sum_v v * E_v = sum_{v >= 1} S_v,  S_v = sum_{u >= v} E_u.
-// Suffix sums by a log-step scan in LDS, then a tree sum of S_1..S_{N-1}.
-// grid (1, nw_local), block N, dynamic LDS = N * 128 B.
-__global__ void __launch_bounds__(256) k_weighted_sum(const ete* __restrict__ in, ete* __restrict__ out_total,
-                                                       ete* __restrict__ out_weighted, uint32_t out_stride) {
+// K4b: weighted sums over N points E_0..E_{N-1} (N a power of two <= blockDim.x):
+//   total = sum_v E_v,  weighted = sum_v v * E_v = sum_{v >= 1} S_v,  S_v = sum_{u >= v} E_u.
+// Suffix sums by a log-step scan in LDS, then a tree sum of S_1..S_{N-1}.  blockIdx.x selects the
+// problem (0: the RH row sums -> total + weighted, 1: the RL column sums -> weighted), blockIdx.y the
+// window; threads >= N hold the identity.  dynamic LDS = blockDim.x * 128 B.
+struct wsum_job { const ete* in; ete* out_total; ete* out_weighted; uint32_t N; };
+__global__ void __launch_bounds__(256) k_weighted_sum(wsum_job j0, wsum_job j1, uint32_t out_stride) {
   extern __shared__ uint4 lds_u4[];
   ete* sm = reinterpret_cast<ete*>(lds_u4);
-  const uint32_t k = blockIdx.y, t = threadIdx.x, N = blockDim.x;
-  ete mine = load_ete(in + (size_t)k * N + t);
+  const wsum_job& j = blockIdx.x == 0 ? j0 : j1;
+  const uint32_t k = blockIdx.y, t = threadIdx.x, T = blockDim.x, N = j.N;
+  ete mine = t < N ? load_ete(j.in + (size_t)k * N + t) : ete_identity();
   for (uint32_t d = 1; d < N; d <<= 1) {            // inclusive suffix scan
     store_ete(&sm[t], mine);
     __syncthreads();
     if (t + d < N) mine = ete_add(mine, load_ete(&sm[t + d]));
     __syncthreads();
   }
-  if (t == 0) { if (out_total) store_ete(out_total + (size_t)k * out_stride, mine); mine = ete_identity(); }
-  for (uint32_t s = N >> 1; s > 0; s >>= 1) {       // tree sum of S_1..S_{N-1} (slot 0 = identity)
+  if (t == 0) { if (j.out_total) store_ete(j.out_total + (size_t)k * out_stride, mine); mine = ete_identity(); }
+  for (uint32_t s = T >> 1; s > 0; s >>= 1) {       // tree sum of S_1..S_{N-1} (slot 0 = identity)
     if (t >= s && t < 2 * s) store_ete(&sm[t], mine);
     __syncthreads();
-    if (t < s) mine = ete_add(mine, load_ete(&sm[t + s]));
+    if (t < s && t + s < N) mine = ete_add(mine, load_ete(&sm[t + s]));
     __syncthreads();
   }
-  if (t == 0) store_ete(out_weighted + (size_t)k * out_stride, mine);
+  if (t == 0) store_ete(j.out_weighted + (size_t)k * out_stride, mine);
 }
 
 }  // namespace te

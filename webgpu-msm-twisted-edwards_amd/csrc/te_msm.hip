@@ -24,7 +24,7 @@ thread_local std::string g_init_error;
 
 enum { ST_PREP = 0, ST_DIGITS, ST_HIST, ST_SCAN, ST_SCATTER, ST_ORDER, ST_ACCUM, ST_TREE, ST_WEIGHTED, ST_COUNT };
 const char* const kStageNames[ST_COUNT] = {"prep_points", "digits", "hist", "scan", "scatter", "order",
-                                           "accumulate", "tree_sum", "weighted_sum"};
+                                           "accumulate", "marginal_sums", "weighted_sum"};
 
 struct plan_t {
   int c = 0, W = 0, nw = 0;           // window bits, total windows, windows of this shard
@@ -44,7 +44,7 @@ struct gpu_t {
   uint16_t* d_digits = nullptr;
   uint32_t *d_counts = nullptr, *d_bucket_count = nullptr, *d_bucket_start = nullptr, *d_local_excl = nullptr;
   uint32_t *d_seg_total = nullptr, *d_sorted = nullptr, *d_order = nullptr, *d_size_hist = nullptr, *d_size_cursor = nullptr;
-  te::ete *d_buckets = nullptr, *d_rowsum = nullptr, *d_colsum = nullptr;
+  te::ete *d_buckets = nullptr, *d_red[4] = {nullptr, nullptr, nullptr, nullptr};   // reduction ping/pong: rows a,b  cols a,b
   uint8_t* d_partials = nullptr;      // W x 384
   uint32_t* d_err = nullptr;
   uint32_t* h_err = nullptr;          // pinned
@@ -137,8 +137,11 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, uint64_t n, const plan_t& p) {
   if ((rc = ensure(ctx, d.d_order, d.cap[7], wb))) return rc;
   if ((rc = ensure(ctx, d.d_buckets, d.cap[8], wb))) return rc;
   if ((rc = ensure(ctx, d.d_seg_total, d.cap[9], (size_t)p.nw * p.nseg))) return rc;
-  if ((rc = ensure(ctx, d.d_rowsum, d.cap[10], (size_t)p.nw * p.RH))) return rc;
-  if ((rc = ensure(ctx, d.d_colsum, d.cap[11], (size_t)p.nw * p.RL))) return rc;
+  // marginal-sum levels fold by 4 (or 2): level 1 output is at most B/2 per window, level 2 at most B/4
+  if ((rc = ensure(ctx, d.d_red[0], d.cap[10], wb / 2 + 1))) return rc;
+  if ((rc = ensure(ctx, d.d_red[1], d.cap[11], wb / 4 + 1))) return rc;
+  if ((rc = ensure(ctx, d.d_red[2], d.cap[12], wb / 2 + 1))) return rc;
+  if ((rc = ensure(ctx, d.d_red[3], d.cap[13], wb / 4 + 1))) return rc;
   if (p.W > d.cap_W) {
     if (d.d_partials) HIP_TRY(ctx, hipFree(d.d_partials));
     if (d.h_partials) HIP_TRY(ctx, hipHostFree(d.h_partials));
@@ -221,16 +224,37 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, const void* d_points, const void* d_s
     hipLaunchKernelGGL(te::k_accumulate, dim3((total + 255) / 256), dim3(256), 0, stream, d.d_recs, d.d_sorted,
                        d.d_bucket_start, d.d_bucket_count, order, d.d_buckets, n32, p.logB, total);
   mark(ST_TREE);
+  const te::ete *row_res = d.d_buckets, *col_res = d.d_buckets;
   if (p.nw > 0) {
-    hipLaunchKernelGGL(te::k_tree_sum, dim3(p.RH, p.nw), dim3(p.RL), (size_t)p.RL * 128, stream, d.d_buckets, d.d_rowsum, p.B, p.RL, 1u);
-    hipLaunchKernelGGL(te::k_tree_sum, dim3(p.RL, p.nw), dim3(p.RH), (size_t)p.RH * 128, stream, d.d_buckets, d.d_colsum, p.B, 1u, p.RL);
+    // rows fold RL = 2^lo_bits contiguous buckets, columns fold RH; both by factors of 4 (last level 2)
+    uint32_t r_left = p.RL, c_left = p.RH, r_n = p.B, c_n = p.B;     // remaining fold factor, elements per window
+    int r_pp = 0, c_pp = 0;
+    while (r_left > 1 || c_left > 1) {
+      te::sum_job jr, jc; memset(&jr, 0, sizeof jr); memset(&jc, 0, sizeof jc);
+      if (r_left > 1) {
+        const uint32_t K = (r_left % 4 == 0) ? 4u : 2u;
+        jr.in = row_res; jr.out = d.d_red[r_pp]; jr.K = K; jr.inner = 1; jr.n_out = r_n / K;
+        jr.in_per_window = r_n; jr.out_per_window = r_n / K;
+        row_res = jr.out; r_pp ^= 1; r_left /= K; r_n /= K;
+      }
+      if (c_left > 1) {
+        const uint32_t K = (c_left % 4 == 0) ? 4u : 2u;
+        jc.in = col_res; jc.out = d.d_red[2 + c_pp]; jc.K = K; jc.inner = p.RL; jc.n_out = c_n / K;
+        jc.in_per_window = c_n; jc.out_per_window = c_n / K;
+        col_res = jc.out; c_pp ^= 1; c_left /= K; c_n /= K;
+      }
+      const uint32_t most = (jr.n_out > jc.n_out ? jr.n_out : jc.n_out) * (uint32_t)p.nw;
+      uint32_t blocks = (most + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+      hipLaunchKernelGGL(te::k_sum_groups, dim3(blocks, 2), dim3(256), 0, stream, jr, jc, (uint32_t)p.nw);
+    }
   }
   mark(ST_WEIGHTED);
   if (p.nw > 0) {
     te::ete* rows = reinterpret_cast<te::ete*>(d_partials_out) + (size_t)d.w_first * 3;
     const uint32_t stride = (uint32_t)d.w_step * 3u;
-    hipLaunchKernelGGL(te::k_weighted_sum, dim3(1, p.nw), dim3(p.RH), (size_t)p.RH * 128, stream, d.d_rowsum, rows, rows + 1, stride);
-    hipLaunchKernelGGL(te::k_weighted_sum, dim3(1, p.nw), dim3(p.RL), (size_t)p.RL * 128, stream, d.d_colsum, (te::ete*)nullptr, rows + 2, stride);
+    te::wsum_job j0 = {row_res, rows, rows + 1, p.RH}, j1 = {col_res, nullptr, rows + 2, p.RL};
+    const uint32_t T = p.RH > p.RL ? p.RH : p.RL;
+    hipLaunchKernelGGL(te::k_weighted_sum, dim3(2, p.nw), dim3(T), (size_t)T * 128, stream, j0, j1, stride);
   }
   mark(ST_COUNT);
   HIP_TRY(ctx, hipMemcpyAsync(d.h_err, d.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -253,7 +277,7 @@ int collect_stage_ms(te_ctx* ctx, gpu_t& d) {
 void free_dev(gpu_t& d) {
   (void)hipSetDevice(d.device);
   void* ptrs[] = {d.d_recs, d.d_digits, d.d_counts, d.d_bucket_count, d.d_bucket_start, d.d_local_excl, d.d_seg_total,
-                  d.d_sorted, d.d_order, d.d_size_hist, d.d_size_cursor, d.d_buckets, d.d_rowsum, d.d_colsum, d.d_partials,
+                  d.d_sorted, d.d_order, d.d_size_hist, d.d_size_cursor, d.d_buckets, d.d_red[0], d.d_red[1], d.d_red[2], d.d_red[3], d.d_partials,
                   d.d_err, d.d_in_points, d.d_in_scalars};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (d.h_err) (void)hipHostFree(d.h_err);
