@@ -235,3 +235,27 @@ def test_zprize_vectors_if_supplied(ctx, pkg, kats):
             pts, sc = td.load_test_case(pp, sp)
             out = ctx.run(pts, sc)
             assert (int.from_bytes(out[:32], "little"), int.from_bytes(out[32:], "little")) == (int(e["x"]), int(e["y"]))
+
+
+def test_node_compute_msm_entry_point(pkg, model, ora, tmp_path):
+    """The reference's own entry point, compute_msm(bufferPoints, bufferScalars) (submission.ts:73-78), through
+    the N-API addon, against the oracle and a WASM golden case."""
+    import json
+    import shutil
+    import subprocess
+    node = shutil.which("node")
+    if not node:
+        pytest.skip("node is not installed on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    js = os.path.join(root, "webgpu-msm-twisted-edwards_amd", "js")
+    if not os.path.exists(os.path.join(js, "te_msm_napi.node")):
+        subprocess.check_call(["make", "-C", js, "-s"])
+    for seed, n, mode in [(0x5EED03E8, 1000, "chain"), (0x5EED0040, 64, "edge"), (4242, 70000, "chain")]:
+        pts, sc = make_inputs(seed, n, mode)
+        (tmp_path / "p.bin").write_bytes(pts)
+        (tmp_path / "s.bin").write_bytes(sc)
+        r = subprocess.run([node, os.path.join(js, "run_msm.js"), str(tmp_path / "p.bin"), str(tmp_path / "s.bin")],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        out = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        assert "x" in out, out
+        assert (int(out["x"]), int(out["y"])) == model.xy_from_bytes(ora.msm(pts, sc, threads=8))

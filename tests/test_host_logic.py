@@ -229,3 +229,32 @@ def test_gloo_two_rank_window_sharding(fpcheck, pkg, tmp_path):
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+# ---------------------------------------------------------------- N-API addon (the reference's host language)
+def _node():
+    import shutil
+    return shutil.which("node")
+
+
+def test_napi_addon_loads_and_fails_loudly_without_gpu(pkg, tmp_path):
+    import json
+    import torch
+    if not _node():
+        pytest.skip("node is not installed")
+    js = os.path.join(ROOT, "webgpu-msm-twisted-edwards_amd", "js")
+    if not os.path.exists(os.path.join(js, "te_msm_napi.node")):
+        subprocess.check_call(["make", "-C", js, "-s"])
+    (tmp_path / "p.bin").write_bytes(bytes(64))
+    (tmp_path / "s.bin").write_bytes(bytes(32))
+    r = subprocess.run([_node(), os.path.join(js, "run_msm.js"), str(tmp_path / "p.bin"), str(tmp_path / "s.bin")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    out = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    if torch.cuda.is_available():
+        assert "x" in out
+    else:
+        assert "no CPU fallback" in out["error"]          # promise rejected, as the reference throws (gpu.ts:19-22)
+    # argument validation rejects synchronously-thrown errors too
+    bad = subprocess.run([_node(), "-e", "require(%r).compute_msm(Buffer.alloc(10), Buffer.alloc(32), false).catch(e => { console.log('rejected:' + e.message); })"
+                          % os.path.join(js, "compute_msm.js")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert b"rejected:" in bad.stdout

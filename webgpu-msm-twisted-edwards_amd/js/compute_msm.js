@@ -1,0 +1,50 @@
+// compute_msm.js -- the reference's entry point, kept intact, over the HIP engine.
+//
+//   export const compute_msm = async (bufferPoints, bufferScalars, log_result = true, force_recompile = false)
+//       : Promise<{ x: bigint; y: bigint }>                       (submission/submission.ts:73-78)
+//
+// bufferPoints : Buffer of n x (x[32 B LE] || y[32 B LE]) canonical affine coordinates (README.md:297-299)
+// bufferScalars: Buffer of n x 32 B LE scalars
+// The BigIntPoint[] / bigint[] forms in the reference's type are converted with the harness's own
+// encoder rule (bigIntsToBufferLE, reference/webgpu/utils.ts:90-99); U32ArrayPoint[] is, as in the
+// reference (submission.ts:159-160 casts to Buffer), not supported.
+'use strict';
+const path = require('path');
+const native = require(path.join(__dirname, 'te_msm_napi.node'));
+
+const toLE32 = (v) => {
+  const b = Buffer.alloc(32);
+  let t = BigInt(v);
+  for (let i = 0; i < 32; i++) { b[i] = Number(t & 0xffn); t >>= 8n; }
+  return b;
+};
+const fromLE32 = (buf, off) => {
+  let v = 0n;
+  for (let i = 31; i >= 0; i--) v = (v << 8n) | BigInt(buf[off + i]);
+  return v;
+};
+
+const asPointsBuffer = (p) => {
+  if (Buffer.isBuffer(p)) return p;
+  if (Array.isArray(p) && (p.length === 0 || typeof p[0].x === 'bigint')) {
+    return Buffer.concat(p.map((q) => Buffer.concat([toLE32(q.x), toLE32(q.y)])));
+  }
+  throw new Error('compute_msm: bufferPoints must be a Buffer (or BigIntPoint[])');
+};
+const asScalarsBuffer = (s) => {
+  if (Buffer.isBuffer(s)) return s;
+  if (Array.isArray(s) && (s.length === 0 || typeof s[0] === 'bigint')) return Buffer.concat(s.map(toLE32));
+  throw new Error('compute_msm: bufferScalars must be a Buffer (or bigint[])');
+};
+
+const compute_msm = async (bufferPoints, bufferScalars, log_result = true, force_recompile = false) => {
+  // force_recompile exists to defeat WGSL pipeline caching (shader_manager.ts:85-92); the closest
+  // meaning here is "drop cached engine state"
+  if (force_recompile) native.resetContext();
+  const out = await native.msmNative(asPointsBuffer(bufferPoints), asScalarsBuffer(bufferScalars));
+  const result = { x: fromLE32(out, 0), y: fromLE32(out, 32) };
+  if (log_result) console.log(result);
+  return result;
+};
+
+module.exports = { compute_msm };

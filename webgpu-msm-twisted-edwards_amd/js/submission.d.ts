@@ -1,0 +1,9 @@
+// Type declaration matching the reference's export (submission/submission.ts:73-78).
+export interface BigIntPoint { x: bigint; y: bigint; t: bigint; z: bigint; }
+export interface U32ArrayPoint { x: Uint32Array; y: Uint32Array; t: Uint32Array; z: Uint32Array; }
+export declare const compute_msm: (
+  bufferPoints: BigIntPoint[] | U32ArrayPoint[] | Buffer,
+  bufferScalars: bigint[] | Uint32Array[] | Buffer,
+  log_result?: boolean,
+  force_recompile?: boolean,
+) => Promise<{ x: bigint; y: bigint }>;
