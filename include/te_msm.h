@@ -91,8 +91,9 @@ int te_msm_finalize_host(const uint8_t* partials, int window_bits, int num_windo
  * stages written; names[i] points to static strings. */
 int te_msm_stage_ms(te_ctx* ctx, float* ms, const char** names, int max_stages);
 /* Copies an intermediate buffer of the last run to host memory.  stage is one of
- * "records" (n x 96 B), "digits" (nw x n u16), "bucket_count" / "bucket_start" (nw x B u32),
- * "sorted" (nw x n u32), "buckets" (nw x B x 128 B), "partials" (nw x 384 B).  Returns bytes copied
+ * "records" (n x 96 B), "digits" / "part_keys" (nw rows of u16, row stride n rounded up to 8), "part_idx" (same rows, u32),
+ * "part_start" / "part_count" (nw x P u32), "bucket_count" / "bucket_start" / "order" (nw x B u32), "sorted" (nw x n u32),
+ * "buckets" (nw x B x 128 B), "partials" (W x 384 B).  Returns bytes copied
  * (<= cap) or a negative error. */
 int64_t te_msm_debug_read(te_ctx* ctx, const char* stage, void* dst, uint64_t cap);
 

@@ -25,7 +25,7 @@ def _dev(buf: bytes):
 
 # ------------------------------------------------------------------ stage verifiers
 # (the reference's per-stage `debug` checks, submission.ts:892-1363)
-@pytest.mark.parametrize("n,c", [(1000, 8), (5000, 13), (70000, 16)])
+@pytest.mark.parametrize("n,c", [(1000, 8), (5003, 13), (70001, 16)])
 def test_stages_against_oracle(ctx, fpcheck, model, ora, n, c):
     pts, sc = ora.gen_points(500 + n, n), ora.gen_scalars(500 + n, n)
     ctx.set_option("window_bits", c)
@@ -39,10 +39,33 @@ def test_stages_against_oracle(ctx, fpcheck, model, ora, n, c):
         fpcheck.fpc_prep_point(pts[64 * i:64 * i + 64], r)
         assert recs[96 * i:96 * i + 96] == r.raw, f"record {i}"
     # K1b: digits == decompose_scalars_signed (miscellaneous/utils.ts:52-95)
-    dig = np.frombuffer(ctx.debug_read("digits", W * n * 2), dtype=np.uint16).reshape(W, n)
+    nst = (n + 7) & ~7                                  # digit rows are padded to a multiple of 8 entries (digit 0)
+    dig = np.frombuffer(ctx.debug_read("digits", W * nst * 2), dtype=np.uint16).reshape(W, nst)
+    assert np.all(dig[:, n:] == B)
+    dig = dig[:, :n]
     exp = ora.decompose_scalars_signed(sc, c)
     assert np.array_equal(dig.astype(np.uint32), exp)
-    # K2: bucket_count/bucket_start == cpu_transpose's column pointers folded by sign (transpose.ts:14-62)
+    # K2 level 1: partitions of S = min(B, 256) buckets (order inside a partition is free)
+    S = min(B, 256)
+    P, logS = B // S, S.bit_length() - 1
+    pstart = np.frombuffer(ctx.debug_read("part_start", W * P * 4), dtype=np.uint32).reshape(W, P)
+    pcount = np.frombuffer(ctx.debug_read("part_count", W * P * 4), dtype=np.uint32).reshape(W, P)
+    pkeys = np.frombuffer(ctx.debug_read("part_keys", W * nst * 2), dtype=np.uint16).reshape(W, nst)
+    pidx = np.frombuffer(ctx.debug_read("part_idx", W * nst * 4), dtype=np.uint32).reshape(W, nst)
+    for w in range(W):
+        d = exp[w].astype(np.int64) - B
+        bucket = np.abs(d) - 1
+        nz = d != 0
+        e_cnt = np.bincount(bucket[nz] >> logS, minlength=P)
+        assert np.array_equal(pcount[w], e_cnt), f"window {w} partition counts"
+        assert np.array_equal(pstart[w], np.concatenate([[0], np.cumsum(e_cnt)[:-1]])), f"window {w} partition starts"
+        used = int(e_cnt.sum())
+        idx, key = pidx[w][:used].astype(np.int64), pkeys[w][:used].astype(np.int64)
+        assert np.array_equal(np.sort(idx), np.nonzero(nz)[0]), "entries are not a permutation of the non-zero digits"
+        assert np.array_equal(bucket[idx] >> logS, np.repeat(np.arange(P), e_cnt)), "entry in the wrong partition"
+        assert np.array_equal(key & 0x7FFF, bucket[idx] & (S - 1)), "key low bits"
+        assert np.array_equal((key >> 15).astype(bool), d[idx] < 0), "sign bit"
+    # K2 level 2: bucket_count/bucket_start == cpu_transpose's column pointers folded by sign (transpose.ts:14-62)
     cnt = np.frombuffer(ctx.debug_read("bucket_count", W * B * 4), dtype=np.uint32).reshape(W, B)
     start = np.frombuffer(ctx.debug_read("bucket_start", W * B * 4), dtype=np.uint32).reshape(W, B)
     srt = np.frombuffer(ctx.debug_read("sorted", W * n * 4), dtype=np.uint32).reshape(W, n)

@@ -4,8 +4,8 @@
 //   K1 convert_point_coords_and_decompose_scalars (wgsl/cuzk/convert_point_coords_and_decompose_scalars
 //      .template.wgsl:37-123)                    -> k_prep_points + k_digits<C>
 //   K2 transpose (wgsl/cuzk/transpose.wgsl:32-76; 16 threads in total)
-//                                                -> k_hist / k_scan_a / k_scan_b / k_scatter
-//                                                   (whole-window histogram held in LDS, one pass)
+//                                                -> k_part_hist / k_part_scan / k_part_scatter / k_l2_count / k_bscan / k_l2_place
+//                                                   (two-level counting sort, all stores coalesced) + k_order_*
 //   K3 smvp (wgsl/cuzk/smvp.template.wgsl:58-152) -> k_accumulate (7-product mixed additions)
 //   K4/K5 bpr stage_1/2 (wgsl/cuzk/bpr.template.wgsl:73-171) + the CPU sum of 4096 points
 //      (submission.ts:362-393)                   -> k_sum_groups (row / column marginals) + k_weighted_sum
@@ -18,7 +18,7 @@ namespace te {
 
 struct digits_params {
   uint32_t half[10];   // sum_w 2^(c*w + c-1) over ALL windows of the decomposition, 9 limbs (+1 zero)
-  uint32_t n;
+  uint32_t n, nst;     // points, digit-row stride (n rounded up to a multiple of 8; pad entries hold digit 0)
   int num_windows;     // total windows W of the decomposition
   int w_first, w_step, nw_local;
 };
@@ -58,7 +58,10 @@ template <int C>
 __global__ void __launch_bounds__(256) k_digits(const uint4* __restrict__ scalars, uint16_t* __restrict__ digits,
                                                 digits_params prm, uint32_t* __restrict__ err) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= prm.n) return;
+  if (i >= prm.n) {
+    if (i < prm.nst) for (int k = 0; k < prm.nw_local; k++) digits[(size_t)k * prm.nst + i] = (uint16_t)(1u << (C - 1));   // digit 0
+    return;
+  }
   const uint4 s0 = scalars[2 * (size_t)i], s1 = scalars[2 * (size_t)i + 1];
   uint32_t s[10] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, 0u, 0u};
   uint64_t c = 0;
@@ -79,7 +82,7 @@ __global__ void __launch_bounds__(256) k_digits(const uint4* __restrict__ scalar
     const int rel = w - prm.w_first;
     if (rel >= 0 && (rel % prm.w_step) == 0) {
       const int k = rel / prm.w_step;
-      if (k < prm.nw_local) digits[(size_t)k * prm.n + i] = (uint16_t)v;
+      if (k < prm.nw_local) digits[(size_t)k * prm.nst + i] = (uint16_t)v;
     }
   }
   if (bad) atomicOr(err, 1u);
@@ -94,25 +97,6 @@ __device__ __forceinline__ bool digit_bucket(uint32_t stored, uint32_t B, uint32
   neg = d < 0 ? 1u : 0u;
   bucket = (uint32_t)(d < 0 ? -d : d) - 1u;
   return true;
-}
-
-// K2a: per (chunk, window) histogram of bucket ids, the window's B counters live in LDS.
-//   grid (CH, nw_local), block 1024, dynamic LDS = B * 4 bytes.  counts[(k*CH + ch)*B + b].
-__global__ void __launch_bounds__(1024) k_hist(const uint16_t* __restrict__ digits, uint32_t* __restrict__ counts,
-                                               uint32_t n, uint32_t B, uint32_t chunk_len) {
-  extern __shared__ uint32_t lds_u32[];
-  const uint32_t ch = blockIdx.x, k = blockIdx.y, CH = gridDim.x;
-  for (uint32_t b = threadIdx.x; b < B; b += 1024u) lds_u32[b] = 0u;
-  __syncthreads();
-  const uint32_t lo = ch * chunk_len, hi = min(n, lo + chunk_len);
-  const uint16_t* d = digits + (size_t)k * n;
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) {
-    uint32_t b, neg;
-    if (digit_bucket(d[i], B, b, neg)) atomicAdd(&lds_u32[b], 1u);
-  }
-  __syncthreads();
-  uint32_t* out = counts + ((size_t)k * CH + ch) * B;
-  for (uint32_t b = threadIdx.x; b < B; b += 1024u) out[b] = lds_u32[b];
 }
 
 // block-wide exclusive scan of one value per thread (blockDim.x <= 1024, multiple of 64 or < 64)
@@ -139,64 +123,295 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds /*
   return res;
 }
 
-// K2b: for each bucket: exclusive prefix over chunks (written back into counts), bucket_count, and an
-// exclusive scan over the buckets of one 1024-bucket segment.  grid (nseg, nw_local), block min(B,1024).
-__global__ void __launch_bounds__(1024) k_scan_a(uint32_t* __restrict__ counts, uint32_t* __restrict__ bucket_count,
-                                                 uint32_t* __restrict__ local_excl, uint32_t* __restrict__ seg_total,
-                                                 uint32_t B, uint32_t CH) {
+// ------------------------------------------------------------------------------------------------
+// K2: counting sort of point indices by bucket, per window, in two levels so that every global store
+// is coalesced.  (The first version scattered 4-byte indices straight to their final position: each
+// store became a 32-byte sector write, 535 MB of write traffic for 67 MB of payload --
+// profiles/r01_rocprofv3_v2_summary.txt.)
+//   level 1  partition = bucket >> logS (P = B/S partitions per window, ~n/P entries each):
+//            k_part_hist -> k_part_scan -> k_part_scatter (4096-entry tiles sorted by partition in LDS,
+//            written out as contiguous runs: u16 key = bucket low bits | sign << 15, u32 index)
+//   level 2  k_l2_count -> k_bscan_a/b -> k_l2_place: blocks take fixed-size slices of the level-1 output, count per
+//            bucket in LDS, reserve ranges with one global atomic per touched bucket, and write each bucket's run
+//            contiguously -- balanced for any digit distribution.
+struct sort_geom {
+  uint32_t n, nst;       // entries per window; row stride of digits / part_keys / part_idx (multiple of 8, >= n)
+  uint32_t B, logS, S, P, CH, chunk_len, cap, dbg;   // chunk_len is a multiple of TE_TILE
+};
+#define TE_TILE 4096u
+
+// All global loads in these kernels are 16 bytes per lane (8 u16 digits / keys, 4 u32 indices): with 2- or
+// 4-byte loads the level-2 kernel spent 160 of its 197 us just fetching 100 MB (the memory pipeline is
+// paid per load INSTRUCTION; profiles/r01_notes.md).
+__device__ __forceinline__ void unpack8(const uint4& v, uint32_t (&d)[8]) {
+  d[0] = v.x & 0xffffu; d[1] = v.x >> 16; d[2] = v.y & 0xffffu; d[3] = v.y >> 16;
+  d[4] = v.z & 0xffffu; d[5] = v.z >> 16; d[6] = v.w & 0xffffu; d[7] = v.w >> 16;
+}
+
+// grid (CH, nw), block 1024.  counts1[window][partition][chunk].
+__global__ void __launch_bounds__(1024) k_part_hist(const uint16_t* __restrict__ digits, uint32_t* __restrict__ counts1, sort_geom g) {
+  __shared__ uint32_t h[16 * 512];                    // one private histogram per wave
+  const uint32_t ch = blockIdx.x, k = blockIdx.y, wave = threadIdx.x >> 6;
+  for (uint32_t j = threadIdx.x; j < 16u * g.P; j += 1024u) h[j] = 0u;
+  __syncthreads();
+  const uint32_t lo8 = (ch * g.chunk_len) >> 3, hi8 = min(g.nst, (ch + 1u) * g.chunk_len) >> 3;   // pad entries are digit 0
+  const uint4* d4 = reinterpret_cast<const uint4*>(digits + (size_t)k * g.nst);
+  for (uint32_t base = lo8; base < hi8; base += 4u * 1024u) {
+    uint4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = d4[min(base + (uint32_t)j * 1024u + threadIdx.x, hi8 - 1u)];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (base + (uint32_t)j * 1024u + threadIdx.x < hi8) {
+        uint32_t dd[8]; unpack8(v[j], dd);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          uint32_t b, neg;
+          if (digit_bucket(dd[e], g.B, b, neg)) atomicAdd(&h[wave * g.P + (b >> g.logS)], 1u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t p = threadIdx.x; p < g.P; p += 1024u) {
+    uint32_t t = 0;
+    for (uint32_t w = 0; w < 16u; w++) t += h[w * g.P + p];
+    counts1[((size_t)k * g.P + p) * g.CH + ch] = t;      // [window][partition][chunk]: scan order
+  }
+}
+
+// one block per window: exclusive scan of counts1 in [partition][chunk] order (in place);
+// part_start / part_count per partition.
+__global__ void __launch_bounds__(1024) k_part_scan(uint32_t* __restrict__ counts1, uint32_t* __restrict__ part_start,
+                                                    uint32_t* __restrict__ part_count, sort_geom g) {
   __shared__ uint32_t sm[17];
-  const uint32_t seg = blockIdx.x, k = blockIdx.y, nseg = gridDim.x;
-  const uint32_t b = seg * blockDim.x + threadIdx.x;
-  uint32_t total = 0;
-  if (b < B) {
-    for (uint32_t ch = 0; ch < CH; ch++) {
-      uint32_t* p = counts + ((size_t)k * CH + ch) * B + b;
-      const uint32_t v = *p; *p = total; total += v;
-    }
-    bucket_count[(size_t)k * B + b] = total;
-  }
+  const uint32_t k = blockIdx.x, total = g.P * g.CH;
+  uint32_t* c = counts1 + (size_t)k * total;
+  const uint32_t per = (total + 1023u) / 1024u;
+  const uint32_t lo = min(total, threadIdx.x * per), hi = min(total, lo + per);
+  uint32_t sum = 0;
+  for (uint32_t j = lo; j < hi; j++) sum += c[j];
   uint32_t bt;
-  const uint32_t ex = block_excl_scan(total, sm, bt);
-  if (b < B) local_excl[(size_t)k * B + b] = ex;
-  if (threadIdx.x == 0) seg_total[k * nseg + seg] = bt;
+  uint32_t run = block_excl_scan(sum, sm, bt);
+  for (uint32_t j = lo; j < hi; j++) { const uint32_t v = c[j]; c[j] = run; run += v; }
+  __syncthreads();
+  for (uint32_t p = threadIdx.x; p < g.P; p += 1024u) {
+    const uint32_t s0 = c[p * g.CH];
+    const uint32_t s1 = (p + 1 < g.P) ? c[(p + 1) * g.CH] : bt;
+    part_start[k * g.P + p] = s0; part_count[k * g.P + p] = s1 - s0;
+  }
 }
 
-// K2c: bucket_start = (sum of the window's earlier segment totals) + local_excl.
-__global__ void __launch_bounds__(1024) k_scan_b(const uint32_t* __restrict__ local_excl, const uint32_t* __restrict__ seg_total,
-                                                 uint32_t* __restrict__ bucket_start, uint32_t B) {
-  __shared__ uint32_t base_s;
-  const uint32_t seg = blockIdx.x, k = blockIdx.y, nseg = gridDim.x;
-  if (threadIdx.x == 0) {
-    uint32_t base = 0;
-    for (uint32_t s = 0; s < seg; s++) base += seg_total[k * nseg + s];
-    base_s = base;
+// grid (CH, nw), block 512: tiles of 4096 entries, 8 consecutive entries per thread (one 16-byte load).
+__global__ void __launch_bounds__(512) k_part_scatter(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ offs1,
+                                                      uint16_t* __restrict__ part_keys, uint32_t* __restrict__ part_idx, sort_geom g) {
+  __shared__ uint32_t st_idx[TE_TILE];
+  __shared__ uint16_t st_key[TE_TILE];
+  __shared__ uint16_t st_part[TE_TILE];
+  __shared__ uint32_t tile_cnt[512], tile_off[512], run_base[512];
+  __shared__ uint32_t sm[17];
+  const uint32_t ch = blockIdx.x, k = blockIdx.y, t = threadIdx.x;
+  for (uint32_t p = t; p < g.P; p += 512u) run_base[p] = offs1[((size_t)k * g.P + p) * g.CH + ch];
+  const uint32_t lo = ch * g.chunk_len, hi = min(g.nst, lo + g.chunk_len);
+  const uint4* d4 = reinterpret_cast<const uint4*>(digits + (size_t)k * g.nst);
+  const uint32_t last8 = (g.nst >> 3) - 1u;
+  uint16_t* ok = part_keys + (size_t)k * g.nst;
+  uint32_t* oi = part_idx + (size_t)k * g.nst;
+  uint4 vnext = d4[min((lo >> 3) + t, last8)];
+  for (uint32_t base = lo; base < hi; base += TE_TILE) {
+    for (uint32_t p = t; p < g.P; p += 512u) tile_cnt[p] = 0u;
+    const uint4 vcur = vnext;
+    vnext = d4[min(((base + TE_TILE) >> 3) + t, last8)];          // prefetch the next tile during the LDS phases
+    __syncthreads();
+    uint32_t dd[8], part[8], key[8], rank[8];
+    unpack8(vcur, dd);
+    const uint32_t i0 = base + t * 8u;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      part[e] = 0xffffffffu;
+      uint32_t b, neg;
+      if (i0 + (uint32_t)e < hi && digit_bucket(dd[e], g.B, b, neg)) {
+        part[e] = b >> g.logS; key[e] = (b & (g.S - 1u)) | (neg << 15);
+        rank[e] = atomicAdd(&tile_cnt[part[e]], 1u);
+      }
+    }
+    __syncthreads();
+    uint32_t tile_total;
+    {
+      const uint32_t v = t < g.P ? tile_cnt[t] : 0u;          // P <= 512 = blockDim
+      const uint32_t ex = block_excl_scan(v, sm, tile_total);
+      if (t < g.P) tile_off[t] = ex;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      if (part[e] != 0xffffffffu) {
+        const uint32_t slot = tile_off[part[e]] + rank[e];
+        st_idx[slot] = i0 + (uint32_t)e; st_key[slot] = (uint16_t)key[e]; st_part[slot] = (uint16_t)part[e];
+      }
+    }
+    __syncthreads();
+    for (uint32_t s = t; s < tile_total; s += 512u) {
+      const uint32_t p = st_part[s];
+      const uint32_t gpos = run_base[p] + (s - tile_off[p]);
+      ok[gpos] = st_key[s]; oi[gpos] = st_idx[s];
+    }
+    __syncthreads();
+    for (uint32_t p = t; p < g.P; p += 512u) run_base[p] += tile_cnt[p];
+    __syncthreads();
   }
+}
+
+// level 2, work split by SLICES of the level-1 output (TE_SLICE consecutive entries of a window), not by
+// partition: every block has the same amount of work whatever the digit distribution.  (The top window of a
+// 253-bit scalar has only ~4.8k of its 32k buckets occupied, 219 entries each: with one block per partition,
+// 19 blocks sorted 55k entries each while the rest of the chip idled -- 200 us of tail.)
+// A slice is cut into pieces at partition boundaries; a piece touches at most S (<= 256) buckets.
+//   k_l2_count : LDS count per bucket of each piece -> global atomicAdd into bucket_count (<= S per piece)
+//   k_bscan_a/b: exclusive scan of bucket_count per window -> bucket_start, bucket_cursor
+//   k_l2_place : LDS count again, reserve [base, base+c) in every touched bucket with one atomicAdd on
+//                bucket_cursor, sort the piece by bucket in LDS and copy each run to its reserved range.
+#define TE_SLICE 8192u
+
+// loads the 16-byte groups covering entries [a, b) of a row (<= TE_SLICE + 8 entries), 5 groups per thread
+struct piece_regs { uint4 k[5], ia[5], ib[5]; };
+__device__ __forceinline__ void load_piece(const uint16_t* __restrict__ keys_row, const uint32_t* __restrict__ idx_row, uint32_t a, uint32_t b,
+                                           uint32_t t, bool with_idx, piece_regs& r, uint32_t& head, uint32_t& total) {
+  const uint32_t a_al = a & ~7u;
+  head = a - a_al; total = head + (b - a);
+  const uint32_t groups = (total + 7u) >> 3;
+  const uint4* k4 = reinterpret_cast<const uint4*>(keys_row + a_al);
+  const uint4* i4 = reinterpret_cast<const uint4*>(idx_row + a_al);
+#pragma unroll
+  for (int c = 0; c < 5; c++) {
+    const uint32_t gi = min((uint32_t)c * 256u + t, groups - 1u);
+    r.k[c] = k4[gi];
+    if (with_idx) { r.ia[c] = i4[2 * gi]; r.ib[c] = i4[2 * gi + 1]; }
+  }
+}
+
+// first partition whose end lies beyond position s (partitions are back to back: start[p+1] = start[p] + count[p])
+__device__ __forceinline__ uint32_t find_partition(const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ pcount, uint32_t P, uint32_t s) {
+  uint32_t lo = 0, hi = P;          // invariant: end(lo-1) <= s
+  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (pstart[mid] + pcount[mid] <= s) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+// grid (nslices, nw), block 256
+__global__ void __launch_bounds__(256) k_l2_count(const uint16_t* __restrict__ part_keys, const uint32_t* __restrict__ part_idx,
+                                                  const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ part_count,
+                                                  uint32_t* __restrict__ bucket_count, sort_geom g) {
+  __shared__ uint32_t cnt_s[256];
+  const uint32_t k = blockIdx.y, t = threadIdx.x;
+  const uint32_t* ps = part_start + k * g.P; const uint32_t* pc = part_count + k * g.P;
+  const uint32_t row_total = ps[g.P - 1] + pc[g.P - 1];
+  uint32_t s0 = blockIdx.x * TE_SLICE;
+  const uint32_t s1 = min(row_total, s0 + TE_SLICE);
+  if (s0 >= s1) return;
+  const uint16_t* keys_row = part_keys + (size_t)k * g.nst; const uint32_t* idx_row = part_idx + (size_t)k * g.nst;
+  uint32_t p = find_partition(ps, pc, g.P, s0);
+  while (s0 < s1) {
+    const uint32_t pe = ps[p] + pc[p], e1 = min(s1, pe);
+    if (e1 <= s0) { p++; continue; }                 // empty partition (uniform branch)
+    cnt_s[t] = 0u;
+    __syncthreads();
+    piece_regs r; uint32_t head, total;
+    load_piece(keys_row, idx_row, s0, e1, t, false, r, head, total);
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+      uint32_t kv[8]; unpack8(r.k[c], kv);
+      const uint32_t e0 = ((uint32_t)c * 256u + t) * 8u;
+#pragma unroll
+      for (int e = 0; e < 8; e++) { const uint32_t pos = e0 + (uint32_t)e; if (pos >= head && pos < total) atomicAdd(&cnt_s[kv[e] & 0x7fffu], 1u); }
+    }
+    __syncthreads();
+    const uint32_t c0 = cnt_s[t];
+    if (c0) atomicAdd(&bucket_count[(size_t)k * g.B + (size_t)p * g.S + t], c0);
+    __syncthreads();
+    s0 = e1; p++;
+  }
+}
+
+// exclusive scan of bucket_count per window: a = per 1024-bucket segment, b = add the bases
+__global__ void __launch_bounds__(1024) k_bscan_a(const uint32_t* __restrict__ bucket_count, uint32_t* __restrict__ local_excl,
+                                                  uint32_t* __restrict__ seg_total, uint32_t B) {
+  __shared__ uint32_t sm[17];
+  const uint32_t seg = blockIdx.x, k = blockIdx.y, b = seg * blockDim.x + threadIdx.x;
+  const uint32_t v = b < B ? bucket_count[(size_t)k * B + b] : 0u;
+  uint32_t bt;
+  const uint32_t ex = block_excl_scan(v, sm, bt);
+  if (b < B) local_excl[(size_t)k * B + b] = ex;
+  if (threadIdx.x == 0) seg_total[k * gridDim.x + seg] = bt;
+}
+__global__ void __launch_bounds__(1024) k_bscan_b(const uint32_t* __restrict__ local_excl, const uint32_t* __restrict__ seg_total,
+                                                  uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ bucket_cursor, uint32_t B) {
+  __shared__ uint32_t base_s;
+  const uint32_t seg = blockIdx.x, k = blockIdx.y;
+  if (threadIdx.x == 0) { uint32_t base = 0; for (uint32_t s = 0; s < seg; s++) base += seg_total[k * gridDim.x + s]; base_s = base; }
   __syncthreads();
   const uint32_t b = seg * blockDim.x + threadIdx.x;
-  if (b < B) bucket_start[(size_t)k * B + b] = base_s + local_excl[(size_t)k * B + b];
+  if (b < B) { const uint32_t v = base_s + local_excl[(size_t)k * B + b]; bucket_start[(size_t)k * B + b] = v; bucket_cursor[(size_t)k * B + b] = v; }
 }
 
-// K2d: scatter point indices into bucket order.  Entry = index | (negative digit ? 1<<31 : 0).
-// Order inside a bucket is whatever the LDS atomics give: the group is commutative, so the bucket sum
-// (and the final affine point) does not depend on it.
-__global__ void __launch_bounds__(1024) k_scatter(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ counts,
-                                                  const uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ sorted,
-                                                  uint32_t n, uint32_t B, uint32_t chunk_len) {
-  extern __shared__ uint32_t lds_u32[];
-  const uint32_t ch = blockIdx.x, k = blockIdx.y, CH = gridDim.x;
-  const uint32_t* cnt = counts + ((size_t)k * CH + ch) * B;
-  const uint32_t* bs = bucket_start + (size_t)k * B;
-  for (uint32_t b = threadIdx.x; b < B; b += 1024u) lds_u32[b] = bs[b] + cnt[b];
-  __syncthreads();
-  const uint32_t lo = ch * chunk_len, hi = min(n, lo + chunk_len);
-  const uint16_t* d = digits + (size_t)k * n;
-  uint32_t* out = sorted + (size_t)k * n;
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024u) {
-    uint32_t b, neg;
-    if (digit_bucket(d[i], B, b, neg)) {
-      const uint32_t pos = atomicAdd(&lds_u32[b], 1u);
-      out[pos] = i | (neg << 31);
+// grid (nslices, nw), block 256
+__global__ void __launch_bounds__(256) k_l2_place(const uint16_t* __restrict__ part_keys, const uint32_t* __restrict__ part_idx,
+                                                  const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ part_count,
+                                                  uint32_t* __restrict__ bucket_cursor, uint32_t* __restrict__ sorted, sort_geom g) {
+  __shared__ uint32_t cnt_s[256], lex_s[256], off_s[256], gbase_s[256];
+  __shared__ uint32_t list[TE_SLICE + 8];
+  __shared__ uint8_t list_b[TE_SLICE + 8];
+  __shared__ uint32_t sm[17];
+  const uint32_t k = blockIdx.y, t = threadIdx.x;
+  const uint32_t* ps = part_start + k * g.P; const uint32_t* pc = part_count + k * g.P;
+  const uint32_t row_total = ps[g.P - 1] + pc[g.P - 1];
+  uint32_t s0 = blockIdx.x * TE_SLICE;
+  const uint32_t s1 = min(row_total, s0 + TE_SLICE);
+  if (s0 >= s1) return;
+  const uint16_t* keys_row = part_keys + (size_t)k * g.nst; const uint32_t* idx_row = part_idx + (size_t)k * g.nst;
+  uint32_t* out = sorted + (size_t)k * g.n;
+  uint32_t p = find_partition(ps, pc, g.P, s0);
+  while (s0 < s1) {
+    const uint32_t pe = ps[p] + pc[p], e1 = min(s1, pe), len = e1 - s0;
+    if (e1 <= s0) { p++; continue; }                 // empty partition (uniform branch)
+    cnt_s[t] = 0u;
+    __syncthreads();
+    piece_regs r; uint32_t head, total;
+    load_piece(keys_row, idx_row, s0, e1, t, true, r, head, total);
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+      uint32_t kv[8]; unpack8(r.k[c], kv);
+      const uint32_t e0 = ((uint32_t)c * 256u + t) * 8u;
+#pragma unroll
+      for (int e = 0; e < 8; e++) { const uint32_t pos = e0 + (uint32_t)e; if (pos >= head && pos < total) atomicAdd(&cnt_s[kv[e] & 0x7fffu], 1u); }
     }
+    __syncthreads();
+    {
+      const uint32_t c0 = cnt_s[t];
+      uint32_t bt;
+      const uint32_t ex = block_excl_scan(c0, sm, bt);
+      lex_s[t] = ex; off_s[t] = ex;
+      gbase_s[t] = c0 ? atomicAdd(&bucket_cursor[(size_t)k * g.B + (size_t)p * g.S + t], c0) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+      uint32_t kv[8]; unpack8(r.k[c], kv);
+      const uint32_t iv[8] = {r.ia[c].x, r.ia[c].y, r.ia[c].z, r.ia[c].w, r.ib[c].x, r.ib[c].y, r.ib[c].z, r.ib[c].w};
+      const uint32_t e0 = ((uint32_t)c * 256u + t) * 8u;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const uint32_t pos = e0 + (uint32_t)e;
+        if (pos >= head && pos < total) {
+          const uint32_t b = kv[e] & 0x7fffu;
+          const uint32_t slot = atomicAdd(&off_s[b], 1u);
+          list[slot] = iv[e] | ((kv[e] >> 15) << 31); list_b[slot] = (uint8_t)b;
+        }
+      }
+    }
+    __syncthreads();
+    for (uint32_t s = t; s < len; s += 256u) { const uint32_t b = list_b[s]; out[gbase_s[b] + (s - lex_s[b])] = list[s]; }
+    __syncthreads();
+    s0 = e1; p++;
   }
 }
 
@@ -244,6 +459,9 @@ __global__ void __launch_bounds__(256) k_order_scatter(const uint32_t* __restric
 // ------------------------------------------------------------------------------------------------
 // K3: bucket accumulation, one thread per (window, bucket), scheduled through order[] (or natural
 // order when order == nullptr).  The next record is fetched while the current addition runs.
+// (A variant that fused level 2 of the sort into this kernel -- one block per 256 buckets, lists consumed
+// straight from LDS -- was measured at 2.8 ms against 1.4 ms: block-granular scheduling leaves < 1 wave per
+// SIMD resident on average (SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE = 0.78), far too few to hide gather latency.)
 __device__ __forceinline__ pnt load_pnt(const pnt* __restrict__ recs, uint32_t entry) {
   const uint4* q = reinterpret_cast<const uint4*>(recs + (entry & 0x7fffffffu));
   const uint4 a0 = q[0], a1 = q[1], b0 = q[2], b1 = q[3], c0 = q[4], c1 = q[5];

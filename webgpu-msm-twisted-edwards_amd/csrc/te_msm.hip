@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -22,28 +23,29 @@ namespace {
 
 thread_local std::string g_init_error;
 
-enum { ST_PREP = 0, ST_DIGITS, ST_HIST, ST_SCAN, ST_SCATTER, ST_ORDER, ST_ACCUM, ST_TREE, ST_WEIGHTED, ST_COUNT };
-const char* const kStageNames[ST_COUNT] = {"prep_points", "digits", "hist", "scan", "scatter", "order",
+enum { ST_PREP = 0, ST_DIGITS, ST_HIST, ST_SCAN, ST_SCATTER, ST_BSORT, ST_ORDER, ST_ACCUM, ST_TREE, ST_WEIGHTED, ST_COUNT };
+const char* const kStageNames[ST_COUNT] = {"prep_points", "digits", "part_hist", "part_scan", "part_scatter", "bucket_sort", "order",
                                            "accumulate", "marginal_sums", "weighted_sum"};
 
 struct plan_t {
   int c = 0, W = 0, nw = 0;           // window bits, total windows, windows of this shard
   uint32_t B = 0, logB = 0;           // buckets per window = 2^(c-1)
   uint32_t RL = 0, RH = 0, lo_bits = 0;
-  uint32_t CH = 0, chunk_len = 0;     // histogram chunks per window
-  uint32_t nseg = 0, seg_threads = 0; // scan segments per window
+  uint32_t CH = 0, chunk_len = 0, nst = 0;   // level-1 chunks per window (chunk_len multiple of 4096); padded row stride
+  uint32_t S = 0, logS = 0, P = 0, cap = 0, cpb = 0;   // level-2 partition: S buckets each, P = B/S per window; LDS list entries (cpb per bucket)
 };
 
 struct gpu_t {
   int device = 0;
   int w_first = 0, w_step = 1;
   hipStream_t stream = nullptr;
-  size_t cap[16] = {};                // per-buffer capacity in bytes (ensure())
+  size_t cap[20] = {};                // per-buffer capacity in bytes (ensure())
   int cap_W = 0;
   te::pnt* d_recs = nullptr;
   uint16_t* d_digits = nullptr;
-  uint32_t *d_counts = nullptr, *d_bucket_count = nullptr, *d_bucket_start = nullptr, *d_local_excl = nullptr;
-  uint32_t *d_seg_total = nullptr, *d_sorted = nullptr, *d_order = nullptr, *d_size_hist = nullptr, *d_size_cursor = nullptr;
+  uint32_t *d_counts1 = nullptr, *d_part_start = nullptr, *d_part_count = nullptr, *d_part_idx = nullptr;
+  uint32_t *d_bucket_count = nullptr, *d_bucket_start = nullptr, *d_bucket_cursor = nullptr, *d_seg_total = nullptr, *d_sorted = nullptr, *d_order = nullptr, *d_size_hist = nullptr, *d_size_cursor = nullptr;
+  uint16_t* d_part_keys = nullptr;
   te::ete *d_buckets = nullptr, *d_red[4] = {nullptr, nullptr, nullptr, nullptr};   // reduction ping/pong: rows a,b  cols a,b
   uint8_t* d_partials = nullptr;      // W x 384
   uint32_t* d_err = nullptr;
@@ -63,6 +65,8 @@ struct te_ctx {
   int opt_window_bits = 0;
   int opt_sort = 1;
   int opt_profile = 0;
+  int opt_dbg = 0;
+  int opt_sort_s = 0;
   float stage_ms[ST_COUNT] = {};
   bool have_stage_ms = false;
 };
@@ -102,15 +106,23 @@ void make_plan(const te_ctx* ctx, const gpu_t& d, uint64_t n, plan_t& p) {
   for (int w = d.w_first; w < p.W; w += d.w_step) p.nw++;
   p.B = 1u << (p.c - 1); p.logB = p.c - 1;
   p.lo_bits = (p.c - 1 + 1) / 2; p.RL = 1u << p.lo_bits; p.RH = p.B / p.RL;
-  uint32_t ch = p.nw > 0 ? 256u / (uint32_t)p.nw : 1u;
+  uint32_t ch = p.nw > 0 ? 1024u / (uint32_t)p.nw : 1u;     // ~4 blocks of 512 threads per CU in k_part_scatter
   if (ch < 1) ch = 1;
-  if (ch > 64) ch = 64;
+  if (ch > 256) ch = 256;
   const uint32_t by_n = (uint32_t)((n + 8191) / 8192);      // at least ~8k digits per chunk
   if (ch > by_n) ch = by_n ? by_n : 1;
+  p.nst = (uint32_t)((n + 7) & ~(uint64_t)7);
+  p.chunk_len = (uint32_t)((p.nst + ch - 1) / ch);
+  p.chunk_len = (p.chunk_len + 4095u) & ~4095u;               // whole 4096-entry tiles
+  ch = (p.nst + p.chunk_len - 1) / p.chunk_len;
   p.CH = ch;
-  p.chunk_len = (uint32_t)((n + ch - 1) / ch);
-  p.seg_threads = p.B < 1024u ? p.B : 1024u;
-  p.nseg = p.B / p.seg_threads;
+  // level-2 partition = the S buckets one k_accumulate block owns; its LDS list holds cpb entries per bucket
+  p.S = p.B < 256u ? p.B : 256u;
+  if (ctx->opt_sort_s && (uint32_t)ctx->opt_sort_s < p.S) p.S = (uint32_t)ctx->opt_sort_s;
+  const double avg = (double)n / (double)p.B;                   // mean bucket size
+  p.cpb = (avg + 8.0 * (avg > 1 ? __builtin_sqrt(avg / p.S) : 1.0) + 1.0 <= 35.0) ? 35u : 70u;
+  p.cap = p.cpb * p.S;
+  p.P = p.B / p.S; p.logS = ilog2(p.S);
 }
 
 template <typename T> int ensure(te_ctx* ctx, T*& ptr, size_t& cap_bytes, size_t need_elems) {
@@ -125,18 +137,22 @@ template <typename T> int ensure(te_ctx* ctx, T*& ptr, size_t& cap_bytes, size_t
 
 int ensure_buffers(te_ctx* ctx, gpu_t& d, uint64_t n, const plan_t& p) {
   HIP_TRY(ctx, hipSetDevice(d.device));
-  const size_t nd = (size_t)p.nw * n, wb = (size_t)p.nw * p.B;
+  const size_t nd = (size_t)p.nw * p.nst + 16, wb = (size_t)p.nw * p.B;
   int rc = 0;
   if ((rc = ensure(ctx, d.d_recs, d.cap[0], (size_t)n))) return rc;
   if ((rc = ensure(ctx, d.d_digits, d.cap[1], nd))) return rc;
   if ((rc = ensure(ctx, d.d_sorted, d.cap[2], nd))) return rc;
-  if ((rc = ensure(ctx, d.d_counts, d.cap[3], (size_t)p.nw * p.CH * p.B))) return rc;
+  if ((rc = ensure(ctx, d.d_counts1, d.cap[3], (size_t)p.nw * p.CH * p.P))) return rc;
   if ((rc = ensure(ctx, d.d_bucket_count, d.cap[4], wb))) return rc;
   if ((rc = ensure(ctx, d.d_bucket_start, d.cap[5], wb))) return rc;
-  if ((rc = ensure(ctx, d.d_local_excl, d.cap[6], wb))) return rc;
+  if ((rc = ensure(ctx, d.d_bucket_cursor, d.cap[0 + 16], wb))) return rc;
+  if ((rc = ensure(ctx, d.d_seg_total, d.cap[17], (size_t)p.nw * 64 + 64))) return rc;
   if ((rc = ensure(ctx, d.d_order, d.cap[7], wb))) return rc;
+  if ((rc = ensure(ctx, d.d_part_start, d.cap[6], (size_t)p.nw * p.P))) return rc;
   if ((rc = ensure(ctx, d.d_buckets, d.cap[8], wb))) return rc;
-  if ((rc = ensure(ctx, d.d_seg_total, d.cap[9], (size_t)p.nw * p.nseg))) return rc;
+  if ((rc = ensure(ctx, d.d_part_count, d.cap[9], (size_t)p.nw * p.P))) return rc;
+  if ((rc = ensure(ctx, d.d_part_keys, d.cap[14], nd))) return rc;
+  if ((rc = ensure(ctx, d.d_part_idx, d.cap[15], nd))) return rc;
   // marginal-sum levels fold by 4 (or 2): level 1 output is at most B/2 per window, level 2 at most B/4
   if ((rc = ensure(ctx, d.d_red[0], d.cap[10], wb / 2 + 1))) return rc;
   if ((rc = ensure(ctx, d.d_red[1], d.cap[11], wb / 4 + 1))) return rc;
@@ -154,7 +170,7 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, uint64_t n, const plan_t& p) {
 }
 
 template <int C> void launch_digits(const uint4* sc, uint16_t* dg, const te::digits_params& prm, uint32_t* err, hipStream_t s) {
-  hipLaunchKernelGGL(te::k_digits<C>, dim3((prm.n + 255) / 256), dim3(256), 0, s, sc, dg, prm, err);
+  hipLaunchKernelGGL(te::k_digits<C>, dim3((prm.nst + 255) / 256), dim3(256), 0, s, sc, dg, prm, err);
 }
 
 int enqueue_partial(te_ctx* ctx, gpu_t& d, const void* d_points, const void* d_scalars, uint64_t n,
@@ -169,13 +185,14 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, const void* d_points, const void* d_s
 
   HIP_TRY(ctx, hipMemsetAsync(d.d_err, 0, sizeof(uint32_t), stream));
   mark(ST_PREP);
-  hipLaunchKernelGGL(te::k_prep_points, dim3((n32 + 255) / 256), dim3(256), 0, stream,
+  {  hipLaunchKernelGGL(te::k_prep_points, dim3((n32 + 255) / 256), dim3(256), 0, stream,
                      (const uint4*)d_points, d.d_recs, n32);
+  }
   mark(ST_DIGITS);
   if (p.nw > 0) {
     te::digits_params prm; memset(&prm, 0, sizeof prm);
     for (int w = 0; w < p.W; w++) { const int bit = w * p.c + p.c - 1; if (bit < 320) prm.half[bit >> 5] |= 1u << (bit & 31); }
-    prm.n = n32; prm.num_windows = p.W; prm.w_first = d.w_first; prm.w_step = d.w_step; prm.nw_local = p.nw;
+    prm.n = n32; prm.nst = p.nst; prm.num_windows = p.W; prm.w_first = d.w_first; prm.w_step = d.w_step; prm.nw_local = p.nw;
     const uint4* sc = (const uint4*)d_scalars;
     switch (p.c) {
       case 4: launch_digits<4>(sc, d.d_digits, prm, d.d_err, stream); break;
@@ -193,22 +210,32 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, const void* d_points, const void* d_s
       default: launch_digits<16>(sc, d.d_digits, prm, d.d_err, stream); break;
     }
   }
-  const uint32_t total = (uint32_t)p.nw * p.B;
-  const size_t lds_hist = (size_t)p.B * 4;
+  te::sort_geom sg;
+  sg.n = n32; sg.nst = p.nst; sg.B = p.B; sg.logS = p.logS; sg.S = p.S; sg.P = p.P; sg.CH = p.CH; sg.chunk_len = p.chunk_len; sg.cap = p.cap; sg.dbg = (uint32_t)ctx->opt_dbg;
   mark(ST_HIST);
-  if (p.nw > 0)
-    hipLaunchKernelGGL(te::k_hist, dim3(p.CH, p.nw), dim3(1024), lds_hist, stream, d.d_digits, d.d_counts, n32, p.B, p.chunk_len);
+  if (p.nw > 0) hipLaunchKernelGGL(te::k_part_hist, dim3(p.CH, p.nw), dim3(1024), 0, stream, d.d_digits, d.d_counts1, sg);
   mark(ST_SCAN);
-  if (p.nw > 0) {
-    hipLaunchKernelGGL(te::k_scan_a, dim3(p.nseg, p.nw), dim3(p.seg_threads), 0, stream, d.d_counts, d.d_bucket_count,
-                       d.d_local_excl, d.d_seg_total, p.B, p.CH);
-    hipLaunchKernelGGL(te::k_scan_b, dim3(p.nseg, p.nw), dim3(p.seg_threads), 0, stream, d.d_local_excl, d.d_seg_total,
-                       d.d_bucket_start, p.B);
-  }
+  if (p.nw > 0) hipLaunchKernelGGL(te::k_part_scan, dim3(p.nw), dim3(1024), 0, stream, d.d_counts1, d.d_part_start, d.d_part_count, sg);
   mark(ST_SCATTER);
   if (p.nw > 0)
-    hipLaunchKernelGGL(te::k_scatter, dim3(p.CH, p.nw), dim3(1024), lds_hist, stream, d.d_digits, d.d_counts,
-                       d.d_bucket_start, d.d_sorted, n32, p.B, p.chunk_len);
+    hipLaunchKernelGGL(te::k_part_scatter, dim3(p.CH, p.nw), dim3(512), 0, stream, d.d_digits, d.d_counts1, d.d_part_keys, d.d_part_idx, sg);
+  if (false) {  hipLaunchKernelGGL(te::k_prep_points, dim3((n32 + 255) / 256), dim3(256), 0, stream,
+                     (const uint4*)d_points, d.d_recs, n32);
+  }
+  mark(ST_BSORT);
+  if (p.nw > 0) {
+    const uint32_t nslices = (p.nst + 8191u) / 8192u;
+    const uint32_t seg_threads = p.B < 1024u ? p.B : 1024u, nseg = p.B / seg_threads;
+    HIP_TRY(ctx, hipMemsetAsync(d.d_bucket_count, 0, (size_t)p.nw * p.B * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(te::k_l2_count, dim3(nslices, p.nw), dim3(256), 0, stream, d.d_part_keys, d.d_part_idx, d.d_part_start,
+                       d.d_part_count, d.d_bucket_count, sg);
+    hipLaunchKernelGGL(te::k_bscan_a, dim3(nseg, p.nw), dim3(seg_threads), 0, stream, d.d_bucket_count, d.d_bucket_cursor, d.d_seg_total, p.B);
+    hipLaunchKernelGGL(te::k_bscan_b, dim3(nseg, p.nw), dim3(seg_threads), 0, stream, d.d_bucket_cursor, d.d_seg_total, d.d_bucket_start,
+                       d.d_bucket_cursor, p.B);
+    hipLaunchKernelGGL(te::k_l2_place, dim3(nslices, p.nw), dim3(256), 0, stream, d.d_part_keys, d.d_part_idx, d.d_part_start,
+                       d.d_part_count, d.d_bucket_cursor, d.d_sorted, sg);
+  }
+  const uint32_t total = (uint32_t)p.nw * p.B;
   mark(ST_ORDER);
   const uint32_t* order = nullptr;
   if (p.nw > 0 && ctx->opt_sort) {
@@ -276,8 +303,8 @@ int collect_stage_ms(te_ctx* ctx, gpu_t& d) {
 
 void free_dev(gpu_t& d) {
   (void)hipSetDevice(d.device);
-  void* ptrs[] = {d.d_recs, d.d_digits, d.d_counts, d.d_bucket_count, d.d_bucket_start, d.d_local_excl, d.d_seg_total,
-                  d.d_sorted, d.d_order, d.d_size_hist, d.d_size_cursor, d.d_buckets, d.d_red[0], d.d_red[1], d.d_red[2], d.d_red[3], d.d_partials,
+  void* ptrs[] = {d.d_recs, d.d_digits, d.d_counts1, d.d_part_start, d.d_part_count, d.d_part_keys, d.d_part_idx, d.d_buckets,
+                  d.d_bucket_count, d.d_bucket_start, d.d_bucket_cursor, d.d_seg_total, d.d_sorted, d.d_order, d.d_size_hist, d.d_size_cursor, d.d_red[0], d.d_red[1], d.d_red[2], d.d_red[3], d.d_partials,
                   d.d_err, d.d_in_points, d.d_in_scalars};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (d.h_err) (void)hipHostFree(d.h_err);
@@ -367,9 +394,6 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
     if (er == hipSuccess) er = hipHostMalloc((void**)&d.h_err, sizeof(uint32_t), hipHostMallocDefault);
     if (er == hipSuccess) er = hipEventCreateWithFlags(&d.ev_done, hipEventDisableTiming);
     for (auto& evn : d.ev) if (er == hipSuccess) er = hipEventCreate(&evn);
-    // the per-window histogram (up to 128 KB for c = 16) lives in LDS: raise the dynamic-LDS limit
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)te::k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-    if (er == hipSuccess) er = hipFuncSetAttribute((const void*)te::k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
     if (er != hipSuccess) {
       g_init_error = std::string("te_msm_init: ") + hipGetErrorString(er);
       for (auto& dd : ctx->devs) free_dev(dd);
@@ -402,6 +426,8 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   if (!strcmp(key, "window_bits")) { if (value != 0 && (value < 4 || value > 16)) return set_err(ctx, TE_MSM_EINVAL, "window_bits must be 0 or in [4,16]"); ctx->opt_window_bits = (int)value; return 0; }
   if (!strcmp(key, "sort_buckets")) { ctx->opt_sort = value ? 1 : 0; return 0; }
   if (!strcmp(key, "profile")) { ctx->opt_profile = value ? 1 : 0; return 0; }
+  if (!strcmp(key, "debug_cut")) { ctx->opt_dbg = (int)value; return 0; }
+  if (!strcmp(key, "sort_s")) { ctx->opt_sort_s = (int)value; return 0; }
   return set_err(ctx, TE_MSM_EINVAL, "unknown option");
 }
 
@@ -472,11 +498,15 @@ int64_t te_msm_debug_read(te_ctx* ctx, const char* stage, void* dst, uint64_t ca
   const plan_t& p = d.last_plan; const uint64_t n = d.last_n;
   const void* src = nullptr; uint64_t bytes = 0;
   if (!strcmp(stage, "records")) { src = d.d_recs; bytes = n * sizeof(te::pnt); }
-  else if (!strcmp(stage, "digits")) { src = d.d_digits; bytes = (uint64_t)p.nw * n * 2; }
+  else if (!strcmp(stage, "digits")) { src = d.d_digits; bytes = (uint64_t)p.nw * p.nst * 2; }   // row stride nst = n rounded up to 8
   else if (!strcmp(stage, "bucket_count")) { src = d.d_bucket_count; bytes = (uint64_t)p.nw * p.B * 4; }
   else if (!strcmp(stage, "bucket_start")) { src = d.d_bucket_start; bytes = (uint64_t)p.nw * p.B * 4; }
   else if (!strcmp(stage, "sorted")) { src = d.d_sorted; bytes = (uint64_t)p.nw * n * 4; }
   else if (!strcmp(stage, "order")) { src = d.d_order; bytes = (uint64_t)p.nw * p.B * 4; }
+  else if (!strcmp(stage, "part_start")) { src = d.d_part_start; bytes = (uint64_t)p.nw * p.P * 4; }
+  else if (!strcmp(stage, "part_count")) { src = d.d_part_count; bytes = (uint64_t)p.nw * p.P * 4; }
+  else if (!strcmp(stage, "part_keys")) { src = d.d_part_keys; bytes = (uint64_t)p.nw * p.nst * 2; }
+  else if (!strcmp(stage, "part_idx")) { src = d.d_part_idx; bytes = (uint64_t)p.nw * p.nst * 4; }
   else if (!strcmp(stage, "buckets")) { src = d.d_buckets; bytes = (uint64_t)p.nw * p.B * sizeof(te::ete); }
   else if (!strcmp(stage, "partials")) { src = d.d_partials; bytes = (uint64_t)p.W * TE_MSM_PARTIAL_BYTES; }
   else return set_err(ctx, TE_MSM_EINVAL, "unknown stage");
