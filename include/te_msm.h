@@ -35,7 +35,7 @@ typedef struct te_ctx te_ctx;
 
 #define TE_MSM_POINT_BYTES   64
 #define TE_MSM_SCALAR_BYTES  32
-#define TE_MSM_PARTIAL_BYTES 384  /* per window: 3 extended points x 128 B (see te_msm_partial_device) */
+#define TE_MSM_PARTIAL_BYTES 432  /* per window: 3 extended points x 144 B (see te_msm_partial_device) */
 
 /* Replaces get_device() + per-call buffer/pipeline creation (implementation/cuzk/gpu.ts:14-25,
  * submission.ts:96-97).  The context is persistent: buffers and streams live across calls.
@@ -59,7 +59,8 @@ int te_msm_run_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_sca
 /* Options (the reference hard-codes these: chunk_size submission.ts:80, dispatch table :109-142).
  *   "window_bits"   c in [4,16]; 0 = choose from n (default)
  *   "sort_buckets"  1 = schedule buckets by descending size (default), 0 = natural order
- *   "profile"       1 = record per-stage HIP events (te_msm_stage_ms)                      */
+ *   "profile"       1 = HIP events around the dominant kernel (accumulate) only, 2 = around every stage
+ *                   (te_msm_stage_ms); 0 = none (default)                                    */
 int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value);
 int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value);
 
@@ -71,8 +72,8 @@ int te_msm_plan(te_ctx* ctx, uint64_t n, int* window_bits, int* num_windows);
 /* Runs every device stage for this context's windows and leaves the partial sums in DEVICE memory:
  * d_partials is W x TE_MSM_PARTIAL_BYTES; only the rows of this context's windows are written
  * (others untouched -- zero the buffer first; an all-zero row means "window not present").
- * Row w = [ sum_j B_j | sum_hi hi*R_hi | sum_lo lo*C_lo ] as extended points (x|y|z|t, 8x32-bit limbs,
- * Montgomery form R = 2^256, lazily reduced).  Asynchronous on `stream` (a hipStream_t, may be NULL
+ * Row w = [ sum_j B_j | sum_hi hi*R_hi | sum_lo lo*C_lo ] as extended points (x|y|z|t, each 9 limbs of 29 bits in
+ * u32 words, Montgomery form R = 2^261, lazily reduced).  Asynchronous on `stream` (a hipStream_t, may be NULL
  * for the context's own stream); returns after enqueueing. */
 int te_msm_partial_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_scalars_le, uint64_t n,
                           void* d_partials, void* stream);
@@ -87,13 +88,13 @@ int te_msm_finalize(te_ctx* ctx, const uint8_t* partials, int window_bits, int n
 int te_msm_finalize_host(const uint8_t* partials, int window_bits, int num_windows, uint8_t out_xy_le[64]);
 
 /* ---- measurement / stage verification (the reference's `debug` flags, submission.ts:892-1363) --- */
-/* Per-stage device time of the last run in ms (needs option "profile" = 1).  Returns the number of
+/* Per-stage device time of the last run in ms (needs option "profile" >= 1; level 1 reports "accumulate" only).  Returns the number of
  * stages written; names[i] points to static strings. */
 int te_msm_stage_ms(te_ctx* ctx, float* ms, const char** names, int max_stages);
 /* Copies an intermediate buffer of the last run to host memory.  stage is one of
- * "records" (n x 96 B), "digits" / "part_keys" (nw rows of u16, row stride n rounded up to 8), "part_idx" (same rows, u32),
+ * "records" (n x 128 B), "digits" / "part_keys" (nw rows of u16, row stride n rounded up to 8), "part_idx" (same rows, u32),
  * "part_start" / "part_count" (nw x P u32), "bucket_count" / "bucket_start" / "order" (nw x B u32), "sorted" (nw x n u32),
- * "buckets" (nw x B x 128 B), "partials" (W x 384 B).  Returns bytes copied
+ * "buckets" (nw x B x 144 B), "partials" (W x 432 B).  Returns bytes copied
  * (<= cap) or a negative error. */
 int64_t te_msm_debug_read(te_ctx* ctx, const char* stage, void* dst, uint64_t cap);
 

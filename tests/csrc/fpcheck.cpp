@@ -10,55 +10,71 @@
 
 using namespace te;
 
+// value of a limb vector as a 320-bit integer, compared with k*p
+static void to_words(const fp& a, uint64_t w[6]) {
+  for (int i = 0; i < 6; i++) w[i] = 0;
+  for (int i = 0; i < NL; i++) {
+    const int bit = 29 * i, j = bit >> 6, s = bit & 63;
+    unsigned __int128 add = (unsigned __int128)a.v[i] << s, c = (unsigned __int128)w[j] + (uint64_t)add;
+    w[j] = (uint64_t)c; c >>= 64; c += (unsigned __int128)w[j + 1] + (uint64_t)(add >> 64); w[j + 1] = (uint64_t)c; c >>= 64;
+    for (int q = j + 2; q < 6 && c; q++) { c += w[q]; w[q] = (uint64_t)c; c >>= 64; }
+  }
+}
 static bool lt_kp(const fp& a, int k) {   // a < k*p ?
-  // compare a with k*p using 64-bit math
-  uint32_t kp[9]; uint64_t c = 0;
-  for (int i = 0; i < 8; i++) { c += (uint64_t)p_limb(i) * k; kp[i] = (uint32_t)c; c >>= 32; }
-  kp[8] = (uint32_t)c;
-  if (kp[8]) return true;
-  for (int i = 7; i >= 0; i--) { if (a.v[i] != kp[i]) return a.v[i] < kp[i]; }
+  static const uint64_t P64[4] = {0x0a11800000000001ULL, 0x59aa76fed0000001ULL, 0x60b44d1e5c37b001ULL, 0x12ab655e9a2ca556ULL};
+  uint64_t kp[6] = {0, 0, 0, 0, 0, 0}; unsigned __int128 c = 0;
+  for (int i = 0; i < 4; i++) { c += (unsigned __int128)P64[i] * (unsigned)k; kp[i] = (uint64_t)c; c >>= 64; }
+  kp[4] = (uint64_t)c;
+  uint64_t w[6]; to_words(a, w);
+  for (int i = 5; i >= 0; i--) { if (w[i] != kp[i]) return w[i] < kp[i]; }
   return false;
 }
+static bool class_n(const fp& a) { for (int i = 0; i < NL - 1; i++) if (a.v[i] >= (1u << 29)) return false; return a.v[NL - 1] < (1u << 24); }
 static int g_bound_violations = 0;
-static void chk2(const ete& e) { if (!(lt_kp(e.x, 2) && lt_kp(e.y, 2) && lt_kp(e.z, 2) && lt_kp(e.t, 2))) g_bound_violations++; }
+static void chk2(const ete& e) {
+  if (!(lt_kp(e.x, 2) && lt_kp(e.y, 2) && lt_kp(e.z, 2) && lt_kp(e.t, 2))) g_bound_violations++;
+  if (!(class_n(e.x) && class_n(e.y) && class_n(e.z) && class_n(e.t))) g_bound_violations++;
+}
 
 extern "C" {
 
 int fpc_bound_violations() { return g_bound_violations; }
 
-void fpc_mont_mul(const uint32_t a[8], const uint32_t b[8], uint32_t out[8]) {
-  fp x, y; memcpy(x.v, a, 32); memcpy(y.v, b, 32); fp r = mont_mul(x, y); memcpy(out, r.v, 32);
+void fpc_mont_mul(const uint32_t a[9], const uint32_t b[9], uint32_t out[9]) {
+  fp x, y; memcpy(x.v, a, 36); memcpy(y.v, b, 36); fp r = mont_mul(x, y); memcpy(out, r.v, 36);
 }
-void fpc_reduce_full(const uint32_t a[8], uint32_t out[8]) { fp x; memcpy(x.v, a, 32); fp r = fp_reduce_full(x); memcpy(out, r.v, 32); }
-void fpc_half(const uint32_t a[8], uint32_t out[8]) { fp x; memcpy(x.v, a, 32); fp r = fp_half(x); memcpy(out, r.v, 32); }
-void fpc_sub2(const uint32_t a[8], const uint32_t b[8], uint32_t out[8]) { fp x, y; memcpy(x.v, a, 32); memcpy(y.v, b, 32); fp r = fp_sub<2>(x, y); memcpy(out, r.v, 32); }
-void fpc_constants(uint32_t out[5 * 8]) {
-  fp c[5] = {fp_R1(), fp_R2(), fp_D_MONT(), fp_K2D_MONT(), fp_ONE_RAW()};
+void fpc_norm(const uint32_t a[9], uint32_t out[9]) { fp x; memcpy(x.v, a, 36); fp r = fp_norm(x); memcpy(out, r.v, 36); }
+void fpc_half(const uint32_t a[9], uint32_t out[9]) { fp x; memcpy(x.v, a, 36); fp r = fp_half(x); memcpy(out, r.v, 36); }
+void fpc_sub2(const uint32_t a[9], const uint32_t b[9], uint32_t out[9]) { fp x, y; memcpy(x.v, a, 36); memcpy(y.v, b, 36); fp r = fp_sub<2>(x, y); memcpy(out, r.v, 36); }
+void fpc_from_words32(const uint32_t w[8], uint32_t out[9]) { uint32_t t[8]; memcpy(t, w, 32); fp r = fp_from_words32(t); memcpy(out, r.v, 36); }
+void fpc_constants(uint32_t out[9 * 9]) {
+  fp c[9] = {fp_R1(), fp_R2(), fp_D_MONT(), fp_K2D_MONT(), fp_ONE_RAW(), fp_P(), fp_kp_offset<2>(), fp_kp_offset<4>(), fp_kp_offset<8>()};
   memcpy(out, c, sizeof c);
 }
-// body of k_prep_points
-void fpc_prep_point(const uint8_t xy_le[64], uint8_t rec[96]) {
-  fp x, y; memcpy(x.v, xy_le, 32); memcpy(y.v, xy_le + 32, 32);
-  const fp xm = fp_csub<1>(mont_mul(fp_R2(), x)), ym = fp_csub<1>(mont_mul(fp_R2(), y));
+// body of k_prep_points: record in a 128-byte slot
+void fpc_prep_point(const uint8_t xy_le[64], uint8_t rec[128]) {
+  uint32_t xw[8], yw[8]; memcpy(xw, xy_le, 32); memcpy(yw, xy_le + 32, 32);
+  const fp xm = mont_mul(fp_from_words32(xw), fp_R2()), ym = mont_mul(fp_from_words32(yw), fp_R2());
   const pnt r = pnt_from_affine_mont(xm, ym);
-  memcpy(rec, &r, 96);
+  memset(rec, 0, 128); memcpy(rec, &r, 108);
+  if (!(class_n(r.hm) && class_n(r.hp) && class_n(r.dt) && lt_kp(r.hm, 3) && lt_kp(r.hp, 2) && lt_kp(r.dt, 2))) g_bound_violations++;
 }
-void fpc_identity(uint8_t out[128]) { ete e = ete_identity(); memcpy(out, &e, 128); }
-void fpc_madd(const uint8_t acc[128], const uint8_t rec[96], int neg, uint8_t out[128]) {
-  ete a; pnt b; memcpy(&a, acc, 128); memcpy(&b, rec, 96);
-  ete r = ete_madd(a, pnt_cneg(b, neg != 0)); chk2(r); memcpy(out, &r, 128);
+void fpc_identity(uint8_t out[144]) { ete e = ete_identity(); memcpy(out, &e, 144); }
+void fpc_madd(const uint8_t acc[144], const uint8_t rec[128], int neg, uint8_t out[144]) {
+  ete a; pnt b; memcpy(&a, acc, 144); memcpy(&b, rec, 108);
+  ete r = ete_madd(a, pnt_cneg(b, neg != 0)); chk2(r); memcpy(out, &r, 144);
 }
-void fpc_add(const uint8_t a_[128], const uint8_t b_[128], uint8_t out[128]) {
-  ete a, b; memcpy(&a, a_, 128); memcpy(&b, b_, 128); ete r = ete_add(a, b); chk2(r); memcpy(out, &r, 128);
+void fpc_add(const uint8_t a_[144], const uint8_t b_[144], uint8_t out[144]) {
+  ete a, b; memcpy(&a, a_, 144); memcpy(&b, b_, 144); ete r = ete_add(a, b); chk2(r); memcpy(out, &r, 144);
 }
 
-// Emulation of the device stages for the windows w = first + k*step.  partials: W x 384 B (rows of other
+// Emulation of the device stages for the windows w = first + k*step.  partials: W x 432 B (rows of other
 // windows untouched).  Returns 0, or -3 on a final carry.
 int fpc_partial_rows(const uint8_t* points, const uint8_t* scalars, uint64_t n, int c, int first, int step, uint8_t* partials) {
   const int W = (256 + c - 1) / c;
   const uint32_t B = 1u << (c - 1), lo_bits = (uint32_t)(c / 2), RL = 1u << lo_bits, RH = B / RL;
   std::vector<pnt> recs(n);
-  for (uint64_t i = 0; i < n; i++) fpc_prep_point(points + 64 * i, (uint8_t*)&recs[i]);
+  for (uint64_t i = 0; i < n; i++) { uint8_t slot[128]; fpc_prep_point(points + 64 * i, slot); memcpy(&recs[i], slot, 108); }
   // half = sum_w 2^(c*w + c-1)
   uint32_t half[10] = {0};
   for (int w = 0; w < W; w++) { int bit = w * c + c - 1; if (bit < 320) half[bit >> 5] |= 1u << (bit & 31); }
@@ -91,8 +107,8 @@ int fpc_partial_rows(const uint8_t* points, const uint8_t* scalars, uint64_t n, 
     run = ete_identity();
     for (uint32_t v = RL; v-- > 1;) { run = ete_add(run, C[v]); WC = ete_add(WC, run); }
     chk2(T); chk2(WR); chk2(WC);
-    uint8_t* row = partials + (size_t)w * 384;
-    memcpy(row, &T, 128); memcpy(row + 128, &WR, 128); memcpy(row + 256, &WC, 128);
+    uint8_t* row = partials + (size_t)w * 432;
+    memcpy(row, &T, 144); memcpy(row + 144, &WR, 144); memcpy(row + 288, &WC, 144);
   }
   return 0;
 }

@@ -33,11 +33,11 @@ def test_stages_against_oracle(ctx, fpcheck, model, ora, n, c):
     res = ctx.run(pts, sc)
     W, B = (256 + c - 1) // c, 1 << (c - 1)
     # K1a: records == the same limb code compiled for the host
-    recs = ctx.debug_read("records", n * 96)
+    recs = ctx.debug_read("records", n * 128)
     for i in list(range(0, n, max(1, n // 97))) + [n - 1]:
-        r = ctypes.create_string_buffer(96)
+        r = ctypes.create_string_buffer(128)
         fpcheck.fpc_prep_point(pts[64 * i:64 * i + 64], r)
-        assert recs[96 * i:96 * i + 96] == r.raw, f"record {i}"
+        assert recs[128 * i:128 * i + 128] == r.raw, f"record {i}"
     # K1b: digits == decompose_scalars_signed (miscellaneous/utils.ts:52-95)
     nst = (n + 7) & ~7                                  # digit rows are padded to a multiple of 8 entries (digit 0)
     dig = np.frombuffer(ctx.debug_read("digits", W * nst * 2), dtype=np.uint16).reshape(W, nst)
@@ -87,13 +87,15 @@ def test_stages_against_oracle(ctx, fpcheck, model, ora, n, c):
     sizes = cnt.reshape(-1)[order]
     assert np.all(np.minimum(sizes[:-1], 1023) >= np.minimum(sizes[1:], 1023)), "order is not descending"
     # K3: a sample of bucket sums == affine sums of the model
-    bk = ctx.debug_read("buckets", W * B * 128)
+    bk = ctx.debug_read("buckets", W * B * 144)
     P = model.P
-    rinv = pow(1 << 256, -1, P)
+    rinv = pow(1 << 261, -1, P)
     rng = np.random.default_rng(1)
     for w, b in [(0, 0), (W - 1, B - 1)] + [(int(rng.integers(W)), int(rng.integers(B))) for _ in range(6)]:
-        raw = bk[(w * B + b) * 128:(w * B + b + 1) * 128]
-        x, y, z, t = [int.from_bytes(raw[32 * k:32 * k + 32], "little") for k in range(4)]
+        raw = bk[(w * B + b) * 144:(w * B + b + 1) * 144]
+        words = np.frombuffer(raw, dtype=np.uint32).reshape(4, 9)
+        assert np.all(words[:, :8] < (1 << 29)), "limb class N violated"
+        x, y, z, t = [sum(int(v) << (29 * i) for i, v in enumerate(words[k])) for k in range(4)]
         assert max(x, y, z, t) < 2 * P, "lazy bound < 2p violated"
         zi = pow(z * rinv % P, -1, P)
         got = (x * rinv * zi % P, y * rinv * zi % P)
@@ -203,7 +205,7 @@ def test_window_shards_on_one_gpu(pkg, ora, world):
         with pkg.MsmContext((0,)) as c:
             c.set_window_shard(*pkg.window_shard_for_rank(r, world))
             cbits, W = c.plan(n)
-            part = torch.zeros(W * 384, dtype=torch.uint8, device="cuda")
+            part = torch.zeros(W * 432, dtype=torch.uint8, device="cuda")
             c.partial_device(dp.data_ptr(), ds.data_ptr(), n, part.data_ptr(), torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
             rows.append(part.cpu().numpy().tobytes())

@@ -12,57 +12,93 @@ import pytest
 from oracle.gen_golden import edge_scalars
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = 1 << 256
+R = 1 << 261            # device Montgomery radix: 9 limbs of 29 bits
+NL, LB = 9, 29
+LM = (1 << LB) - 1
 
 
 def limbs(v):
-    return (ctypes.c_uint32 * 8)(*[(v >> (32 * i)) & 0xFFFFFFFF for i in range(8)])
+    """integer -> 9 normalised 29-bit limbs (ctypes array)"""
+    return (ctypes.c_uint32 * NL)(*[(v >> (LB * i)) & LM if i < NL - 1 else v >> (LB * i) for i in range(NL)])
+
+
+def raw(ls):
+    return (ctypes.c_uint32 * NL)(*ls)
 
 
 def val(a):
-    return sum(int(a[i]) << (32 * i) for i in range(8))
+    return sum(int(a[i]) << (LB * i) for i in range(NL))
 
 
 def test_field_constants(fpcheck, model):
-    out = (ctypes.c_uint32 * 40)()
+    out = (ctypes.c_uint32 * 81)()
     fpcheck.fpc_constants(out)
-    got = [sum(int(out[8 * k + i]) << (32 * i) for i in range(8)) for k in range(5)]
+    got = [[int(out[9 * k + i]) for i in range(9)] for k in range(9)]
     P = model.P
-    assert got == [R % P, R * R % P, model.D * R % P, 2 * model.D * R % P, 1]
+    vals = [sum(l << (LB * i) for i, l in enumerate(g)) for g in got]
+    assert vals[:6] == [R % P, R * R % P, model.D * R % P, 2 * model.D * R % P, 1, P]
+    for g in got[:6]:
+        assert all(l <= LM for l in g)
+    for k, g in zip((2, 4, 8), got[6:]):             # offset forms: same value as K*p, every lower limb >= 2^29 - 1
+        assert sum(l << (LB * i) for i, l in enumerate(g)) == k * P
+        assert all(LM <= l < (1 << 30) for l in g[:8]) and g[8] > 0
 
 
-def test_mont_mul_and_lazy_bounds(fpcheck, model):
+def test_mont_mul_values_and_limb_classes(fpcheck, model):
+    """exactness for normalised operands and for the widest limb classes the formulas use (S x D)"""
     P, rnd = model.P, random.Random(11)
     rinv = pow(R, -1, P)
-    cases = [(8 * P - 1, R - 1), (0, 0), (1, 1), (P, P), (8 * P - 1, 0)]
-    cases += [(rnd.randrange(8 * P), rnd.randrange(R)) for _ in range(3000)]
-    for a, b in cases:
-        out = (ctypes.c_uint32 * 8)()
-        fpcheck.fpc_mont_mul(limbs(a), limbs(b), out)
-        r = val(out)
+    out = (ctypes.c_uint32 * NL)()
+
+    def check(la, lb):
+        fpcheck.fpc_mont_mul(raw(la), raw(lb), out)
+        a, b, r = val(la), val(lb), val(out)
         assert r % P == a * b * rinv % P
-        assert r < a * b // R + P + 1            # the bound every caller relies on: a*b/R + p
+        assert r < a * b // R + P + 1                       # value bound every caller relies on
+        assert all(int(out[i]) <= LM for i in range(NL - 1))  # class N
+
+    for _ in range(2000):
+        check(list(limbs(rnd.randrange(8 * P))), list(limbs(rnd.randrange(16 * P))))
+    # limb-magnitude edge: D-class limbs (2^29 - 1 + largest offset limb) against S-class limbs (2 * (2^29 - 1))
+    offs = (ctypes.c_uint32 * 81)()
+    fpcheck.fpc_constants(offs)
+    max_off = max(int(offs[9 * 6 + i]) for i in range(8))
+    d_max, s_max = LM + max_off, 2 * LM
+    assert 9 * d_max * s_max + 8 * (1 << 58) + (1 << 36) < (1 << 64)      # the accumulator bound stated in fp.hpp
+    check([d_max] * 8 + [1 << 22], [s_max] * 8 + [1 << 22])
+    check([s_max] * 8 + [1 << 22], [s_max] * 8 + [1 << 22])
+    check([LM] * 8 + [1 << 22], [(1 << 31) - 1] * 8 + [1 << 22])
+    for _ in range(500):
+        check([rnd.randrange(d_max + 1) for _ in range(8)] + [rnd.randrange(1 << 22)],
+              [rnd.randrange(s_max + 1) for _ in range(8)] + [rnd.randrange(1 << 22)])
 
 
 def test_field_helpers(fpcheck, model):
     P, rnd = model.P, random.Random(12)
+    out = (ctypes.c_uint32 * NL)()
     for _ in range(500):
-        a = rnd.randrange(R)
-        out = (ctypes.c_uint32 * 8)()
-        fpcheck.fpc_reduce_full(limbs(a), out)
-        assert val(out) == a % P
-        c = rnd.randrange(P)
+        ls = [rnd.randrange(1 << 32) for _ in range(8)] + [rnd.randrange(1 << 20)]
+        fpcheck.fpc_norm(raw(ls), out)
+        assert val(out) == val(ls) and all(int(out[i]) <= LM for i in range(8))
+        c = rnd.randrange(4 * P)
         fpcheck.fpc_half(limbs(c), out)
-        assert val(out) * 2 % P == c and val(out) < P
+        assert val(out) * 2 % P == c % P and val(out) <= (c + P) // 2
         x, y = rnd.randrange(2 * P), rnd.randrange(2 * P)
         fpcheck.fpc_sub2(limbs(x), limbs(y), out)
         assert val(out) == x - y + 2 * P
+        w = rnd.randrange(1 << 256)
+        fpcheck.fpc_from_words32((ctypes.c_uint32 * 8)(*[(w >> (32 * i)) & 0xFFFFFFFF for i in range(8)]), out)
+        assert val(out) == w and all(int(out[i]) <= LM for i in range(NL))
 
 
 def _ete_affine(model, b):
     P = model.P
     rinv = pow(R, -1, P)
-    x, y, z, t = [int.from_bytes(b[32 * i:32 * i + 32], "little") * rinv % P for i in range(4)]
+    coords = []
+    for c in range(4):
+        ws = [int.from_bytes(b[36 * c + 4 * i:36 * c + 4 * i + 4], "little") for i in range(NL)]
+        coords.append(sum(w << (LB * i) for i, w in enumerate(ws)) * rinv % P)
+    x, y, z, t = coords
     zi = pow(z, -1, P)
     assert t * z % P == x * y % P           # T = XY/Z stays consistent
     return (x * zi % P, y * zi % P)
@@ -70,22 +106,22 @@ def _ete_affine(model, b):
 
 def test_point_formulas(fpcheck, model, ora):
     pts = [model.xy_from_bytes(ora.gen_points(21, 12)[64 * i:64 * i + 64]) for i in range(12)]
-    ident = ctypes.create_string_buffer(128)
+    ident = ctypes.create_string_buffer(144)
     fpcheck.fpc_identity(ident)
     acc, exp = ident.raw, model.ZERO
     recs = []
     for p in pts:
-        rec = ctypes.create_string_buffer(96)
+        rec = ctypes.create_string_buffer(128)
         fpcheck.fpc_prep_point(model.points_to_bytes([p]), rec)
         recs.append(rec.raw)
     for i, p in enumerate(pts + pts[:3]):             # the last three re-add points: P + P through the unified law
         neg = i % 3 == 1
-        out = ctypes.create_string_buffer(128)
+        out = ctypes.create_string_buffer(144)
         fpcheck.fpc_madd(acc, recs[i % 12], int(neg), out)
         acc = out.raw
         exp = model.add(exp, model.neg(p) if neg else p)
         assert _ete_affine(model, acc) == exp
-    out = ctypes.create_string_buffer(128)
+    out = ctypes.create_string_buffer(144)
     fpcheck.fpc_add(acc, acc, out)                    # doubling through ete_add
     assert _ete_affine(model, out.raw) == model.add(exp, exp)
     fpcheck.fpc_add(out.raw, ident.raw, out)
@@ -103,7 +139,7 @@ def test_emulated_stages_plus_host_tail(fpcheck, pkg, model, ora, n, c, mode):
     pts = ora.gen_points_fixed(n) if mode == "fixed" else ora.gen_points(seed, n)
     sc = model.scalars_to_bytes(edge_scalars(seed, n)) if mode == "edge" else ora.gen_scalars(seed, n)
     W = (256 + c - 1) // c
-    buf = ctypes.create_string_buffer(W * 384)
+    buf = ctypes.create_string_buffer(W * 432)
     assert fpcheck.fpc_partial_rows(pts, sc, n, c, 0, 1, buf) == 0
     assert pkg.finalize_host(buf.raw, c, W) == ora.msm(pts, sc, threads=4)
     assert fpcheck.fpc_bound_violations() == 0
@@ -118,7 +154,7 @@ def test_window_shards_merge(fpcheck, pkg, ora):
         bufs = []
         for r in range(world):
             first, step = pkg.window_shard_for_rank(r, world)
-            b = ctypes.create_string_buffer(W * 384)
+            b = ctypes.create_string_buffer(W * 432)
             assert fpcheck.fpc_partial_rows(pts, sc, n, c, first, step, b) == 0
             bufs.append(b.raw)
         assert pkg.finalize_host(pkg.merge_partials(bufs, W, world), c, W) == exp
@@ -127,15 +163,15 @@ def test_window_shards_merge(fpcheck, pkg, ora):
 def test_final_carry_detected_by_emulation(fpcheck, model, ora):
     pts = ora.gen_points(1, 2)
     sc = model.scalars_to_bytes([5, (1 << 256) - 1])
-    buf = ctypes.create_string_buffer(16 * 384)
+    buf = ctypes.create_string_buffer(16 * 432)
     assert fpcheck.fpc_partial_rows(pts, sc, 2, 16, 0, 1, buf) == -3
 
 
 def test_host_tail_identity_and_args(pkg):
     ident = bytes(32) + (1).to_bytes(32, "little")
-    assert pkg.finalize_host(bytes(16 * 384), 16, 16) == ident
+    assert pkg.finalize_host(bytes(16 * 432), 16, 16) == ident
     with pytest.raises(pkg.MsmError):
-        pkg.finalize_host(bytes(384), 99, 1)
+        pkg.finalize_host(bytes(432), 99, 1)
 
 
 # ---------------------------------------------------------------- C-ABI surface
@@ -209,7 +245,7 @@ n, c = 300, 10
 W = (256 + c - 1) // c
 pts, sc = o.gen_points(77, n), o.gen_scalars(77, n)
 first, step = pkg.window_shard_for_rank(rank, world)
-buf = ctypes.create_string_buffer(W * 384)
+buf = ctypes.create_string_buffer(W * 432)
 assert L.fpc_partial_rows(pts, sc, n, c, first, step, buf) == 0       # stands in for the GPU stage
 t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
 merged = pkg.exchange_partials(t, W, dist)

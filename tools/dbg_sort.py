@@ -5,7 +5,7 @@ from oracle import oracle
 n=1<<20
 pts=oracle.gen_points(1,n); sc=oracle.gen_scalars(1,n)
 dp=torch.frombuffer(bytearray(pts),dtype=torch.uint8).cuda(); ds=torch.frombuffer(bytearray(sc),dtype=torch.uint8).cuda()
-ctx=pkg.MsmContext((0,)); ctx.set_option("window_bits",16); ctx.set_option("profile",1)
+ctx=pkg.MsmContext((0,)); ctx.set_option("window_bits",16); ctx.set_option("profile",2)
 for cut in (0,):
     ctx.set_option("debug_cut",cut)
     for _ in range(3):

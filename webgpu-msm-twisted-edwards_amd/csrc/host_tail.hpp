@@ -2,7 +2,9 @@
 // sums with Horner's rule and convert to affine.  The reference does this with @noble/curves bigints
 // over up to 4096 points; here the device has already reduced every window to three points, so the
 // host executes ~256 doublings, ~50 additions and one inversion (tens of microseconds).
-// 4 x 64-bit limbs, Montgomery form R = 2^256 (the same bytes the device writes as 8 x 32-bit limbs).
+// Host arithmetic: 4 x 64-bit limbs, Montgomery form R = 2^256.  The device writes 9 x 29-bit limbs in Montgomery
+// form R' = 2^261, lazily reduced; load_point() reassembles the integer, reduces it and multiplies by
+// 2^-261 * 2^512 (one host product) to land in the host's Montgomery domain.
 #pragma once
 #include <stdint.h>
 #include <string.h>
@@ -11,7 +13,7 @@ namespace te_host {
 
 typedef unsigned __int128 u128;
 struct Fe { uint64_t l[4]; };
-struct Pt { Fe x, y, z, t; };   // device layout: x | y | z | t
+struct Pt { Fe x, y, z, t; };   // device row layout: x | y | z | t, 36 bytes each
 
 static const uint64_t MOD[4] = {0x0a11800000000001ULL, 0x59aa76fed0000001ULL, 0x60b44d1e5c37b001ULL, 0x12ab655e9a2ca556ULL};
 static const uint64_t MOD_NEG_INV = 0x0a117fffffffffffULL;   // -p^-1 mod 2^64 (checked in tail_selftest)
@@ -68,9 +70,32 @@ static inline bool is_zero(const Fe& a) { return (a.l[0] | a.l[1] | a.l[2] | a.l
 static inline Pt identity() { Pt r; memset(&r, 0, sizeof r); r.y = ONE_M; r.z = ONE_M; return r; }
 static inline bool all_zero_bytes(const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) if (p[i]) return false; return true; }
 
-static inline Pt load_point(const uint8_t* src) {      // 128 B device extended point, lazily reduced
-  Pt r; memcpy(&r, src, 128);
-  r.x = canon(r.x); r.y = canon(r.y); r.z = canon(r.z); r.t = canon(r.t);
+#define TE_TAIL_POINT_BYTES 144
+#define TE_TAIL_ROW_BYTES 432
+// one coordinate: 9 u32 words holding 29-bit limbs (possibly unnormalised), value < 2^262
+static inline Fe load_coord(const uint8_t* src) {
+  uint32_t l[9]; memcpy(l, src, 36);
+  uint64_t w[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 9; i++) {                      // w += l[i] << (29 i), with carries (limbs may exceed 29 bits)
+    const int bit = 29 * i, j = bit >> 6, s = bit & 63;
+    const u128 add = (u128)l[i] << s;
+    u128 c = (u128)w[j] + (uint64_t)add; w[j] = (uint64_t)c; c >>= 64;
+    c += (u128)w[j + 1] + (uint64_t)(add >> 64); w[j + 1] = (uint64_t)c; c >>= 64;
+    for (int q = j + 2; q < 6 && c; q++) { c += w[q]; w[q] = (uint64_t)c; c >>= 64; }
+  }
+  // reduce below p: the device keeps values under ~2p, so this loop runs a couple of times at most
+  Fe r = {{w[0], w[1], w[2], w[3]}};
+  uint64_t top = w[4];
+  for (int guard = 0; guard < 4096 && (top || ge_mod(r)); guard++) {
+    uint64_t br = 0;
+    for (int i = 0; i < 4; i++) { u128 d = (u128)r.l[i] - MOD[i] - br; r.l[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
+    top -= br;
+  }
+  const Fe conv = {{0, 0, 0, 0x0800000000000000ULL}};   // 2^-261 * 2^512 = 2^251 (< p)
+  return mul(r, conv);                               // = value * 2^-261 * 2^256: the host Montgomery form
+}
+static inline Pt load_point(const uint8_t* src) {      // 144 B device extended point
+  Pt r; r.x = load_coord(src); r.y = load_coord(src + 36); r.z = load_coord(src + 72); r.t = load_coord(src + 108);
   return r;
 }
 // unified addition, a = -1, k = 2d (add-2008-hwcd-3)
@@ -97,7 +122,7 @@ static inline Pt pdbl(const Pt& a) {
   return r;
 }
 
-// partials: W rows of 384 B = [T | WR | WC]; window value = T + WC + 2^lo_bits * WR, lo_bits = ceil((c-1)/2).
+// partials: W rows of 432 B = [T | WR | WC]; window value = T + WC + 2^lo_bits * WR, lo_bits = ceil((c-1)/2).
 // result = sum_w 2^(c*w) * window_w, evaluated top-down with c doublings per window, split as
 // (c - lo_bits) doublings -> + WR -> lo_bits doublings -> + (T + WC): no doubling is added by the split.
 static inline void horner_to_affine(const uint8_t* partials, int c, int W, uint8_t out_xy_le[64]) {
@@ -107,12 +132,12 @@ static inline void horner_to_affine(const uint8_t* partials, int c, int W, uint8
   const int lo_bits = (c - 1 + 1) / 2;
   Pt acc = identity();
   for (int w = W - 1; w >= 0; w--) {
-    const uint8_t* row = partials + (size_t)w * 384;
-    const bool present = !all_zero_bytes(row, 384);
+    const uint8_t* row = partials + (size_t)w * TE_TAIL_ROW_BYTES;
+    const bool present = !all_zero_bytes(row, TE_TAIL_ROW_BYTES);
     for (int k = 0; k < c - lo_bits; k++) acc = pdbl(acc);
-    if (present) acc = padd(acc, load_point(row + 128), k2d);
+    if (present) acc = padd(acc, load_point(row + TE_TAIL_POINT_BYTES), k2d);
     for (int k = 0; k < lo_bits; k++) acc = pdbl(acc);
-    if (present) { acc = padd(acc, load_point(row), k2d); acc = padd(acc, load_point(row + 256), k2d); }
+    if (present) { acc = padd(acc, load_point(row), k2d); acc = padd(acc, load_point(row + 2 * TE_TAIL_POINT_BYTES), k2d); }
   }
   const Fe zi = inv(acc.z);
   const Fe one_raw = {{1, 0, 0, 0}};

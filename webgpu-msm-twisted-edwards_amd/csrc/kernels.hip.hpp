@@ -24,26 +24,28 @@ struct digits_params {
 };
 
 // ------------------------------------------------------------------------------------------------
-// K1a: affine (x, y) little-endian canonical  ->  Montgomery record ((y-x)/2, (y+x)/2, d*x*y).
-__global__ void __launch_bounds__(256) k_prep_points(const uint4* __restrict__ pts, pnt* __restrict__ recs, uint32_t n) {
+// K1a: affine (x, y) little-endian canonical  ->  Montgomery record ((y-x)/2, (y+x)/2, d*x*y) in a 128-byte slot
+// (27 limb words + padding: one gather touches exactly one 128-byte line).
+struct pnt_slot { uint4 q[8]; };
+__global__ void __launch_bounds__(256) k_prep_points(const uint4* __restrict__ pts, pnt_slot* __restrict__ recs, uint32_t n) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
   const uint4 a0 = pts[4 * (size_t)i + 0], a1 = pts[4 * (size_t)i + 1];
   const uint4 b0 = pts[4 * (size_t)i + 2], b1 = pts[4 * (size_t)i + 3];
-  fp x, y;
-  x.v[0] = a0.x; x.v[1] = a0.y; x.v[2] = a0.z; x.v[3] = a0.w; x.v[4] = a1.x; x.v[5] = a1.y; x.v[6] = a1.z; x.v[7] = a1.w;
-  y.v[0] = b0.x; y.v[1] = b0.y; y.v[2] = b0.z; y.v[3] = b0.w; y.v[4] = b1.x; y.v[5] = b1.y; y.v[6] = b1.z; y.v[7] = b1.w;
-  // to Montgomery form: R2 * x / R.  R2 < p is the bounded operand, x may be any 256-bit value.
-  const fp xm = fp_csub<1>(mont_mul(fp_R2(), x));
-  const fp ym = fp_csub<1>(mont_mul(fp_R2(), y));
+  const uint32_t xw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+  const uint32_t yw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+  // to Montgomery form: x * R^2 / R.  Any 256-bit x (< 13.8p) gives a value < 1.04p.
+  const fp xm = mont_mul(fp_from_words32(xw), fp_R2());
+  const fp ym = mont_mul(fp_from_words32(yw), fp_R2());
   const pnt r = pnt_from_affine_mont(xm, ym);
-  uint4* o = reinterpret_cast<uint4*>(recs + i);
-  o[0] = make_uint4(r.hm.v[0], r.hm.v[1], r.hm.v[2], r.hm.v[3]);
-  o[1] = make_uint4(r.hm.v[4], r.hm.v[5], r.hm.v[6], r.hm.v[7]);
-  o[2] = make_uint4(r.hp.v[0], r.hp.v[1], r.hp.v[2], r.hp.v[3]);
-  o[3] = make_uint4(r.hp.v[4], r.hp.v[5], r.hp.v[6], r.hp.v[7]);
-  o[4] = make_uint4(r.dt.v[0], r.dt.v[1], r.dt.v[2], r.dt.v[3]);
-  o[5] = make_uint4(r.dt.v[4], r.dt.v[5], r.dt.v[6], r.dt.v[7]);
+  uint32_t w[32];
+#pragma unroll
+  for (int j = 0; j < NL; j++) { w[j] = r.hm.v[j]; w[NL + j] = r.hp.v[j]; w[2 * NL + j] = r.dt.v[j]; }
+#pragma unroll
+  for (int j = 3 * NL; j < 32; j++) w[j] = 0u;
+  uint4* o = recs[i].q;
+#pragma unroll
+  for (int j = 0; j < 8; j++) o[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -462,33 +464,40 @@ __global__ void __launch_bounds__(256) k_order_scatter(const uint32_t* __restric
 // (A variant that fused level 2 of the sort into this kernel -- one block per 256 buckets, lists consumed
 // straight from LDS -- was measured at 2.8 ms against 1.4 ms: block-granular scheduling leaves < 1 wave per
 // SIMD resident on average (SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE = 0.78), far too few to hide gather latency.)
-__device__ __forceinline__ pnt load_pnt(const pnt* __restrict__ recs, uint32_t entry) {
-  const uint4* q = reinterpret_cast<const uint4*>(recs + (entry & 0x7fffffffu));
-  const uint4 a0 = q[0], a1 = q[1], b0 = q[2], b1 = q[3], c0 = q[4], c1 = q[5];
+__device__ __forceinline__ pnt load_pnt(const pnt_slot* __restrict__ recs, uint32_t entry) {
+  const uint4* q = recs[entry & 0x7fffffffu].q;
+  uint4 u[7];
+#pragma unroll
+  for (int j = 0; j < 7; j++) u[j] = q[j];
+  const uint32_t w[28] = {u[0].x, u[0].y, u[0].z, u[0].w, u[1].x, u[1].y, u[1].z, u[1].w, u[2].x, u[2].y, u[2].z, u[2].w,
+                          u[3].x, u[3].y, u[3].z, u[3].w, u[4].x, u[4].y, u[4].z, u[4].w, u[5].x, u[5].y, u[5].z, u[5].w,
+                          u[6].x, u[6].y, u[6].z, u[6].w};
   pnt r;
-  r.hm.v[0] = a0.x; r.hm.v[1] = a0.y; r.hm.v[2] = a0.z; r.hm.v[3] = a0.w; r.hm.v[4] = a1.x; r.hm.v[5] = a1.y; r.hm.v[6] = a1.z; r.hm.v[7] = a1.w;
-  r.hp.v[0] = b0.x; r.hp.v[1] = b0.y; r.hp.v[2] = b0.z; r.hp.v[3] = b0.w; r.hp.v[4] = b1.x; r.hp.v[5] = b1.y; r.hp.v[6] = b1.z; r.hp.v[7] = b1.w;
-  r.dt.v[0] = c0.x; r.dt.v[1] = c0.y; r.dt.v[2] = c0.z; r.dt.v[3] = c0.w; r.dt.v[4] = c1.x; r.dt.v[5] = c1.y; r.dt.v[6] = c1.z; r.dt.v[7] = c1.w;
+#pragma unroll
+  for (int j = 0; j < NL; j++) { r.hm.v[j] = w[j]; r.hp.v[j] = w[NL + j]; r.dt.v[j] = w[2 * NL + j]; }
   return r;
 }
+// an extended point is 36 words = 9 x 16 bytes
 __device__ __forceinline__ void store_ete(ete* dst, const ete& a) {
+  uint32_t w[36];
+#pragma unroll
+  for (int j = 0; j < NL; j++) { w[j] = a.x.v[j]; w[NL + j] = a.y.v[j]; w[2 * NL + j] = a.z.v[j]; w[3 * NL + j] = a.t.v[j]; }
   uint4* o = reinterpret_cast<uint4*>(dst);
-  o[0] = make_uint4(a.x.v[0], a.x.v[1], a.x.v[2], a.x.v[3]); o[1] = make_uint4(a.x.v[4], a.x.v[5], a.x.v[6], a.x.v[7]);
-  o[2] = make_uint4(a.y.v[0], a.y.v[1], a.y.v[2], a.y.v[3]); o[3] = make_uint4(a.y.v[4], a.y.v[5], a.y.v[6], a.y.v[7]);
-  o[4] = make_uint4(a.z.v[0], a.z.v[1], a.z.v[2], a.z.v[3]); o[5] = make_uint4(a.z.v[4], a.z.v[5], a.z.v[6], a.z.v[7]);
-  o[6] = make_uint4(a.t.v[0], a.t.v[1], a.t.v[2], a.t.v[3]); o[7] = make_uint4(a.t.v[4], a.t.v[5], a.t.v[6], a.t.v[7]);
+#pragma unroll
+  for (int j = 0; j < 9; j++) o[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
 }
 __device__ __forceinline__ ete load_ete(const ete* src) {
   const uint4* q = reinterpret_cast<const uint4*>(src);
-  ete a; uint4 u;
-  u = q[0]; a.x.v[0] = u.x; a.x.v[1] = u.y; a.x.v[2] = u.z; a.x.v[3] = u.w; u = q[1]; a.x.v[4] = u.x; a.x.v[5] = u.y; a.x.v[6] = u.z; a.x.v[7] = u.w;
-  u = q[2]; a.y.v[0] = u.x; a.y.v[1] = u.y; a.y.v[2] = u.z; a.y.v[3] = u.w; u = q[3]; a.y.v[4] = u.x; a.y.v[5] = u.y; a.y.v[6] = u.z; a.y.v[7] = u.w;
-  u = q[4]; a.z.v[0] = u.x; a.z.v[1] = u.y; a.z.v[2] = u.z; a.z.v[3] = u.w; u = q[5]; a.z.v[4] = u.x; a.z.v[5] = u.y; a.z.v[6] = u.z; a.z.v[7] = u.w;
-  u = q[6]; a.t.v[0] = u.x; a.t.v[1] = u.y; a.t.v[2] = u.z; a.t.v[3] = u.w; u = q[7]; a.t.v[4] = u.x; a.t.v[5] = u.y; a.t.v[6] = u.z; a.t.v[7] = u.w;
+  uint32_t w[36];
+#pragma unroll
+  for (int j = 0; j < 9; j++) { const uint4 u = q[j]; w[4 * j] = u.x; w[4 * j + 1] = u.y; w[4 * j + 2] = u.z; w[4 * j + 3] = u.w; }
+  ete a;
+#pragma unroll
+  for (int j = 0; j < NL; j++) { a.x.v[j] = w[j]; a.y.v[j] = w[NL + j]; a.z.v[j] = w[2 * NL + j]; a.t.v[j] = w[3 * NL + j]; }
   return a;
 }
 
-__global__ void __launch_bounds__(256) k_accumulate(const pnt* __restrict__ recs, const uint32_t* __restrict__ sorted,
+__global__ void __launch_bounds__(256) k_accumulate(const pnt_slot* __restrict__ recs, const uint32_t* __restrict__ sorted,
                                                     const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ bucket_count,
                                                     const uint32_t* __restrict__ order, ete* __restrict__ buckets,
                                                     uint32_t n, uint32_t logB, uint32_t total) {
@@ -545,7 +554,7 @@ __global__ void __launch_bounds__(256) k_sum_groups(sum_job j0, sum_job j1, uint
 //   total = sum_v E_v,  weighted = sum_v v * E_v = sum_{v >= 1} S_v,  S_v = sum_{u >= v} E_u.
 // Suffix sums by a log-step scan in LDS, then a tree sum of S_1..S_{N-1}.  blockIdx.x selects the
 // problem (0: the RH row sums -> total + weighted, 1: the RL column sums -> weighted), blockIdx.y the
-// window; threads >= N hold the identity.  dynamic LDS = blockDim.x * 128 B.
+// window; threads >= N hold the identity.  dynamic LDS = blockDim.x * 144 B.
 struct wsum_job { const ete* in; ete* out_total; ete* out_weighted; uint32_t N; };
 __global__ void __launch_bounds__(256) k_weighted_sum(wsum_job j0, wsum_job j1, uint32_t out_stride) {
   extern __shared__ uint4 lds_u4[];

@@ -41,13 +41,13 @@ struct gpu_t {
   hipStream_t stream = nullptr;
   size_t cap[20] = {};                // per-buffer capacity in bytes (ensure())
   int cap_W = 0;
-  te::pnt* d_recs = nullptr;
+  te::pnt_slot* d_recs = nullptr;
   uint16_t* d_digits = nullptr;
   uint32_t *d_counts1 = nullptr, *d_part_start = nullptr, *d_part_count = nullptr, *d_part_idx = nullptr;
   uint32_t *d_bucket_count = nullptr, *d_bucket_start = nullptr, *d_bucket_cursor = nullptr, *d_seg_total = nullptr, *d_sorted = nullptr, *d_order = nullptr, *d_size_hist = nullptr, *d_size_cursor = nullptr;
   uint16_t* d_part_keys = nullptr;
   te::ete *d_buckets = nullptr, *d_red[4] = {nullptr, nullptr, nullptr, nullptr};   // reduction ping/pong: rows a,b  cols a,b
-  uint8_t* d_partials = nullptr;      // W x 384
+  uint8_t* d_partials = nullptr;      // W x 432
   uint32_t* d_err = nullptr;
   uint32_t* h_err = nullptr;          // pinned
   uint8_t* h_partials = nullptr;      // pinned, W x 384
@@ -179,8 +179,10 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, const void* d_points, const void* d_s
   if (int rc = ensure_buffers(ctx, d, n, p)) return rc;
   d.last_plan = p; d.last_n = n; d.have_last = true;
   HIP_TRY(ctx, hipSetDevice(d.device));
-  const bool prof = ctx->opt_profile != 0;
-  auto mark = [&](int i) { if (prof) (void)hipEventRecord(d.ev[i], stream); };
+  // profile 1: two events around the dominant kernel only (what bench.py times live); 2: every stage boundary
+  // (an event between two kernels costs ~4 us of idle stream time, 11 of them ~2 % of a 2^20 MSM)
+  const int prof = ctx->opt_profile;
+  auto mark = [&](int i) { if (prof >= 2 || (prof == 1 && (i == ST_ACCUM || i == ST_ACCUM + 1))) (void)hipEventRecord(d.ev[i], stream); };
   const uint32_t n32 = (uint32_t)n;
 
   HIP_TRY(ctx, hipMemsetAsync(d.d_err, 0, sizeof(uint32_t), stream));
@@ -281,7 +283,7 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, const void* d_points, const void* d_s
     const uint32_t stride = (uint32_t)d.w_step * 3u;
     te::wsum_job j0 = {row_res, rows, rows + 1, p.RH}, j1 = {col_res, nullptr, rows + 2, p.RL};
     const uint32_t T = p.RH > p.RL ? p.RH : p.RL;
-    hipLaunchKernelGGL(te::k_weighted_sum, dim3(2, p.nw), dim3(T), (size_t)T * 128, stream, j0, j1, stride);
+    hipLaunchKernelGGL(te::k_weighted_sum, dim3(2, p.nw), dim3(T), (size_t)T * sizeof(te::ete), stream, j0, j1, stride);
   }
   mark(ST_COUNT);
   HIP_TRY(ctx, hipMemcpyAsync(d.h_err, d.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -293,8 +295,8 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, const void* d_points, const void* d_s
 int collect_stage_ms(te_ctx* ctx, gpu_t& d) {
   if (!ctx->opt_profile) return 0;
   for (int i = 0; i < ST_COUNT; i++) {
-    float ms = 0;
-    HIP_TRY(ctx, hipEventElapsedTime(&ms, d.ev[i], d.ev[i + 1]));
+    float ms = -1.0f;
+    if (ctx->opt_profile >= 2 || i == ST_ACCUM) HIP_TRY(ctx, hipEventElapsedTime(&ms, d.ev[i], d.ev[i + 1]));
     ctx->stage_ms[i] = ms;
   }
   ctx->have_stage_ms = true;
@@ -425,7 +427,7 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   if (!ctx || !key) return TE_MSM_EINVAL;
   if (!strcmp(key, "window_bits")) { if (value != 0 && (value < 4 || value > 16)) return set_err(ctx, TE_MSM_EINVAL, "window_bits must be 0 or in [4,16]"); ctx->opt_window_bits = (int)value; return 0; }
   if (!strcmp(key, "sort_buckets")) { ctx->opt_sort = value ? 1 : 0; return 0; }
-  if (!strcmp(key, "profile")) { ctx->opt_profile = value ? 1 : 0; return 0; }
+  if (!strcmp(key, "profile")) { ctx->opt_profile = value < 0 ? 0 : (value > 2 ? 2 : (int)value); ctx->have_stage_ms = false; return 0; }
   if (!strcmp(key, "debug_cut")) { ctx->opt_dbg = (int)value; return 0; }
   if (!strcmp(key, "sort_s")) { ctx->opt_sort_s = (int)value; return 0; }
   return set_err(ctx, TE_MSM_EINVAL, "unknown option");
@@ -487,7 +489,10 @@ int te_msm_stage_ms(te_ctx* ctx, float* ms, const char** names, int max_stages) 
   if (!ctx || !ms) return TE_MSM_EINVAL;
   if (!ctx->have_stage_ms) return set_err(ctx, TE_MSM_ESTATE, "no profiled run yet (set option profile=1)");
   int k = 0;
-  for (; k < ST_COUNT && k < max_stages; k++) { ms[k] = ctx->stage_ms[k]; if (names) names[k] = kStageNames[k]; }
+  for (int i = 0; i < ST_COUNT && k < max_stages; i++) {
+    if (ctx->stage_ms[i] < 0) continue;            // not measured at this profile level
+    ms[k] = ctx->stage_ms[i]; if (names) names[k] = kStageNames[i]; k++;
+  }
   return k;
 }
 
@@ -497,7 +502,7 @@ int64_t te_msm_debug_read(te_ctx* ctx, const char* stage, void* dst, uint64_t ca
   if (!d.have_last) return set_err(ctx, TE_MSM_ESTATE, "no run yet");
   const plan_t& p = d.last_plan; const uint64_t n = d.last_n;
   const void* src = nullptr; uint64_t bytes = 0;
-  if (!strcmp(stage, "records")) { src = d.d_recs; bytes = n * sizeof(te::pnt); }
+  if (!strcmp(stage, "records")) { src = d.d_recs; bytes = n * sizeof(te::pnt_slot); }
   else if (!strcmp(stage, "digits")) { src = d.d_digits; bytes = (uint64_t)p.nw * p.nst * 2; }   // row stride nst = n rounded up to 8
   else if (!strcmp(stage, "bucket_count")) { src = d.d_bucket_count; bytes = (uint64_t)p.nw * p.B * 4; }
   else if (!strcmp(stage, "bucket_start")) { src = d.d_bucket_start; bytes = (uint64_t)p.nw * p.B * 4; }
