@@ -59,6 +59,7 @@ int te_msm_run_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_sca
 /* Options (the reference hard-codes these: chunk_size submission.ts:80, dispatch table :109-142).
  *   "window_bits"   c in [4,16]; 0 = choose from n (default)
  *   "sort_buckets"  1 = schedule buckets by descending size (default), 0 = natural order
+ *   "segment_len"   a bucket longer than this is accumulated by several threads (default 64)
  *   "profile"       1 = HIP events around the dominant kernel (accumulate) only, 2 = around every stage
  *                   (te_msm_stage_ms); 0 = none (default)                                    */
 int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value);
@@ -93,7 +94,8 @@ int te_msm_finalize_host(const uint8_t* partials, int window_bits, int num_windo
 int te_msm_stage_ms(te_ctx* ctx, float* ms, const char** names, int max_stages);
 /* Copies an intermediate buffer of the last run to host memory.  stage is one of
  * "records" (n x 128 B), "digits" / "part_keys" (nw rows of u16, row stride n rounded up to 8), "part_idx" (same rows, u32),
- * "part_start" / "part_count" (nw x P u32), "bucket_count" / "bucket_start" / "order" (nw x B u32), "sorted" (nw x n u32),
+ * "part_start" / "part_count" (nw x P u32), "bucket_count" / "bucket_start" (nw x B u32), "sorted" (nw x n u32), "num_segments" (u32),
+ * "seg_bucket" / "seg_len" / "order" (num_segments u32),
  * "buckets" (nw x B x 144 B), "partials" (W x 432 B).  Returns bytes copied
  * (<= cap) or a negative error. */
 int64_t te_msm_debug_read(te_ctx* ctx, const char* stage, void* dst, uint64_t cap);

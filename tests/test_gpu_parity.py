@@ -82,10 +82,21 @@ def test_stages_against_oracle(ctx, fpcheck, model, ora, n, c):
         assert np.array_equal(np.sort(idx), np.sort(np.nonzero(nz)[0])), "sorted is not a permutation of the non-zero digits"
         assert np.array_equal(bucket[idx], np.repeat(np.arange(B), e_cnt)), "entry in the wrong bucket"
         assert np.array_equal(neg.astype(bool), d[idx] < 0), "sign bit"
-    order = np.frombuffer(ctx.debug_read("order", W * B * 4), dtype=np.uint32)
-    assert np.array_equal(np.sort(order), np.arange(W * B)), "order is not a permutation"
-    sizes = cnt.reshape(-1)[order]
-    assert np.all(np.minimum(sizes[:-1], 1023) >= np.minimum(sizes[1:], 1023)), "order is not descending"
+    # work segments: every bucket is cut into pieces of at most segment_len entries; the schedule is a permutation of
+    # the segments in descending length
+    seg_len = ctx.get_option("segment_len")
+    nseg = int(np.frombuffer(ctx.debug_read("num_segments", 4), dtype=np.uint32)[0])
+    per_bucket = np.maximum(1, -(-cnt.reshape(-1).astype(np.int64) // seg_len))
+    assert nseg == int(per_bucket.sum())
+    seg_bucket = np.frombuffer(ctx.debug_read("seg_bucket", nseg * 4), dtype=np.uint32)
+    seg_lens = np.frombuffer(ctx.debug_read("seg_len", nseg * 4), dtype=np.uint32)
+    assert np.array_equal(seg_bucket, np.repeat(np.arange(W * B), per_bucket))
+    assert np.array_equal(np.bincount(seg_bucket, weights=seg_lens, minlength=W * B).astype(np.int64), cnt.reshape(-1).astype(np.int64))
+    assert seg_lens.max() <= seg_len
+    order = np.frombuffer(ctx.debug_read("order", nseg * 4), dtype=np.uint32)
+    assert np.array_equal(np.sort(order), np.arange(nseg)), "order is not a permutation of the segments"
+    sizes = seg_lens[order]
+    assert np.all(sizes[:-1] >= sizes[1:]), "order is not descending"
     # K3: a sample of bucket sums == affine sums of the model
     bk = ctx.debug_read("buckets", W * B * 144)
     P = model.P
@@ -136,6 +147,20 @@ def test_every_window_size(ctx, ora, c):
 def test_ragged_sizes(ctx, ora, n):
     pts, sc = ora.gen_points(n, n), ora.gen_scalars(n, n)
     assert ctx.run(pts, sc) == ora.msm(pts, sc, threads=8)
+
+
+@pytest.mark.parametrize("seg_len", [1, 3, 16, 64, 100000])
+def test_segment_lengths(ctx, ora, seg_len):
+    """bucket splitting: any segment length gives the same point (the top window of a 253-bit scalar has ~219-entry buckets at n = 2^20)"""
+    n = 40000
+    pts, sc = ora.gen_points(61, n), ora.gen_scalars(61, n)
+    exp = ora.msm(pts, sc, threads=8)
+    ctx.set_option("segment_len", seg_len)
+    for c in (8, 13):
+        ctx.set_option("window_bits", c)
+        assert ctx.run(pts, sc) == exp
+    ctx.set_option("window_bits", 0)
+    ctx.set_option("segment_len", 64)
 
 
 def test_empty_input(ctx):

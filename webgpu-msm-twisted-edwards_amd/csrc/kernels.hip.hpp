@@ -335,24 +335,41 @@ __global__ void __launch_bounds__(256) k_l2_count(const uint16_t* __restrict__ p
 }
 
 // exclusive scan of bucket_count per window: a = per 1024-bucket segment, b = add the bases
+// Two quantities are scanned together: the bucket sizes (-> bucket_start / bucket_cursor, per window) and the number
+// of work segments per bucket, max(1, ceil(count / seg_len)) (-> seg_base, one running index over ALL windows).
 __global__ void __launch_bounds__(1024) k_bscan_a(const uint32_t* __restrict__ bucket_count, uint32_t* __restrict__ local_excl,
-                                                  uint32_t* __restrict__ seg_total, uint32_t B) {
+                                                  uint32_t* __restrict__ local_excl_seg, uint32_t* __restrict__ seg_total,
+                                                  uint32_t B, uint32_t seg_len) {
   __shared__ uint32_t sm[17];
   const uint32_t seg = blockIdx.x, k = blockIdx.y, b = seg * blockDim.x + threadIdx.x;
   const uint32_t v = b < B ? bucket_count[(size_t)k * B + b] : 0u;
-  uint32_t bt;
+  const uint32_t ns = b < B ? max(1u, (v + seg_len - 1u) / seg_len) : 0u;
+  uint32_t bt, bt2;
   const uint32_t ex = block_excl_scan(v, sm, bt);
-  if (b < B) local_excl[(size_t)k * B + b] = ex;
-  if (threadIdx.x == 0) seg_total[k * gridDim.x + seg] = bt;
+  const uint32_t ex2 = block_excl_scan(ns, sm, bt2);
+  if (b < B) { local_excl[(size_t)k * B + b] = ex; local_excl_seg[(size_t)k * B + b] = ex2; }
+  if (threadIdx.x == 0) { seg_total[2 * (k * gridDim.x + seg)] = bt; seg_total[2 * (k * gridDim.x + seg) + 1] = bt2; }
 }
-__global__ void __launch_bounds__(1024) k_bscan_b(const uint32_t* __restrict__ local_excl, const uint32_t* __restrict__ seg_total,
-                                                  uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ bucket_cursor, uint32_t B) {
-  __shared__ uint32_t base_s;
-  const uint32_t seg = blockIdx.x, k = blockIdx.y;
-  if (threadIdx.x == 0) { uint32_t base = 0; for (uint32_t s = 0; s < seg; s++) base += seg_total[k * gridDim.x + s]; base_s = base; }
+__global__ void __launch_bounds__(1024) k_bscan_b(const uint32_t* __restrict__ local_excl, uint32_t* __restrict__ seg_base /* in: local, out: global */,
+                                                  const uint32_t* __restrict__ seg_total, uint32_t* __restrict__ bucket_start,
+                                                  uint32_t* __restrict__ bucket_cursor, uint32_t* __restrict__ num_segments, uint32_t B) {
+  __shared__ uint32_t base_s, base2_s;
+  const uint32_t seg = blockIdx.x, k = blockIdx.y, nseg = gridDim.x;
+  if (threadIdx.x == 0) {
+    uint32_t base = 0, base2 = 0;
+    for (uint32_t s = 0; s < seg; s++) base += seg_total[2 * (k * nseg + s)];
+    for (uint32_t s = 0; s < k * nseg + seg; s++) base2 += seg_total[2 * s + 1];      // segments are numbered across windows
+    base_s = base; base2_s = base2;
+    if (k == gridDim.y - 1 && seg == nseg - 1) *num_segments = base2 + seg_total[2 * (k * nseg + seg) + 1];
+  }
   __syncthreads();
   const uint32_t b = seg * blockDim.x + threadIdx.x;
-  if (b < B) { const uint32_t v = base_s + local_excl[(size_t)k * B + b]; bucket_start[(size_t)k * B + b] = v; bucket_cursor[(size_t)k * B + b] = v; }
+  if (b < B) {
+    const size_t g = (size_t)k * B + b;
+    const uint32_t v = base_s + local_excl[g];
+    bucket_start[g] = v; bucket_cursor[g] = v;
+    seg_base[g] = base2_s + seg_base[g];
+  }
 }
 
 // grid (nslices, nw), block 256
@@ -418,19 +435,38 @@ __global__ void __launch_bounds__(256) k_l2_place(const uint16_t* __restrict__ p
 }
 
 // ------------------------------------------------------------------------------------------------
-// Bucket scheduling: the work of bucket accumulation is one thread per bucket; bucket sizes are
-// Poisson(n/B), so a wave of 64 natural-order buckets idles ~30 % of its lanes.  k_order_* sort the
-// (window, bucket) pairs by descending size (counting sort on min(count, 1023)) so that the 64
-// buckets of a wave have (nearly) equal length and the biggest buckets start first.
-__global__ void __launch_bounds__(256) k_order_hist(const uint32_t* __restrict__ bucket_count, uint32_t total, uint32_t* __restrict__ size_hist) {
+// Work scheduling.  The unit of work of bucket accumulation is a SEGMENT: at most seg_len consecutive entries of one
+// bucket, one thread each.  Two reasons:
+//  * bucket sizes are Poisson(n/B): a wave of 64 natural-order buckets idles ~30 % of its lanes, so segments are
+//    sorted by descending length (counting sort on the length) and a wave gets 64 segments of equal length;
+//  * a bucket that is much larger than the rest would otherwise be ONE thread's serial chain and set the kernel's
+//    duration on its own -- every 253-bit scalar does this: its top window has only ~4.8k occupied buckets of ~219
+//    entries (1.13 ms of serial additions against ~1 ms for everything else); skewed scalars do it in general.
+// Buckets split into several segments are summed afterwards by k_seg_combine.
+//   k_seg_build  : thread per segment -> (bucket, part) by binary search in seg_base, and its length
+//   k_order_*    : counting sort of segment ids by descending length
+__global__ void __launch_bounds__(256) k_seg_build(const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ bucket_count,
+                                                   const uint32_t* __restrict__ num_segments, uint32_t total_buckets, uint32_t seg_len,
+                                                   uint32_t* __restrict__ seg_bucket, uint32_t* __restrict__ seg_lenv) {
+  const uint32_t ns = *num_segments;
+  for (uint32_t s = blockIdx.x * 256u + threadIdx.x; s < ns; s += gridDim.x * 256u) {
+    uint32_t lo = 0, hi = total_buckets;            // last bucket g with seg_base[g] <= s
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seg_base[mid] <= s) lo = mid; else hi = mid; }
+    const uint32_t part = s - seg_base[lo], cnt = bucket_count[lo];
+    seg_bucket[s] = lo;
+    seg_lenv[s] = cnt > part * seg_len ? min(seg_len, cnt - part * seg_len) : 0u;
+  }
+}
+__global__ void __launch_bounds__(256) k_order_hist(const uint32_t* __restrict__ lenv, const uint32_t* __restrict__ num_items, uint32_t* __restrict__ size_hist) {
   __shared__ uint32_t h[1024];
+  const uint32_t total = *num_items;
   for (uint32_t j = threadIdx.x; j < 1024u; j += 256u) h[j] = 0;
   __syncthreads();
-  for (uint32_t g = blockIdx.x * 256u + threadIdx.x; g < total; g += gridDim.x * 256u) atomicAdd(&h[min(bucket_count[g], 1023u)], 1u);
+  for (uint32_t g = blockIdx.x * 256u + threadIdx.x; g < total; g += gridDim.x * 256u) atomicAdd(&h[min(lenv[g], 1023u)], 1u);
   __syncthreads();
   for (uint32_t j = threadIdx.x; j < 1024u; j += 256u) if (h[j]) atomicAdd(&size_hist[j], h[j]);
 }
-// one block of 1024: size_cursor[s] = number of buckets with size > s  (descending order start)
+// one block of 1024: size_cursor[s] = number of items with size > s  (descending order start)
 __global__ void __launch_bounds__(1024) k_order_scan(const uint32_t* __restrict__ size_hist, uint32_t* __restrict__ size_cursor) {
   __shared__ uint32_t sm[17];
   const uint32_t s = 1023u - threadIdx.x;          // thread 0 handles the largest size
@@ -438,29 +474,31 @@ __global__ void __launch_bounds__(1024) k_order_scan(const uint32_t* __restrict_
   const uint32_t ex = block_excl_scan(size_hist[s], sm, bt);
   size_cursor[s] = ex;
 }
-__global__ void __launch_bounds__(256) k_order_scatter(const uint32_t* __restrict__ bucket_count, uint32_t total,
+__global__ void __launch_bounds__(256) k_order_scatter(const uint32_t* __restrict__ lenv, const uint32_t* __restrict__ num_items,
                                                        uint32_t* __restrict__ size_cursor, uint32_t* __restrict__ order) {
   __shared__ uint32_t h[1024];
   __shared__ uint32_t base[1024];
+  const uint32_t total = *num_items;
   for (uint32_t j = threadIdx.x; j < 1024u; j += 256u) h[j] = 0;
   __syncthreads();
   // the block owns a contiguous slice so that each thread sees the same elements in both passes
   const uint32_t per = (total + gridDim.x - 1) / gridDim.x;
   const uint32_t lo = blockIdx.x * per, hi = min(total, lo + per);
-  for (uint32_t g = lo + threadIdx.x; g < hi; g += 256u) atomicAdd(&h[min(bucket_count[g], 1023u)], 1u);
+  for (uint32_t g = lo + threadIdx.x; g < hi; g += 256u) atomicAdd(&h[min(lenv[g], 1023u)], 1u);
   __syncthreads();
   for (uint32_t j = threadIdx.x; j < 1024u; j += 256u) { base[j] = h[j] ? atomicAdd(&size_cursor[j], h[j]) : 0u; h[j] = 0; }
   __syncthreads();
   for (uint32_t g = lo + threadIdx.x; g < hi; g += 256u) {
-    const uint32_t s = min(bucket_count[g], 1023u);
+    const uint32_t s = min(lenv[g], 1023u);
     const uint32_t pos = base[s] + atomicAdd(&h[s], 1u);
     order[pos] = g;
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3: bucket accumulation, one thread per (window, bucket), scheduled through order[] (or natural
-// order when order == nullptr).  The next record is fetched while the current addition runs.
+// K3: bucket accumulation, one thread per segment, scheduled through order[] (or natural order when
+// order == nullptr).  The next record is fetched while the current addition runs.  A bucket that is a single
+// segment is written straight to buckets[]; parts of a split bucket go to seg_out[] for k_seg_combine.
 // (A variant that fused level 2 of the sort into this kernel -- one block per 256 buckets, lists consumed
 // straight from LDS -- was measured at 2.8 ms against 1.4 ms: block-granular scheduling leaves < 1 wave per
 // SIMD resident on average (SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE = 0.78), far too few to hide gather latency.)
@@ -499,14 +537,18 @@ __device__ __forceinline__ ete load_ete(const ete* src) {
 
 __global__ void __launch_bounds__(256) k_accumulate(const pnt_slot* __restrict__ recs, const uint32_t* __restrict__ sorted,
                                                     const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ bucket_count,
-                                                    const uint32_t* __restrict__ order, ete* __restrict__ buckets,
-                                                    uint32_t n, uint32_t logB, uint32_t total) {
+                                                    const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ seg_bucket,
+                                                    const uint32_t* __restrict__ seg_lenv, const uint32_t* __restrict__ order,
+                                                    const uint32_t* __restrict__ num_segments, ete* __restrict__ buckets,
+                                                    ete* __restrict__ seg_out, uint32_t n, uint32_t logB, uint32_t seg_len) {
   const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
-  if (gid >= total) return;
-  const uint32_t g = order ? order[gid] : gid;      // g = k * B + b
+  if (gid >= *num_segments) return;
+  const uint32_t sgm = order ? order[gid] : gid;
+  const uint32_t g = seg_bucket[sgm];                // g = k * B + b
   const uint32_t k = g >> logB;
-  const uint32_t cnt = bucket_count[g];
-  const uint32_t* lst = sorted + (size_t)k * n + bucket_start[g];
+  const uint32_t part = sgm - seg_base[g];
+  const uint32_t cnt = seg_lenv[sgm];
+  const uint32_t* lst = sorted + (size_t)k * n + bucket_start[g] + part * seg_len;
   ete acc = ete_identity();
   if (cnt) {
     uint32_t e = lst[0];
@@ -519,6 +561,20 @@ __global__ void __launch_bounds__(256) k_accumulate(const pnt_slot* __restrict__
       cur = nxt;
     }
   }
+  const bool whole = bucket_count[g] <= seg_len;
+  store_ete(whole ? buckets + g : seg_out + sgm, acc);
+}
+
+// sums the parts of every split bucket (thread per bucket; unsplit buckets were written by k_accumulate)
+__global__ void __launch_bounds__(256) k_seg_combine(const uint32_t* __restrict__ bucket_count, const uint32_t* __restrict__ seg_base,
+                                                     const ete* __restrict__ seg_out, ete* __restrict__ buckets, uint32_t total_buckets, uint32_t seg_len) {
+  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+  if (g >= total_buckets) return;
+  const uint32_t cnt = bucket_count[g];
+  if (cnt <= seg_len) return;
+  const uint32_t ns = (cnt + seg_len - 1u) / seg_len, s0 = seg_base[g];
+  ete acc = load_ete(seg_out + s0);
+  for (uint32_t j = 1; j < ns; j++) acc = ete_add(acc, load_ete(seg_out + s0 + j));
   store_ete(buckets + g, acc);
 }
 

@@ -32,6 +32,7 @@ struct plan_t {
   uint32_t B = 0, logB = 0;           // buckets per window = 2^(c-1)
   uint32_t RL = 0, RH = 0, lo_bits = 0;
   uint32_t CH = 0, chunk_len = 0, nst = 0;   // level-1 chunks per window (chunk_len multiple of 4096); padded row stride
+  uint32_t seg_len = 64;
   uint32_t S = 0, logS = 0, P = 0, cap = 0, cpb = 0;   // level-2 partition: S buckets each, P = B/S per window; LDS list entries (cpb per bucket)
 };
 
@@ -39,11 +40,13 @@ struct gpu_t {
   int device = 0;
   int w_first = 0, w_step = 1;
   hipStream_t stream = nullptr;
-  size_t cap[20] = {};                // per-buffer capacity in bytes (ensure())
+  size_t cap[28] = {};                // per-buffer capacity in bytes (ensure())
   int cap_W = 0;
   te::pnt_slot* d_recs = nullptr;
   uint16_t* d_digits = nullptr;
   uint32_t *d_counts1 = nullptr, *d_part_start = nullptr, *d_part_count = nullptr, *d_part_idx = nullptr;
+  uint32_t *d_seg_base = nullptr, *d_seg_bucket = nullptr, *d_seg_lenv = nullptr, *d_num_seg = nullptr;
+  te::ete* d_seg_out = nullptr;
   uint32_t *d_bucket_count = nullptr, *d_bucket_start = nullptr, *d_bucket_cursor = nullptr, *d_seg_total = nullptr, *d_sorted = nullptr, *d_order = nullptr, *d_size_hist = nullptr, *d_size_cursor = nullptr;
   uint16_t* d_part_keys = nullptr;
   te::ete *d_buckets = nullptr, *d_red[4] = {nullptr, nullptr, nullptr, nullptr};   // reduction ping/pong: rows a,b  cols a,b
@@ -67,6 +70,7 @@ struct te_ctx {
   int opt_profile = 0;
   int opt_dbg = 0;
   int opt_sort_s = 0;
+  int opt_seg_len = 64;        // work segment: at most this many entries of one bucket per thread
   float stage_ms[ST_COUNT] = {};
   bool have_stage_ms = false;
 };
@@ -122,6 +126,7 @@ void make_plan(const te_ctx* ctx, const gpu_t& d, uint64_t n, plan_t& p) {
   const double avg = (double)n / (double)p.B;                   // mean bucket size
   p.cpb = (avg + 8.0 * (avg > 1 ? __builtin_sqrt(avg / p.S) : 1.0) + 1.0 <= 35.0) ? 35u : 70u;
   p.cap = p.cpb * p.S;
+  p.seg_len = (uint32_t)ctx->opt_seg_len;
   p.P = p.B / p.S; p.logS = ilog2(p.S);
 }
 
@@ -146,8 +151,13 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, uint64_t n, const plan_t& p) {
   if ((rc = ensure(ctx, d.d_bucket_count, d.cap[4], wb))) return rc;
   if ((rc = ensure(ctx, d.d_bucket_start, d.cap[5], wb))) return rc;
   if ((rc = ensure(ctx, d.d_bucket_cursor, d.cap[0 + 16], wb))) return rc;
-  if ((rc = ensure(ctx, d.d_seg_total, d.cap[17], (size_t)p.nw * 64 + 64))) return rc;
-  if ((rc = ensure(ctx, d.d_order, d.cap[7], wb))) return rc;
+  if ((rc = ensure(ctx, d.d_seg_total, d.cap[17], (size_t)p.nw * 128 + 128))) return rc;
+  const size_t smax = wb + (size_t)p.nw * (n / (uint64_t)p.seg_len) + 16;      // segments <= buckets + entries / seg_len
+  if ((rc = ensure(ctx, d.d_order, d.cap[7], smax))) return rc;
+  if ((rc = ensure(ctx, d.d_seg_bucket, d.cap[20], smax))) return rc;
+  if ((rc = ensure(ctx, d.d_seg_lenv, d.cap[21], smax))) return rc;
+  if ((rc = ensure(ctx, d.d_seg_out, d.cap[22], smax))) return rc;
+  if ((rc = ensure(ctx, d.d_seg_base, d.cap[23], wb + 1))) return rc;
   if ((rc = ensure(ctx, d.d_part_start, d.cap[6], (size_t)p.nw * p.P))) return rc;
   if ((rc = ensure(ctx, d.d_buckets, d.cap[8], wb))) return rc;
   if ((rc = ensure(ctx, d.d_part_count, d.cap[9], (size_t)p.nw * p.P))) return rc;
@@ -231,27 +241,36 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, const void* d_points, const void* d_s
     HIP_TRY(ctx, hipMemsetAsync(d.d_bucket_count, 0, (size_t)p.nw * p.B * sizeof(uint32_t), stream));
     hipLaunchKernelGGL(te::k_l2_count, dim3(nslices, p.nw), dim3(256), 0, stream, d.d_part_keys, d.d_part_idx, d.d_part_start,
                        d.d_part_count, d.d_bucket_count, sg);
-    hipLaunchKernelGGL(te::k_bscan_a, dim3(nseg, p.nw), dim3(seg_threads), 0, stream, d.d_bucket_count, d.d_bucket_cursor, d.d_seg_total, p.B);
-    hipLaunchKernelGGL(te::k_bscan_b, dim3(nseg, p.nw), dim3(seg_threads), 0, stream, d.d_bucket_cursor, d.d_seg_total, d.d_bucket_start,
-                       d.d_bucket_cursor, p.B);
+    hipLaunchKernelGGL(te::k_bscan_a, dim3(nseg, p.nw), dim3(seg_threads), 0, stream, d.d_bucket_count, d.d_bucket_cursor, d.d_seg_base,
+                       d.d_seg_total, p.B, p.seg_len);
+    hipLaunchKernelGGL(te::k_bscan_b, dim3(nseg, p.nw), dim3(seg_threads), 0, stream, d.d_bucket_cursor, d.d_seg_base, d.d_seg_total,
+                       d.d_bucket_start, d.d_bucket_cursor, d.d_num_seg, p.B);
     hipLaunchKernelGGL(te::k_l2_place, dim3(nslices, p.nw), dim3(256), 0, stream, d.d_part_keys, d.d_part_idx, d.d_part_start,
                        d.d_part_count, d.d_bucket_cursor, d.d_sorted, sg);
   }
   const uint32_t total = (uint32_t)p.nw * p.B;
+  const uint32_t smax = total + (uint32_t)((uint64_t)p.nw * (n / p.seg_len));
   mark(ST_ORDER);
   const uint32_t* order = nullptr;
-  if (p.nw > 0 && ctx->opt_sort) {
-    HIP_TRY(ctx, hipMemsetAsync(d.d_size_hist, 0, 1024 * sizeof(uint32_t), stream));
-    uint32_t ob = (total + 4095) / 4096; if (ob > 512) ob = 512; if (ob < 1) ob = 1;
-    hipLaunchKernelGGL(te::k_order_hist, dim3(ob), dim3(256), 0, stream, d.d_bucket_count, total, d.d_size_hist);
-    hipLaunchKernelGGL(te::k_order_scan, dim3(1), dim3(1024), 0, stream, d.d_size_hist, d.d_size_cursor);
-    hipLaunchKernelGGL(te::k_order_scatter, dim3(ob), dim3(256), 0, stream, d.d_bucket_count, total, d.d_size_cursor, d.d_order);
-    order = d.d_order;
+  if (p.nw > 0) {
+    hipLaunchKernelGGL(te::k_seg_build, dim3(1024), dim3(256), 0, stream, d.d_seg_base, d.d_bucket_count, d.d_num_seg, total, p.seg_len,
+                       d.d_seg_bucket, d.d_seg_lenv);
+    if (ctx->opt_sort) {
+      HIP_TRY(ctx, hipMemsetAsync(d.d_size_hist, 0, 1024 * sizeof(uint32_t), stream));
+      hipLaunchKernelGGL(te::k_order_hist, dim3(256), dim3(256), 0, stream, d.d_seg_lenv, d.d_num_seg, d.d_size_hist);
+      hipLaunchKernelGGL(te::k_order_scan, dim3(1), dim3(1024), 0, stream, d.d_size_hist, d.d_size_cursor);
+      hipLaunchKernelGGL(te::k_order_scatter, dim3(256), dim3(256), 0, stream, d.d_seg_lenv, d.d_num_seg, d.d_size_cursor, d.d_order);
+      order = d.d_order;
+    }
   }
   mark(ST_ACCUM);
-  if (p.nw > 0)
-    hipLaunchKernelGGL(te::k_accumulate, dim3((total + 255) / 256), dim3(256), 0, stream, d.d_recs, d.d_sorted,
-                       d.d_bucket_start, d.d_bucket_count, order, d.d_buckets, n32, p.logB, total);
+  if (p.nw > 0) {
+    hipLaunchKernelGGL(te::k_accumulate, dim3((smax + 255) / 256), dim3(256), 0, stream, d.d_recs, d.d_sorted, d.d_bucket_start,
+                       d.d_bucket_count, d.d_seg_base, d.d_seg_bucket, d.d_seg_lenv, order, d.d_num_seg, d.d_buckets, d.d_seg_out,
+                       n32, p.logB, p.seg_len);
+    hipLaunchKernelGGL(te::k_seg_combine, dim3((total + 255) / 256), dim3(256), 0, stream, d.d_bucket_count, d.d_seg_base, d.d_seg_out,
+                       d.d_buckets, total, p.seg_len);
+  }
   mark(ST_TREE);
   const te::ete *row_res = d.d_buckets, *col_res = d.d_buckets;
   if (p.nw > 0) {
@@ -306,7 +325,7 @@ int collect_stage_ms(te_ctx* ctx, gpu_t& d) {
 void free_dev(gpu_t& d) {
   (void)hipSetDevice(d.device);
   void* ptrs[] = {d.d_recs, d.d_digits, d.d_counts1, d.d_part_start, d.d_part_count, d.d_part_keys, d.d_part_idx, d.d_buckets,
-                  d.d_bucket_count, d.d_bucket_start, d.d_bucket_cursor, d.d_seg_total, d.d_sorted, d.d_order, d.d_size_hist, d.d_size_cursor, d.d_red[0], d.d_red[1], d.d_red[2], d.d_red[3], d.d_partials,
+                  d.d_bucket_count, d.d_bucket_start, d.d_bucket_cursor, d.d_seg_total, d.d_sorted, d.d_seg_base, d.d_seg_bucket, d.d_seg_lenv, d.d_seg_out, d.d_num_seg, d.d_order, d.d_size_hist, d.d_size_cursor, d.d_red[0], d.d_red[1], d.d_red[2], d.d_red[3], d.d_partials,
                   d.d_err, d.d_in_points, d.d_in_scalars};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (d.h_err) (void)hipHostFree(d.h_err);
@@ -391,6 +410,7 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
     hipError_t er = hipSetDevice(d.device);
     if (er == hipSuccess) er = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
     if (er == hipSuccess) er = hipMalloc((void**)&d.d_err, sizeof(uint32_t));
+    if (er == hipSuccess) er = hipMalloc((void**)&d.d_num_seg, 4 * sizeof(uint32_t));
     if (er == hipSuccess) er = hipMalloc((void**)&d.d_size_hist, 1024 * sizeof(uint32_t));
     if (er == hipSuccess) er = hipMalloc((void**)&d.d_size_cursor, 1024 * sizeof(uint32_t));
     if (er == hipSuccess) er = hipHostMalloc((void**)&d.h_err, sizeof(uint32_t), hipHostMallocDefault);
@@ -430,6 +450,7 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   if (!strcmp(key, "profile")) { ctx->opt_profile = value < 0 ? 0 : (value > 2 ? 2 : (int)value); ctx->have_stage_ms = false; return 0; }
   if (!strcmp(key, "debug_cut")) { ctx->opt_dbg = (int)value; return 0; }
   if (!strcmp(key, "sort_s")) { ctx->opt_sort_s = (int)value; return 0; }
+  if (!strcmp(key, "segment_len")) { if (value < 1 || value > 1000000) return set_err(ctx, TE_MSM_EINVAL, "segment_len must be in [1, 1e6]"); ctx->opt_seg_len = (int)value; return 0; }
   return set_err(ctx, TE_MSM_EINVAL, "unknown option");
 }
 
@@ -439,6 +460,7 @@ int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value) {
   if (!strcmp(key, "sort_buckets")) { *value = ctx->opt_sort; return 0; }
   if (!strcmp(key, "profile")) { *value = ctx->opt_profile; return 0; }
   if (!strcmp(key, "num_devices")) { *value = (int64_t)ctx->devs.size(); return 0; }
+  if (!strcmp(key, "segment_len")) { *value = ctx->opt_seg_len; return 0; }
   return set_err(ctx, TE_MSM_EINVAL, "unknown option");
 }
 
@@ -507,7 +529,10 @@ int64_t te_msm_debug_read(te_ctx* ctx, const char* stage, void* dst, uint64_t ca
   else if (!strcmp(stage, "bucket_count")) { src = d.d_bucket_count; bytes = (uint64_t)p.nw * p.B * 4; }
   else if (!strcmp(stage, "bucket_start")) { src = d.d_bucket_start; bytes = (uint64_t)p.nw * p.B * 4; }
   else if (!strcmp(stage, "sorted")) { src = d.d_sorted; bytes = (uint64_t)p.nw * n * 4; }
-  else if (!strcmp(stage, "order")) { src = d.d_order; bytes = (uint64_t)p.nw * p.B * 4; }
+  else if (!strcmp(stage, "num_segments")) { src = d.d_num_seg; bytes = 4; }
+  else if (!strcmp(stage, "seg_bucket")) { src = d.d_seg_bucket; bytes = ((uint64_t)p.nw * p.B + (uint64_t)p.nw * (n / p.seg_len)) * 4; }
+  else if (!strcmp(stage, "seg_len")) { src = d.d_seg_lenv; bytes = ((uint64_t)p.nw * p.B + (uint64_t)p.nw * (n / p.seg_len)) * 4; }
+  else if (!strcmp(stage, "order")) { src = d.d_order; bytes = ((uint64_t)p.nw * p.B + (uint64_t)p.nw * (n / p.seg_len)) * 4; }
   else if (!strcmp(stage, "part_start")) { src = d.d_part_start; bytes = (uint64_t)p.nw * p.P * 4; }
   else if (!strcmp(stage, "part_count")) { src = d.d_part_count; bytes = (uint64_t)p.nw * p.P * 4; }
   else if (!strcmp(stage, "part_keys")) { src = d.d_part_keys; bytes = (uint64_t)p.nw * p.nst * 2; }
