@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--window-bits", type=int, default=16)
     ap.add_argument("--points", choices=["chain", "fixed"], default="chain", help="chain: distinct points (a+i*b)G; fixed: harness mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--segment-len", type=int, default=0)
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
@@ -49,8 +50,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # TE_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box): every rank uses cuda:0 and the exchange goes over gloo
+        share = os.environ.get("TE_BENCH_SHARE_GPU") == "1"
+        if share:
+            local_rank = 0
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = local_rank if world > 1 else 0
     torch.cuda.set_device(dev)
@@ -70,6 +77,8 @@ def main():
 
     ctx = pkg.MsmContext((dev,))
     ctx.set_option("window_bits", args.window_bits)
+    if args.segment_len:
+        ctx.set_option("segment_len", args.segment_len)
     ctx.set_option("profile", 1)          # two HIP events around the dominant kernel, on the engine's stream
     c, W = ctx.plan(n)
     B = 1 << (c - 1)
@@ -160,6 +169,20 @@ def main():
         if exp != result:
             print(json.dumps(out))
             raise SystemExit("GPU result differs from the oracle")
+    if world > 1:
+        # untimed cross-check of the sharded path: the same MSM on this rank's GPU alone must give the same point
+        with pkg.MsmContext((dev,)) as solo:
+            solo.set_option("window_bits", args.window_bits)
+            same = solo.run_device(d_pts.data_ptr(), d_sc.data_ptr(), n) == result
+        flag = torch.tensor([1 if same else 0], dtype=torch.int32, device="cuda")
+        if dist.get_backend() == "gloo":
+            flag = flag.cpu()
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        out["parity"] = "identical to the single-GPU result on every rank" if int(flag.item()) == 1 else "MISMATCH vs single-GPU result"
+        if int(flag.item()) != 1:
+            if rank == 0:
+                print(json.dumps(out))
+            raise SystemExit("window-sharded result differs from the single-GPU result")
     if rank == 0:
         print(json.dumps(out))
     ctx.close()

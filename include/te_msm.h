@@ -74,8 +74,10 @@ int te_msm_plan(te_ctx* ctx, uint64_t n, int* window_bits, int* num_windows);
  * d_partials is W x TE_MSM_PARTIAL_BYTES; only the rows of this context's windows are written
  * (others untouched -- zero the buffer first; an all-zero row means "window not present").
  * Row w = [ sum_j B_j | sum_hi hi*R_hi | sum_lo lo*C_lo ] as extended points (x|y|z|t, each 9 limbs of 29 bits in
- * u32 words, Montgomery form R = 2^261, lazily reduced).  Asynchronous on `stream` (a hipStream_t, may be NULL
- * for the context's own stream); returns after enqueueing. */
+ * u32 words, Montgomery form R = 2^261, lazily reduced).  Asynchronous on `stream`: any hipStream_t (NULL is HIP's
+ * default stream, which is also what PyTorch calls its default stream), or TE_MSM_OWN_STREAM for the context's
+ * private stream; returns after enqueueing. */
+#define TE_MSM_OWN_STREAM ((void*)(intptr_t)-1)
 int te_msm_partial_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_scalars_le, uint64_t n,
                           void* d_partials, void* stream);
 /* Host tail (replaces submission.ts:362-412: de-Montgomery, sum, Horner, toAffine): folds the W rows

@@ -162,8 +162,10 @@ class MsmContext:
         return out.raw
 
     # ---- window-sharded building blocks
-    def partial_device(self, d_points: int, d_scalars: int, n: int, d_partials: int, stream: int = 0):
-        self._check(self._L.te_msm_partial_device(self._h, d_points, d_scalars, n, d_partials, stream))
+    def partial_device(self, d_points: int, d_scalars: int, n: int, d_partials: int, stream: int = -1):
+        """stream: a hipStream_t handle (0 = HIP's default stream, as torch.cuda.current_stream().cuda_stream
+        reports for torch's default stream); -1 = the context's private stream (TE_MSM_OWN_STREAM)."""
+        self._check(self._L.te_msm_partial_device(self._h, d_points, d_scalars, n, d_partials, ctypes.c_void_p(stream)))
 
     def finalize(self, partials: bytes, window_bits: int, num_windows: int) -> bytes:
         out = ctypes.create_string_buffer(64)

@@ -70,10 +70,23 @@ template <int K> TE_HD fp fp_kp_offset();
 // p = 1 (mod 2^29), so -p^-1 mod 2^29 = 2^29 - 1: the quotient digit of a column is q = (-acc) & mask, and adding
 // q*p[0] = q clears the low 29 bits.  Takes operands whose limb magnitudes satisfy the rule above; returns class N
 // with value < a*b/R + p.
+// p[0] = 1 as a value the optimiser cannot see through: "acc += q * one" is then one v_mad_u64_u32 like every
+// other term, instead of a zero-extension (v_mov) plus a 64-bit add.
+TE_HD uint32_t opaque_one() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t one;
+  asm("s_mov_b32 %0, 1" : "=s"(one));
+  return one;
+#else
+  return 1u;
+#endif
+}
+
 TE_HD fp mont_mul(const fp& a, const fp& b) {
   uint32_t q[NL];
   fp r;
   uint64_t acc = 0;
+  const uint32_t one = opaque_one();
 #pragma unroll
   for (int k = 0; k < NL; k++) {
 #pragma unroll
@@ -81,7 +94,7 @@ TE_HD fp mont_mul(const fp& a, const fp& b) {
 #pragma unroll
     for (int i = 0; i < k; i++) acc += (uint64_t)q[i] * p_limb(k - i);
     q[k] = (0u - (uint32_t)acc) & LM;
-    acc += q[k];                       // + q*p[0]: the low 29 bits are now zero
+    acc += (uint64_t)q[k] * one;       // + q*p[0]: the low 29 bits are now zero
     acc >>= LB;
   }
 #pragma unroll

@@ -485,7 +485,7 @@ int te_msm_partial_device(te_ctx* ctx, const void* d_points_xy_le, const void* d
   if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_partial_device needs a single-device context");
   if (!d_points_xy_le || !d_scalars_le || !d_partials || n == 0 || n >= (1ull << 31)) return set_err(ctx, TE_MSM_EINVAL, "bad arguments");
   gpu_t& d = ctx->devs[0];
-  return enqueue_partial(ctx, d, d_points_xy_le, d_scalars_le, n, d_partials, stream ? (hipStream_t)stream : d.stream);
+  return enqueue_partial(ctx, d, d_points_xy_le, d_scalars_le, n, d_partials, stream == TE_MSM_OWN_STREAM ? d.stream : (hipStream_t)stream);
 }
 
 int te_msm_finalize(te_ctx* ctx, const uint8_t* partials, int window_bits, int num_windows, uint8_t out_xy_le[64]) {

@@ -34,6 +34,8 @@ def exchange_partials(partials, num_windows: int, dist=None, group=None, gather_
 
     if dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1:
         world = dist.get_world_size(group)
+        if partials.is_cuda and dist.get_backend(group) == "gloo":
+            partials, gather_list = partials.cpu(), None          # gloo has no CUDA all_gather; .cpu() synchronises the stream
         if gather_list is None:
             gather_list = [torch.empty_like(partials) for _ in range(world)]
         dist.all_gather(gather_list, partials, group=group)
