@@ -56,6 +56,14 @@ int te_msm_run(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars_
 int te_msm_run_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_scalars_le, uint64_t n,
                       uint8_t out_xy_le[64]);
 
+/* Pipelined form of te_msm_run_device (single-device contexts): te_msm_submit_device enqueues every device stage plus
+ * the 7 KB read-back and returns at once with a ticket; te_msm_collect waits for that MSM, runs the host tail and
+ * writes the result.  Up to TWO MSMs may be in flight, so the host tail of MSM k overlaps the device work of MSM
+ * k+1 (the reference's full_benchmarks.ts loop awaits each call; a prover calling MSMs back to back does not have to).
+ * Inputs must stay valid until the ticket is collected.  Tickets must be collected in submission order. */
+int te_msm_submit_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_scalars_le, uint64_t n, uint64_t* ticket);
+int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]);
+
 /* Options (the reference hard-codes these: chunk_size submission.ts:80, dispatch table :109-142).
  *   "window_bits"   c in [4,16]; 0 = choose from n (default)
  *   "sort_buckets"  1 = schedule buckets by descending size (default), 0 = natural order

@@ -309,3 +309,28 @@ def test_node_compute_msm_entry_point(pkg, model, ora, tmp_path):
         out = json.loads(r.stdout.decode().strip().splitlines()[-1])
         assert "x" in out, out
         assert (int(out["x"]), int(out["y"])) == model.xy_from_bytes(ora.msm(pts, sc, threads=8))
+
+
+def test_pipelined_submit_collect(pkg, ora):
+    """two MSMs in flight: results in submission order, each equal to the oracle; protocol errors are reported"""
+    import torch
+    cases = [(11, 30000), (12, 70000), (13, 5000), (14, 30000)]
+    data = []
+    for seed, n in cases:
+        pts, sc = ora.gen_points(seed, n), ora.gen_scalars(seed, n)
+        data.append((_dev(pts), _dev(sc), n, ora.msm(pts, sc, threads=8)))
+    torch.cuda.synchronize()
+    with pkg.MsmContext((0,)) as c:
+        t0 = c.submit_device(data[0][0].data_ptr(), data[0][1].data_ptr(), data[0][2])
+        t1 = c.submit_device(data[1][0].data_ptr(), data[1][1].data_ptr(), data[1][2])
+        with pytest.raises(pkg.MsmError):
+            c.submit_device(data[2][0].data_ptr(), data[2][1].data_ptr(), data[2][2])       # a third one in flight
+        with pytest.raises(pkg.MsmError):
+            c.collect(t1)                                                                     # out of order
+        assert c.collect(t0) == data[0][3]
+        t2 = c.submit_device(data[2][0].data_ptr(), data[2][1].data_ptr(), data[2][2])
+        assert c.collect(t1) == data[1][3]
+        t3 = c.submit_device(data[3][0].data_ptr(), data[3][1].data_ptr(), data[3][2])
+        assert c.collect(t2) == data[2][3]
+        assert c.collect(t3) == data[3][3]
+        assert c.run_device(data[0][0].data_ptr(), data[0][1].data_ptr(), data[0][2]) == data[0][3]

@@ -76,6 +76,10 @@ def _lib() -> ctypes.CDLL:
         L.te_msm_run.restype = ci
         L.te_msm_run_device.argtypes = [vp, vp, vp, u64, cp]
         L.te_msm_run_device.restype = ci
+        L.te_msm_submit_device.argtypes = [vp, vp, vp, u64, ctypes.POINTER(u64)]
+        L.te_msm_submit_device.restype = ci
+        L.te_msm_collect.argtypes = [vp, u64, cp]
+        L.te_msm_collect.restype = ci
         L.te_msm_set_option.argtypes = [vp, cp, ctypes.c_int64]
         L.te_msm_set_option.restype = ci
         L.te_msm_get_option.argtypes = [vp, cp, ctypes.POINTER(ctypes.c_int64)]
@@ -159,6 +163,17 @@ class MsmContext:
     def run_device(self, d_points: int, d_scalars: int, n: int) -> bytes:
         out = ctypes.create_string_buffer(64)
         self._check(self._L.te_msm_run_device(self._h, d_points, d_scalars, n, out))
+        return out.raw
+
+    # ---- pipelined form: up to two MSMs in flight (the host tail of one overlaps the device work of the next)
+    def submit_device(self, d_points: int, d_scalars: int, n: int) -> int:
+        t = ctypes.c_uint64()
+        self._check(self._L.te_msm_submit_device(self._h, d_points, d_scalars, n, ctypes.byref(t)))
+        return t.value
+
+    def collect(self, ticket: int) -> bytes:
+        out = ctypes.create_string_buffer(64)
+        self._check(self._L.te_msm_collect(self._h, ticket, out))
         return out.raw
 
     # ---- window-sharded building blocks

@@ -56,8 +56,12 @@ struct gpu_t {
   uint8_t* h_partials = nullptr;      // pinned, W x 384
   void *d_in_points = nullptr, *d_in_scalars = nullptr; uint64_t cap_in = 0;
   hipEvent_t ev_done = nullptr;
-  hipEvent_t ev[ST_COUNT + 1] = {};
+  hipEvent_t ev[2][ST_COUNT + 1] = {};     // per pipeline slot
   plan_t last_plan; uint64_t last_n = 0; bool have_last = false;
+  // pipelined submit/collect: two slots
+  uint8_t* h_slot_partials[2] = {nullptr, nullptr}; uint32_t* h_slot_err[2] = {nullptr, nullptr};
+  hipEvent_t ev_slot[2] = {nullptr, nullptr}; int slot_c[2] = {0, 0}, slot_W[2] = {0, 0}; int slot_capW = 0;
+  uint64_t next_ticket = 1, next_collect = 1;
 };
 
 }  // namespace
@@ -172,9 +176,10 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, uint64_t n, const plan_t& p) {
     if (d.d_partials) HIP_TRY(ctx, hipFree(d.d_partials));
     if (d.h_partials) HIP_TRY(ctx, hipHostFree(d.h_partials));
     d.d_partials = nullptr; d.h_partials = nullptr; d.cap_W = 0;
-    HIP_TRY(ctx, hipMalloc((void**)&d.d_partials, (size_t)p.W * TE_MSM_PARTIAL_BYTES));
-    HIP_TRY(ctx, hipHostMalloc((void**)&d.h_partials, (size_t)p.W * TE_MSM_PARTIAL_BYTES, hipHostMallocDefault));
-    d.cap_W = p.W;
+    const int wcap = p.W > 64 ? p.W : 64;             // W <= 64 for c >= 4: allocated once
+    HIP_TRY(ctx, hipMalloc((void**)&d.d_partials, (size_t)wcap * TE_MSM_PARTIAL_BYTES));
+    HIP_TRY(ctx, hipHostMalloc((void**)&d.h_partials, (size_t)wcap * TE_MSM_PARTIAL_BYTES, hipHostMallocDefault));
+    d.cap_W = wcap;
   }
   return 0;
 }
@@ -184,7 +189,7 @@ template <int C> void launch_digits(const uint4* sc, uint16_t* dg, const te::dig
 }
 
 int enqueue_partial(te_ctx* ctx, gpu_t& d, const void* d_points, const void* d_scalars, uint64_t n,
-                    void* d_partials_out, hipStream_t stream) {
+                    void* d_partials_out, hipStream_t stream, int slot = 0) {
   plan_t p; make_plan(ctx, d, n, p);
   if (int rc = ensure_buffers(ctx, d, n, p)) return rc;
   d.last_plan = p; d.last_n = n; d.have_last = true;
@@ -192,7 +197,7 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, const void* d_points, const void* d_s
   // profile 1: two events around the dominant kernel only (what bench.py times live); 2: every stage boundary
   // (an event between two kernels costs ~4 us of idle stream time, 11 of them ~2 % of a 2^20 MSM)
   const int prof = ctx->opt_profile;
-  auto mark = [&](int i) { if (prof >= 2 || (prof == 1 && (i == ST_ACCUM || i == ST_ACCUM + 1))) (void)hipEventRecord(d.ev[i], stream); };
+  auto mark = [&](int i) { if (prof >= 2 || (prof == 1 && (i == ST_ACCUM || i == ST_ACCUM + 1))) (void)hipEventRecord(d.ev[slot][i], stream); };
   const uint32_t n32 = (uint32_t)n;
 
   HIP_TRY(ctx, hipMemsetAsync(d.d_err, 0, sizeof(uint32_t), stream));
@@ -311,11 +316,11 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, const void* d_points, const void* d_s
   return 0;
 }
 
-int collect_stage_ms(te_ctx* ctx, gpu_t& d) {
+int collect_stage_ms(te_ctx* ctx, gpu_t& d, int slot = 0) {
   if (!ctx->opt_profile) return 0;
   for (int i = 0; i < ST_COUNT; i++) {
     float ms = -1.0f;
-    if (ctx->opt_profile >= 2 || i == ST_ACCUM) HIP_TRY(ctx, hipEventElapsedTime(&ms, d.ev[i], d.ev[i + 1]));
+    if (ctx->opt_profile >= 2 || i == ST_ACCUM) HIP_TRY(ctx, hipEventElapsedTime(&ms, d.ev[slot][i], d.ev[slot][i + 1]));
     ctx->stage_ms[i] = ms;
   }
   ctx->have_stage_ms = true;
@@ -330,8 +335,9 @@ void free_dev(gpu_t& d) {
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (d.h_err) (void)hipHostFree(d.h_err);
   if (d.h_partials) (void)hipHostFree(d.h_partials);
+  for (int i = 0; i < 2; i++) { if (d.h_slot_partials[i]) (void)hipHostFree(d.h_slot_partials[i]); if (d.h_slot_err[i]) (void)hipHostFree(d.h_slot_err[i]); if (d.ev_slot[i]) (void)hipEventDestroy(d.ev_slot[i]); }
   if (d.ev_done) (void)hipEventDestroy(d.ev_done);
-  for (auto& e : d.ev) if (e) (void)hipEventDestroy(e);
+  for (auto& es : d.ev) for (auto& e : es) if (e) (void)hipEventDestroy(e);
   if (d.stream) (void)hipStreamDestroy(d.stream);
 }
 
@@ -415,7 +421,7 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
     if (er == hipSuccess) er = hipMalloc((void**)&d.d_size_cursor, 1024 * sizeof(uint32_t));
     if (er == hipSuccess) er = hipHostMalloc((void**)&d.h_err, sizeof(uint32_t), hipHostMallocDefault);
     if (er == hipSuccess) er = hipEventCreateWithFlags(&d.ev_done, hipEventDisableTiming);
-    for (auto& evn : d.ev) if (er == hipSuccess) er = hipEventCreate(&evn);
+    for (auto& evs : d.ev) for (auto& evn : evs) if (er == hipSuccess) er = hipEventCreate(&evn);
     if (er != hipSuccess) {
       g_init_error = std::string("te_msm_init: ") + hipGetErrorString(er);
       for (auto& dd : ctx->devs) free_dev(dd);
@@ -441,6 +447,49 @@ int te_msm_run(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars_
 
 int te_msm_run_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_scalars_le, uint64_t n, uint8_t out_xy_le[64]) {
   return run_common(ctx, d_points_xy_le, d_scalars_le, false, n, out_xy_le);
+}
+
+int te_msm_submit_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_scalars_le, uint64_t n, uint64_t* ticket) {
+  if (!ctx || !ticket) return TE_MSM_EINVAL;
+  if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_submit_device needs a single-device context");
+  if (!d_points_xy_le || !d_scalars_le || n == 0 || n >= (1ull << 31)) return set_err(ctx, TE_MSM_EINVAL, "bad arguments");
+  gpu_t& d = ctx->devs[0];
+  if (d.next_ticket - d.next_collect >= 2) return set_err(ctx, TE_MSM_ESTATE, "two MSMs are already in flight: collect one first");
+  const int slot = (int)(d.next_ticket & 1);
+  plan_t p; make_plan(ctx, d, n, p);
+  HIP_TRY(ctx, hipSetDevice(d.device));
+  if (int rc = ensure_buffers(ctx, d, n, p)) return rc;
+  if (!d.slot_capW) {                                 // once, for the largest possible W (c >= 4 -> 64 windows): never
+    const int wmax = 64;                              // reallocated while an MSM is in flight
+    for (int i = 0; i < 2; i++) {
+      HIP_TRY(ctx, hipHostMalloc((void**)&d.h_slot_partials[i], (size_t)wmax * TE_MSM_PARTIAL_BYTES, hipHostMallocDefault));
+      HIP_TRY(ctx, hipHostMalloc((void**)&d.h_slot_err[i], sizeof(uint32_t), hipHostMallocDefault));
+      HIP_TRY(ctx, hipEventCreateWithFlags(&d.ev_slot[i], hipEventDisableTiming));
+    }
+    d.slot_capW = wmax;
+  }
+  HIP_TRY(ctx, hipMemsetAsync(d.d_partials, 0, (size_t)p.W * TE_MSM_PARTIAL_BYTES, d.stream));
+  if (int rc = enqueue_partial(ctx, d, d_points_xy_le, d_scalars_le, n, d.d_partials, d.stream, slot)) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(d.h_slot_partials[slot], d.d_partials, (size_t)p.W * TE_MSM_PARTIAL_BYTES, hipMemcpyDeviceToHost, d.stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d.h_slot_err[slot], d.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
+  HIP_TRY(ctx, hipEventRecord(d.ev_slot[slot], d.stream));
+  d.slot_c[slot] = p.c; d.slot_W[slot] = p.W;
+  *ticket = d.next_ticket++;
+  return 0;
+}
+
+int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]) {
+  if (!ctx || !out_xy_le) return TE_MSM_EINVAL;
+  if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_collect needs a single-device context");
+  gpu_t& d = ctx->devs[0];
+  if (ticket != d.next_collect || ticket >= d.next_ticket) return set_err(ctx, TE_MSM_ESTATE, "tickets must be collected in submission order");
+  const int slot = (int)(ticket & 1);
+  HIP_TRY(ctx, hipEventSynchronize(d.ev_slot[slot]));
+  d.next_collect++;
+  if (int rc = collect_stage_ms(ctx, d, slot)) return rc;
+  if (*d.h_slot_err[slot]) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
+  te_host::horner_to_affine(d.h_slot_partials[slot], d.slot_c[slot], d.slot_W[slot], out_xy_le);
+  return 0;
 }
 
 int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
