@@ -2,7 +2,7 @@
 
 A "step" is one full MSM (n = 2^20 Twisted-Edwards BLS12 points, 16-bit signed windows) over
 synthetic inputs already resident in HBM.  N = 1: te_msm_run_device (device stages + host tail).
-N > 1: the MSM's 16 windows are sharded over the ranks (one process per GPU), the 6 KB of partial
+N > 1: the MSM's 16 windows are sharded over the ranks (one process per GPU), the 11 KB of partial
 sums are exchanged with one RCCL all-gather, and every rank runs the host tail ("scaling": "strong").
 
     python bench.py --gpus 1 --steps 10 --warmup 2
@@ -173,7 +173,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": "n=2^%d TE-BLS12 MSM, %d-bit signed windows (%d windows x %d buckets), points=%s, inputs resident in HBM"
                                % (args.log2n, c, W, B, args.points),
-                   "parallelism": "windows sharded over %d GPU(s), RCCL all-gather of %d B partial sums" % (world, W * 432) if world > 1 else "single GPU"},
+                   "parallelism": "windows sharded over %d GPU(s), RCCL all-gather of %d B partial sums" % (world, W * 720) if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "algorithmic_bytes_per_launch": acc_bytes_rank, "kernel_ms": acc_ms,

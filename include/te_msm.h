@@ -35,7 +35,7 @@ typedef struct te_ctx te_ctx;
 
 #define TE_MSM_POINT_BYTES   64
 #define TE_MSM_SCALAR_BYTES  32
-#define TE_MSM_PARTIAL_BYTES 432  /* per window: 3 extended points x 144 B (see te_msm_partial_device) */
+#define TE_MSM_PARTIAL_BYTES 720  /* per window: 5 extended points x 144 B (see te_msm_partial_device) */
 
 /* Replaces get_device() + per-call buffer/pipeline creation (implementation/cuzk/gpu.ts:14-25,
  * submission.ts:96-97).  The context is persistent: buffers and streams live across calls.
@@ -81,7 +81,8 @@ int te_msm_plan(te_ctx* ctx, uint64_t n, int* window_bits, int* num_windows);
 /* Runs every device stage for this context's windows and leaves the partial sums in DEVICE memory:
  * d_partials is W x TE_MSM_PARTIAL_BYTES; only the rows of this context's windows are written
  * (others untouched -- zero the buffer first; an all-zero row means "window not present").
- * Row w = [ sum_j B_j | sum_hi hi*R_hi | sum_lo lo*C_lo ] as extended points (x|y|z|t, each 9 limbs of 29 bits in
+ * Row w = [ T | W0 | W1 | W2 | W3 ]: T = sum of the window's buckets, Wk = sum_v v * (sum of the buckets whose index has
+ * digit k equal to v), digits of (c+2-k)/4 bits; as extended points (x|y|z|t, each 9 limbs of 29 bits in
  * u32 words, Montgomery form R = 2^261, lazily reduced).  Asynchronous on `stream`: any hipStream_t (NULL is HIP's
  * default stream, which is also what PyTorch calls its default stream), or TE_MSM_OWN_STREAM for the context's
  * private stream; returns after enqueueing. */
@@ -106,7 +107,7 @@ int te_msm_stage_ms(te_ctx* ctx, float* ms, const char** names, int max_stages);
  * "records" (n x 128 B), "digits" / "part_keys" (nw rows of u16, row stride n rounded up to 8), "part_idx" (same rows, u32),
  * "part_start" / "part_count" (nw x P u32), "bucket_count" / "bucket_start" (nw x B u32), "sorted" (nw x n u32), "num_segments" (u32),
  * "seg_bucket" / "seg_len" / "order" (num_segments u32),
- * "buckets" (nw x B x 144 B), "partials" (W x 432 B).  Returns bytes copied
+ * "buckets" (nw x B x 144 B), "partials" (W x 720 B).  Returns bytes copied
  * (<= cap) or a negative error. */
 int64_t te_msm_debug_read(te_ctx* ctx, const char* stage, void* dst, uint64_t cap);
 

@@ -68,11 +68,11 @@ void fpc_add(const uint8_t a_[144], const uint8_t b_[144], uint8_t out[144]) {
   ete a, b; memcpy(&a, a_, 144); memcpy(&b, b_, 144); ete r = ete_add(a, b); chk2(r); memcpy(out, &r, 144);
 }
 
-// Emulation of the device stages for the windows w = first + k*step.  partials: W x 432 B (rows of other
+// Emulation of the device stages for the windows w = first + k*step.  partials: W x 720 B (rows of other
 // windows untouched).  Returns 0, or -3 on a final carry.
 int fpc_partial_rows(const uint8_t* points, const uint8_t* scalars, uint64_t n, int c, int first, int step, uint8_t* partials) {
   const int W = (256 + c - 1) / c;
-  const uint32_t B = 1u << (c - 1), lo_bits = (uint32_t)(c / 2), RL = 1u << lo_bits, RH = B / RL;
+  const uint32_t B = 1u << (c - 1);
   std::vector<pnt> recs(n);
   for (uint64_t i = 0; i < n; i++) { uint8_t slot[128]; fpc_prep_point(points + 64 * i, slot); memcpy(&recs[i], slot, 108); }
   // half = sum_w 2^(c*w + c-1)
@@ -99,16 +99,22 @@ int fpc_partial_rows(const uint8_t* points, const uint8_t* scalars, uint64_t n, 
       const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
       bk[b] = ete_madd(bk[b], pnt_cneg(recs[i], d < 0)); chk2(bk[b]);
     }
-    std::vector<ete> R(RH, ete_identity()), C(RL, ete_identity());
-    for (uint32_t j = 0; j < B; j++) { R[j / RL] = ete_add(R[j / RL], bk[j]); C[j % RL] = ete_add(C[j % RL], bk[j]); chk2(R[j / RL]); chk2(C[j % RL]); }
-    ete T = ete_identity(), WR = ete_identity(), WC = ete_identity(), run = ete_identity();
-    for (uint32_t v = RH; v-- > 1;) { run = ete_add(run, R[v]); WR = ete_add(WR, run); }
-    T = ete_add(run, R[0]);
-    run = ete_identity();
-    for (uint32_t v = RL; v-- > 1;) { run = ete_add(run, C[v]); WC = ete_add(WC, run); }
-    chk2(T); chk2(WR); chk2(WC);
-    uint8_t* row = partials + (size_t)w * 432;
-    memcpy(row, &T, 144); memcpy(row + 144, &WR, 144); memcpy(row + 288, &WC, 144);
+    // digit marginals M_k[v] and their weighted sums, straight from the definition
+    uint32_t dw[4], sh[4]; uint32_t acc_sh = 0;
+    for (int k = 0; k < 4; k++) { dw[k] = (uint32_t)(c - 1 + 3 - k) / 4u; sh[k] = acc_sh; acc_sh += dw[k]; }
+    ete T = ete_identity(), Wk[4];
+    for (uint32_t j = 0; j < B; j++) { T = ete_add(T, bk[j]); chk2(T); }
+    for (int k = 0; k < 4; k++) {
+      const uint32_t N = 1u << dw[k];
+      std::vector<ete> M(N, ete_identity());
+      for (uint32_t j = 0; j < B; j++) { ete& m = M[(j >> sh[k]) & (N - 1u)]; m = ete_add(m, bk[j]); chk2(m); }
+      ete run = ete_identity(); Wk[k] = ete_identity();
+      for (uint32_t v = N; v-- > 1;) { run = ete_add(run, M[v]); Wk[k] = ete_add(Wk[k], run); }
+      chk2(Wk[k]);
+    }
+    uint8_t* row = partials + (size_t)w * 720;
+    memcpy(row, &T, 144);
+    for (int k = 0; k < 4; k++) memcpy(row + 144 * (1 + k), &Wk[k], 144);
   }
   return 0;
 }

@@ -230,7 +230,7 @@ def test_window_shards_on_one_gpu(pkg, ora, world):
         with pkg.MsmContext((0,)) as c:
             c.set_window_shard(*pkg.window_shard_for_rank(r, world))
             cbits, W = c.plan(n)
-            part = torch.zeros(W * 432, dtype=torch.uint8, device="cuda")
+            part = torch.zeros(W * 720, dtype=torch.uint8, device="cuda")
             c.partial_device(dp.data_ptr(), ds.data_ptr(), n, part.data_ptr(), torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
             rows.append(part.cpu().numpy().tobytes())

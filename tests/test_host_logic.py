@@ -139,7 +139,7 @@ def test_emulated_stages_plus_host_tail(fpcheck, pkg, model, ora, n, c, mode):
     pts = ora.gen_points_fixed(n) if mode == "fixed" else ora.gen_points(seed, n)
     sc = model.scalars_to_bytes(edge_scalars(seed, n)) if mode == "edge" else ora.gen_scalars(seed, n)
     W = (256 + c - 1) // c
-    buf = ctypes.create_string_buffer(W * 432)
+    buf = ctypes.create_string_buffer(W * 720)
     assert fpcheck.fpc_partial_rows(pts, sc, n, c, 0, 1, buf) == 0
     assert pkg.finalize_host(buf.raw, c, W) == ora.msm(pts, sc, threads=4)
     assert fpcheck.fpc_bound_violations() == 0
@@ -154,7 +154,7 @@ def test_window_shards_merge(fpcheck, pkg, ora):
         bufs = []
         for r in range(world):
             first, step = pkg.window_shard_for_rank(r, world)
-            b = ctypes.create_string_buffer(W * 432)
+            b = ctypes.create_string_buffer(W * 720)
             assert fpcheck.fpc_partial_rows(pts, sc, n, c, first, step, b) == 0
             bufs.append(b.raw)
         assert pkg.finalize_host(pkg.merge_partials(bufs, W, world), c, W) == exp
@@ -163,15 +163,15 @@ def test_window_shards_merge(fpcheck, pkg, ora):
 def test_final_carry_detected_by_emulation(fpcheck, model, ora):
     pts = ora.gen_points(1, 2)
     sc = model.scalars_to_bytes([5, (1 << 256) - 1])
-    buf = ctypes.create_string_buffer(16 * 432)
+    buf = ctypes.create_string_buffer(16 * 720)
     assert fpcheck.fpc_partial_rows(pts, sc, 2, 16, 0, 1, buf) == -3
 
 
 def test_host_tail_identity_and_args(pkg):
     ident = bytes(32) + (1).to_bytes(32, "little")
-    assert pkg.finalize_host(bytes(16 * 432), 16, 16) == ident
+    assert pkg.finalize_host(bytes(16 * 720), 16, 16) == ident
     with pytest.raises(pkg.MsmError):
-        pkg.finalize_host(bytes(432), 99, 1)
+        pkg.finalize_host(bytes(720), 99, 1)
 
 
 # ---------------------------------------------------------------- C-ABI surface
@@ -245,7 +245,7 @@ n, c = 300, 10
 W = (256 + c - 1) // c
 pts, sc = o.gen_points(77, n), o.gen_scalars(77, n)
 first, step = pkg.window_shard_for_rank(rank, world)
-buf = ctypes.create_string_buffer(W * 432)
+buf = ctypes.create_string_buffer(W * 720)
 assert L.fpc_partial_rows(pts, sc, n, c, first, step, buf) == 0       # stands in for the GPU stage
 t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
 merged = pkg.exchange_partials(t, W, dist)

@@ -12,7 +12,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
-PARTIAL_BYTES = 432
+PARTIAL_BYTES = 720
 
 
 class MsmError(RuntimeError):
@@ -201,7 +201,7 @@ class MsmContext:
 
 
 def finalize_host(partials: bytes, window_bits: int, num_windows: int) -> bytes:
-    """Context-free host tail (te_msm_finalize_host): Horner + affine over W rows of 432 bytes."""
+    """Context-free host tail (te_msm_finalize_host): Horner + affine over W rows of 720 bytes."""
     out = ctypes.create_string_buffer(64)
     rc = _lib().te_msm_finalize_host(bytes(partials), window_bits, num_windows, out)
     if rc:

@@ -71,7 +71,7 @@ static inline Pt identity() { Pt r; memset(&r, 0, sizeof r); r.y = ONE_M; r.z = 
 static inline bool all_zero_bytes(const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) if (p[i]) return false; return true; }
 
 #define TE_TAIL_POINT_BYTES 144
-#define TE_TAIL_ROW_BYTES 432
+#define TE_TAIL_ROW_BYTES 720
 // one coordinate: 9 u32 words holding 29-bit limbs (possibly unnormalised), value < 2^262
 static inline Fe load_coord(const uint8_t* src) {
   uint32_t l[9]; memcpy(l, src, 36);
@@ -122,22 +122,29 @@ static inline Pt pdbl(const Pt& a) {
   return r;
 }
 
-// partials: W rows of 432 B = [T | WR | WC]; window value = T + WC + 2^lo_bits * WR, lo_bits = ceil((c-1)/2).
-// result = sum_w 2^(c*w) * window_w, evaluated top-down with c doublings per window, split as
-// (c - lo_bits) doublings -> + WR -> lo_bits doublings -> + (T + WC): no doubling is added by the split.
+// partials: W rows of 720 B = [T | W0 | W1 | W2 | W3]: T = sum of the window's buckets, Wk = sum_v v * M_k[v] for digit k of
+// the bucket index (digit widths w_k = (c - 1 + 3 - k) / 4, e.g. 4,4,4,3 for c = 16).  Window value
+//     V = T + W0 + 2^w0 W1 + 2^(w0+w1) W2 + 2^(w0+w1+w2) W3,      result = sum_w 2^(c*w) V_w,
+// evaluated top-down; the c doublings per window are split around the digit terms, so no doubling is added.
 static inline void horner_to_affine(const uint8_t* partials, int c, int W, uint8_t out_xy_le[64]) {
   const Fe d2 = {{2 * 3021, 0, 0, 0}};
   const Fe R2 = {{0x25d577bab861857bULL, 0xcc2c27b58860591fULL, 0xa7cc008fe5dc8593ULL, 0x011fdae7eff1c939ULL}};
   const Fe k2d = mul(d2, R2);
-  const int lo_bits = (c - 1 + 1) / 2;
+  int dw[4];
+  for (int k = 0; k < 4; k++) dw[k] = (c - 1 + 3 - k) / 4;
+  const int s3 = dw[0] + dw[1] + dw[2];
   Pt acc = identity();
   for (int w = W - 1; w >= 0; w--) {
     const uint8_t* row = partials + (size_t)w * TE_TAIL_ROW_BYTES;
     const bool present = !all_zero_bytes(row, TE_TAIL_ROW_BYTES);
-    for (int k = 0; k < c - lo_bits; k++) acc = pdbl(acc);
-    if (present) acc = padd(acc, load_point(row + TE_TAIL_POINT_BYTES), k2d);
-    for (int k = 0; k < lo_bits; k++) acc = pdbl(acc);
-    if (present) { acc = padd(acc, load_point(row), k2d); acc = padd(acc, load_point(row + 2 * TE_TAIL_POINT_BYTES), k2d); }
+    for (int k = 0; k < c - s3; k++) acc = pdbl(acc);
+    if (present) acc = padd(acc, load_point(row + 4 * TE_TAIL_POINT_BYTES), k2d);      // W3
+    for (int k = 0; k < dw[2]; k++) acc = pdbl(acc);
+    if (present) acc = padd(acc, load_point(row + 3 * TE_TAIL_POINT_BYTES), k2d);      // W2
+    for (int k = 0; k < dw[1]; k++) acc = pdbl(acc);
+    if (present) acc = padd(acc, load_point(row + 2 * TE_TAIL_POINT_BYTES), k2d);      // W1
+    for (int k = 0; k < dw[0]; k++) acc = pdbl(acc);
+    if (present) { acc = padd(acc, load_point(row + TE_TAIL_POINT_BYTES), k2d); acc = padd(acc, load_point(row), k2d); }   // W0, T
   }
   const Fe zi = inv(acc.z);
   const Fe one_raw = {{1, 0, 0, 0}};

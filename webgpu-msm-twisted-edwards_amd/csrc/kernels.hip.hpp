@@ -8,7 +8,7 @@
 //                                                   (two-level counting sort, all stores coalesced) + k_order_*
 //   K3 smvp (wgsl/cuzk/smvp.template.wgsl:58-152) -> k_accumulate (7-product mixed additions)
 //   K4/K5 bpr stage_1/2 (wgsl/cuzk/bpr.template.wgsl:73-171) + the CPU sum of 4096 points
-//      (submission.ts:362-393)                   -> k_sum_groups (row / column marginals) + k_weighted_sum
+//      (submission.ts:362-393)                   -> k_sum_groups[_team] (digit marginals) + k_weighted_sum
 // Window w of this context is  w = w_first + k * w_step  for local index k (multi-GPU window sharding).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -353,16 +353,18 @@ __global__ void __launch_bounds__(1024) k_bscan_a(const uint32_t* __restrict__ b
 __global__ void __launch_bounds__(1024) k_bscan_b(const uint32_t* __restrict__ local_excl, uint32_t* __restrict__ seg_base /* in: local, out: global */,
                                                   const uint32_t* __restrict__ seg_total, uint32_t* __restrict__ bucket_start,
                                                   uint32_t* __restrict__ bucket_cursor, uint32_t* __restrict__ num_segments, uint32_t B) {
-  __shared__ uint32_t base_s, base2_s;
+  __shared__ uint32_t sm[17];
   const uint32_t seg = blockIdx.x, k = blockIdx.y, nseg = gridDim.x;
-  if (threadIdx.x == 0) {
-    uint32_t base = 0, base2 = 0;
-    for (uint32_t s = 0; s < seg; s++) base += seg_total[2 * (k * nseg + s)];
-    for (uint32_t s = 0; s < k * nseg + seg; s++) base2 += seg_total[2 * s + 1];      // segments are numbered across windows
-    base_s = base; base2_s = base2;
-    if (k == gridDim.y - 1 && seg == nseg - 1) *num_segments = base2 + seg_total[2 * (k * nseg + seg) + 1];
-  }
-  __syncthreads();
+  // block-wide sums of the earlier segments' totals (a serial loop in one thread cost 20 us of dependent loads)
+  uint32_t part = 0, part2 = 0;
+  for (uint32_t s = threadIdx.x; s < seg; s += blockDim.x) part += seg_total[2 * (k * nseg + s)];
+  const uint32_t lim2 = k * nseg + seg;
+  for (uint32_t s = threadIdx.x; s < lim2; s += blockDim.x) part2 += seg_total[2 * s + 1];      // segments are numbered across windows
+  uint32_t base, base2;
+  (void)block_excl_scan(part, sm, base);
+  (void)block_excl_scan(part2, sm, base2);
+  const uint32_t base_s = base, base2_s = base2;
+  if (threadIdx.x == 0 && k == gridDim.y - 1 && seg == nseg - 1) *num_segments = base2 + seg_total[2 * (k * nseg + seg) + 1];
   const uint32_t b = seg * blockDim.x + threadIdx.x;
   if (b < B) {
     const size_t g = (size_t)k * B + b;
@@ -579,22 +581,24 @@ __global__ void __launch_bounds__(256) k_seg_combine(const uint32_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4a: marginal sums of the bucket grid.  A window's B buckets form an RH x RL grid, bucket
-// j = hi * RL + lo, weight j + 1.  With R_hi = sum_lo B[hi,lo] and C_lo = sum_hi B[hi,lo]:
-//     sum_j (j+1) B_j = sum_hi R_hi + RL * sum_hi hi R_hi + sum_lo lo C_lo.
-// Each level of k_sum_groups folds K (2 or 4) elements per thread with full additions, so every lane
-// of every wave does the same amount of work (the earlier LDS tree left 3/4 of the lanes idle):
-//     out[o] = sum_{k<K} in[(outer*K + k)*inner + q],   o = outer*inner + q.
-// rows fold the contiguous (lo) dimension: inner = 1;  columns fold hi: inner = RL.
-// Two independent jobs (rows, columns) share one launch: blockIdx.y selects the job.
+// K4a: marginal sums.  Bucket j of a window has weight j + 1; write j in four digits j = (d3 d2 d1 d0) of w3..w0 bits
+// (15 = 3+4+4+4 for c = 16).  With M_k[v] = sum of all buckets whose digit k equals v (<= 16 values per digit):
+//     sum_j (j+1) B_j = sum_j B_j + sum_k 2^(w0+..+w(k-1)) * sum_v v * M_k[v].
+// The powers of two cost nothing: they are folded into Horner's doublings on the host.  Everything here is plain
+// sums, computed by folding one digit at a time, 4 (or 2) points per thread per level:
+//     out[o] = sum_{t<K} in[(outer*K + t)*inner + q],   o = outer*inner + q
+// (inner = 1 folds a contiguous digit, inner > 1 folds a higher one).  Up to four independent jobs share a launch
+// (blockIdx.y).  The first level is throughput-bound (one thread per output); the later, small levels are
+// latency-bound and use four lanes per output (k_sum_groups_team below).
 struct sum_job {
   const ete* in; ete* out;
-  uint32_t n_out;      // outputs per window
+  uint32_t n_out;      // outputs per window (0 = no job)
   uint32_t K, inner;
   uint32_t in_per_window, out_per_window;
 };
-__global__ void __launch_bounds__(256) k_sum_groups(sum_job j0, sum_job j1, uint32_t nw) {
-  const sum_job& j = blockIdx.y == 0 ? j0 : j1;
+struct sum_jobs { sum_job j[4]; };
+__global__ void __launch_bounds__(256) k_sum_groups(sum_jobs js, uint32_t nw) {
+  const sum_job& j = js.j[blockIdx.y];
   const uint32_t total = j.n_out * nw;
   for (uint32_t g = blockIdx.x * 256u + threadIdx.x; g < total; g += gridDim.x * 256u) {
     const uint32_t k = g / j.n_out, o = g - k * j.n_out;
@@ -606,32 +610,121 @@ __global__ void __launch_bounds__(256) k_sum_groups(sum_job j0, sum_job j1, uint
   }
 }
 
-// K4b: weighted sums over N points E_0..E_{N-1} (N a power of two <= blockDim.x):
-//   total = sum_v E_v,  weighted = sum_v v * E_v = sum_{v >= 1} S_v,  S_v = sum_{u >= v} E_u.
-// Suffix sums by a log-step scan in LDS, then a tree sum of S_1..S_{N-1}.  blockIdx.x selects the
-// problem (0: the RH row sums -> total + weighted, 1: the RL column sums -> weighted), blockIdx.y the
-// window; threads >= N hold the identity.  dynamic LDS = blockDim.x * 144 B.
-struct wsum_job { const ete* in; ete* out_total; ete* out_weighted; uint32_t N; };
-__global__ void __launch_bounds__(256) k_weighted_sum(wsum_job j0, wsum_job j1, uint32_t out_stride) {
-  extern __shared__ uint4 lds_u4[];
-  ete* sm = reinterpret_cast<ete*>(lds_u4);
-  const wsum_job& j = blockIdx.x == 0 ? j0 : j1;
-  const uint32_t k = blockIdx.y, t = threadIdx.x, T = blockDim.x, N = j.N;
-  ete mine = t < N ? load_ete(j.in + (size_t)k * N + t) : ete_identity();
+// ------------------------------------------------------------------------------------------------
+// Team additions for the latency-bound tail of the reduction.  The last marginal-sum levels and the weighted sums
+// are chains of dependent full additions executed by a handful of waves: one lane doing the 9 products of an
+// addition in sequence takes ~5 us per link.  Here FOUR adjacent lanes share one point -- lane q of the quad holds
+// coordinate q of (X, Y, T, Z) -- and an addition is three rounds of one product per lane:
+//     round 1   lane0: A = (Y1-X1)(Y2-X2)   lane1: B = (Y1+X1)(Y2+X2)   lane2: T1*T2        lane3: Z1*Z2
+//     round 2   lane2: C = 2d * T1T2 (the other lanes' product is discarded; lane3: D = 2 Z1Z2 by an addition)
+//     round 3   lane0: X3 = EF              lane1: Y3 = HG              lane2: T3 = EH       lane3: Z3 = FG
+// with E = B-A, H = B+A, F = D-C, G = D+C formed on every lane after a quad broadcast (DPP quad_perm, no LDS).
+// 3 product latencies instead of 9, at 75 % lane efficiency -- the right trade when the machine is idle anyway.
+__device__ __forceinline__ fp quad_bcast(const fp& v, const int k) {     // value of lane k of my quad, k uniform constant 0..3
+  fp r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    const int x = (int)v.v[i];
+    int y;
+    switch (k) {
+      case 0: y = __builtin_amdgcn_mov_dpp(x, 0x00, 0xf, 0xf, true); break;
+      case 1: y = __builtin_amdgcn_mov_dpp(x, 0x55, 0xf, 0xf, true); break;
+      case 2: y = __builtin_amdgcn_mov_dpp(x, 0xaa, 0xf, 0xf, true); break;
+      default: y = __builtin_amdgcn_mov_dpp(x, 0xff, 0xf, 0xf, true); break;
+    }
+    r.v[i] = (uint32_t)y;
+  }
+  return r;
+}
+__device__ __forceinline__ fp quad_swap1(const fp& v) {                 // lanes 0<->1, 2<->3 of every quad
+  fp r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)v.v[i], 0xb1, 0xf, 0xf, true);
+  return r;
+}
+__device__ __forceinline__ fp fp_select(bool c, const fp& a, const fp& b) {
+  fp r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.v[i] = c ? a.v[i] : b.v[i];
+  return r;
+}
+// q = lane & 3 selects the coordinate this lane holds: 0 X, 1 Y, 2 T, 3 Z.  All four lanes of a quad must call.
+__device__ __forceinline__ fp ete_add_team(const fp& m1, const fp& m2, const uint32_t q) {
+  const fp o1 = quad_swap1(m1), o2 = quad_swap1(m2);                    // lane0 sees Y, lane1 sees X (lanes 2,3: unused)
+  // round 1 operands
+  const fp u0 = fp_norm(fp_sub<2>(o1, m1)), v0 = fp_sub<2>(o2, m2);     // lane0: Y1-X1, Y2-X2
+  const fp u1 = fp_add(m1, o1), v1 = fp_add(m2, o2);                    // lane1: Y1+X1, Y2+X2
+  const fp u = q == 0 ? u0 : (q == 1 ? u1 : m1);
+  const fp v = q == 0 ? v0 : (q == 1 ? v1 : m2);
+  const fp s1 = mont_mul(u, v);                                         // A | B | T1T2 | Z1Z2
+  // round 2
+  const fp s2 = mont_mul(s1, fp_K2D_MONT());                            // meaningful on lane2 only
+  const fp val = q == 2 ? s2 : (q == 3 ? fp_add(s1, s1) : s1);          // A | B | C | D
+  // round 3
+  const fp A = quad_bcast(val, 0), B = quad_bcast(val, 1), C = quad_bcast(val, 2), D = quad_bcast(val, 3);
+  const fp E = fp_norm(fp_sub<2>(B, A)), H = fp_add(B, A), F = fp_norm(fp_sub<2>(D, C)), G = fp_norm(fp_add(D, C));
+  const fp uu = (q == 0 || q == 2) ? E : (q == 1 ? H : F);
+  const fp vv = q == 0 ? F : (q == 2 ? H : G);
+  return mont_mul(uu, vv);                                              // X3 | Y3 | T3 | Z3
+}
+// word offset of coordinate q inside a stored point (memory order x | y | z | t)
+__device__ __forceinline__ uint32_t team_word(uint32_t q) { return (q == 0 ? 0u : q == 1 ? 1u : q == 2 ? 3u : 2u) * NL; }
+__device__ __forceinline__ fp load_coord(const uint32_t* p) { fp r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.v[i] = p[i];
+  return r; }
+__device__ __forceinline__ void store_coord(uint32_t* p, const fp& a) {
+#pragma unroll
+  for (int i = 0; i < NL; i++) p[i] = a.v[i];
+}
+__device__ __forceinline__ fp identity_coord(uint32_t q) { return (q == 1 || q == 3) ? fp_R1() : fp_zero(); }
+
+// k_sum_groups with a quad per output (levels where the grid is too small to fill the machine): 4 threads per output.
+__global__ void __launch_bounds__(256) k_sum_groups_team(sum_jobs js, uint32_t nw) {
+  const sum_job& j = js.j[blockIdx.y];
+  const uint32_t total = j.n_out * nw, q = threadIdx.x & 3u;
+  for (uint32_t g = (blockIdx.x * 256u + threadIdx.x) >> 2; g < total; g += (gridDim.x * 256u) >> 2) {
+    const uint32_t k = g / j.n_out, o = g - k * j.n_out;
+    const uint32_t outer = o / j.inner, qq = o - outer * j.inner;
+    const ete* src = j.in + (size_t)k * j.in_per_window + (size_t)outer * j.K * j.inner + qq;
+    fp acc = load_coord(reinterpret_cast<const uint32_t*>(src) + team_word(q));
+    for (uint32_t t = 1; t < j.K; t++)
+      acc = ete_add_team(acc, load_coord(reinterpret_cast<const uint32_t*>(src + (size_t)t * j.inner) + team_word(q)), q);
+    store_coord(reinterpret_cast<uint32_t*>(j.out + (size_t)k * j.out_per_window + o) + team_word(q), acc);
+  }
+}
+
+// K4b: the four digit sums of a window, each over N <= 16 points M[0..N):
+//   total = sum_v M[v] (digit 0 only),  weighted = sum_v v * M[v] = sum_{v >= 1} S_v,  S_v = sum_{u >= v} M[u].
+// Suffix sums by a log-step scan in LDS, then a tree sum of S_1..S_{N-1}; every addition is a team addition.
+// grid (4 digits, nw), block 64 = 16 quads; quads >= N hold the identity.  Row layout written: [T | W0 | W1 | W2 | W3].
+struct wsum_jobs { const ete* in[4]; uint32_t N[4]; };
+__global__ void __launch_bounds__(64) k_weighted_sum(wsum_jobs js, ete* __restrict__ rows, uint32_t row_stride /* points */) {
+  __shared__ uint32_t lds_w[16 * 36];
+  const uint32_t dgt = blockIdx.x, k = blockIdx.y, t = threadIdx.x >> 2, q = threadIdx.x & 3u, N = js.N[dgt];
+  const uint32_t w = team_word(q);
+  fp mine = t < N ? load_coord(reinterpret_cast<const uint32_t*>(js.in[dgt] + (size_t)k * N + t) + w) : identity_coord(q);
   for (uint32_t d = 1; d < N; d <<= 1) {            // inclusive suffix scan
-    store_ete(&sm[t], mine);
+    store_coord(lds_w + (size_t)t * 36 + w, mine);
     __syncthreads();
-    if (t + d < N) mine = ete_add(mine, load_ete(&sm[t + d]));
-    __syncthreads();
-  }
-  if (t == 0) { if (j.out_total) store_ete(j.out_total + (size_t)k * out_stride, mine); mine = ete_identity(); }
-  for (uint32_t s = T >> 1; s > 0; s >>= 1) {       // tree sum of S_1..S_{N-1} (slot 0 = identity)
-    if (t >= s && t < 2 * s) store_ete(&sm[t], mine);
-    __syncthreads();
-    if (t < s && t + s < N) mine = ete_add(mine, load_ete(&sm[t + s]));
+    const bool act = t + d < N;                     // uniform per quad
+    const fp other = act ? load_coord(lds_w + (size_t)(t + d) * 36 + w) : identity_coord(q);
+    const fp sum = ete_add_team(mine, other, q);    // every lane takes part (DPP needs the whole quad)
+    mine = fp_select(act, sum, mine);
     __syncthreads();
   }
-  if (t == 0) store_ete(j.out_weighted + (size_t)k * out_stride, mine);
+  ete* row = rows + (size_t)k * row_stride;
+  if (t == 0) { if (dgt == 0) store_coord(reinterpret_cast<uint32_t*>(row) + w, mine); mine = identity_coord(q); }
+  for (uint32_t s = 8; s > 0; s >>= 1) {            // tree sum of S_1..S_{N-1} (slot 0 = identity)
+    if (t >= s && t < 2 * s) store_coord(lds_w + (size_t)t * 36 + w, mine);
+    __syncthreads();
+    const bool act = t < s && t + s < N;
+    const fp other = act ? load_coord(lds_w + (size_t)(t + s) * 36 + w) : identity_coord(q);
+    const fp sum = ete_add_team(mine, other, q);
+    mine = fp_select(act, sum, mine);
+    __syncthreads();
+  }
+  if (t == 0) store_coord(reinterpret_cast<uint32_t*>(row + 1 + dgt) + w, mine);
 }
 
 }  // namespace te

@@ -14,6 +14,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <algorithm>
 
 #include "../../include/te_msm.h"
 #include "host_tail.hpp"
@@ -30,7 +31,7 @@ const char* const kStageNames[ST_COUNT] = {"prep_points", "digits", "part_hist",
 struct plan_t {
   int c = 0, W = 0, nw = 0;           // window bits, total windows, windows of this shard
   uint32_t B = 0, logB = 0;           // buckets per window = 2^(c-1)
-  uint32_t RL = 0, RH = 0, lo_bits = 0;
+  uint32_t dw[4] = {0, 0, 0, 0};      // bits of the four digits of a bucket index (dw[0] lowest)
   uint32_t CH = 0, chunk_len = 0, nst = 0;   // level-1 chunks per window (chunk_len multiple of 4096); padded row stride
   uint32_t seg_len = 64;
   uint32_t S = 0, logS = 0, P = 0, cap = 0, cpb = 0;   // level-2 partition: S buckets each, P = B/S per window; LDS list entries (cpb per bucket)
@@ -40,7 +41,7 @@ struct gpu_t {
   int device = 0;
   int w_first = 0, w_step = 1;
   hipStream_t stream = nullptr;
-  size_t cap[28] = {};                // per-buffer capacity in bytes (ensure())
+  size_t cap[28] = {}, red_cap[12] = {};                // per-buffer capacity in bytes (ensure())
   int cap_W = 0;
   te::pnt_slot* d_recs = nullptr;
   uint16_t* d_digits = nullptr;
@@ -49,7 +50,7 @@ struct gpu_t {
   te::ete* d_seg_out = nullptr;
   uint32_t *d_bucket_count = nullptr, *d_bucket_start = nullptr, *d_bucket_cursor = nullptr, *d_seg_total = nullptr, *d_sorted = nullptr, *d_order = nullptr, *d_size_hist = nullptr, *d_size_cursor = nullptr;
   uint16_t* d_part_keys = nullptr;
-  te::ete *d_buckets = nullptr, *d_red[4] = {nullptr, nullptr, nullptr, nullptr};   // reduction ping/pong: rows a,b  cols a,b
+  te::ete *d_buckets = nullptr, *d_red[12] = {};   // reduction: [0..3] ping/pong of the two first-phase chains, [4..11] small
   uint8_t* d_partials = nullptr;      // W x 432
   uint32_t* d_err = nullptr;
   uint32_t* h_err = nullptr;          // pinned
@@ -113,7 +114,7 @@ void make_plan(const te_ctx* ctx, const gpu_t& d, uint64_t n, plan_t& p) {
   p.nw = 0;
   for (int w = d.w_first; w < p.W; w += d.w_step) p.nw++;
   p.B = 1u << (p.c - 1); p.logB = p.c - 1;
-  p.lo_bits = (p.c - 1 + 1) / 2; p.RL = 1u << p.lo_bits; p.RH = p.B / p.RL;
+  for (int k = 0; k < 4; k++) p.dw[k] = (uint32_t)(p.c - 1 + 3 - k) / 4u;       // 15 -> 4,4,4,3
   uint32_t ch = p.nw > 0 ? 1024u / (uint32_t)p.nw : 1u;     // ~4 blocks of 512 threads per CU in k_part_scatter
   if (ch < 1) ch = 1;
   if (ch > 256) ch = 256;
@@ -172,6 +173,7 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, uint64_t n, const plan_t& p) {
   if ((rc = ensure(ctx, d.d_red[1], d.cap[11], wb / 4 + 1))) return rc;
   if ((rc = ensure(ctx, d.d_red[2], d.cap[12], wb / 2 + 1))) return rc;
   if ((rc = ensure(ctx, d.d_red[3], d.cap[13], wb / 4 + 1))) return rc;
+  for (int i = 4; i < 12; i++) if ((rc = ensure(ctx, d.d_red[i], d.red_cap[i], (size_t)p.nw * 256 + 16))) return rc;
   if (p.W > d.cap_W) {
     if (d.d_partials) HIP_TRY(ctx, hipFree(d.d_partials));
     if (d.h_partials) HIP_TRY(ctx, hipHostFree(d.h_partials));
@@ -277,37 +279,60 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, const void* d_points, const void* d_s
                        d.d_buckets, total, p.seg_len);
   }
   mark(ST_TREE);
-  const te::ete *row_res = d.d_buckets, *col_res = d.d_buckets;
+  // digit marginals M_k[v], k = 0..3 (see K4a in kernels.hip.hpp).  Chains of folds, 4 (or 2) points per level:
+  //   rows chain  B[d3 d2 d1 d0] -fold d0-> -fold d1-> X2[d3 d2]      cols chain  B -fold d3-> -fold d2-> Y2[d1 d0]
+  //   then M3 = fold d2 of X2, M2 = fold d3 of X2, M1 = fold d0 of Y2, M0 = fold d1 of Y2.
+  const te::ete* marg[4] = {d.d_buckets, d.d_buckets, d.d_buckets, d.d_buckets};
   if (p.nw > 0) {
-    // rows fold RL = 2^lo_bits contiguous buckets, columns fold RH; both by factors of 4 (last level 2)
-    uint32_t r_left = p.RL, c_left = p.RH, r_n = p.B, c_n = p.B;     // remaining fold factor, elements per window
-    int r_pp = 0, c_pp = 0;
-    while (r_left > 1 || c_left > 1) {
-      te::sum_job jr, jc; memset(&jr, 0, sizeof jr); memset(&jc, 0, sizeof jc);
-      if (r_left > 1) {
-        const uint32_t K = (r_left % 4 == 0) ? 4u : 2u;
-        jr.in = row_res; jr.out = d.d_red[r_pp]; jr.K = K; jr.inner = 1; jr.n_out = r_n / K;
-        jr.in_per_window = r_n; jr.out_per_window = r_n / K;
-        row_res = jr.out; r_pp ^= 1; r_left /= K; r_n /= K;
+    struct chain_t { const te::ete* cur; uint32_t n; uint32_t steps[2][2]; int nsteps, step; uint32_t left; te::ete* buf[2]; int pp; };
+    const uint32_t w0 = p.dw[0], w1 = p.dw[1], w2 = p.dw[2], w3 = p.dw[3];
+    auto run_phase = [&](chain_t* ch, int nch) {
+      for (int i = 0; i < nch; i++) { ch[i].step = 0; ch[i].left = ch[i].nsteps ? ch[i].steps[0][0] : 1u; ch[i].pp = 0; }
+      for (;;) {
+        te::sum_jobs js; memset(&js, 0, sizeof js);
+        uint32_t most = 0; bool any = false;
+        for (int i = 0; i < nch; i++) {
+          chain_t& c = ch[i];
+          while (c.step < c.nsteps && c.left <= 1) { c.step++; if (c.step < c.nsteps) c.left = c.steps[c.step][0]; }
+          if (c.step >= c.nsteps) continue;
+          const uint32_t K = (c.left % 4 == 0) ? 4u : 2u, inner = c.steps[c.step][1];   // stride of the digit being folded
+          te::sum_job& j = js.j[i];
+          // fold the HIGH part of the remaining digit: groups of K adjacent sub-blocks of size inner * (left / K)
+          j.in = c.cur; j.out = c.buf[c.pp]; j.K = K; j.inner = inner * (c.left / K); j.n_out = c.n / K;
+          j.in_per_window = c.n; j.out_per_window = c.n / K;
+          c.cur = j.out; c.pp ^= 1; c.left /= K; c.n /= K;
+          most = std::max(most, j.n_out * (uint32_t)p.nw); any = true;
+        }
+        if (!any) break;
+        if (most >= 131072u) {      // enough outputs to fill the chip with one thread each: throughput-bound level
+          uint32_t blocks = (most + 255) / 256; if (blocks > 4096) blocks = 4096;
+          hipLaunchKernelGGL(te::k_sum_groups, dim3(blocks, nch), dim3(256), 0, stream, js, (uint32_t)p.nw);
+        } else {                    // latency-bound level: four lanes per output
+          uint32_t blocks = (most * 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+          hipLaunchKernelGGL(te::k_sum_groups_team, dim3(blocks, nch), dim3(256), 0, stream, js, (uint32_t)p.nw);
+        }
       }
-      if (c_left > 1) {
-        const uint32_t K = (c_left % 4 == 0) ? 4u : 2u;
-        jc.in = col_res; jc.out = d.d_red[2 + c_pp]; jc.K = K; jc.inner = p.RL; jc.n_out = c_n / K;
-        jc.in_per_window = c_n; jc.out_per_window = c_n / K;
-        col_res = jc.out; c_pp ^= 1; c_left /= K; c_n /= K;
-      }
-      const uint32_t most = (jr.n_out > jc.n_out ? jr.n_out : jc.n_out) * (uint32_t)p.nw;
-      uint32_t blocks = (most + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
-      hipLaunchKernelGGL(te::k_sum_groups, dim3(blocks, 2), dim3(256), 0, stream, jr, jc, (uint32_t)p.nw);
-    }
+    };
+    // phase 1: X2[d3 d2] (fold the low w0 + w1 bits, contiguous) and Y2[d1 d0] (fold the high w3 + w2 bits)
+    chain_t ph1[2] = {
+        {d.d_buckets, p.B, {{1u << (w0 + w1), 1u}, {0, 0}}, 1, 0, 0, {d.d_red[0], d.d_red[1]}, 0},
+        {d.d_buckets, p.B, {{1u << (w2 + w3), 1u << (w0 + w1)}, {0, 0}}, 1, 0, 0, {d.d_red[2], d.d_red[3]}, 0}};
+    run_phase(ph1, 2);
+    // phase 2: from X2 (index d3 * 2^w2 + d2) and Y2 (index d1 * 2^w0 + d0)
+    chain_t ph2[4] = {
+        {ph1[1].cur, 1u << (w0 + w1), {{1u << w1, 1u << w0}, {0, 0}}, 1, 0, 0, {d.d_red[4], d.d_red[5]}, 0},    // M0[d0]: fold d1 (high)
+        {ph1[1].cur, 1u << (w0 + w1), {{1u << w0, 1u}, {0, 0}}, 1, 0, 0, {d.d_red[6], d.d_red[7]}, 0},          // M1[d1]: fold d0 (low)
+        {ph1[0].cur, 1u << (w2 + w3), {{1u << w3, 1u << w2}, {0, 0}}, 1, 0, 0, {d.d_red[8], d.d_red[9]}, 0},    // M2[d2]: fold d3 (high)
+        {ph1[0].cur, 1u << (w2 + w3), {{1u << w2, 1u}, {0, 0}}, 1, 0, 0, {d.d_red[10], d.d_red[11]}, 0}};       // M3[d3]: fold d2 (low)
+    run_phase(ph2, 4);
+    for (int k = 0; k < 4; k++) marg[k] = ph2[k].cur;
   }
   mark(ST_WEIGHTED);
   if (p.nw > 0) {
-    te::ete* rows = reinterpret_cast<te::ete*>(d_partials_out) + (size_t)d.w_first * 3;
-    const uint32_t stride = (uint32_t)d.w_step * 3u;
-    te::wsum_job j0 = {row_res, rows, rows + 1, p.RH}, j1 = {col_res, nullptr, rows + 2, p.RL};
-    const uint32_t T = p.RH > p.RL ? p.RH : p.RL;
-    hipLaunchKernelGGL(te::k_weighted_sum, dim3(2, p.nw), dim3(T), (size_t)T * sizeof(te::ete), stream, j0, j1, stride);
+    te::ete* rows = reinterpret_cast<te::ete*>(d_partials_out) + (size_t)d.w_first * 5;
+    te::wsum_jobs wj;
+    for (int k = 0; k < 4; k++) { wj.in[k] = marg[k]; wj.N[k] = 1u << p.dw[k]; }
+    hipLaunchKernelGGL(te::k_weighted_sum, dim3(4, p.nw), dim3(64), 0, stream, wj, rows, (uint32_t)d.w_step * 5u);
   }
   mark(ST_COUNT);
   HIP_TRY(ctx, hipMemcpyAsync(d.h_err, d.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));

@@ -2,13 +2,13 @@
 
 The W windows of the signed-digit decomposition are independent until Horner's rule
 (submission.ts:369-407).  Rank r of D owns windows {w : w mod D == r}; every rank converts all n points
-and decomposes only its own windows, reduces them on its GPU to W/D rows of 432 bytes, and the rows are
-exchanged with ONE all-gather of W*432 bytes (6 KB for c = 16) -- RCCL over xGMI when the tensors are
+and decomposes only its own windows, reduces them on its GPU to W/D rows of 720 bytes, and the rows are
+exchanged with ONE all-gather of W*720 bytes (11 KB for c = 16) -- RCCL over xGMI when the tensors are
 on GPUs, gloo in the CPU tests.  Group addition is exact, so the result is bit-identical for every D.
 """
 from __future__ import annotations
 
-PARTIAL_BYTES = 432
+PARTIAL_BYTES = 720
 
 
 def window_shard_for_rank(rank: int, world: int):
@@ -19,7 +19,7 @@ def window_shard_for_rank(rank: int, world: int):
 
 
 def merge_partials(rows_per_rank, num_windows: int, world: int) -> bytes:
-    """rows_per_rank[r] is rank r's full W x 432 B buffer (only its own rows non-zero)."""
+    """rows_per_rank[r] is rank r's full W x 720 B buffer (only its own rows non-zero)."""
     out = bytearray(num_windows * PARTIAL_BYTES)
     for w in range(num_windows):
         r = w % world
@@ -28,7 +28,7 @@ def merge_partials(rows_per_rank, num_windows: int, world: int) -> bytes:
 
 
 def exchange_partials(partials, num_windows: int, dist=None, group=None, gather_list=None) -> bytes:
-    """All-gathers every rank's W x 432 B tensor (CUDA tensor -> RCCL, CPU tensor -> gloo) and returns
+    """All-gathers every rank's W x 720 B tensor (CUDA tensor -> RCCL, CPU tensor -> gloo) and returns
     the merged rows as bytes.  `partials` must be complete on the current stream when called."""
     import torch
 
@@ -52,7 +52,7 @@ def compute_msm_sharded(ctx, d_points, d_scalars, n: int, partials, dist=None, g
 
     ctx        MsmContext whose window shard is (rank, world)
     d_points / d_scalars   torch uint8 CUDA tensors holding the FULL inputs on this rank's GPU
-    partials   torch uint8 CUDA tensor of W*432 bytes (scratch, overwritten)
+    partials   torch uint8 CUDA tensor of W*720 bytes (scratch, overwritten)
     dist       torch.distributed (initialised) or None for a single rank
     Returns the 64-byte affine result (identical on every rank).  All device work is enqueued on
     torch's current stream so that the collective is ordered behind it.
