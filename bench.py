@@ -184,6 +184,15 @@ def main():
         "result_x": str(int.from_bytes(result[:32], "little")),
     }
 
+    if rank == 0 and world == 1:
+        # the boundary hands over host buffers (te_msm_run): PCIe-inclusive latency, reported but never `value`
+        t_pcie = []
+        for _ in range(2):
+            t1 = time.perf_counter()
+            r_host = ctx.run(pts, sc)
+            t_pcie.append((time.perf_counter() - t1) * 1e3)
+        out["pcie_inclusive_ms_host_buffers"] = min(t_pcie)
+        assert r_host == result
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         threads = args.cpu_threads or min(16, os.cpu_count() or 1)
         t0 = time.perf_counter()
