@@ -49,7 +49,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_dist = os.environ.get("TE_BENCH_FORCE_DIST") == "1"      # rehearsal: run the N > 1 code path with one rank over RCCL
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # TE_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box): every rank uses cuda:0 and the exchange goes over gloo
         share = os.environ.get("TE_BENCH_SHARE_GPU") == "1"
@@ -83,17 +84,19 @@ def main():
     ctx.set_option("profile", 1)          # two HIP events around the dominant kernel, on the engine's stream
     c, W = ctx.plan(n)
     B = 1 << (c - 1)
-    if world > 1:
+    if world > 1 or force_dist:
         ctx.set_window_shard(*pkg.window_shard_for_rank(rank, world))
         partials = torch.zeros(W * pkg.PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
         gather_list = [torch.empty_like(partials) for _ in range(world)]
 
     def step():
-        if world > 1:
+        if sharded:
             return pkg.compute_msm_sharded(ctx, d_pts, d_sc, n, partials, dist, None, gather_list)
         return ctx.run_device(d_pts.data_ptr(), d_sc.data_ptr(), n)
 
-    pipelined = world == 1 and not args.no_pipeline
+    pipelined = not args.no_pipeline
+    sharded = world > 1 or force_dist
+    pipe = pkg.ShardedPipeline(ctx, n, dist) if (sharded and pipelined) else None
 
     result = None
     for _ in range(args.warmup):
@@ -101,7 +104,7 @@ def main():
     stage_acc = {}
 
     def sync():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -120,7 +123,18 @@ def main():
 
     sync()
     t0 = time.perf_counter()
-    if pipelined:
+    if pipelined and sharded:
+        # the same with window shards: all-gather, read-back and host tail of MSM i overlap the device work of MSM i+1
+        tickets = [pipe.submit(d_pts, d_sc)]
+        for i in range(1, args.steps):
+            tickets.append(pipe.submit(d_pts, d_sc))
+            result = pipe.collect(tickets[i - 1])
+        result = pipe.collect(tickets[-1])
+        torch.cuda.synchronize()
+        note_stage()                                   # events of the last MSM: a sample, not the mean
+        for k in list(stage_acc):
+            stage_acc[k] *= args.steps
+    elif pipelined:
         # K independent MSMs back to back, two in flight: the host tail of MSM i overlaps the device work of MSM i+1
         tickets = [ctx.submit_device(d_pts.data_ptr(), d_sc.data_ptr(), n)]
         for i in range(1, args.steps):
@@ -135,8 +149,8 @@ def main():
             note_stage()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if sharded:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() != "gloo" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -165,7 +179,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "latency_ms_single_msm": min(lat),
-        "mode": "pipelined: 2 MSMs in flight (te_msm_submit_device / te_msm_collect)" if pipelined else "synchronous: one MSM at a time",
+        "mode": ("pipelined: 2 MSMs in flight (te_msm_submit_device / te_msm_collect)" if world == 1 else "pipelined: 2 window-sharded MSMs in flight per rank") if pipelined else "synchronous: one MSM at a time",
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -205,7 +219,7 @@ def main():
         if exp != result:
             print(json.dumps(out))
             raise SystemExit("GPU result differs from the oracle")
-    if world > 1:
+    if sharded:
         # untimed cross-check of the sharded path: the same MSM on this rank's GPU alone must give the same point
         with pkg.MsmContext((dev,)) as solo:
             solo.set_option("window_bits", args.window_bits)
@@ -222,7 +236,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     ctx.close()
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -19,4 +19,4 @@ from .binding import (  # noqa: F401
     library_path,
     PARTIAL_BYTES,
 )
-from .sharding import compute_msm_sharded, exchange_partials, merge_partials, window_shard_for_rank  # noqa: F401
+from .sharding import ShardedPipeline, compute_msm_sharded, exchange_partials, merge_partials, window_shard_for_rank  # noqa: F401

@@ -65,3 +65,61 @@ def compute_msm_sharded(ctx, d_points, d_scalars, n: int, partials, dist=None, g
                        torch.cuda.current_stream().cuda_stream)
     merged = exchange_partials(partials, W, dist, group, gather_list)
     return ctx.finalize(merged, c, W)
+
+
+class ShardedPipeline:
+    """Window-sharded MSMs with two in flight per rank: the all-gather, the 11 KiB read-back and the host tail of
+    MSM i overlap the device work of MSM i+1 (the multi-GPU counterpart of te_msm_submit_device / te_msm_collect).
+
+        pipe = ShardedPipeline(ctx, n, dist)          # ctx: MsmContext with window shard (rank, world)
+        t = pipe.submit(d_points, d_scalars); ...; xy = pipe.collect(t)      # collect in submission order
+    """
+
+    def __init__(self, ctx, n: int, dist, group=None):
+        import torch
+
+        self.torch, self.ctx, self.n, self.dist, self.group = torch, ctx, n, dist, group
+        self.world = dist.get_world_size(group)
+        self.c, self.W = ctx.plan(n)
+        nbytes = self.W * PARTIAL_BYTES
+        self.gloo = dist.get_backend(group) == "gloo"
+        self.part = [torch.zeros(nbytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        gdev = "cpu" if self.gloo else "cuda"
+        self.gathered = [torch.zeros(self.world * nbytes, dtype=torch.uint8, device=gdev) for _ in range(2)]
+        self.host = [torch.zeros(self.world * nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream()
+        self.ev = [torch.cuda.Event() for _ in range(2)]
+        self.next_ticket = self.next_collect = 0
+
+    def submit(self, d_points, d_scalars) -> int:
+        torch = self.torch
+        assert self.next_ticket - self.next_collect < 2, "two MSMs are already in flight"
+        slot = self.next_ticket & 1
+        cur = torch.cuda.current_stream()
+        self.part[slot].zero_()
+        self.ctx.partial_device(d_points.data_ptr(), d_scalars.data_ptr(), self.n, self.part[slot].data_ptr(), cur.cuda_stream)
+        if self.gloo:                                   # rehearsal path (no CUDA all_gather in gloo): blocking
+            src = self.part[slot].cpu()
+            self.dist.all_gather_into_tensor(self.gathered[slot], src, group=self.group)
+            self.host[slot].copy_(self.gathered[slot])
+            self.ev[slot].record(cur)
+        else:
+            work = self.dist.all_gather_into_tensor(self.gathered[slot], self.part[slot], group=self.group, async_op=True)
+            with torch.cuda.stream(self.copy_stream):   # the copy stream, not the compute stream, waits for the collective
+                work.wait()
+                self.host[slot].copy_(self.gathered[slot], non_blocking=True)
+                self.ev[slot].record(self.copy_stream)
+        t = self.next_ticket
+        self.next_ticket += 1
+        return t
+
+    def collect(self, ticket: int) -> bytes:
+        from .binding import finalize_host
+        assert ticket == self.next_collect, "collect in submission order"
+        slot = ticket & 1
+        self.ev[slot].synchronize()
+        self.next_collect += 1
+        nbytes = self.W * PARTIAL_BYTES
+        flat = self.host[slot].numpy().tobytes()
+        merged = merge_partials([flat[r * nbytes:(r + 1) * nbytes] for r in range(self.world)], self.W, self.world)
+        return finalize_host(merged, self.c, self.W)
