@@ -447,24 +447,26 @@ __global__ void __launch_bounds__(256) k_l2_place(const uint16_t* __restrict__ p
 // Buckets split into several segments are summed afterwards by k_seg_combine.
 //   k_seg_build  : thread per segment -> (bucket, part) by binary search in seg_base, and its length
 //   k_order_*    : counting sort of segment ids by descending length
+// also: histogram of the segment lengths (for the schedule) and the list of split buckets (for k_seg_combine)
 __global__ void __launch_bounds__(256) k_seg_build(const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ bucket_count,
                                                    const uint32_t* __restrict__ num_segments, uint32_t total_buckets, uint32_t seg_len,
-                                                   uint32_t* __restrict__ seg_bucket, uint32_t* __restrict__ seg_lenv) {
+                                                   uint32_t* __restrict__ seg_bucket, uint32_t* __restrict__ seg_lenv,
+                                                   uint32_t* __restrict__ size_hist, uint32_t* __restrict__ split_list,
+                                                   uint32_t* __restrict__ split_count) {
+  __shared__ uint32_t h[1024];
+  for (uint32_t j = threadIdx.x; j < 1024u; j += 256u) h[j] = 0;
+  __syncthreads();
   const uint32_t ns = *num_segments;
   for (uint32_t s = blockIdx.x * 256u + threadIdx.x; s < ns; s += gridDim.x * 256u) {
     uint32_t lo = 0, hi = total_buckets;            // last bucket g with seg_base[g] <= s
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seg_base[mid] <= s) lo = mid; else hi = mid; }
     const uint32_t part = s - seg_base[lo], cnt = bucket_count[lo];
+    const uint32_t len = cnt > part * seg_len ? min(seg_len, cnt - part * seg_len) : 0u;
     seg_bucket[s] = lo;
-    seg_lenv[s] = cnt > part * seg_len ? min(seg_len, cnt - part * seg_len) : 0u;
+    seg_lenv[s] = len;
+    atomicAdd(&h[min(len, 1023u)], 1u);
+    if (part == 0 && cnt > seg_len) split_list[atomicAdd(split_count, 1u)] = lo;
   }
-}
-__global__ void __launch_bounds__(256) k_order_hist(const uint32_t* __restrict__ lenv, const uint32_t* __restrict__ num_items, uint32_t* __restrict__ size_hist) {
-  __shared__ uint32_t h[1024];
-  const uint32_t total = *num_items;
-  for (uint32_t j = threadIdx.x; j < 1024u; j += 256u) h[j] = 0;
-  __syncthreads();
-  for (uint32_t g = blockIdx.x * 256u + threadIdx.x; g < total; g += gridDim.x * 256u) atomicAdd(&h[min(lenv[g], 1023u)], 1u);
   __syncthreads();
   for (uint32_t j = threadIdx.x; j < 1024u; j += 256u) if (h[j]) atomicAdd(&size_hist[j], h[j]);
 }
@@ -567,18 +569,10 @@ __global__ void __launch_bounds__(256) k_accumulate(const pnt_slot* __restrict__
   store_ete(whole ? buckets + g : seg_out + sgm, acc);
 }
 
-// sums the parts of every split bucket (thread per bucket; unsplit buckets were written by k_accumulate)
-__global__ void __launch_bounds__(256) k_seg_combine(const uint32_t* __restrict__ bucket_count, const uint32_t* __restrict__ seg_base,
-                                                     const ete* __restrict__ seg_out, ete* __restrict__ buckets, uint32_t total_buckets, uint32_t seg_len) {
-  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
-  if (g >= total_buckets) return;
-  const uint32_t cnt = bucket_count[g];
-  if (cnt <= seg_len) return;
-  const uint32_t ns = (cnt + seg_len - 1u) / seg_len, s0 = seg_base[g];
-  ete acc = load_ete(seg_out + s0);
-  for (uint32_t j = 1; j < ns; j++) acc = ete_add(acc, load_ete(seg_out + s0 + j));
-  store_ete(buckets + g, acc);
-}
+// sums the parts of every split bucket: one quad (team addition) per entry of the split list
+__global__ void __launch_bounds__(256) k_seg_combine(const uint32_t* __restrict__ split_list, const uint32_t* __restrict__ split_count,
+                                                     const uint32_t* __restrict__ bucket_count, const uint32_t* __restrict__ seg_base,
+                                                     const ete* __restrict__ seg_out, ete* __restrict__ buckets, uint32_t seg_len);
 
 // ------------------------------------------------------------------------------------------------
 // K4a: marginal sums.  Bucket j of a window has weight j + 1; write j in four digits j = (d3 d2 d1 d0) of w3..w0 bits
@@ -678,6 +672,19 @@ __device__ __forceinline__ void store_coord(uint32_t* p, const fp& a) {
   for (int i = 0; i < NL; i++) p[i] = a.v[i];
 }
 __device__ __forceinline__ fp identity_coord(uint32_t q) { return (q == 1 || q == 3) ? fp_R1() : fp_zero(); }
+
+__global__ void __launch_bounds__(256) k_seg_combine(const uint32_t* __restrict__ split_list, const uint32_t* __restrict__ split_count,
+                                                     const uint32_t* __restrict__ bucket_count, const uint32_t* __restrict__ seg_base,
+                                                     const ete* __restrict__ seg_out, ete* __restrict__ buckets, uint32_t seg_len) {
+  const uint32_t nsplit = *split_count, q = threadIdx.x & 3u;
+  for (uint32_t i = (blockIdx.x * 256u + threadIdx.x) >> 2; i < nsplit; i += (gridDim.x * 256u) >> 2) {
+    const uint32_t g = split_list[i];
+    const uint32_t ns = (bucket_count[g] + seg_len - 1u) / seg_len, s0 = seg_base[g];
+    fp acc = load_coord(reinterpret_cast<const uint32_t*>(seg_out + s0) + team_word(q));
+    for (uint32_t j = 1; j < ns; j++) acc = ete_add_team(acc, load_coord(reinterpret_cast<const uint32_t*>(seg_out + s0 + j) + team_word(q)), q);
+    store_coord(reinterpret_cast<uint32_t*>(buckets + g) + team_word(q), acc);
+  }
+}
 
 // k_sum_groups with a quad per output (levels where the grid is too small to fill the machine): 4 threads per output.
 __global__ void __launch_bounds__(256) k_sum_groups_team(sum_jobs js, uint32_t nw) {

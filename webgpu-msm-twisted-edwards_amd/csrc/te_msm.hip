@@ -46,7 +46,7 @@ struct gpu_t {
   te::pnt_slot* d_recs = nullptr;
   uint16_t* d_digits = nullptr;
   uint32_t *d_counts1 = nullptr, *d_part_start = nullptr, *d_part_count = nullptr, *d_part_idx = nullptr;
-  uint32_t *d_seg_base = nullptr, *d_seg_bucket = nullptr, *d_seg_lenv = nullptr, *d_num_seg = nullptr;
+  uint32_t *d_seg_base = nullptr, *d_seg_bucket = nullptr, *d_seg_lenv = nullptr, *d_num_seg = nullptr, *d_split_list = nullptr;
   te::ete* d_seg_out = nullptr;
   uint32_t *d_bucket_count = nullptr, *d_bucket_start = nullptr, *d_bucket_cursor = nullptr, *d_seg_total = nullptr, *d_sorted = nullptr, *d_order = nullptr, *d_size_hist = nullptr, *d_size_cursor = nullptr;
   uint16_t* d_part_keys = nullptr;
@@ -163,6 +163,7 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, uint64_t n, const plan_t& p) {
   if ((rc = ensure(ctx, d.d_seg_lenv, d.cap[21], smax))) return rc;
   if ((rc = ensure(ctx, d.d_seg_out, d.cap[22], smax))) return rc;
   if ((rc = ensure(ctx, d.d_seg_base, d.cap[23], wb + 1))) return rc;
+  if ((rc = ensure(ctx, d.d_split_list, d.cap[24], wb + 1))) return rc;
   if ((rc = ensure(ctx, d.d_part_start, d.cap[6], (size_t)p.nw * p.P))) return rc;
   if ((rc = ensure(ctx, d.d_buckets, d.cap[8], wb))) return rc;
   if ((rc = ensure(ctx, d.d_part_count, d.cap[9], (size_t)p.nw * p.P))) return rc;
@@ -202,7 +203,7 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, const void* d_points, const void* d_s
   auto mark = [&](int i) { if (prof >= 2 || (prof == 1 && (i == ST_ACCUM || i == ST_ACCUM + 1))) (void)hipEventRecord(d.ev[slot][i], stream); };
   const uint32_t n32 = (uint32_t)n;
 
-  HIP_TRY(ctx, hipMemsetAsync(d.d_err, 0, sizeof(uint32_t), stream));
+  HIP_TRY(ctx, hipMemsetAsync(d.d_err, 0, 1032 * sizeof(uint32_t), stream));     // flag, counters, length histogram
   mark(ST_PREP);
   {  hipLaunchKernelGGL(te::k_prep_points, dim3((n32 + 255) / 256), dim3(256), 0, stream,
                      (const uint4*)d_points, d.d_recs, n32);
@@ -260,11 +261,10 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, const void* d_points, const void* d_s
   mark(ST_ORDER);
   const uint32_t* order = nullptr;
   if (p.nw > 0) {
+    // d_num_seg[1] = number of split buckets; size_hist zeroed together with it
     hipLaunchKernelGGL(te::k_seg_build, dim3(1024), dim3(256), 0, stream, d.d_seg_base, d.d_bucket_count, d.d_num_seg, total, p.seg_len,
-                       d.d_seg_bucket, d.d_seg_lenv);
+                       d.d_seg_bucket, d.d_seg_lenv, d.d_size_hist, d.d_split_list, d.d_num_seg + 1);
     if (ctx->opt_sort) {
-      HIP_TRY(ctx, hipMemsetAsync(d.d_size_hist, 0, 1024 * sizeof(uint32_t), stream));
-      hipLaunchKernelGGL(te::k_order_hist, dim3(256), dim3(256), 0, stream, d.d_seg_lenv, d.d_num_seg, d.d_size_hist);
       hipLaunchKernelGGL(te::k_order_scan, dim3(1), dim3(1024), 0, stream, d.d_size_hist, d.d_size_cursor);
       hipLaunchKernelGGL(te::k_order_scatter, dim3(256), dim3(256), 0, stream, d.d_seg_lenv, d.d_num_seg, d.d_size_cursor, d.d_order);
       order = d.d_order;
@@ -275,8 +275,8 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, const void* d_points, const void* d_s
     hipLaunchKernelGGL(te::k_accumulate, dim3((smax + 255) / 256), dim3(256), 0, stream, d.d_recs, d.d_sorted, d.d_bucket_start,
                        d.d_bucket_count, d.d_seg_base, d.d_seg_bucket, d.d_seg_lenv, order, d.d_num_seg, d.d_buckets, d.d_seg_out,
                        n32, p.logB, p.seg_len);
-    hipLaunchKernelGGL(te::k_seg_combine, dim3((total + 255) / 256), dim3(256), 0, stream, d.d_bucket_count, d.d_seg_base, d.d_seg_out,
-                       d.d_buckets, total, p.seg_len);
+    hipLaunchKernelGGL(te::k_seg_combine, dim3(256), dim3(256), 0, stream, d.d_split_list, d.d_num_seg + 1, d.d_bucket_count, d.d_seg_base,
+                       d.d_seg_out, d.d_buckets, p.seg_len);
   }
   mark(ST_TREE);
   // digit marginals M_k[v], k = 0..3 (see K4a in kernels.hip.hpp).  Chains of folds, 4 (or 2) points per level:
@@ -355,7 +355,7 @@ int collect_stage_ms(te_ctx* ctx, gpu_t& d, int slot = 0) {
 void free_dev(gpu_t& d) {
   (void)hipSetDevice(d.device);
   void* ptrs[] = {d.d_recs, d.d_digits, d.d_counts1, d.d_part_start, d.d_part_count, d.d_part_keys, d.d_part_idx, d.d_buckets,
-                  d.d_bucket_count, d.d_bucket_start, d.d_bucket_cursor, d.d_seg_total, d.d_sorted, d.d_seg_base, d.d_seg_bucket, d.d_seg_lenv, d.d_seg_out, d.d_num_seg, d.d_order, d.d_size_hist, d.d_size_cursor, d.d_red[0], d.d_red[1], d.d_red[2], d.d_red[3], d.d_partials,
+                  d.d_bucket_count, d.d_bucket_start, d.d_bucket_cursor, d.d_seg_total, d.d_sorted, d.d_seg_base, d.d_seg_bucket, d.d_seg_lenv, d.d_seg_out, d.d_split_list, d.d_order, d.d_red[0], d.d_red[1], d.d_red[2], d.d_red[3], d.d_partials,
                   d.d_err, d.d_in_points, d.d_in_scalars};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (d.h_err) (void)hipHostFree(d.h_err);
@@ -398,7 +398,6 @@ int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, boo
       dp = d.d_in_points; ds = d.d_in_scalars;
     }
     if (int rc = ensure_buffers(ctx, d, n, p0)) return rc;     // sizes d_partials before the memset below
-    HIP_TRY(ctx, hipMemsetAsync(d.d_partials, 0, (size_t)p0.W * TE_MSM_PARTIAL_BYTES, d.stream));
     if (int rc = enqueue_partial(ctx, d, dp, ds, n, d.d_partials, d.stream)) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(d.h_partials, d.d_partials, (size_t)p0.W * TE_MSM_PARTIAL_BYTES, hipMemcpyDeviceToHost, d.stream));
   }
@@ -440,10 +439,10 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
     if (d.device < 0 || d.device >= count) { g_init_error = "te_msm_init: device id out of range"; delete ctx; return TE_MSM_EINVAL; }
     hipError_t er = hipSetDevice(d.device);
     if (er == hipSuccess) er = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
-    if (er == hipSuccess) er = hipMalloc((void**)&d.d_err, sizeof(uint32_t));
-    if (er == hipSuccess) er = hipMalloc((void**)&d.d_num_seg, 4 * sizeof(uint32_t));
-    if (er == hipSuccess) er = hipMalloc((void**)&d.d_size_hist, 1024 * sizeof(uint32_t));
-    if (er == hipSuccess) er = hipMalloc((void**)&d.d_size_cursor, 1024 * sizeof(uint32_t));
+    // one scratch block, zeroed by a single memset per MSM: [0] final-carry flag, [1] number of segments, [2] number of
+    // split buckets, [8..1031] segment-length histogram; [1032..2055] its cursor (not zeroed)
+    if (er == hipSuccess) er = hipMalloc((void**)&d.d_err, 2056 * sizeof(uint32_t));
+    if (er == hipSuccess) { d.d_num_seg = d.d_err + 1; d.d_size_hist = d.d_err + 8; d.d_size_cursor = d.d_err + 1032; }
     if (er == hipSuccess) er = hipHostMalloc((void**)&d.h_err, sizeof(uint32_t), hipHostMallocDefault);
     if (er == hipSuccess) er = hipEventCreateWithFlags(&d.ev_done, hipEventDisableTiming);
     for (auto& evs : d.ev) for (auto& evn : evs) if (er == hipSuccess) er = hipEventCreate(&evn);
@@ -493,7 +492,6 @@ int te_msm_submit_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_
     }
     d.slot_capW = wmax;
   }
-  HIP_TRY(ctx, hipMemsetAsync(d.d_partials, 0, (size_t)p.W * TE_MSM_PARTIAL_BYTES, d.stream));
   if (int rc = enqueue_partial(ctx, d, d_points_xy_le, d_scalars_le, n, d.d_partials, d.stream, slot)) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(d.h_slot_partials[slot], d.d_partials, (size_t)p.W * TE_MSM_PARTIAL_BYTES, hipMemcpyDeviceToHost, d.stream));
   HIP_TRY(ctx, hipMemcpyAsync(d.h_slot_err[slot], d.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
