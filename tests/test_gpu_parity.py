@@ -334,3 +334,18 @@ def test_pipelined_submit_collect(pkg, ora):
         assert c.collect(t2) == data[2][3]
         assert c.collect(t3) == data[3][3]
         assert c.run_device(data[0][0].data_ptr(), data[0][1].data_ptr(), data[0][2]) == data[0][3]
+
+
+def test_giant_buckets(ctx, model, ora):
+    """skew: all scalars equal (one bucket per window holds every point) and a window size whose top window has a single
+    occupied bucket -- buckets of 10^5 entries are split into thousands of parts and summed by the block-level combine"""
+    n = 200000
+    pts = ora.gen_points(71, n)
+    same = model.scalars_to_bytes([0x0123456789ABCDEF0123456789ABCDEF0123456789ABCDEF0123456789ABCDEF % model.P] * n)
+    assert ctx.run(pts, same) == ora.msm(pts, same, threads=16)
+    sc = ora.gen_scalars(72, n)
+    exp = ora.msm(pts, sc, threads=16)
+    for c in (12, 14, 13):                      # 253-bit scalars: 12- and 14-bit windows leave ONE bit for the top window
+        ctx.set_option("window_bits", c)
+        assert ctx.run(pts, sc) == exp
+    ctx.set_option("window_bits", 0)

@@ -447,12 +447,15 @@ __global__ void __launch_bounds__(256) k_l2_place(const uint16_t* __restrict__ p
 // Buckets split into several segments are summed afterwards by k_seg_combine.
 //   k_seg_build  : thread per segment -> (bucket, part) by binary search in seg_base, and its length
 //   k_order_*    : counting sort of segment ids by descending length
-// also: histogram of the segment lengths (for the schedule) and the list of split buckets (for k_seg_combine)
+// also: histogram of the segment lengths (for the schedule) and the lists of split buckets (for k_seg_combine*)
+#define TE_COMBINE_SMALL 16u
 __global__ void __launch_bounds__(256) k_seg_build(const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ bucket_count,
                                                    const uint32_t* __restrict__ num_segments, uint32_t total_buckets, uint32_t seg_len,
                                                    uint32_t* __restrict__ seg_bucket, uint32_t* __restrict__ seg_lenv,
                                                    uint32_t* __restrict__ size_hist, uint32_t* __restrict__ split_list,
-                                                   uint32_t* __restrict__ split_count) {
+                                                   uint32_t* __restrict__ split_count /* [0] small, [1] large buckets, [2] large chunks */,
+                                                   uint32_t* __restrict__ large_list, uint32_t* __restrict__ chunk_list /* pairs (bucket, first part) */,
+                                                   uint32_t list_cap) {
   __shared__ uint32_t h[1024];
   for (uint32_t j = threadIdx.x; j < 1024u; j += 256u) h[j] = 0;
   __syncthreads();
@@ -465,7 +468,13 @@ __global__ void __launch_bounds__(256) k_seg_build(const uint32_t* __restrict__ 
     seg_bucket[s] = lo;
     seg_lenv[s] = len;
     atomicAdd(&h[min(len, 1023u)], 1u);
-    if (part == 0 && cnt > seg_len) split_list[atomicAdd(split_count, 1u)] = lo;
+    // buckets cut into 2..TE_COMBINE_SMALL parts are summed by one quad; longer ones by blocks, 1024 parts at a time
+    const uint32_t nparts = (cnt + seg_len - 1u) / seg_len;
+    if (nparts > 1u && nparts <= TE_COMBINE_SMALL) { if (part == 0) split_list[atomicAdd(&split_count[0], 1u)] = lo; }
+    else if (nparts > TE_COMBINE_SMALL) {
+      if (part == 0) { const uint32_t i = atomicAdd(&split_count[1], 1u); if (i < list_cap) large_list[i] = lo; }
+      if ((part & 1023u) == 0) { const uint32_t i = atomicAdd(&split_count[2], 1u); if (i < list_cap) { chunk_list[2 * i] = lo; chunk_list[2 * i + 1] = part; } }
+    }
   }
   __syncthreads();
   for (uint32_t j = threadIdx.x; j < 1024u; j += 256u) if (h[j]) atomicAdd(&size_hist[j], h[j]);
@@ -683,6 +692,56 @@ __global__ void __launch_bounds__(256) k_seg_combine(const uint32_t* __restrict_
     fp acc = load_coord(reinterpret_cast<const uint32_t*>(seg_out + s0) + team_word(q));
     for (uint32_t j = 1; j < ns; j++) acc = ete_add_team(acc, load_coord(reinterpret_cast<const uint32_t*>(seg_out + s0 + j) + team_word(q)), q);
     store_coord(reinterpret_cast<uint32_t*>(buckets + g) + team_word(q), acc);
+  }
+}
+
+// block-wide sum of cnt points src[0], src[stride], ... by 64 quads: strided serial team additions, then an LDS tree.
+// Returns the sum in quad 0.  blockDim.x must be 256; lds holds 64 * 36 words.
+__device__ __forceinline__ fp block_sum_points(const ete* __restrict__ src, uint32_t stride, uint32_t cnt, uint32_t* lds) {
+  const uint32_t i = threadIdx.x >> 2, q = threadIdx.x & 3u, w = team_word(q);
+  fp acc = identity_coord(q);
+  for (uint32_t j = i; j < cnt; j += 64u) {       // quad-uniform trip count differs between quads: DPP stays inside a quad
+    const fp e = load_coord(reinterpret_cast<const uint32_t*>(src + (size_t)j * stride) + w);
+    acc = j == i ? e : ete_add_team(acc, e, q);
+  }
+  for (uint32_t s = 32; s > 0; s >>= 1) {
+    if (i >= s && i < 2 * s) store_coord(lds + (size_t)i * 36 + w, acc);
+    __syncthreads();
+    const bool act = i < s && i + s < cnt;
+    const fp other = act ? load_coord(lds + (size_t)(i + s) * 36 + w) : identity_coord(q);
+    const fp sum = ete_add_team(acc, other, q);
+    acc = fp_select(act, sum, acc);
+    __syncthreads();
+  }
+  return acc;
+}
+// giant buckets (skewed scalars, or a top window with one or two occupied buckets): stage 1 sums each run of 1024 parts
+// into its first slot, stage 2 sums those slots into the bucket.  One block per work item, grid-stride.
+__global__ void __launch_bounds__(256) k_seg_combine_large1(const uint32_t* __restrict__ chunk_list, const uint32_t* __restrict__ counts,
+                                                            const uint32_t* __restrict__ bucket_count, const uint32_t* __restrict__ seg_base,
+                                                            ete* __restrict__ seg_out, uint32_t seg_len, uint32_t list_cap) {
+  __shared__ uint32_t lds[64 * 36];
+  const uint32_t items = min(counts[2], list_cap), q = threadIdx.x & 3u;
+  for (uint32_t it = blockIdx.x; it < items; it += gridDim.x) {
+    const uint32_t g = chunk_list[2 * it], part = chunk_list[2 * it + 1];
+    const uint32_t ns = (bucket_count[g] + seg_len - 1u) / seg_len, cnt = min(1024u, ns - part);
+    ete* base = seg_out + seg_base[g] + part;
+    const fp r = block_sum_points(base, 1u, cnt, lds);
+    if ((threadIdx.x >> 2) == 0) store_coord(reinterpret_cast<uint32_t*>(base) + team_word(q), r);
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(256) k_seg_combine_large2(const uint32_t* __restrict__ large_list, const uint32_t* __restrict__ counts,
+                                                            const uint32_t* __restrict__ bucket_count, const uint32_t* __restrict__ seg_base,
+                                                            const ete* __restrict__ seg_out, ete* __restrict__ buckets, uint32_t seg_len, uint32_t list_cap) {
+  __shared__ uint32_t lds[64 * 36];
+  const uint32_t items = min(counts[1], list_cap), q = threadIdx.x & 3u;
+  for (uint32_t it = blockIdx.x; it < items; it += gridDim.x) {
+    const uint32_t g = large_list[it];
+    const uint32_t ns = (bucket_count[g] + seg_len - 1u) / seg_len, cnt = (ns + 1023u) >> 10;
+    const fp r = block_sum_points(seg_out + seg_base[g], 1024u, cnt, lds);
+    if ((threadIdx.x >> 2) == 0) store_coord(reinterpret_cast<uint32_t*>(buckets + g) + team_word(q), r);
+    __syncthreads();
   }
 }
 

@@ -46,7 +46,7 @@ struct gpu_t {
   te::pnt_slot* d_recs = nullptr;
   uint16_t* d_digits = nullptr;
   uint32_t *d_counts1 = nullptr, *d_part_start = nullptr, *d_part_count = nullptr, *d_part_idx = nullptr;
-  uint32_t *d_seg_base = nullptr, *d_seg_bucket = nullptr, *d_seg_lenv = nullptr, *d_num_seg = nullptr, *d_split_list = nullptr;
+  uint32_t *d_seg_base = nullptr, *d_seg_bucket = nullptr, *d_seg_lenv = nullptr, *d_num_seg = nullptr, *d_split_list = nullptr, *d_large_list = nullptr, *d_chunk_list = nullptr;
   te::ete* d_seg_out = nullptr;
   uint32_t *d_bucket_count = nullptr, *d_bucket_start = nullptr, *d_bucket_cursor = nullptr, *d_seg_total = nullptr, *d_sorted = nullptr, *d_order = nullptr, *d_size_hist = nullptr, *d_size_cursor = nullptr;
   uint16_t* d_part_keys = nullptr;
@@ -98,14 +98,16 @@ int set_err(te_ctx* ctx, int code, const char* msg) { ctx->err = msg; return cod
 uint32_t ilog2(uint32_t v) { uint32_t l = 0; while ((1u << l) < v) l++; return l; }
 
 int auto_window_bits(uint64_t n) {
-  // field products: accumulation 7 per point and window; bucket reduction ~ 2 full additions (9) per bucket
-  double best = 0; int bc = 16;
-  for (int c = 8; c <= 16; c++) {
-    const double W = (256 + c - 1) / c, B = (double)(1u << (c - 1));
-    const double cost = W * (7.0 * (double)n + 18.0 * B + 4000.0);
-    if (c == 8 || cost < best) { best = cost; bc = c; }
-  }
-  return bc;
+  // measured on MI355X (profiles/r01_window_sweep.txt): 16 bits from 2^18 points up, 15 bits for 2^14..2^17 (fewer
+  // buckets to reduce, and at that size the fixed stages weigh more than the additions); below that about
+  // log2(n) + 1 bits so that the W * 2^(c-1) buckets do not dwarf the n points.
+  if (n >= (1ull << 18)) return 16;
+  if (n >= (1ull << 14)) return 15;
+  int lg = 0; while ((1ull << (lg + 1)) <= n) lg++;
+  int c = lg + 1;
+  if (c < 8) c = 8;
+  if (c > 15) c = 15;
+  return c;
 }
 
 void make_plan(const te_ctx* ctx, const gpu_t& d, uint64_t n, plan_t& p) {
@@ -164,6 +166,8 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, uint64_t n, const plan_t& p) {
   if ((rc = ensure(ctx, d.d_seg_out, d.cap[22], smax))) return rc;
   if ((rc = ensure(ctx, d.d_seg_base, d.cap[23], wb + 1))) return rc;
   if ((rc = ensure(ctx, d.d_split_list, d.cap[24], wb + 1))) return rc;
+  if ((rc = ensure(ctx, d.d_large_list, d.cap[25], wb + 1))) return rc;
+  if ((rc = ensure(ctx, d.d_chunk_list, d.cap[26], 2 * wb + 2))) return rc;
   if ((rc = ensure(ctx, d.d_part_start, d.cap[6], (size_t)p.nw * p.P))) return rc;
   if ((rc = ensure(ctx, d.d_buckets, d.cap[8], wb))) return rc;
   if ((rc = ensure(ctx, d.d_part_count, d.cap[9], (size_t)p.nw * p.P))) return rc;
@@ -263,7 +267,7 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, const void* d_points, const void* d_s
   if (p.nw > 0) {
     // d_num_seg[1] = number of split buckets; size_hist zeroed together with it
     hipLaunchKernelGGL(te::k_seg_build, dim3(1024), dim3(256), 0, stream, d.d_seg_base, d.d_bucket_count, d.d_num_seg, total, p.seg_len,
-                       d.d_seg_bucket, d.d_seg_lenv, d.d_size_hist, d.d_split_list, d.d_num_seg + 1);
+                       d.d_seg_bucket, d.d_seg_lenv, d.d_size_hist, d.d_split_list, d.d_num_seg + 1, d.d_large_list, d.d_chunk_list, total);
     if (ctx->opt_sort) {
       hipLaunchKernelGGL(te::k_order_scan, dim3(1), dim3(1024), 0, stream, d.d_size_hist, d.d_size_cursor);
       hipLaunchKernelGGL(te::k_order_scatter, dim3(256), dim3(256), 0, stream, d.d_seg_lenv, d.d_num_seg, d.d_size_cursor, d.d_order);
@@ -277,6 +281,11 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, const void* d_points, const void* d_s
                        n32, p.logB, p.seg_len);
     hipLaunchKernelGGL(te::k_seg_combine, dim3(256), dim3(256), 0, stream, d.d_split_list, d.d_num_seg + 1, d.d_bucket_count, d.d_seg_base,
                        d.d_seg_out, d.d_buckets, p.seg_len);
+    // giant buckets (empty lists for well-spread digits: two near-empty launches)
+    hipLaunchKernelGGL(te::k_seg_combine_large1, dim3(512), dim3(256), 0, stream, d.d_chunk_list, d.d_num_seg + 1, d.d_bucket_count, d.d_seg_base,
+                       d.d_seg_out, p.seg_len, total);
+    hipLaunchKernelGGL(te::k_seg_combine_large2, dim3(256), dim3(256), 0, stream, d.d_large_list, d.d_num_seg + 1, d.d_bucket_count, d.d_seg_base,
+                       d.d_seg_out, d.d_buckets, p.seg_len, total);
   }
   mark(ST_TREE);
   // digit marginals M_k[v], k = 0..3 (see K4a in kernels.hip.hpp).  Chains of folds, 4 (or 2) points per level:
@@ -355,7 +364,7 @@ int collect_stage_ms(te_ctx* ctx, gpu_t& d, int slot = 0) {
 void free_dev(gpu_t& d) {
   (void)hipSetDevice(d.device);
   void* ptrs[] = {d.d_recs, d.d_digits, d.d_counts1, d.d_part_start, d.d_part_count, d.d_part_keys, d.d_part_idx, d.d_buckets,
-                  d.d_bucket_count, d.d_bucket_start, d.d_bucket_cursor, d.d_seg_total, d.d_sorted, d.d_seg_base, d.d_seg_bucket, d.d_seg_lenv, d.d_seg_out, d.d_split_list, d.d_order, d.d_red[0], d.d_red[1], d.d_red[2], d.d_red[3], d.d_partials,
+                  d.d_bucket_count, d.d_bucket_start, d.d_bucket_cursor, d.d_seg_total, d.d_sorted, d.d_seg_base, d.d_seg_bucket, d.d_seg_lenv, d.d_seg_out, d.d_split_list, d.d_large_list, d.d_chunk_list, d.d_order, d.d_red[0], d.d_red[1], d.d_red[2], d.d_red[3], d.d_partials,
                   d.d_err, d.d_in_points, d.d_in_scalars};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (d.h_err) (void)hipHostFree(d.h_err);
