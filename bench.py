@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--log2n", type=int, default=20)
     ap.add_argument("--window-bits", type=int, default=16)
     ap.add_argument("--points", choices=["chain", "fixed"], default="chain", help="chain: distinct points (a+i*b)G; fixed: harness mode")
+    ap.add_argument("--scalars", choices=["uniform", "equal", "small"], default="uniform",
+                    help="uniform: the harness's distribution; equal: one scalar repeated (worst-case skew); small: 64-bit scalars")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--segment-len", type=int, default=0)
     ap.add_argument("--no-pipeline", action="store_true", help="N=1: await every MSM before submitting the next (latency mode)")
@@ -72,6 +74,10 @@ def main():
     t0 = time.time()
     pts = oracle.gen_points(seed, n) if args.points == "chain" else oracle.gen_points_fixed(n)
     sc = oracle.gen_scalars(seed, n)
+    if args.scalars == "equal":
+        sc = sc[:32] * n
+    elif args.scalars == "small":
+        sc = b"".join(sc[32 * i:32 * i + 8] + bytes(24) for i in range(n))
     gen_s = time.time() - t0
     d_pts = torch.frombuffer(bytearray(pts), dtype=torch.uint8).cuda()
     d_sc = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
@@ -185,8 +191,8 @@ def main():
         "vs_baseline": None,
         "dtype": "u32",
         "data": "synthetic",
-        "config": {"workload": "n=2^%d TE-BLS12 MSM, %d-bit signed windows (%d windows x %d buckets), points=%s, inputs resident in HBM"
-                               % (args.log2n, c, W, B, args.points),
+        "config": {"workload": "n=2^%d TE-BLS12 MSM, %d-bit signed windows (%d windows x %d buckets), points=%s, scalars=%s, inputs resident in HBM"
+                               % (args.log2n, c, W, B, args.points, args.scalars),
                    "parallelism": "windows sharded over %d GPU(s), RCCL all-gather of %d B partial sums" % (world, W * 720) if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
