@@ -41,6 +41,7 @@ def main():
                     help="uniform: the harness's distribution; equal: one scalar repeated (worst-case skew); small: 64-bit scalars")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--segment-len", type=int, default=0)
+    ap.add_argument("--inflight", type=int, default=2, help="MSMs in flight in pipelined mode (1..4, each on its own stream / work set)")
     ap.add_argument("--no-pipeline", action="store_true", help="N=1: await every MSM before submitting the next (latency mode)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -102,7 +103,8 @@ def main():
 
     pipelined = not args.no_pipeline
     sharded = world > 1 or force_dist
-    pipe = pkg.ShardedPipeline(ctx, n, dist) if (sharded and pipelined) else None
+    depth = max(1, min(args.inflight, pkg.WORKSETS))
+    pipe = pkg.ShardedPipeline(ctx, n, dist, depth=depth) if (sharded and pipelined) else None
 
     result = None
     for _ in range(args.warmup):
@@ -131,24 +133,29 @@ def main():
     t0 = time.perf_counter()
     if pipelined and sharded:
         # the same with window shards: all-gather, read-back and host tail of MSM i overlap the device work of MSM i+1
-        tickets = [pipe.submit(d_pts, d_sc)]
-        for i in range(1, args.steps):
+        tickets = []
+        for i in range(args.steps):
             tickets.append(pipe.submit(d_pts, d_sc))
-            result = pipe.collect(tickets[i - 1])
-        result = pipe.collect(tickets[-1])
+            if len(tickets) >= depth:
+                result = pipe.collect(tickets.pop(0))
+        while tickets:
+            result = pipe.collect(tickets.pop(0))
         torch.cuda.synchronize()
         note_stage()                                   # events of the last MSM: a sample, not the mean
         for k in list(stage_acc):
             stage_acc[k] *= args.steps
     elif pipelined:
-        # K independent MSMs back to back, two in flight: the host tail of MSM i overlaps the device work of MSM i+1
-        tickets = [ctx.submit_device(d_pts.data_ptr(), d_sc.data_ptr(), n)]
-        for i in range(1, args.steps):
+        # K independent MSMs back to back, `depth` in flight on as many streams: host tail and device work of consecutive
+        # MSMs overlap, and on the GPU the gaps and latency-bound tail of one are filled by the wide kernels of another
+        tickets = []
+        for i in range(args.steps):
             tickets.append(ctx.submit_device(d_pts.data_ptr(), d_sc.data_ptr(), n))
-            result = ctx.collect(tickets[i - 1])
+            if len(tickets) >= depth:
+                result = ctx.collect(tickets.pop(0))
+                note_stage()
+        while tickets:
+            result = ctx.collect(tickets.pop(0))
             note_stage()
-        result = ctx.collect(tickets[-1])
-        note_stage()
     else:
         for _ in range(args.steps):
             result = step()
@@ -185,7 +192,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "latency_ms_single_msm": min(lat),
-        "mode": ("pipelined: 2 MSMs in flight (te_msm_submit_device / te_msm_collect)" if world == 1 else "pipelined: 2 window-sharded MSMs in flight per rank") if pipelined else "synchronous: one MSM at a time",
+        "mode": (("pipelined: %d MSMs in flight (te_msm_submit_device / te_msm_collect)" if world == 1 else "pipelined: %d window-sharded MSMs in flight per rank") % depth) if pipelined else "synchronous: one MSM at a time",
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,

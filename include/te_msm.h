@@ -35,6 +35,7 @@ typedef struct te_ctx te_ctx;
 
 #define TE_MSM_POINT_BYTES   64
 #define TE_MSM_SCALAR_BYTES  32
+#define TE_MSM_WORKSETS      4    /* MSMs one context can have in flight (submit/collect, partial_device) */
 #define TE_MSM_PARTIAL_BYTES 720  /* per window: 5 extended points x 144 B (see te_msm_partial_device) */
 
 /* Replaces get_device() + per-call buffer/pipeline creation (implementation/cuzk/gpu.ts:14-25,
@@ -57,9 +58,11 @@ int te_msm_run_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_sca
                       uint8_t out_xy_le[64]);
 
 /* Pipelined form of te_msm_run_device (single-device contexts): te_msm_submit_device enqueues every device stage plus
- * the 7 KB read-back and returns at once with a ticket; te_msm_collect waits for that MSM, runs the host tail and
- * writes the result.  Up to TWO MSMs may be in flight, so the host tail of MSM k overlaps the device work of MSM
- * k+1 (the reference's full_benchmarks.ts loop awaits each call; a prover calling MSMs back to back does not have to).
+ * the 11 KB read-back and returns at once with a ticket; te_msm_collect waits for that MSM, runs the host tail and
+ * writes the result.  Up to TE_MSM_WORKSETS MSMs may be in flight, each on its own stream and device work set: the host
+ * tail of MSM k overlaps the device work of MSM k+1, and on the GPU the launch gaps and the latency-bound reduction tail
+ * of one MSM are filled by the wide kernels of the others (the reference's full_benchmarks.ts loop awaits each call; a
+ * prover calling MSMs back to back does not have to).
  * Inputs must stay valid until the ticket is collected.  Tickets must be collected in submission order. */
 int te_msm_submit_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_scalars_le, uint64_t n, uint64_t* ticket);
 int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]);
@@ -89,9 +92,14 @@ int te_msm_plan(te_ctx* ctx, uint64_t n, int* window_bits, int* num_windows);
 #define TE_MSM_OWN_STREAM ((void*)(intptr_t)-1)
 int te_msm_partial_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_scalars_le, uint64_t n,
                           void* d_partials, void* stream);
+/* A context owns TE_MSM_WORKSETS device work sets (option "workset" selects the one te_msm_partial_device uses), so a
+ * caller can keep that many MSMs in flight on as many streams: their kernels overlap on the GPU.  te_msm_partial_wait blocks until the
+ * last te_msm_partial_device call on that work set has finished and returns its status (TE_MSM_ESCALAR if a scalar was
+ * out of range). */
+int te_msm_partial_wait(te_ctx* ctx, int workset);
 /* Host tail (replaces submission.ts:362-412: de-Montgomery, sum, Horner, toAffine): folds the W rows
  * (host memory; rows of absent windows all-zero are skipped as identity) into the affine result.
- * Also reports a pending TE_MSM_ESCALAR of the last te_msm_partial_device call of this context. */
+ * Waits for, and reports a pending TE_MSM_ESCALAR of, the last te_msm_partial_device call of this context. */
 int te_msm_finalize(te_ctx* ctx, const uint8_t* partials, int window_bits, int num_windows,
                     uint8_t out_xy_le[64]);
 

@@ -312,28 +312,67 @@ def test_node_compute_msm_entry_point(pkg, model, ora, tmp_path):
 
 
 def test_pipelined_submit_collect(pkg, ora):
-    """two MSMs in flight: results in submission order, each equal to the oracle; protocol errors are reported"""
+    """MSMs in flight on rotating work sets: results in submission order, each equal to the oracle; protocol errors are
+    reported"""
     import torch
-    cases = [(11, 30000), (12, 70000), (13, 5000), (14, 30000)]
+    cases = [(11, 30000), (12, 70000), (13, 5000), (14, 30000), (15, 1000), (16, 40000)]
     data = []
     for seed, n in cases:
         pts, sc = ora.gen_points(seed, n), ora.gen_scalars(seed, n)
         data.append((_dev(pts), _dev(sc), n, ora.msm(pts, sc, threads=8)))
     torch.cuda.synchronize()
     with pkg.MsmContext((0,)) as c:
-        t0 = c.submit_device(data[0][0].data_ptr(), data[0][1].data_ptr(), data[0][2])
-        t1 = c.submit_device(data[1][0].data_ptr(), data[1][1].data_ptr(), data[1][2])
+        sub = lambda i: c.submit_device(data[i][0].data_ptr(), data[i][1].data_ptr(), data[i][2])
+        t = [sub(i) for i in range(pkg.WORKSETS)]
         with pytest.raises(pkg.MsmError):
-            c.submit_device(data[2][0].data_ptr(), data[2][1].data_ptr(), data[2][2])       # a third one in flight
+            sub(4)                                                                            # every work set is busy
         with pytest.raises(pkg.MsmError):
-            c.collect(t1)                                                                     # out of order
-        assert c.collect(t0) == data[0][3]
-        t2 = c.submit_device(data[2][0].data_ptr(), data[2][1].data_ptr(), data[2][2])
-        assert c.collect(t1) == data[1][3]
-        t3 = c.submit_device(data[3][0].data_ptr(), data[3][1].data_ptr(), data[3][2])
-        assert c.collect(t2) == data[2][3]
-        assert c.collect(t3) == data[3][3]
+            c.collect(t[1])                                                                   # out of order
+        assert c.collect(t[0]) == data[0][3]
+        t.append(sub(4))
+        assert c.collect(t[1]) == data[1][3]
+        t.append(sub(5))
+        for i in range(2, 6):
+            assert c.collect(t[i]) == data[i][3]
         assert c.run_device(data[0][0].data_ptr(), data[0][1].data_ptr(), data[0][2]) == data[0][3]
+
+
+def test_two_work_sets_overlap_on_two_streams(pkg, model, ora):
+    """te_msm_partial_device on alternating work sets and streams: many MSMs in flight pairwise, each equal to the oracle;
+    a scalar-range error is reported by te_msm_partial_wait for the work set that saw it"""
+    import torch
+    n = 40000
+    cases = []
+    for seed in (21, 22, 23, 24, 25, 26):
+        pts, sc = ora.gen_points(seed, n), ora.gen_scalars(seed, n)
+        cases.append((_dev(pts), _dev(sc), ora.msm(pts, sc, threads=8)))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    with pkg.MsmContext((0,)) as c:
+        cbits, W = c.plan(n)
+        parts = [torch.zeros(W * 720, dtype=torch.uint8, device="cuda") for _ in cases]
+        torch.cuda.synchronize()
+        for i, (dp, ds, _) in enumerate(cases):
+            if i >= 2:
+                c.partial_wait(i & 1)                   # the work set's previous MSM must be done before it is reused
+            c.set_option("workset", i & 1)
+            c.partial_device(dp.data_ptr(), ds.data_ptr(), n, parts[i].data_ptr(), streams[i & 1].cuda_stream)
+        c.partial_wait(0); c.partial_wait(1)
+        for i, (_, _, exp) in enumerate(cases):
+            assert pkg.finalize_host(parts[i].cpu().numpy().tobytes(), cbits, W) == exp, i
+        # error on work set 1 only
+        bad = _dev(model.scalars_to_bytes([(1 << 256) - 1] * 4)); pts4 = _dev(ora.gen_points(3, 4))
+        good = _dev(model.scalars_to_bytes([1, 2, 3, 4]))
+        c.set_option("window_bits", 16)
+        W16 = c.plan(4)[1]
+        p0, p1 = (torch.zeros(W16 * 720, dtype=torch.uint8, device="cuda") for _ in range(2))
+        torch.cuda.synchronize()
+        c.set_option("workset", 0); c.partial_device(pts4.data_ptr(), good.data_ptr(), 4, p0.data_ptr(), streams[0].cuda_stream)
+        c.set_option("workset", 1); c.partial_device(pts4.data_ptr(), bad.data_ptr(), 4, p1.data_ptr(), streams[1].cuda_stream)
+        c.partial_wait(0)
+        with pytest.raises(pkg.MsmError) as e:
+            c.partial_wait(1)
+        assert e.value.code == -3
 
 
 def test_giant_buckets(ctx, model, ora):

@@ -18,5 +18,6 @@ from .binding import (  # noqa: F401
     build_library,
     library_path,
     PARTIAL_BYTES,
+    WORKSETS,
 )
 from .sharding import ShardedPipeline, compute_msm_sharded, exchange_partials, merge_partials, window_shard_for_rank  # noqa: F401

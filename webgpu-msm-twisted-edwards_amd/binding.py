@@ -13,6 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 PARTIAL_BYTES = 720
+WORKSETS = 4            # TE_MSM_WORKSETS: MSMs one context can have in flight
 
 
 class MsmError(RuntimeError):
@@ -90,6 +91,8 @@ def _lib() -> ctypes.CDLL:
         L.te_msm_plan.restype = ci
         L.te_msm_partial_device.argtypes = [vp, vp, vp, u64, vp, vp]
         L.te_msm_partial_device.restype = ci
+        L.te_msm_partial_wait.argtypes = [vp, ci]
+        L.te_msm_partial_wait.restype = ci
         L.te_msm_finalize.argtypes = [vp, cp, ci, ci, cp]
         L.te_msm_finalize.restype = ci
         L.te_msm_finalize_host.argtypes = [cp, ci, ci, cp]
@@ -165,7 +168,7 @@ class MsmContext:
         self._check(self._L.te_msm_run_device(self._h, d_points, d_scalars, n, out))
         return out.raw
 
-    # ---- pipelined form: up to two MSMs in flight (the host tail of one overlaps the device work of the next)
+    # ---- pipelined form: up to WORKSETS MSMs in flight (host tail and device work of consecutive MSMs overlap)
     def submit_device(self, d_points: int, d_scalars: int, n: int) -> int:
         t = ctypes.c_uint64()
         self._check(self._L.te_msm_submit_device(self._h, d_points, d_scalars, n, ctypes.byref(t)))
@@ -181,6 +184,10 @@ class MsmContext:
         """stream: a hipStream_t handle (0 = HIP's default stream, as torch.cuda.current_stream().cuda_stream
         reports for torch's default stream); -1 = the context's private stream (TE_MSM_OWN_STREAM)."""
         self._check(self._L.te_msm_partial_device(self._h, d_points, d_scalars, n, d_partials, ctypes.c_void_p(stream)))
+
+    def partial_wait(self, workset: int = 0):
+        """Blocks until the last partial_device call on that work set is done; raises on a scalar-range error."""
+        self._check(self._L.te_msm_partial_wait(self._h, workset))
 
     def finalize(self, partials: bytes, window_bits: int, num_windows: int) -> bytes:
         out = ctypes.create_string_buffer(64)

@@ -51,38 +51,41 @@ TE_HD pnt pnt_from_affine_mont(const fp& xm, const fp& ym) {
 // H, G are S;  HG = S x S, EH = N x S, GF = S x D (9 * 2^30 * 1.37 * 2^30 + 8 * 2^58 = 0.9 * 2^64).
 // Values: everything is below 5p before a product and below 1.1p after it; nothing is reduced mod p.
 TE_HD ete ete_madd(const ete& a, const pnt& b) {
-  const fp A = mont_mul(fp_sub<2>(a.y, a.x), b.hm);
-  const fp B = mont_mul(fp_add(a.y, a.x), b.hp);
-  const fp C = mont_mul(a.t, b.dt);
+  const fp in1[3] = {fp_sub<2>(a.y, a.x), fp_add(a.y, a.x), a.t}, in2[3] = {b.hm, b.hp, b.dt};
+  fp abc[3];
+  mont_mul_x<3>(in1, in2, abc);
+  const fp &A = abc[0], &B = abc[1], &C = abc[2];
   const fp E = fp_norm(fp_sub<2>(B, A));
   const fp H = fp_add(B, A);
   const fp F = fp_sub<2>(a.z, C);
   const fp G = fp_add(a.z, C);
+  const fp l[4] = {E, H, E, G}, rr[4] = {F, G, H, F};
+  fp o[4];
+  mont_mul_x<4>(l, rr, o);
   ete r;
-  r.x = mont_mul(E, F);
-  r.y = mont_mul(H, G);
-  r.t = mont_mul(E, H);
-  r.z = mont_mul(G, F);
+  r.x = o[0]; r.y = o[1]; r.t = o[2]; r.z = o[3];
   return r;
 }
 
 // Full addition a + b of two accumulators (add-2008-hwcd-3 shape, k = 2d), 9 products.
 // (Y1-X1), F = 2 Z1Z2 - C and G = 2 Z1Z2 + C are normalised so that no product sees two wide operands.
 TE_HD ete ete_add(const ete& a, const ete& b) {
-  const fp A = mont_mul(fp_norm(fp_sub<2>(a.y, a.x)), fp_sub<2>(b.y, b.x));
-  const fp B = mont_mul(fp_add(a.y, a.x), fp_add(b.y, b.x));
-  const fp C = mont_mul(mont_mul(a.t, b.t), fp_K2D_MONT());
-  const fp zz = mont_mul(a.z, b.z);
-  const fp D = fp_add(zz, zz);
+  const fp in1[4] = {fp_norm(fp_sub<2>(a.y, a.x)), fp_add(a.y, a.x), a.t, a.z};
+  const fp in2[4] = {fp_sub<2>(b.y, b.x), fp_add(b.y, b.x), b.t, b.z};
+  fp p1[4];
+  mont_mul_x<4>(in1, in2, p1);
+  const fp &A = p1[0], &B = p1[1];
+  const fp C = mont_mul(p1[2], fp_K2D_MONT());
+  const fp D = fp_add(p1[3], p1[3]);
   const fp E = fp_norm(fp_sub<2>(B, A));
   const fp H = fp_add(B, A);
   const fp F = fp_norm(fp_sub<2>(D, C));
   const fp G = fp_norm(fp_add(D, C));
+  const fp l[4] = {E, H, E, F}, rr[4] = {F, G, H, G};
+  fp o[4];
+  mont_mul_x<4>(l, rr, o);
   ete r;
-  r.x = mont_mul(E, F);
-  r.y = mont_mul(H, G);
-  r.t = mont_mul(E, H);
-  r.z = mont_mul(F, G);
+  r.x = o[0]; r.y = o[1]; r.t = o[2]; r.z = o[3];
   return r;
 }
 

@@ -35,9 +35,10 @@ __global__ void __launch_bounds__(256) k_prep_points(const uint4* __restrict__ p
   const uint32_t xw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
   const uint32_t yw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
   // to Montgomery form: x * R^2 / R.  Any 256-bit x (< 13.8p) gives a value < 1.04p.
-  const fp xm = mont_mul(fp_from_words32(xw), fp_R2());
-  const fp ym = mont_mul(fp_from_words32(yw), fp_R2());
-  const pnt r = pnt_from_affine_mont(xm, ym);
+  const fp raw[2] = {fp_from_words32(xw), fp_from_words32(yw)}, r2[2] = {fp_R2(), fp_R2()};
+  fp m[2];
+  mont_mul_x<2>(raw, r2, m);
+  const pnt r = pnt_from_affine_mont(m[0], m[1]);
   uint32_t w[32];
 #pragma unroll
   for (int j = 0; j < NL; j++) { w[j] = r.hm.v[j]; w[NL + j] = r.hp.v[j]; w[2 * NL + j] = r.dt.v[j]; }
@@ -138,7 +139,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds /*
 //            contiguously -- balanced for any digit distribution.
 struct sort_geom {
   uint32_t n, nst;       // entries per window; row stride of digits / part_keys / part_idx (multiple of 8, >= n)
-  uint32_t B, logS, S, P, CH, chunk_len, cap, dbg;   // chunk_len is a multiple of TE_TILE
+  uint32_t B, logS, S, P, CH, chunk_len;   // chunk_len is a multiple of TE_TILE
 };
 #define TE_TILE 4096u
 
@@ -548,7 +549,7 @@ __device__ __forceinline__ ete load_ete(const ete* src) {
   return a;
 }
 
-__global__ void __launch_bounds__(256) k_accumulate(const pnt_slot* __restrict__ recs, const uint32_t* __restrict__ sorted,
+__global__ void __launch_bounds__(256, 4) k_accumulate(const pnt_slot* __restrict__ recs, const uint32_t* __restrict__ sorted,
                                                     const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ bucket_count,
                                                     const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ seg_bucket,
                                                     const uint32_t* __restrict__ seg_lenv, const uint32_t* __restrict__ order,

@@ -34,34 +34,40 @@ struct plan_t {
   uint32_t dw[4] = {0, 0, 0, 0};      // bits of the four digits of a bucket index (dw[0] lowest)
   uint32_t CH = 0, chunk_len = 0, nst = 0;   // level-1 chunks per window (chunk_len multiple of 4096); padded row stride
   uint32_t seg_len = 64;
-  uint32_t S = 0, logS = 0, P = 0, cap = 0, cpb = 0;   // level-2 partition: S buckets each, P = B/S per window; LDS list entries (cpb per bucket)
+  uint32_t S = 0, logS = 0, P = 0;   // level-1 partition: S buckets each, P = B/S partitions per window
 };
+
+// Everything one MSM in flight needs on the device.  A GPU owns TE_MSM_WORKSETS work sets with their own streams so that
+// several MSMs overlap ON THE DEVICE: the launch gaps and the latency-bound reduction tail of one are filled by the wide kernels of the
+// other (te_msm_submit_device alternates them; "workset" option for te_msm_partial_device callers).
+struct workset_t {
+  hipStream_t stream = nullptr;
+  size_t cap[40] = {};                                  // per-buffer capacity in bytes (ensure())
+  te::pnt_slot* d_recs = nullptr;
+  uint16_t *d_digits = nullptr, *d_part_keys = nullptr;
+  uint32_t *d_counts1 = nullptr, *d_part_start = nullptr, *d_part_count = nullptr, *d_part_idx = nullptr;
+  uint32_t *d_bucket_count = nullptr, *d_bucket_start = nullptr, *d_bucket_cursor = nullptr, *d_seg_total = nullptr, *d_sorted = nullptr;
+  uint32_t *d_seg_base = nullptr, *d_seg_bucket = nullptr, *d_seg_lenv = nullptr, *d_order = nullptr;
+  uint32_t *d_split_list = nullptr, *d_large_list = nullptr, *d_chunk_list = nullptr;
+  te::ete *d_seg_out = nullptr, *d_buckets = nullptr, *d_red[12] = {};   // reduction: [0..3] ping/pong of the two first-phase chains, [4..11] small
+  // one scratch block, zeroed by a single memset per MSM: [0] final-carry flag, [1] number of segments, [2..4] split /
+  // giant bucket counters, [8..1031] segment-length histogram; [1032..2055] its cursor (not zeroed)
+  uint32_t *d_err = nullptr, *d_num_seg = nullptr, *d_size_hist = nullptr, *d_size_cursor = nullptr;
+  uint8_t* d_partials = nullptr;      // TE_MAX_WINDOWS x 720, allocated once
+  uint32_t* h_err = nullptr;          // pinned
+  uint8_t* h_partials = nullptr;      // pinned, TE_MAX_WINDOWS x 720
+  hipEvent_t ev_done = nullptr;
+  hipEvent_t ev[ST_COUNT + 1] = {};
+  plan_t plan; uint64_t n = 0; bool used = false;
+};
+constexpr int TE_MAX_WINDOWS = 64;    // window_bits >= 4
 
 struct gpu_t {
   int device = 0;
   int w_first = 0, w_step = 1;
-  hipStream_t stream = nullptr;
-  size_t cap[28] = {}, red_cap[12] = {};                // per-buffer capacity in bytes (ensure())
-  int cap_W = 0;
-  te::pnt_slot* d_recs = nullptr;
-  uint16_t* d_digits = nullptr;
-  uint32_t *d_counts1 = nullptr, *d_part_start = nullptr, *d_part_count = nullptr, *d_part_idx = nullptr;
-  uint32_t *d_seg_base = nullptr, *d_seg_bucket = nullptr, *d_seg_lenv = nullptr, *d_num_seg = nullptr, *d_split_list = nullptr, *d_large_list = nullptr, *d_chunk_list = nullptr;
-  te::ete* d_seg_out = nullptr;
-  uint32_t *d_bucket_count = nullptr, *d_bucket_start = nullptr, *d_bucket_cursor = nullptr, *d_seg_total = nullptr, *d_sorted = nullptr, *d_order = nullptr, *d_size_hist = nullptr, *d_size_cursor = nullptr;
-  uint16_t* d_part_keys = nullptr;
-  te::ete *d_buckets = nullptr, *d_red[12] = {};   // reduction: [0..3] ping/pong of the two first-phase chains, [4..11] small
-  uint8_t* d_partials = nullptr;      // W x 432
-  uint32_t* d_err = nullptr;
-  uint32_t* h_err = nullptr;          // pinned
-  uint8_t* h_partials = nullptr;      // pinned, W x 384
-  void *d_in_points = nullptr, *d_in_scalars = nullptr; uint64_t cap_in = 0;
-  hipEvent_t ev_done = nullptr;
-  hipEvent_t ev[2][ST_COUNT + 1] = {};     // per pipeline slot
-  plan_t last_plan; uint64_t last_n = 0; bool have_last = false;
-  // pipelined submit/collect: two slots
-  uint8_t* h_slot_partials[2] = {nullptr, nullptr}; uint32_t* h_slot_err[2] = {nullptr, nullptr};
-  hipEvent_t ev_slot[2] = {nullptr, nullptr}; int slot_c[2] = {0, 0}, slot_W[2] = {0, 0}; int slot_capW = 0;
+  workset_t ws[TE_MSM_WORKSETS];
+  int last_ws = 0;
+  void *d_in_points = nullptr, *d_in_scalars = nullptr; uint64_t cap_in = 0;   // te_msm_run staging
   uint64_t next_ticket = 1, next_collect = 1;
 };
 
@@ -73,9 +79,8 @@ struct te_ctx {
   int opt_window_bits = 0;
   int opt_sort = 1;
   int opt_profile = 0;
-  int opt_dbg = 0;
-  int opt_sort_s = 0;
   int opt_seg_len = 64;        // work segment: at most this many entries of one bucket per thread
+  int opt_workset = 0;         // work set used by te_msm_run* / te_msm_partial_device
   float stage_ms[ST_COUNT] = {};
   bool have_stage_ms = false;
 };
@@ -127,12 +132,8 @@ void make_plan(const te_ctx* ctx, const gpu_t& d, uint64_t n, plan_t& p) {
   p.chunk_len = (p.chunk_len + 4095u) & ~4095u;               // whole 4096-entry tiles
   ch = (p.nst + p.chunk_len - 1) / p.chunk_len;
   p.CH = ch;
-  // level-2 partition = the S buckets one k_accumulate block owns; its LDS list holds cpb entries per bucket
+  // level-1 partition = S consecutive buckets of one window
   p.S = p.B < 256u ? p.B : 256u;
-  if (ctx->opt_sort_s && (uint32_t)ctx->opt_sort_s < p.S) p.S = (uint32_t)ctx->opt_sort_s;
-  const double avg = (double)n / (double)p.B;                   // mean bucket size
-  p.cpb = (avg + 8.0 * (avg > 1 ? __builtin_sqrt(avg / p.S) : 1.0) + 1.0 <= 35.0) ? 35u : 70u;
-  p.cap = p.cpb * p.S;
   p.seg_len = (uint32_t)ctx->opt_seg_len;
   p.P = p.B / p.S; p.logS = ilog2(p.S);
 }
@@ -147,47 +148,38 @@ template <typename T> int ensure(te_ctx* ctx, T*& ptr, size_t& cap_bytes, size_t
   return 0;
 }
 
-int ensure_buffers(te_ctx* ctx, gpu_t& d, uint64_t n, const plan_t& p) {
+int ensure_buffers(te_ctx* ctx, gpu_t& d, workset_t& ws, uint64_t n, const plan_t& p) {
   HIP_TRY(ctx, hipSetDevice(d.device));
   const size_t nd = (size_t)p.nw * p.nst + 16, wb = (size_t)p.nw * p.B;
   int rc = 0;
-  if ((rc = ensure(ctx, d.d_recs, d.cap[0], (size_t)n))) return rc;
-  if ((rc = ensure(ctx, d.d_digits, d.cap[1], nd))) return rc;
-  if ((rc = ensure(ctx, d.d_sorted, d.cap[2], nd))) return rc;
-  if ((rc = ensure(ctx, d.d_counts1, d.cap[3], (size_t)p.nw * p.CH * p.P))) return rc;
-  if ((rc = ensure(ctx, d.d_bucket_count, d.cap[4], wb))) return rc;
-  if ((rc = ensure(ctx, d.d_bucket_start, d.cap[5], wb))) return rc;
-  if ((rc = ensure(ctx, d.d_bucket_cursor, d.cap[0 + 16], wb))) return rc;
-  if ((rc = ensure(ctx, d.d_seg_total, d.cap[17], (size_t)p.nw * 128 + 128))) return rc;
+  if ((rc = ensure(ctx, ws.d_recs, ws.cap[0], (size_t)n))) return rc;
+  if ((rc = ensure(ctx, ws.d_digits, ws.cap[1], nd))) return rc;
+  if ((rc = ensure(ctx, ws.d_sorted, ws.cap[2], nd))) return rc;
+  if ((rc = ensure(ctx, ws.d_counts1, ws.cap[3], (size_t)p.nw * p.CH * p.P))) return rc;
+  if ((rc = ensure(ctx, ws.d_bucket_count, ws.cap[4], wb))) return rc;
+  if ((rc = ensure(ctx, ws.d_bucket_start, ws.cap[5], wb))) return rc;
+  if ((rc = ensure(ctx, ws.d_bucket_cursor, ws.cap[16], wb))) return rc;
+  if ((rc = ensure(ctx, ws.d_seg_total, ws.cap[17], (size_t)p.nw * 128 + 128))) return rc;
   const size_t smax = wb + (size_t)p.nw * (n / (uint64_t)p.seg_len) + 16;      // segments <= buckets + entries / seg_len
-  if ((rc = ensure(ctx, d.d_order, d.cap[7], smax))) return rc;
-  if ((rc = ensure(ctx, d.d_seg_bucket, d.cap[20], smax))) return rc;
-  if ((rc = ensure(ctx, d.d_seg_lenv, d.cap[21], smax))) return rc;
-  if ((rc = ensure(ctx, d.d_seg_out, d.cap[22], smax))) return rc;
-  if ((rc = ensure(ctx, d.d_seg_base, d.cap[23], wb + 1))) return rc;
-  if ((rc = ensure(ctx, d.d_split_list, d.cap[24], wb + 1))) return rc;
-  if ((rc = ensure(ctx, d.d_large_list, d.cap[25], wb + 1))) return rc;
-  if ((rc = ensure(ctx, d.d_chunk_list, d.cap[26], 2 * wb + 2))) return rc;
-  if ((rc = ensure(ctx, d.d_part_start, d.cap[6], (size_t)p.nw * p.P))) return rc;
-  if ((rc = ensure(ctx, d.d_buckets, d.cap[8], wb))) return rc;
-  if ((rc = ensure(ctx, d.d_part_count, d.cap[9], (size_t)p.nw * p.P))) return rc;
-  if ((rc = ensure(ctx, d.d_part_keys, d.cap[14], nd))) return rc;
-  if ((rc = ensure(ctx, d.d_part_idx, d.cap[15], nd))) return rc;
+  if ((rc = ensure(ctx, ws.d_order, ws.cap[7], smax))) return rc;
+  if ((rc = ensure(ctx, ws.d_seg_bucket, ws.cap[20], smax))) return rc;
+  if ((rc = ensure(ctx, ws.d_seg_lenv, ws.cap[21], smax))) return rc;
+  if ((rc = ensure(ctx, ws.d_seg_out, ws.cap[22], smax))) return rc;
+  if ((rc = ensure(ctx, ws.d_seg_base, ws.cap[23], wb + 1))) return rc;
+  if ((rc = ensure(ctx, ws.d_split_list, ws.cap[24], wb + 1))) return rc;
+  if ((rc = ensure(ctx, ws.d_large_list, ws.cap[25], wb + 1))) return rc;
+  if ((rc = ensure(ctx, ws.d_chunk_list, ws.cap[26], 2 * wb + 2))) return rc;
+  if ((rc = ensure(ctx, ws.d_part_start, ws.cap[6], (size_t)p.nw * p.P))) return rc;
+  if ((rc = ensure(ctx, ws.d_buckets, ws.cap[8], wb))) return rc;
+  if ((rc = ensure(ctx, ws.d_part_count, ws.cap[9], (size_t)p.nw * p.P))) return rc;
+  if ((rc = ensure(ctx, ws.d_part_keys, ws.cap[14], nd))) return rc;
+  if ((rc = ensure(ctx, ws.d_part_idx, ws.cap[15], nd))) return rc;
   // marginal-sum levels fold by 4 (or 2): level 1 output is at most B/2 per window, level 2 at most B/4
-  if ((rc = ensure(ctx, d.d_red[0], d.cap[10], wb / 2 + 1))) return rc;
-  if ((rc = ensure(ctx, d.d_red[1], d.cap[11], wb / 4 + 1))) return rc;
-  if ((rc = ensure(ctx, d.d_red[2], d.cap[12], wb / 2 + 1))) return rc;
-  if ((rc = ensure(ctx, d.d_red[3], d.cap[13], wb / 4 + 1))) return rc;
-  for (int i = 4; i < 12; i++) if ((rc = ensure(ctx, d.d_red[i], d.red_cap[i], (size_t)p.nw * 256 + 16))) return rc;
-  if (p.W > d.cap_W) {
-    if (d.d_partials) HIP_TRY(ctx, hipFree(d.d_partials));
-    if (d.h_partials) HIP_TRY(ctx, hipHostFree(d.h_partials));
-    d.d_partials = nullptr; d.h_partials = nullptr; d.cap_W = 0;
-    const int wcap = p.W > 64 ? p.W : 64;             // W <= 64 for c >= 4: allocated once
-    HIP_TRY(ctx, hipMalloc((void**)&d.d_partials, (size_t)wcap * TE_MSM_PARTIAL_BYTES));
-    HIP_TRY(ctx, hipHostMalloc((void**)&d.h_partials, (size_t)wcap * TE_MSM_PARTIAL_BYTES, hipHostMallocDefault));
-    d.cap_W = wcap;
-  }
+  if ((rc = ensure(ctx, ws.d_red[0], ws.cap[10], wb / 2 + 1))) return rc;
+  if ((rc = ensure(ctx, ws.d_red[1], ws.cap[11], wb / 4 + 1))) return rc;
+  if ((rc = ensure(ctx, ws.d_red[2], ws.cap[12], wb / 2 + 1))) return rc;
+  if ((rc = ensure(ctx, ws.d_red[3], ws.cap[13], wb / 4 + 1))) return rc;
+  for (int i = 4; i < 12; i++) if ((rc = ensure(ctx, ws.d_red[i], ws.cap[24 + i], (size_t)p.nw * 256 + 16))) return rc;
   return 0;
 }
 
@@ -195,22 +187,22 @@ template <int C> void launch_digits(const uint4* sc, uint16_t* dg, const te::dig
   hipLaunchKernelGGL(te::k_digits<C>, dim3((prm.nst + 255) / 256), dim3(256), 0, s, sc, dg, prm, err);
 }
 
-int enqueue_partial(te_ctx* ctx, gpu_t& d, const void* d_points, const void* d_scalars, uint64_t n,
-                    void* d_partials_out, hipStream_t stream, int slot = 0) {
+int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, const void* d_scalars, uint64_t n,
+                    void* d_partials_out, hipStream_t stream) {
   plan_t p; make_plan(ctx, d, n, p);
-  if (int rc = ensure_buffers(ctx, d, n, p)) return rc;
-  d.last_plan = p; d.last_n = n; d.have_last = true;
+  if (int rc = ensure_buffers(ctx, d, ws, n, p)) return rc;
+  ws.plan = p; ws.n = n; ws.used = true; d.last_ws = (int)(&ws - d.ws);
   HIP_TRY(ctx, hipSetDevice(d.device));
   // profile 1: two events around the dominant kernel only (what bench.py times live); 2: every stage boundary
   // (an event between two kernels costs ~4 us of idle stream time, 11 of them ~2 % of a 2^20 MSM)
   const int prof = ctx->opt_profile;
-  auto mark = [&](int i) { if (prof >= 2 || (prof == 1 && (i == ST_ACCUM || i == ST_ACCUM + 1))) (void)hipEventRecord(d.ev[slot][i], stream); };
+  auto mark = [&](int i) { if (prof >= 2 || (prof == 1 && (i == ST_ACCUM || i == ST_ACCUM + 1))) (void)hipEventRecord(ws.ev[i], stream); };
   const uint32_t n32 = (uint32_t)n;
 
-  HIP_TRY(ctx, hipMemsetAsync(d.d_err, 0, 1032 * sizeof(uint32_t), stream));     // flag, counters, length histogram
+  HIP_TRY(ctx, hipMemsetAsync(ws.d_err, 0, 1032 * sizeof(uint32_t), stream));     // flag, counters, length histogram
   mark(ST_PREP);
   {  hipLaunchKernelGGL(te::k_prep_points, dim3((n32 + 255) / 256), dim3(256), 0, stream,
-                     (const uint4*)d_points, d.d_recs, n32);
+                     (const uint4*)d_points, ws.d_recs, n32);
   }
   mark(ST_DIGITS);
   if (p.nw > 0) {
@@ -219,46 +211,43 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, const void* d_points, const void* d_s
     prm.n = n32; prm.nst = p.nst; prm.num_windows = p.W; prm.w_first = d.w_first; prm.w_step = d.w_step; prm.nw_local = p.nw;
     const uint4* sc = (const uint4*)d_scalars;
     switch (p.c) {
-      case 4: launch_digits<4>(sc, d.d_digits, prm, d.d_err, stream); break;
-      case 5: launch_digits<5>(sc, d.d_digits, prm, d.d_err, stream); break;
-      case 6: launch_digits<6>(sc, d.d_digits, prm, d.d_err, stream); break;
-      case 7: launch_digits<7>(sc, d.d_digits, prm, d.d_err, stream); break;
-      case 8: launch_digits<8>(sc, d.d_digits, prm, d.d_err, stream); break;
-      case 9: launch_digits<9>(sc, d.d_digits, prm, d.d_err, stream); break;
-      case 10: launch_digits<10>(sc, d.d_digits, prm, d.d_err, stream); break;
-      case 11: launch_digits<11>(sc, d.d_digits, prm, d.d_err, stream); break;
-      case 12: launch_digits<12>(sc, d.d_digits, prm, d.d_err, stream); break;
-      case 13: launch_digits<13>(sc, d.d_digits, prm, d.d_err, stream); break;
-      case 14: launch_digits<14>(sc, d.d_digits, prm, d.d_err, stream); break;
-      case 15: launch_digits<15>(sc, d.d_digits, prm, d.d_err, stream); break;
-      default: launch_digits<16>(sc, d.d_digits, prm, d.d_err, stream); break;
+      case 4: launch_digits<4>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+      case 5: launch_digits<5>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+      case 6: launch_digits<6>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+      case 7: launch_digits<7>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+      case 8: launch_digits<8>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+      case 9: launch_digits<9>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+      case 10: launch_digits<10>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+      case 11: launch_digits<11>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+      case 12: launch_digits<12>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+      case 13: launch_digits<13>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+      case 14: launch_digits<14>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+      case 15: launch_digits<15>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+      default: launch_digits<16>(sc, ws.d_digits, prm, ws.d_err, stream); break;
     }
   }
   te::sort_geom sg;
-  sg.n = n32; sg.nst = p.nst; sg.B = p.B; sg.logS = p.logS; sg.S = p.S; sg.P = p.P; sg.CH = p.CH; sg.chunk_len = p.chunk_len; sg.cap = p.cap; sg.dbg = (uint32_t)ctx->opt_dbg;
+  sg.n = n32; sg.nst = p.nst; sg.B = p.B; sg.logS = p.logS; sg.S = p.S; sg.P = p.P; sg.CH = p.CH; sg.chunk_len = p.chunk_len;
   mark(ST_HIST);
-  if (p.nw > 0) hipLaunchKernelGGL(te::k_part_hist, dim3(p.CH, p.nw), dim3(1024), 0, stream, d.d_digits, d.d_counts1, sg);
+  if (p.nw > 0) hipLaunchKernelGGL(te::k_part_hist, dim3(p.CH, p.nw), dim3(1024), 0, stream, ws.d_digits, ws.d_counts1, sg);
   mark(ST_SCAN);
-  if (p.nw > 0) hipLaunchKernelGGL(te::k_part_scan, dim3(p.nw), dim3(1024), 0, stream, d.d_counts1, d.d_part_start, d.d_part_count, sg);
+  if (p.nw > 0) hipLaunchKernelGGL(te::k_part_scan, dim3(p.nw), dim3(1024), 0, stream, ws.d_counts1, ws.d_part_start, ws.d_part_count, sg);
   mark(ST_SCATTER);
   if (p.nw > 0)
-    hipLaunchKernelGGL(te::k_part_scatter, dim3(p.CH, p.nw), dim3(512), 0, stream, d.d_digits, d.d_counts1, d.d_part_keys, d.d_part_idx, sg);
-  if (false) {  hipLaunchKernelGGL(te::k_prep_points, dim3((n32 + 255) / 256), dim3(256), 0, stream,
-                     (const uint4*)d_points, d.d_recs, n32);
-  }
+    hipLaunchKernelGGL(te::k_part_scatter, dim3(p.CH, p.nw), dim3(512), 0, stream, ws.d_digits, ws.d_counts1, ws.d_part_keys, ws.d_part_idx, sg);
   mark(ST_BSORT);
   if (p.nw > 0) {
     const uint32_t nslices = (p.nst + 8191u) / 8192u;
     const uint32_t seg_threads = p.B < 1024u ? p.B : 1024u, nseg = p.B / seg_threads;
-    HIP_TRY(ctx, hipMemsetAsync(d.d_bucket_count, 0, (size_t)p.nw * p.B * sizeof(uint32_t), stream));
-    hipLaunchKernelGGL(te::k_l2_count, dim3(nslices, p.nw), dim3(256), 0, stream, d.d_part_keys, d.d_part_idx, d.d_part_start,
-                       d.d_part_count, d.d_bucket_count, sg);
-    hipLaunchKernelGGL(te::k_bscan_a, dim3(nseg, p.nw), dim3(seg_threads), 0, stream, d.d_bucket_count, d.d_bucket_cursor, d.d_seg_base,
-                       d.d_seg_total, p.B, p.seg_len);
-    hipLaunchKernelGGL(te::k_bscan_b, dim3(nseg, p.nw), dim3(seg_threads), 0, stream, d.d_bucket_cursor, d.d_seg_base, d.d_seg_total,
-                       d.d_bucket_start, d.d_bucket_cursor, d.d_num_seg, p.B);
-    hipLaunchKernelGGL(te::k_l2_place, dim3(nslices, p.nw), dim3(256), 0, stream, d.d_part_keys, d.d_part_idx, d.d_part_start,
-                       d.d_part_count, d.d_bucket_cursor, d.d_sorted, sg);
+    HIP_TRY(ctx, hipMemsetAsync(ws.d_bucket_count, 0, (size_t)p.nw * p.B * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(te::k_l2_count, dim3(nslices, p.nw), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx, ws.d_part_start,
+                       ws.d_part_count, ws.d_bucket_count, sg);
+    hipLaunchKernelGGL(te::k_bscan_a, dim3(nseg, p.nw), dim3(seg_threads), 0, stream, ws.d_bucket_count, ws.d_bucket_cursor, ws.d_seg_base,
+                       ws.d_seg_total, p.B, p.seg_len);
+    hipLaunchKernelGGL(te::k_bscan_b, dim3(nseg, p.nw), dim3(seg_threads), 0, stream, ws.d_bucket_cursor, ws.d_seg_base, ws.d_seg_total,
+                       ws.d_bucket_start, ws.d_bucket_cursor, ws.d_num_seg, p.B);
+    hipLaunchKernelGGL(te::k_l2_place, dim3(nslices, p.nw), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx, ws.d_part_start,
+                       ws.d_part_count, ws.d_bucket_cursor, ws.d_sorted, sg);
   }
   const uint32_t total = (uint32_t)p.nw * p.B;
   const uint32_t smax = total + (uint32_t)((uint64_t)p.nw * (n / p.seg_len));
@@ -266,32 +255,32 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, const void* d_points, const void* d_s
   const uint32_t* order = nullptr;
   if (p.nw > 0) {
     // d_num_seg[1] = number of split buckets; size_hist zeroed together with it
-    hipLaunchKernelGGL(te::k_seg_build, dim3(1024), dim3(256), 0, stream, d.d_seg_base, d.d_bucket_count, d.d_num_seg, total, p.seg_len,
-                       d.d_seg_bucket, d.d_seg_lenv, d.d_size_hist, d.d_split_list, d.d_num_seg + 1, d.d_large_list, d.d_chunk_list, total);
+    hipLaunchKernelGGL(te::k_seg_build, dim3(1024), dim3(256), 0, stream, ws.d_seg_base, ws.d_bucket_count, ws.d_num_seg, total, p.seg_len,
+                       ws.d_seg_bucket, ws.d_seg_lenv, ws.d_size_hist, ws.d_split_list, ws.d_num_seg + 1, ws.d_large_list, ws.d_chunk_list, total);
     if (ctx->opt_sort) {
-      hipLaunchKernelGGL(te::k_order_scan, dim3(1), dim3(1024), 0, stream, d.d_size_hist, d.d_size_cursor);
-      hipLaunchKernelGGL(te::k_order_scatter, dim3(256), dim3(256), 0, stream, d.d_seg_lenv, d.d_num_seg, d.d_size_cursor, d.d_order);
-      order = d.d_order;
+      hipLaunchKernelGGL(te::k_order_scan, dim3(1), dim3(1024), 0, stream, ws.d_size_hist, ws.d_size_cursor);
+      hipLaunchKernelGGL(te::k_order_scatter, dim3(256), dim3(256), 0, stream, ws.d_seg_lenv, ws.d_num_seg, ws.d_size_cursor, ws.d_order);
+      order = ws.d_order;
     }
   }
   mark(ST_ACCUM);
   if (p.nw > 0) {
-    hipLaunchKernelGGL(te::k_accumulate, dim3((smax + 255) / 256), dim3(256), 0, stream, d.d_recs, d.d_sorted, d.d_bucket_start,
-                       d.d_bucket_count, d.d_seg_base, d.d_seg_bucket, d.d_seg_lenv, order, d.d_num_seg, d.d_buckets, d.d_seg_out,
+    hipLaunchKernelGGL(te::k_accumulate, dim3((smax + 255) / 256), dim3(256), 0, stream, ws.d_recs, ws.d_sorted, ws.d_bucket_start,
+                       ws.d_bucket_count, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv, order, ws.d_num_seg, ws.d_buckets, ws.d_seg_out,
                        n32, p.logB, p.seg_len);
-    hipLaunchKernelGGL(te::k_seg_combine, dim3(256), dim3(256), 0, stream, d.d_split_list, d.d_num_seg + 1, d.d_bucket_count, d.d_seg_base,
-                       d.d_seg_out, d.d_buckets, p.seg_len);
+    hipLaunchKernelGGL(te::k_seg_combine, dim3(256), dim3(256), 0, stream, ws.d_split_list, ws.d_num_seg + 1, ws.d_bucket_count, ws.d_seg_base,
+                       ws.d_seg_out, ws.d_buckets, p.seg_len);
     // giant buckets (empty lists for well-spread digits: two near-empty launches)
-    hipLaunchKernelGGL(te::k_seg_combine_large1, dim3(512), dim3(256), 0, stream, d.d_chunk_list, d.d_num_seg + 1, d.d_bucket_count, d.d_seg_base,
-                       d.d_seg_out, p.seg_len, total);
-    hipLaunchKernelGGL(te::k_seg_combine_large2, dim3(256), dim3(256), 0, stream, d.d_large_list, d.d_num_seg + 1, d.d_bucket_count, d.d_seg_base,
-                       d.d_seg_out, d.d_buckets, p.seg_len, total);
+    hipLaunchKernelGGL(te::k_seg_combine_large1, dim3(512), dim3(256), 0, stream, ws.d_chunk_list, ws.d_num_seg + 1, ws.d_bucket_count, ws.d_seg_base,
+                       ws.d_seg_out, p.seg_len, total);
+    hipLaunchKernelGGL(te::k_seg_combine_large2, dim3(256), dim3(256), 0, stream, ws.d_large_list, ws.d_num_seg + 1, ws.d_bucket_count, ws.d_seg_base,
+                       ws.d_seg_out, ws.d_buckets, p.seg_len, total);
   }
   mark(ST_TREE);
   // digit marginals M_k[v], k = 0..3 (see K4a in kernels.hip.hpp).  Chains of folds, 4 (or 2) points per level:
   //   rows chain  B[d3 d2 d1 d0] -fold d0-> -fold d1-> X2[d3 d2]      cols chain  B -fold d3-> -fold d2-> Y2[d1 d0]
   //   then M3 = fold d2 of X2, M2 = fold d3 of X2, M1 = fold d0 of Y2, M0 = fold d1 of Y2.
-  const te::ete* marg[4] = {d.d_buckets, d.d_buckets, d.d_buckets, d.d_buckets};
+  const te::ete* marg[4] = {ws.d_buckets, ws.d_buckets, ws.d_buckets, ws.d_buckets};
   if (p.nw > 0) {
     struct chain_t { const te::ete* cur; uint32_t n; uint32_t steps[2][2]; int nsteps, step; uint32_t left; te::ete* buf[2]; int pp; };
     const uint32_t w0 = p.dw[0], w1 = p.dw[1], w2 = p.dw[2], w3 = p.dw[3];
@@ -324,15 +313,15 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, const void* d_points, const void* d_s
     };
     // phase 1: X2[d3 d2] (fold the low w0 + w1 bits, contiguous) and Y2[d1 d0] (fold the high w3 + w2 bits)
     chain_t ph1[2] = {
-        {d.d_buckets, p.B, {{1u << (w0 + w1), 1u}, {0, 0}}, 1, 0, 0, {d.d_red[0], d.d_red[1]}, 0},
-        {d.d_buckets, p.B, {{1u << (w2 + w3), 1u << (w0 + w1)}, {0, 0}}, 1, 0, 0, {d.d_red[2], d.d_red[3]}, 0}};
+        {ws.d_buckets, p.B, {{1u << (w0 + w1), 1u}, {0, 0}}, 1, 0, 0, {ws.d_red[0], ws.d_red[1]}, 0},
+        {ws.d_buckets, p.B, {{1u << (w2 + w3), 1u << (w0 + w1)}, {0, 0}}, 1, 0, 0, {ws.d_red[2], ws.d_red[3]}, 0}};
     run_phase(ph1, 2);
     // phase 2: from X2 (index d3 * 2^w2 + d2) and Y2 (index d1 * 2^w0 + d0)
     chain_t ph2[4] = {
-        {ph1[1].cur, 1u << (w0 + w1), {{1u << w1, 1u << w0}, {0, 0}}, 1, 0, 0, {d.d_red[4], d.d_red[5]}, 0},    // M0[d0]: fold d1 (high)
-        {ph1[1].cur, 1u << (w0 + w1), {{1u << w0, 1u}, {0, 0}}, 1, 0, 0, {d.d_red[6], d.d_red[7]}, 0},          // M1[d1]: fold d0 (low)
-        {ph1[0].cur, 1u << (w2 + w3), {{1u << w3, 1u << w2}, {0, 0}}, 1, 0, 0, {d.d_red[8], d.d_red[9]}, 0},    // M2[d2]: fold d3 (high)
-        {ph1[0].cur, 1u << (w2 + w3), {{1u << w2, 1u}, {0, 0}}, 1, 0, 0, {d.d_red[10], d.d_red[11]}, 0}};       // M3[d3]: fold d2 (low)
+        {ph1[1].cur, 1u << (w0 + w1), {{1u << w1, 1u << w0}, {0, 0}}, 1, 0, 0, {ws.d_red[4], ws.d_red[5]}, 0},    // M0[d0]: fold d1 (high)
+        {ph1[1].cur, 1u << (w0 + w1), {{1u << w0, 1u}, {0, 0}}, 1, 0, 0, {ws.d_red[6], ws.d_red[7]}, 0},          // M1[d1]: fold d0 (low)
+        {ph1[0].cur, 1u << (w2 + w3), {{1u << w3, 1u << w2}, {0, 0}}, 1, 0, 0, {ws.d_red[8], ws.d_red[9]}, 0},    // M2[d2]: fold d3 (high)
+        {ph1[0].cur, 1u << (w2 + w3), {{1u << w2, 1u}, {0, 0}}, 1, 0, 0, {ws.d_red[10], ws.d_red[11]}, 0}};       // M3[d3]: fold d2 (low)
     run_phase(ph2, 4);
     for (int k = 0; k < 4; k++) marg[k] = ph2[k].cur;
   }
@@ -344,17 +333,17 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, const void* d_points, const void* d_s
     hipLaunchKernelGGL(te::k_weighted_sum, dim3(4, p.nw), dim3(64), 0, stream, wj, rows, (uint32_t)d.w_step * 5u);
   }
   mark(ST_COUNT);
-  HIP_TRY(ctx, hipMemcpyAsync(d.h_err, d.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-  HIP_TRY(ctx, hipEventRecord(d.ev_done, stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ws.h_err, ws.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(ctx, hipEventRecord(ws.ev_done, stream));
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }
 
-int collect_stage_ms(te_ctx* ctx, gpu_t& d, int slot = 0) {
+int collect_stage_ms(te_ctx* ctx, workset_t& ws) {
   if (!ctx->opt_profile) return 0;
   for (int i = 0; i < ST_COUNT; i++) {
     float ms = -1.0f;
-    if (ctx->opt_profile >= 2 || i == ST_ACCUM) HIP_TRY(ctx, hipEventElapsedTime(&ms, d.ev[slot][i], d.ev[slot][i + 1]));
+    if (ctx->opt_profile >= 2 || i == ST_ACCUM) HIP_TRY(ctx, hipEventElapsedTime(&ms, ws.ev[i], ws.ev[i + 1]));
     ctx->stage_ms[i] = ms;
   }
   ctx->have_stage_ms = true;
@@ -363,16 +352,20 @@ int collect_stage_ms(te_ctx* ctx, gpu_t& d, int slot = 0) {
 
 void free_dev(gpu_t& d) {
   (void)hipSetDevice(d.device);
-  void* ptrs[] = {d.d_recs, d.d_digits, d.d_counts1, d.d_part_start, d.d_part_count, d.d_part_keys, d.d_part_idx, d.d_buckets,
-                  d.d_bucket_count, d.d_bucket_start, d.d_bucket_cursor, d.d_seg_total, d.d_sorted, d.d_seg_base, d.d_seg_bucket, d.d_seg_lenv, d.d_seg_out, d.d_split_list, d.d_large_list, d.d_chunk_list, d.d_order, d.d_red[0], d.d_red[1], d.d_red[2], d.d_red[3], d.d_partials,
-                  d.d_err, d.d_in_points, d.d_in_scalars};
-  for (void* p : ptrs) if (p) (void)hipFree(p);
-  if (d.h_err) (void)hipHostFree(d.h_err);
-  if (d.h_partials) (void)hipHostFree(d.h_partials);
-  for (int i = 0; i < 2; i++) { if (d.h_slot_partials[i]) (void)hipHostFree(d.h_slot_partials[i]); if (d.h_slot_err[i]) (void)hipHostFree(d.h_slot_err[i]); if (d.ev_slot[i]) (void)hipEventDestroy(d.ev_slot[i]); }
-  if (d.ev_done) (void)hipEventDestroy(d.ev_done);
-  for (auto& es : d.ev) for (auto& e : es) if (e) (void)hipEventDestroy(e);
-  if (d.stream) (void)hipStreamDestroy(d.stream);
+  for (workset_t& ws : d.ws) {
+    void* ptrs[] = {ws.d_recs, ws.d_digits, ws.d_part_keys, ws.d_counts1, ws.d_part_start, ws.d_part_count, ws.d_part_idx, ws.d_bucket_count,
+                    ws.d_bucket_start, ws.d_bucket_cursor, ws.d_seg_total, ws.d_sorted, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv,
+                    ws.d_order, ws.d_split_list, ws.d_large_list, ws.d_chunk_list, ws.d_seg_out, ws.d_buckets, ws.d_err, ws.d_partials};
+    for (void* q : ptrs) if (q) (void)hipFree(q);
+    for (te::ete* q : ws.d_red) if (q) (void)hipFree(q);
+    if (ws.h_err) (void)hipHostFree(ws.h_err);
+    if (ws.h_partials) (void)hipHostFree(ws.h_partials);
+    if (ws.ev_done) (void)hipEventDestroy(ws.ev_done);
+    for (auto& ev : ws.ev) if (ev) (void)hipEventDestroy(ev);
+    if (ws.stream) (void)hipStreamDestroy(ws.stream);
+  }
+  if (d.d_in_points) (void)hipFree(d.d_in_points);
+  if (d.d_in_scalars) (void)hipFree(d.d_in_scalars);
 }
 
 int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, bool src_is_host, uint64_t n, uint8_t out[64]) {
@@ -385,6 +378,7 @@ int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, boo
   // stage inputs on every device
   for (size_t i = 0; i < nd; i++) {
     gpu_t& d = ctx->devs[i];
+    workset_t& ws = d.ws[ctx->opt_workset];
     HIP_TRY(ctx, hipSetDevice(d.device));
     const void *dp = src_points, *ds = src_scalars;
     if (src_is_host || i > 0) {
@@ -397,29 +391,29 @@ int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, boo
         d.cap_in = n;
       }
       if (src_is_host) {
-        HIP_TRY(ctx, hipMemcpyAsync(d.d_in_points, src_points, n * TE_MSM_POINT_BYTES, hipMemcpyHostToDevice, d.stream));
-        HIP_TRY(ctx, hipMemcpyAsync(d.d_in_scalars, src_scalars, n * TE_MSM_SCALAR_BYTES, hipMemcpyHostToDevice, d.stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d.d_in_points, src_points, n * TE_MSM_POINT_BYTES, hipMemcpyHostToDevice, ws.stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d.d_in_scalars, src_scalars, n * TE_MSM_SCALAR_BYTES, hipMemcpyHostToDevice, ws.stream));
       } else {
         // inputs live on device 0's memory: wait for nothing (caller's data is ready), copy peer-to-peer
-        HIP_TRY(ctx, hipMemcpyPeerAsync(d.d_in_points, d.device, src_points, ctx->devs[0].device, n * TE_MSM_POINT_BYTES, d.stream));
-        HIP_TRY(ctx, hipMemcpyPeerAsync(d.d_in_scalars, d.device, src_scalars, ctx->devs[0].device, n * TE_MSM_SCALAR_BYTES, d.stream));
+        HIP_TRY(ctx, hipMemcpyPeerAsync(d.d_in_points, d.device, src_points, ctx->devs[0].device, n * TE_MSM_POINT_BYTES, ws.stream));
+        HIP_TRY(ctx, hipMemcpyPeerAsync(d.d_in_scalars, d.device, src_scalars, ctx->devs[0].device, n * TE_MSM_SCALAR_BYTES, ws.stream));
       }
       dp = d.d_in_points; ds = d.d_in_scalars;
     }
-    if (int rc = ensure_buffers(ctx, d, n, p0)) return rc;     // sizes d_partials before the memset below
-    if (int rc = enqueue_partial(ctx, d, dp, ds, n, d.d_partials, d.stream)) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(d.h_partials, d.d_partials, (size_t)p0.W * TE_MSM_PARTIAL_BYTES, hipMemcpyDeviceToHost, d.stream));
+    if (int rc = enqueue_partial(ctx, d, ws, dp, ds, n, ws.d_partials, ws.stream)) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ws.h_partials, ws.d_partials, (size_t)p0.W * TE_MSM_PARTIAL_BYTES, hipMemcpyDeviceToHost, ws.stream));
   }
   std::vector<uint8_t> merged((size_t)p0.W * TE_MSM_PARTIAL_BYTES, 0);
   for (size_t i = 0; i < nd; i++) {
     gpu_t& d = ctx->devs[i];
+    workset_t& ws = d.ws[ctx->opt_workset];
     HIP_TRY(ctx, hipSetDevice(d.device));
-    HIP_TRY(ctx, hipStreamSynchronize(d.stream));
-    if (*d.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
+    HIP_TRY(ctx, hipStreamSynchronize(ws.stream));
+    if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
     for (int w = d.w_first; w < p0.W; w += d.w_step)
-      memcpy(&merged[(size_t)w * TE_MSM_PARTIAL_BYTES], d.h_partials + (size_t)w * TE_MSM_PARTIAL_BYTES, TE_MSM_PARTIAL_BYTES);
+      memcpy(&merged[(size_t)w * TE_MSM_PARTIAL_BYTES], ws.h_partials + (size_t)w * TE_MSM_PARTIAL_BYTES, TE_MSM_PARTIAL_BYTES);
   }
-  if (int rc = collect_stage_ms(ctx, ctx->devs[0])) return rc;
+  if (int rc = collect_stage_ms(ctx, ctx->devs[0].ws[ctx->opt_workset])) return rc;
   te_host::horner_to_affine(merged.data(), p0.c, p0.W, out);
   return 0;
 }
@@ -447,20 +441,22 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
     d.w_first = i; d.w_step = n_dev;
     if (d.device < 0 || d.device >= count) { g_init_error = "te_msm_init: device id out of range"; delete ctx; return TE_MSM_EINVAL; }
     hipError_t er = hipSetDevice(d.device);
-    if (er == hipSuccess) er = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
-    // one scratch block, zeroed by a single memset per MSM: [0] final-carry flag, [1] number of segments, [2] number of
-    // split buckets, [8..1031] segment-length histogram; [1032..2055] its cursor (not zeroed)
-    if (er == hipSuccess) er = hipMalloc((void**)&d.d_err, 2056 * sizeof(uint32_t));
-    if (er == hipSuccess) { d.d_num_seg = d.d_err + 1; d.d_size_hist = d.d_err + 8; d.d_size_cursor = d.d_err + 1032; }
-    if (er == hipSuccess) er = hipHostMalloc((void**)&d.h_err, sizeof(uint32_t), hipHostMallocDefault);
-    if (er == hipSuccess) er = hipEventCreateWithFlags(&d.ev_done, hipEventDisableTiming);
-    for (auto& evs : d.ev) for (auto& evn : evs) if (er == hipSuccess) er = hipEventCreate(&evn);
+    for (workset_t& ws : d.ws) {       // the small fixed allocations of both work sets; the big buffers come with the first MSM
+      if (er == hipSuccess) er = hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking);
+      if (er == hipSuccess) er = hipMalloc((void**)&ws.d_err, 2056 * sizeof(uint32_t));
+      if (er == hipSuccess) { ws.d_num_seg = ws.d_err + 1; ws.d_size_hist = ws.d_err + 8; ws.d_size_cursor = ws.d_err + 1032; }
+      if (er == hipSuccess) er = hipMalloc((void**)&ws.d_partials, (size_t)TE_MAX_WINDOWS * TE_MSM_PARTIAL_BYTES);
+      if (er == hipSuccess) er = hipHostMalloc((void**)&ws.h_err, sizeof(uint32_t), hipHostMallocDefault);
+      if (er == hipSuccess) er = hipHostMalloc((void**)&ws.h_partials, (size_t)TE_MAX_WINDOWS * TE_MSM_PARTIAL_BYTES, hipHostMallocDefault);
+      if (er == hipSuccess) er = hipEventCreateWithFlags(&ws.ev_done, hipEventDisableTiming);
+      for (auto& evn : ws.ev) if (er == hipSuccess) er = hipEventCreate(&evn);
+      if (er == hipSuccess) *ws.h_err = 0;
+    }
     if (er != hipSuccess) {
       g_init_error = std::string("te_msm_init: ") + hipGetErrorString(er);
       for (auto& dd : ctx->devs) free_dev(dd);
       delete ctx; return TE_MSM_EDEVICE;
     }
-    *d.h_err = 0;
   }
   *out = ctx;
   return 0;
@@ -468,7 +464,7 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
 
 void te_msm_destroy(te_ctx* ctx) {
   if (!ctx) return;
-  for (auto& d : ctx->devs) { (void)hipSetDevice(d.device); if (d.stream) (void)hipStreamSynchronize(d.stream); free_dev(d); }
+  for (auto& d : ctx->devs) { (void)hipSetDevice(d.device); (void)hipDeviceSynchronize(); free_dev(d); }
   delete ctx;
 }
 
@@ -487,25 +483,12 @@ int te_msm_submit_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_
   if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_submit_device needs a single-device context");
   if (!d_points_xy_le || !d_scalars_le || n == 0 || n >= (1ull << 31)) return set_err(ctx, TE_MSM_EINVAL, "bad arguments");
   gpu_t& d = ctx->devs[0];
-  if (d.next_ticket - d.next_collect >= 2) return set_err(ctx, TE_MSM_ESTATE, "two MSMs are already in flight: collect one first");
-  const int slot = (int)(d.next_ticket & 1);
-  plan_t p; make_plan(ctx, d, n, p);
+  if (d.next_ticket - d.next_collect >= TE_MSM_WORKSETS) return set_err(ctx, TE_MSM_ESTATE, "every work set has an MSM in flight: collect one first");
+  workset_t& ws = d.ws[d.next_ticket % TE_MSM_WORKSETS];   // rotate work sets (and their streams): the MSMs overlap on the device
   HIP_TRY(ctx, hipSetDevice(d.device));
-  if (int rc = ensure_buffers(ctx, d, n, p)) return rc;
-  if (!d.slot_capW) {                                 // once, for the largest possible W (c >= 4 -> 64 windows): never
-    const int wmax = 64;                              // reallocated while an MSM is in flight
-    for (int i = 0; i < 2; i++) {
-      HIP_TRY(ctx, hipHostMalloc((void**)&d.h_slot_partials[i], (size_t)wmax * TE_MSM_PARTIAL_BYTES, hipHostMallocDefault));
-      HIP_TRY(ctx, hipHostMalloc((void**)&d.h_slot_err[i], sizeof(uint32_t), hipHostMallocDefault));
-      HIP_TRY(ctx, hipEventCreateWithFlags(&d.ev_slot[i], hipEventDisableTiming));
-    }
-    d.slot_capW = wmax;
-  }
-  if (int rc = enqueue_partial(ctx, d, d_points_xy_le, d_scalars_le, n, d.d_partials, d.stream, slot)) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(d.h_slot_partials[slot], d.d_partials, (size_t)p.W * TE_MSM_PARTIAL_BYTES, hipMemcpyDeviceToHost, d.stream));
-  HIP_TRY(ctx, hipMemcpyAsync(d.h_slot_err[slot], d.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
-  HIP_TRY(ctx, hipEventRecord(d.ev_slot[slot], d.stream));
-  d.slot_c[slot] = p.c; d.slot_W[slot] = p.W;
+  if (int rc = enqueue_partial(ctx, d, ws, d_points_xy_le, d_scalars_le, n, ws.d_partials, ws.stream)) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ws.h_partials, ws.d_partials, (size_t)ws.plan.W * TE_MSM_PARTIAL_BYTES, hipMemcpyDeviceToHost, ws.stream));
+  HIP_TRY(ctx, hipEventRecord(ws.ev_done, ws.stream));
   *ticket = d.next_ticket++;
   return 0;
 }
@@ -515,12 +498,12 @@ int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]) {
   if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_collect needs a single-device context");
   gpu_t& d = ctx->devs[0];
   if (ticket != d.next_collect || ticket >= d.next_ticket) return set_err(ctx, TE_MSM_ESTATE, "tickets must be collected in submission order");
-  const int slot = (int)(ticket & 1);
-  HIP_TRY(ctx, hipEventSynchronize(d.ev_slot[slot]));
+  workset_t& ws = d.ws[ticket % TE_MSM_WORKSETS];
+  HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));
   d.next_collect++;
-  if (int rc = collect_stage_ms(ctx, d, slot)) return rc;
-  if (*d.h_slot_err[slot]) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
-  te_host::horner_to_affine(d.h_slot_partials[slot], d.slot_c[slot], d.slot_W[slot], out_xy_le);
+  if (int rc = collect_stage_ms(ctx, ws)) return rc;
+  if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
+  te_host::horner_to_affine(ws.h_partials, ws.plan.c, ws.plan.W, out_xy_le);
   return 0;
 }
 
@@ -529,8 +512,7 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   if (!strcmp(key, "window_bits")) { if (value != 0 && (value < 4 || value > 16)) return set_err(ctx, TE_MSM_EINVAL, "window_bits must be 0 or in [4,16]"); ctx->opt_window_bits = (int)value; return 0; }
   if (!strcmp(key, "sort_buckets")) { ctx->opt_sort = value ? 1 : 0; return 0; }
   if (!strcmp(key, "profile")) { ctx->opt_profile = value < 0 ? 0 : (value > 2 ? 2 : (int)value); ctx->have_stage_ms = false; return 0; }
-  if (!strcmp(key, "debug_cut")) { ctx->opt_dbg = (int)value; return 0; }
-  if (!strcmp(key, "sort_s")) { ctx->opt_sort_s = (int)value; return 0; }
+  if (!strcmp(key, "workset")) { if (value < 0 || value >= TE_MSM_WORKSETS) return set_err(ctx, TE_MSM_EINVAL, "workset out of range"); ctx->opt_workset = (int)value; return 0; }
   if (!strcmp(key, "segment_len")) { if (value < 1 || value > 1000000) return set_err(ctx, TE_MSM_EINVAL, "segment_len must be in [1, 1e6]"); ctx->opt_seg_len = (int)value; return 0; }
   return set_err(ctx, TE_MSM_EINVAL, "unknown option");
 }
@@ -542,6 +524,7 @@ int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value) {
   if (!strcmp(key, "profile")) { *value = ctx->opt_profile; return 0; }
   if (!strcmp(key, "num_devices")) { *value = (int64_t)ctx->devs.size(); return 0; }
   if (!strcmp(key, "segment_len")) { *value = ctx->opt_seg_len; return 0; }
+  if (!strcmp(key, "workset")) { *value = ctx->opt_workset; return 0; }
   return set_err(ctx, TE_MSM_EINVAL, "unknown option");
 }
 
@@ -566,16 +549,29 @@ int te_msm_partial_device(te_ctx* ctx, const void* d_points_xy_le, const void* d
   if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_partial_device needs a single-device context");
   if (!d_points_xy_le || !d_scalars_le || !d_partials || n == 0 || n >= (1ull << 31)) return set_err(ctx, TE_MSM_EINVAL, "bad arguments");
   gpu_t& d = ctx->devs[0];
-  return enqueue_partial(ctx, d, d_points_xy_le, d_scalars_le, n, d_partials, stream == TE_MSM_OWN_STREAM ? d.stream : (hipStream_t)stream);
+  workset_t& ws = d.ws[ctx->opt_workset];
+  HIP_TRY(ctx, hipSetDevice(d.device));
+  return enqueue_partial(ctx, d, ws, d_points_xy_le, d_scalars_le, n, d_partials, stream == TE_MSM_OWN_STREAM ? ws.stream : (hipStream_t)stream);
+}
+
+int te_msm_partial_wait(te_ctx* ctx, int workset) {
+  if (!ctx || workset < 0 || workset >= TE_MSM_WORKSETS) return TE_MSM_EINVAL;
+  if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_partial_wait needs a single-device context");
+  workset_t& ws = ctx->devs[0].ws[workset];
+  if (!ws.used) return 0;
+  HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));
+  if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
+  return 0;
 }
 
 int te_msm_finalize(te_ctx* ctx, const uint8_t* partials, int window_bits, int num_windows, uint8_t out_xy_le[64]) {
   if (!ctx || !partials || !out_xy_le || window_bits < 2 || window_bits > 16 || num_windows < 1 || num_windows > 128) return TE_MSM_EINVAL;
   gpu_t& d = ctx->devs[0];
-  if (d.have_last) {
-    HIP_TRY(ctx, hipEventSynchronize(d.ev_done));
-    if (*d.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
-    if (int rc = collect_stage_ms(ctx, d)) return rc;
+  workset_t& ws = d.ws[d.last_ws];
+  if (ws.used) {
+    HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));
+    if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
+    if (int rc = collect_stage_ms(ctx, ws)) return rc;
   }
   te_host::horner_to_affine(partials, window_bits, num_windows, out_xy_le);
   return 0;
@@ -602,28 +598,29 @@ int te_msm_stage_ms(te_ctx* ctx, float* ms, const char** names, int max_stages) 
 int64_t te_msm_debug_read(te_ctx* ctx, const char* stage, void* dst, uint64_t cap) {
   if (!ctx || !stage || !dst) return TE_MSM_EINVAL;
   gpu_t& d = ctx->devs[0];
-  if (!d.have_last) return set_err(ctx, TE_MSM_ESTATE, "no run yet");
-  const plan_t& p = d.last_plan; const uint64_t n = d.last_n;
+  workset_t& ws = d.ws[d.last_ws];
+  if (!ws.used) return set_err(ctx, TE_MSM_ESTATE, "no run yet");
+  const plan_t& p = ws.plan; const uint64_t n = ws.n;
   const void* src = nullptr; uint64_t bytes = 0;
-  if (!strcmp(stage, "records")) { src = d.d_recs; bytes = n * sizeof(te::pnt_slot); }
-  else if (!strcmp(stage, "digits")) { src = d.d_digits; bytes = (uint64_t)p.nw * p.nst * 2; }   // row stride nst = n rounded up to 8
-  else if (!strcmp(stage, "bucket_count")) { src = d.d_bucket_count; bytes = (uint64_t)p.nw * p.B * 4; }
-  else if (!strcmp(stage, "bucket_start")) { src = d.d_bucket_start; bytes = (uint64_t)p.nw * p.B * 4; }
-  else if (!strcmp(stage, "sorted")) { src = d.d_sorted; bytes = (uint64_t)p.nw * n * 4; }
-  else if (!strcmp(stage, "num_segments")) { src = d.d_num_seg; bytes = 4; }
-  else if (!strcmp(stage, "seg_bucket")) { src = d.d_seg_bucket; bytes = ((uint64_t)p.nw * p.B + (uint64_t)p.nw * (n / p.seg_len)) * 4; }
-  else if (!strcmp(stage, "seg_len")) { src = d.d_seg_lenv; bytes = ((uint64_t)p.nw * p.B + (uint64_t)p.nw * (n / p.seg_len)) * 4; }
-  else if (!strcmp(stage, "order")) { src = d.d_order; bytes = ((uint64_t)p.nw * p.B + (uint64_t)p.nw * (n / p.seg_len)) * 4; }
-  else if (!strcmp(stage, "part_start")) { src = d.d_part_start; bytes = (uint64_t)p.nw * p.P * 4; }
-  else if (!strcmp(stage, "part_count")) { src = d.d_part_count; bytes = (uint64_t)p.nw * p.P * 4; }
-  else if (!strcmp(stage, "part_keys")) { src = d.d_part_keys; bytes = (uint64_t)p.nw * p.nst * 2; }
-  else if (!strcmp(stage, "part_idx")) { src = d.d_part_idx; bytes = (uint64_t)p.nw * p.nst * 4; }
-  else if (!strcmp(stage, "buckets")) { src = d.d_buckets; bytes = (uint64_t)p.nw * p.B * sizeof(te::ete); }
-  else if (!strcmp(stage, "partials")) { src = d.d_partials; bytes = (uint64_t)p.W * TE_MSM_PARTIAL_BYTES; }
+  if (!strcmp(stage, "records")) { src = ws.d_recs; bytes = n * sizeof(te::pnt_slot); }
+  else if (!strcmp(stage, "digits")) { src = ws.d_digits; bytes = (uint64_t)p.nw * p.nst * 2; }   // row stride nst = n rounded up to 8
+  else if (!strcmp(stage, "bucket_count")) { src = ws.d_bucket_count; bytes = (uint64_t)p.nw * p.B * 4; }
+  else if (!strcmp(stage, "bucket_start")) { src = ws.d_bucket_start; bytes = (uint64_t)p.nw * p.B * 4; }
+  else if (!strcmp(stage, "sorted")) { src = ws.d_sorted; bytes = (uint64_t)p.nw * n * 4; }
+  else if (!strcmp(stage, "num_segments")) { src = ws.d_num_seg; bytes = 4; }
+  else if (!strcmp(stage, "seg_bucket")) { src = ws.d_seg_bucket; bytes = ((uint64_t)p.nw * p.B + (uint64_t)p.nw * (n / p.seg_len)) * 4; }
+  else if (!strcmp(stage, "seg_len")) { src = ws.d_seg_lenv; bytes = ((uint64_t)p.nw * p.B + (uint64_t)p.nw * (n / p.seg_len)) * 4; }
+  else if (!strcmp(stage, "order")) { src = ws.d_order; bytes = ((uint64_t)p.nw * p.B + (uint64_t)p.nw * (n / p.seg_len)) * 4; }
+  else if (!strcmp(stage, "part_start")) { src = ws.d_part_start; bytes = (uint64_t)p.nw * p.P * 4; }
+  else if (!strcmp(stage, "part_count")) { src = ws.d_part_count; bytes = (uint64_t)p.nw * p.P * 4; }
+  else if (!strcmp(stage, "part_keys")) { src = ws.d_part_keys; bytes = (uint64_t)p.nw * p.nst * 2; }
+  else if (!strcmp(stage, "part_idx")) { src = ws.d_part_idx; bytes = (uint64_t)p.nw * p.nst * 4; }
+  else if (!strcmp(stage, "buckets")) { src = ws.d_buckets; bytes = (uint64_t)p.nw * p.B * sizeof(te::ete); }
+  else if (!strcmp(stage, "partials")) { src = ws.d_partials; bytes = (uint64_t)p.W * TE_MSM_PARTIAL_BYTES; }
   else return set_err(ctx, TE_MSM_EINVAL, "unknown stage");
   if (bytes > cap) bytes = cap;
   HIP_TRY(ctx, hipSetDevice(d.device));
-  HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+  HIP_TRY(ctx, hipDeviceSynchronize());
   HIP_TRY(ctx, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
   return (int64_t)bytes;
 }

@@ -68,44 +68,54 @@ def compute_msm_sharded(ctx, d_points, d_scalars, n: int, partials, dist=None, g
 
 
 class ShardedPipeline:
-    """Window-sharded MSMs with two in flight per rank: the all-gather, the 11 KiB read-back and the host tail of
-    MSM i overlap the device work of MSM i+1 (the multi-GPU counterpart of te_msm_submit_device / te_msm_collect).
+    """Window-sharded MSMs with `depth` in flight per rank, each on its own stream and device work set: the all-gather,
+    the 11 KiB read-back and the host tail of MSM i overlap the device work of the following ones (the multi-GPU
+    counterpart of te_msm_submit_device / te_msm_collect).
 
         pipe = ShardedPipeline(ctx, n, dist)          # ctx: MsmContext with window shard (rank, world)
         t = pipe.submit(d_points, d_scalars); ...; xy = pipe.collect(t)      # collect in submission order
     """
 
-    def __init__(self, ctx, n: int, dist, group=None):
+    def __init__(self, ctx, n: int, dist, group=None, depth: int = 2):
         import torch
+        from .binding import WORKSETS
+
+        assert 1 <= depth <= WORKSETS
+        self.depth = depth
 
         self.torch, self.ctx, self.n, self.dist, self.group = torch, ctx, n, dist, group
         self.world = dist.get_world_size(group)
         self.c, self.W = ctx.plan(n)
         nbytes = self.W * PARTIAL_BYTES
         self.gloo = dist.get_backend(group) == "gloo"
-        self.part = [torch.zeros(nbytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        self.part = [torch.zeros(nbytes, dtype=torch.uint8, device="cuda") for _ in range(depth)]
         gdev = "cpu" if self.gloo else "cuda"
-        self.gathered = [torch.zeros(self.world * nbytes, dtype=torch.uint8, device=gdev) for _ in range(2)]
-        self.host = [torch.zeros(self.world * nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.gathered = [torch.zeros(self.world * nbytes, dtype=torch.uint8, device=gdev) for _ in range(depth)]
+        self.host = [torch.zeros(self.world * nbytes, dtype=torch.uint8).pin_memory() for _ in range(depth)]
         self.copy_stream = torch.cuda.Stream()
-        self.ev = [torch.cuda.Event() for _ in range(2)]
+        self.compute_streams = [torch.cuda.Stream() for _ in range(depth)]   # one per work set: the MSMs overlap on the GPU
+        self.ev = [torch.cuda.Event() for _ in range(depth)]
         self.next_ticket = self.next_collect = 0
 
     def submit(self, d_points, d_scalars) -> int:
         torch = self.torch
-        assert self.next_ticket - self.next_collect < 2, "two MSMs are already in flight"
-        slot = self.next_ticket & 1
-        cur = torch.cuda.current_stream()
-        self.part[slot].zero_()
-        self.ctx.partial_device(d_points.data_ptr(), d_scalars.data_ptr(), self.n, self.part[slot].data_ptr(), cur.cuda_stream)
-        if self.gloo:                                   # rehearsal path (no CUDA all_gather in gloo): blocking
-            src = self.part[slot].cpu()
-            self.dist.all_gather_into_tensor(self.gathered[slot], src, group=self.group)
-            self.host[slot].copy_(self.gathered[slot])
-            self.ev[slot].record(cur)
-        else:
-            work = self.dist.all_gather_into_tensor(self.gathered[slot], self.part[slot], group=self.group, async_op=True)
-            with torch.cuda.stream(self.copy_stream):   # the copy stream, not the compute stream, waits for the collective
+        assert self.next_ticket - self.next_collect < self.depth, "every slot has an MSM in flight"
+        slot = self.next_ticket % self.depth
+        cur = self.compute_streams[slot]
+        cur.wait_stream(torch.cuda.current_stream())    # the caller's inputs are ready on its stream
+        self.ctx.set_option("workset", slot)            # the slot's previous MSM was collected: its buffers are free
+        with torch.cuda.stream(cur):
+            self.part[slot].zero_()
+            self.ctx.partial_device(d_points.data_ptr(), d_scalars.data_ptr(), self.n, self.part[slot].data_ptr(), cur.cuda_stream)
+            if self.gloo:                               # rehearsal path (no CUDA all_gather in gloo): blocking
+                src = self.part[slot].cpu()
+                self.dist.all_gather_into_tensor(self.gathered[slot], src, group=self.group)
+                self.host[slot].copy_(self.gathered[slot])
+                self.ev[slot].record(cur)
+            else:                                       # the collective is ordered behind this slot's compute stream
+                work = self.dist.all_gather_into_tensor(self.gathered[slot], self.part[slot], group=self.group, async_op=True)
+        if not self.gloo:
+            with torch.cuda.stream(self.copy_stream):   # the copy stream, not a compute stream, waits for the collective
                 work.wait()
                 self.host[slot].copy_(self.gathered[slot], non_blocking=True)
                 self.ev[slot].record(self.copy_stream)
@@ -116,9 +126,10 @@ class ShardedPipeline:
     def collect(self, ticket: int) -> bytes:
         from .binding import finalize_host
         assert ticket == self.next_collect, "collect in submission order"
-        slot = ticket & 1
+        slot = ticket % self.depth
         self.ev[slot].synchronize()
         self.next_collect += 1
+        self.ctx.partial_wait(slot)                     # done already (the copy is ordered behind it): reports scalar-range errors
         nbytes = self.W * PARTIAL_BYTES
         flat = self.host[slot].numpy().tobytes()
         merged = merge_partials([flat[r * nbytes:(r + 1) * nbytes] for r in range(self.world)], self.W, self.world)
