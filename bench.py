@@ -55,6 +55,8 @@ def main():
     force_dist = os.environ.get("TE_BENCH_FORCE_DIST") == "1"      # rehearsal: run the N > 1 code path with one rank over RCCL
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_dist and world == 1:
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("MASTER_PORT", "29533")
         # TE_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box): every rank uses cuda:0 and the exchange goes over gloo
         share = os.environ.get("TE_BENCH_SHARE_GPU") == "1"
         if share:
@@ -92,7 +94,10 @@ def main():
     c, W = ctx.plan(n)
     B = 1 << (c - 1)
     if world > 1 or force_dist:
-        ctx.set_window_shard(*pkg.window_shard_for_rank(rank, world))
+        # TE_BENCH_REHEARSE_WORLD=D (with TE_BENCH_FORCE_DIST=1, one rank): this rank does the work of rank 0 of D -- the
+        # per-rank step of a D-GPU run without the other D-1 GPUs.  The result is a partial sum: no parity claim is made.
+        rehearse = int(os.environ.get("TE_BENCH_REHEARSE_WORLD", "0")) if (force_dist and world == 1) else 0
+        ctx.set_window_shard(*pkg.window_shard_for_rank(rank, rehearse or world))
         partials = torch.zeros(W * pkg.PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
         gather_list = [torch.empty_like(partials) for _ in range(world)]
 
@@ -232,7 +237,12 @@ def main():
         if exp != result:
             print(json.dumps(out))
             raise SystemExit("GPU result differs from the oracle")
-    if sharded:
+    if "parity" not in out and not sharded:
+        out["parity"] = "not checked (--no-cpu-baseline)"
+    if sharded and rehearse:
+        out["parity"] = "not checked: rehearsal of rank 0 of %d (partial sum)" % rehearse
+        out["config"]["parallelism"] = "REHEARSAL: the per-rank step of a %d-GPU run on one GPU" % rehearse
+    elif sharded:
         # untimed cross-check of the sharded path: the same MSM on this rank's GPU alone must give the same point
         with pkg.MsmContext((dev,)) as solo:
             solo.set_option("window_bits", args.window_bits)

@@ -72,7 +72,12 @@ int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]);
  *   "sort_buckets"  1 = schedule buckets by descending size (default), 0 = natural order
  *   "segment_len"   a bucket longer than this is accumulated by several threads (default 64)
  *   "profile"       1 = HIP events around the dominant kernel (accumulate) only, 2 = around every stage
- *                   (te_msm_stage_ms); 0 = none (default)                                    */
+ *                   (te_msm_stage_ms); 0 = none (default)
+ *   "graph"         1 = replay the ~30 launches before and after the accumulate kernel as two HIP graphs, captured on
+ *                   first use and re-captured when pointers, n or options change; 0 = launch every kernel (default: on
+ *                   ROCm 7.2 / MI355X the replay measured ~5 % slower than plain launches).
+ *                   Ignored at profile level 2.
+ *   "workset"       which of the TE_MSM_WORKSETS device work sets te_msm_run* / te_msm_partial_device use (default 0) */
 int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value);
 int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value);
 

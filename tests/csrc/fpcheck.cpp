@@ -44,20 +44,22 @@ void fpc_mont_mul(const uint32_t a[9], const uint32_t b[9], uint32_t out[9]) {
   fp x, y; memcpy(x.v, a, 36); memcpy(y.v, b, 36); fp r = mont_mul(x, y); memcpy(out, r.v, 36);
 }
 void fpc_norm(const uint32_t a[9], uint32_t out[9]) { fp x; memcpy(x.v, a, 36); fp r = fp_norm(x); memcpy(out, r.v, 36); }
-void fpc_half(const uint32_t a[9], uint32_t out[9]) { fp x; memcpy(x.v, a, 36); fp r = fp_half(x); memcpy(out, r.v, 36); }
 void fpc_sub2(const uint32_t a[9], const uint32_t b[9], uint32_t out[9]) { fp x, y; memcpy(x.v, a, 36); memcpy(y.v, b, 36); fp r = fp_sub<2>(x, y); memcpy(out, r.v, 36); }
 void fpc_from_words32(const uint32_t w[8], uint32_t out[9]) { uint32_t t[8]; memcpy(t, w, 32); fp r = fp_from_words32(t); memcpy(out, r.v, 36); }
 void fpc_constants(uint32_t out[9 * 9]) {
   fp c[9] = {fp_R1(), fp_R2(), fp_D_MONT(), fp_K2D_MONT(), fp_ONE_RAW(), fp_P(), fp_kp_offset<2>(), fp_kp_offset<4>(), fp_kp_offset<8>()};
   memcpy(out, c, sizeof c);
 }
+void fpc_constants2(uint32_t out[3 * 9]) {
+  fp c[3] = {fp_R2_HALF(), fp_D_R3(), fp_kp_offset<16>()};
+  memcpy(out, c, sizeof c);
+}
 // body of k_prep_points: record in a 128-byte slot
 void fpc_prep_point(const uint8_t xy_le[64], uint8_t rec[128]) {
   uint32_t xw[8], yw[8]; memcpy(xw, xy_le, 32); memcpy(yw, xy_le + 32, 32);
-  const fp xm = mont_mul(fp_from_words32(xw), fp_R2()), ym = mont_mul(fp_from_words32(yw), fp_R2());
-  const pnt r = pnt_from_affine_mont(xm, ym);
+  const pnt r = pnt_from_affine_raw(fp_from_words32(xw), fp_from_words32(yw));
   memset(rec, 0, 128); memcpy(rec, &r, 108);
-  if (!(class_n(r.hm) && class_n(r.hp) && class_n(r.dt) && lt_kp(r.hm, 3) && lt_kp(r.hp, 2) && lt_kp(r.dt, 2))) g_bound_violations++;
+  if (!(class_n(r.hm) && class_n(r.hp) && class_n(r.dt) && lt_kp(r.hm, 2) && lt_kp(r.hp, 2) && lt_kp(r.dt, 2))) g_bound_violations++;
 }
 void fpc_identity(uint8_t out[144]) { ete e = ete_identity(); memcpy(out, &e, 144); }
 void fpc_madd(const uint8_t acc[144], const uint8_t rec[128], int neg, uint8_t out[144]) {

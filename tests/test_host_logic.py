@@ -39,9 +39,15 @@ def test_field_constants(fpcheck, model):
     assert vals[:6] == [R % P, R * R % P, model.D * R % P, 2 * model.D * R % P, 1, P]
     for g in got[:6]:
         assert all(l <= LM for l in g)
-    for k, g in zip((2, 4, 8), got[6:]):             # offset forms: same value as K*p, every lower limb >= 2^29 - 1
+    out2 = (ctypes.c_uint32 * 27)()
+    fpcheck.fpc_constants2(out2)
+    got2 = [[int(out2[9 * k + i]) for i in range(9)] for k in range(3)]
+    assert [sum(l << (LB * i) for i, l in enumerate(g)) for g in got2[:2]] == [R * R * pow(2, -1, P) % P, model.D * pow(R, 3, P) % P]
+    assert all(l <= LM for g in got2[:2] for l in g)
+    for k, g in zip((2, 4, 8, 16), got[6:] + got2[2:]):   # offset forms: same value as K*p, every lower limb >= 2^29 - 1
         assert sum(l << (LB * i) for i, l in enumerate(g)) == k * P
         assert all(LM <= l < (1 << 30) for l in g[:8]) and g[8] > 0
+    assert 16 * P > 1 << 256                              # y - x + 16p >= 0 for any 256-bit x
 
 
 def test_mont_mul_values_and_limb_classes(fpcheck, model):
@@ -80,9 +86,6 @@ def test_field_helpers(fpcheck, model):
         ls = [rnd.randrange(1 << 32) for _ in range(8)] + [rnd.randrange(1 << 20)]
         fpcheck.fpc_norm(raw(ls), out)
         assert val(out) == val(ls) and all(int(out[i]) <= LM for i in range(8))
-        c = rnd.randrange(4 * P)
-        fpcheck.fpc_half(limbs(c), out)
-        assert val(out) * 2 % P == c % P and val(out) <= (c + P) // 2
         x, y = rnd.randrange(2 * P), rnd.randrange(2 * P)
         fpcheck.fpc_sub2(limbs(x), limbs(y), out)
         assert val(out) == x - y + 2 * P

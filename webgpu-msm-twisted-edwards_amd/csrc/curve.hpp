@@ -17,7 +17,7 @@ namespace te {
 // Every coordinate is a mont_mul output: limb class N, value < 1.1p.  144 bytes, x | y | z | t.
 struct ete { fp x, y, z, t; };
 
-// Precomputed affine point: hm = (y - x)/2, hp = (y + x)/2, dt = d*x*y (mod p, lazily reduced: values < 2.1p,
+// Precomputed affine point: hm = (y - x)/2, hp = (y + x)/2, dt = d*x*y (mod p, lazily reduced: values < 1.1p,
 // class N; a negated record holds dt' = 2p - dt with limbs < 2^30).  108 bytes, stored in 128-byte slots.
 struct pnt { fp hm, hp, dt; };
 
@@ -35,12 +35,17 @@ TE_HD pnt pnt_cneg(const pnt& a, bool neg) {
   return r;
 }
 
-// Affine (x, y) in Montgomery form (class N, values < 1.1p) -> record.
-TE_HD pnt pnt_from_affine_mont(const fp& xm, const fp& ym) {
+// Affine (x, y) as plain integers (class N, ANY 256-bit value) -> record, in four products and nothing else:
+//   hm = (y - x + 16p) * (R^2/2) / R,   hp = (y + x) * (R^2/2) / R,   dt = (x * y / R) * (d R^3) / R.
+// The constants fold the conversion to Montgomery form, the halving and the factor d into the products
+// (16p > 2^256 keeps y - x non-negative for non-canonical inputs).  Values: hm, hp < 1.07p, dt < 1.01p.
+TE_HD pnt pnt_from_affine_raw(const fp& x, const fp& y) {
+  const fp a[3] = {fp_sub<16>(y, x), fp_add(y, x), x}, b[3] = {fp_R2_HALF(), fp_R2_HALF(), y};
+  fp o[3];
+  mont_mul_x<3>(a, b, o);
   pnt r;
-  r.hm = fp_half(fp_sub<2>(ym, xm));                            // (y - x + 2p [+ p]) / 2  < 2.1p
-  r.hp = fp_half(fp_add(ym, xm));                               // (y + x [+ p]) / 2      < 1.6p
-  r.dt = mont_mul(mont_mul(xm, ym), fp_D_MONT());               // < 1.01p
+  r.hm = o[0]; r.hp = o[1];
+  r.dt = mont_mul(o[2], fp_D_R3());
   return r;
 }
 

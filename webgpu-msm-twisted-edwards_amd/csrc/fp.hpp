@@ -62,7 +62,7 @@ TE_HD uint32_t p_limb(int i) {
 TE_HD fp fp_zero() { fp r; for (int i = 0; i < NL; i++) r.v[i] = 0; return r; }
 
 // K*p in "offset form": limbs 0..7 raised by 2^29, the next limb lowered by 1 (same value), so that
-// a_i + off_i - b_i cannot underflow for normalised b.  Specialisations in fp_constants.inc (K = 2, 4, 8).
+// a_i + off_i - b_i cannot underflow for normalised b.  Specialisations in fp_constants.inc (K = 2, 4, 8, 16).
 template <int K> TE_HD fp fp_kp_offset();
 
 // ---------------------------------------------------------------------------------------------
@@ -189,21 +189,6 @@ TE_HD fp fp_norm(const fp& a) {
   r.v[NL - 1] = a.v[NL - 1] + c;
   return r;
 }
-// a/2 mod p: (a + (a odd ? p : 0)) >> 1.  Takes any class, returns N; value (a + p)/2 at most.
-TE_HD fp fp_half(const fp& a) {
-  const fp n = fp_norm(a);
-  const uint32_t odd = n.v[0] & 1u;
-  fp t;
-#pragma unroll
-  for (int i = 0; i < NL; i++) t.v[i] = n.v[i] + (odd ? p_limb(i) : 0u);
-  t = fp_norm(t);
-  fp r;
-#pragma unroll
-  for (int i = 0; i < NL - 1; i++) r.v[i] = (t.v[i] >> 1) | ((t.v[i + 1] & 1u) << (LB - 1));
-  r.v[NL - 1] = t.v[NL - 1] >> 1;
-  return r;
-}
-
 // 8 little-endian 32-bit words (any 256-bit value)  ->  9 x 29-bit limbs (class N)
 TE_HD fp fp_from_words32(const uint32_t (&w)[8]) {
   fp r;

@@ -27,26 +27,41 @@ struct digits_params {
 // K1a: affine (x, y) little-endian canonical  ->  Montgomery record ((y-x)/2, (y+x)/2, d*x*y) in a 128-byte slot
 // (27 limb words + padding: one gather touches exactly one 128-byte line).
 struct pnt_slot { uint4 q[8]; };
+// Global traffic is staged through LDS so that every load and store instruction covers 1 KB of consecutive addresses:
+// with one point per lane straight to memory (16-B pieces at 64-B / 128-B stride) the kernel spent most of its 70 us
+// issuing 12 million 16-byte requests.  Records are swizzled in LDS (16-B piece q of record r at piece q ^ (r & 7)) so
+// that both the per-record writes and the per-piece reads are conflict-free.
 __global__ void __launch_bounds__(256) k_prep_points(const uint4* __restrict__ pts, pnt_slot* __restrict__ recs, uint32_t n) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n) return;
-  const uint4 a0 = pts[4 * (size_t)i + 0], a1 = pts[4 * (size_t)i + 1];
-  const uint4 b0 = pts[4 * (size_t)i + 2], b1 = pts[4 * (size_t)i + 3];
+  __shared__ uint4 lds[256 * 8];                        // 32 KB: first the block's 256 points (16 KB), then its 256 records
+  const uint32_t t = threadIdx.x, base = blockIdx.x * 256u;
+  const uint32_t pieces_in = (n - base < 256u ? n - base : 256u) * 4u;     // valid 16-B input pieces of this block
+  const uint4* __restrict__ src = pts + (size_t)base * 4u;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t g = (uint32_t)j * 256u + t;
+    lds[g] = src[g < pieces_in ? g : 0u];               // clamped: unconditional loads
+  }
+  __syncthreads();
+  const uint4 a0 = lds[4 * t + 0], a1 = lds[4 * t + 1], b0 = lds[4 * t + 2], b1 = lds[4 * t + 3];
+  __syncthreads();
   const uint32_t xw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
   const uint32_t yw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-  // to Montgomery form: x * R^2 / R.  Any 256-bit x (< 13.8p) gives a value < 1.04p.
-  const fp raw[2] = {fp_from_words32(xw), fp_from_words32(yw)}, r2[2] = {fp_R2(), fp_R2()};
-  fp m[2];
-  mont_mul_x<2>(raw, r2, m);
-  const pnt r = pnt_from_affine_mont(m[0], m[1]);
+  const pnt r = pnt_from_affine_raw(fp_from_words32(xw), fp_from_words32(yw));
   uint32_t w[32];
 #pragma unroll
   for (int j = 0; j < NL; j++) { w[j] = r.hm.v[j]; w[NL + j] = r.hp.v[j]; w[2 * NL + j] = r.dt.v[j]; }
 #pragma unroll
   for (int j = 3 * NL; j < 32; j++) w[j] = 0u;
-  uint4* o = recs[i].q;
 #pragma unroll
-  for (int j = 0; j < 8; j++) o[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+  for (int q = 0; q < 8; q++) lds[8 * t + ((uint32_t)q ^ (t & 7u))] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+  __syncthreads();
+  const uint32_t pieces_out = pieces_in * 2u;
+  uint4* __restrict__ dst = reinterpret_cast<uint4*>(recs + base);
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const uint32_t g = (uint32_t)j * 256u + t, rr = g >> 3, q = g & 7u;
+    if (g < pieces_out) dst[g] = lds[8 * rr + (q ^ (rr & 7u))];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -57,35 +72,50 @@ __global__ void __launch_bounds__(256) k_prep_points(const uint4* __restrict__ p
 // window everywhere performs exactly those carries.  A non-zero bit at or above c*W is the
 // reference's "final carry is 1" error (utils.ts:80-83) and sets *err.
 // digits[k * n + i] (u16) for local window k.
+// Each thread decomposes TWO consecutive scalars and stores their digits as one packed u32 per window (nst is even).
 template <int C>
 __global__ void __launch_bounds__(256) k_digits(const uint4* __restrict__ scalars, uint16_t* __restrict__ digits,
                                                 digits_params prm, uint32_t* __restrict__ err) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= prm.n) {
-    if (i < prm.nst) for (int k = 0; k < prm.nw_local; k++) digits[(size_t)k * prm.nst + i] = (uint16_t)(1u << (C - 1));   // digit 0
+  const uint32_t pair = blockIdx.x * 256u + threadIdx.x, i0 = 2u * pair;
+  if (i0 >= prm.nst) return;
+  uint32_t* __restrict__ out = reinterpret_cast<uint32_t*>(digits);
+  const uint32_t half_stride = prm.nst >> 1;
+  constexpr uint32_t ZERO_DIGIT = 1u << (C - 1);
+  if (i0 >= prm.n) {                                   // padding entries: digit 0
+    for (int k = 0; k < prm.nw_local; k++) out[(size_t)k * half_stride + pair] = ZERO_DIGIT | (ZERO_DIGIT << 16);
     return;
   }
-  const uint4 s0 = scalars[2 * (size_t)i], s1 = scalars[2 * (size_t)i + 1];
-  uint32_t s[10] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, 0u, 0u};
-  uint64_t c = 0;
+  const bool second = i0 + 1u < prm.n;
+  const size_t j1 = second ? (size_t)i0 + 1 : (size_t)i0;       // clamped: unconditional loads
+  const uint4 a0 = scalars[2 * (size_t)i0], a1 = scalars[2 * (size_t)i0 + 1], b0 = scalars[2 * j1], b1 = scalars[2 * j1 + 1];
+  uint32_t s[2][10] = {{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, 0u, 0u}, {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, 0u, 0u}};
 #pragma unroll
-  for (int j = 0; j < 9; j++) { c += (uint64_t)s[j] + prm.half[j]; s[j] = (uint32_t)c; c >>= 32; }
+  for (int t = 0; t < 2; t++) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) { c += (uint64_t)s[t][j] + prm.half[j]; s[t][j] = (uint32_t)c; c >>= 32; }
+  }
   // window extraction with compile-time bit positions (runtime-indexed register arrays would spill)
   constexpr int WMAX = (255 + C) / C + 1;
   bool bad = false;
+  int next = prm.w_first, k = 0;                       // next owned window and its local index
 #pragma unroll
   for (int w = 0; w < WMAX; w++) {
     const int bit = w * C;
     if (bit >= 288) break;
     const int word = bit >> 5, off = bit & 31;
-    uint32_t v = s[word] >> off;
-    if (off + C > 32 && word + 1 < 10) v |= s[word + 1] << (32 - off);
-    v &= (1u << C) - 1u;
-    if (w >= prm.num_windows) { bad |= (v != 0u); continue; }
-    const int rel = w - prm.w_first;
-    if (rel >= 0 && (rel % prm.w_step) == 0) {
-      const int k = rel / prm.w_step;
-      if (k < prm.nw_local) digits[(size_t)k * prm.nst + i] = (uint16_t)v;
+    uint32_t v[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      v[t] = s[t][word] >> off;
+      if (off + C > 32 && word + 1 < 10) v[t] |= s[t][word + 1] << (32 - off);
+      v[t] &= (1u << C) - 1u;
+    }
+    if (!second) v[1] = w < prm.num_windows ? ZERO_DIGIT : 0u;
+    if (w >= prm.num_windows) { bad |= ((v[0] | v[1]) != 0u); continue; }
+    if (w == next) {
+      if (k < prm.nw_local) out[(size_t)k * half_stride + pair] = v[0] | (v[1] << 16);
+      k++; next += prm.w_step;
     }
   }
   if (bad) atomicOr(err, 1u);

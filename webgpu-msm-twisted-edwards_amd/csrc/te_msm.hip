@@ -37,6 +37,8 @@ struct plan_t {
   uint32_t S = 0, logS = 0, P = 0;   // level-1 partition: S buckets each, P = B/S partitions per window
 };
 
+struct graph_key { const void *pts, *sc, *out; uint64_t n, generation; int c, w_first, w_step, seg_len, sort; };
+
 // Everything one MSM in flight needs on the device.  A GPU owns TE_MSM_WORKSETS work sets with their own streams so that
 // several MSMs overlap ON THE DEVICE: the launch gaps and the latency-bound reduction tail of one are filled by the wide kernels of the
 // other (te_msm_submit_device alternates them; "workset" option for te_msm_partial_device callers).
@@ -59,6 +61,8 @@ struct workset_t {
   hipEvent_t ev_done = nullptr;
   hipEvent_t ev[ST_COUNT + 1] = {};
   plan_t plan; uint64_t n = 0; bool used = false;
+  uint64_t generation = 0;            // bumped whenever ensure() reallocates a buffer of this set
+  hipGraphExec_t g_front = nullptr, g_back = nullptr; graph_key g_key = {};
 };
 constexpr int TE_MAX_WINDOWS = 64;    // window_bits >= 4
 
@@ -80,6 +84,7 @@ struct te_ctx {
   int opt_sort = 1;
   int opt_profile = 0;
   int opt_seg_len = 64;        // work segment: at most this many entries of one bucket per thread
+  int opt_graph = 0;           // replay the launch sequence around k_accumulate as HIP graphs
   int opt_workset = 0;         // work set used by te_msm_run* / te_msm_partial_device
   float stage_ms[ST_COUNT] = {};
   bool have_stage_ms = false;
@@ -138,9 +143,10 @@ void make_plan(const te_ctx* ctx, const gpu_t& d, uint64_t n, plan_t& p) {
   p.P = p.B / p.S; p.logS = ilog2(p.S);
 }
 
-template <typename T> int ensure(te_ctx* ctx, T*& ptr, size_t& cap_bytes, size_t need_elems) {
+template <typename T> int ensure(te_ctx* ctx, workset_t& ws, T*& ptr, size_t& cap_bytes, size_t need_elems) {
   const size_t need = need_elems * sizeof(T);
   if (ptr && need <= cap_bytes) return 0;
+  ws.generation++;                     // captured graphs hold the old pointer
   if (ptr) HIP_TRY(ctx, hipFree(ptr));
   ptr = nullptr; cap_bytes = 0;
   HIP_TRY(ctx, hipMalloc((void**)&ptr, need ? need : 16));
@@ -152,188 +158,248 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, workset_t& ws, uint64_t n, const plan_
   HIP_TRY(ctx, hipSetDevice(d.device));
   const size_t nd = (size_t)p.nw * p.nst + 16, wb = (size_t)p.nw * p.B;
   int rc = 0;
-  if ((rc = ensure(ctx, ws.d_recs, ws.cap[0], (size_t)n))) return rc;
-  if ((rc = ensure(ctx, ws.d_digits, ws.cap[1], nd))) return rc;
-  if ((rc = ensure(ctx, ws.d_sorted, ws.cap[2], nd))) return rc;
-  if ((rc = ensure(ctx, ws.d_counts1, ws.cap[3], (size_t)p.nw * p.CH * p.P))) return rc;
-  if ((rc = ensure(ctx, ws.d_bucket_count, ws.cap[4], wb))) return rc;
-  if ((rc = ensure(ctx, ws.d_bucket_start, ws.cap[5], wb))) return rc;
-  if ((rc = ensure(ctx, ws.d_bucket_cursor, ws.cap[16], wb))) return rc;
-  if ((rc = ensure(ctx, ws.d_seg_total, ws.cap[17], (size_t)p.nw * 128 + 128))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_recs, ws.cap[0], (size_t)n))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_digits, ws.cap[1], nd))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_sorted, ws.cap[2], nd))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_counts1, ws.cap[3], (size_t)p.nw * p.CH * p.P))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_bucket_count, ws.cap[4], wb))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_bucket_start, ws.cap[5], wb))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_bucket_cursor, ws.cap[16], wb))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_seg_total, ws.cap[17], (size_t)p.nw * 128 + 128))) return rc;
   const size_t smax = wb + (size_t)p.nw * (n / (uint64_t)p.seg_len) + 16;      // segments <= buckets + entries / seg_len
-  if ((rc = ensure(ctx, ws.d_order, ws.cap[7], smax))) return rc;
-  if ((rc = ensure(ctx, ws.d_seg_bucket, ws.cap[20], smax))) return rc;
-  if ((rc = ensure(ctx, ws.d_seg_lenv, ws.cap[21], smax))) return rc;
-  if ((rc = ensure(ctx, ws.d_seg_out, ws.cap[22], smax))) return rc;
-  if ((rc = ensure(ctx, ws.d_seg_base, ws.cap[23], wb + 1))) return rc;
-  if ((rc = ensure(ctx, ws.d_split_list, ws.cap[24], wb + 1))) return rc;
-  if ((rc = ensure(ctx, ws.d_large_list, ws.cap[25], wb + 1))) return rc;
-  if ((rc = ensure(ctx, ws.d_chunk_list, ws.cap[26], 2 * wb + 2))) return rc;
-  if ((rc = ensure(ctx, ws.d_part_start, ws.cap[6], (size_t)p.nw * p.P))) return rc;
-  if ((rc = ensure(ctx, ws.d_buckets, ws.cap[8], wb))) return rc;
-  if ((rc = ensure(ctx, ws.d_part_count, ws.cap[9], (size_t)p.nw * p.P))) return rc;
-  if ((rc = ensure(ctx, ws.d_part_keys, ws.cap[14], nd))) return rc;
-  if ((rc = ensure(ctx, ws.d_part_idx, ws.cap[15], nd))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_order, ws.cap[7], smax))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_seg_bucket, ws.cap[20], smax))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_seg_lenv, ws.cap[21], smax))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_seg_out, ws.cap[22], smax))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_seg_base, ws.cap[23], wb + 1))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_split_list, ws.cap[24], wb + 1))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_large_list, ws.cap[25], wb + 1))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_chunk_list, ws.cap[26], 2 * wb + 2))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_part_start, ws.cap[6], (size_t)p.nw * p.P))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_buckets, ws.cap[8], wb))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_part_count, ws.cap[9], (size_t)p.nw * p.P))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_part_keys, ws.cap[14], nd))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_part_idx, ws.cap[15], nd))) return rc;
   // marginal-sum levels fold by 4 (or 2): level 1 output is at most B/2 per window, level 2 at most B/4
-  if ((rc = ensure(ctx, ws.d_red[0], ws.cap[10], wb / 2 + 1))) return rc;
-  if ((rc = ensure(ctx, ws.d_red[1], ws.cap[11], wb / 4 + 1))) return rc;
-  if ((rc = ensure(ctx, ws.d_red[2], ws.cap[12], wb / 2 + 1))) return rc;
-  if ((rc = ensure(ctx, ws.d_red[3], ws.cap[13], wb / 4 + 1))) return rc;
-  for (int i = 4; i < 12; i++) if ((rc = ensure(ctx, ws.d_red[i], ws.cap[24 + i], (size_t)p.nw * 256 + 16))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_red[0], ws.cap[10], wb / 2 + 1))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_red[1], ws.cap[11], wb / 4 + 1))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_red[2], ws.cap[12], wb / 2 + 1))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_red[3], ws.cap[13], wb / 4 + 1))) return rc;
+  for (int i = 4; i < 12; i++) if ((rc = ensure(ctx, ws, ws.d_red[i], ws.cap[24 + i], (size_t)p.nw * 256 + 16))) return rc;
   return 0;
 }
 
 template <int C> void launch_digits(const uint4* sc, uint16_t* dg, const te::digits_params& prm, uint32_t* err, hipStream_t s) {
-  hipLaunchKernelGGL(te::k_digits<C>, dim3((prm.nst + 255) / 256), dim3(256), 0, s, sc, dg, prm, err);
+  hipLaunchKernelGGL(te::k_digits<C>, dim3((prm.nst / 2 + 255) / 256), dim3(256), 0, s, sc, dg, prm, err);
+}
+
+// One MSM's device work in three parts, so that the parts before and after the dominant kernel can be replayed as HIP
+// graphs (one launch each instead of ~30: the host-side enqueue cost, ~0.35 ms, is what bounds small MSMs and the
+// per-rank step of a window-sharded one) while k_accumulate stays an ordinary launch bracketed by timing events.
+struct msm_launch {
+  te_ctx* ctx; gpu_t& d; workset_t& ws; plan_t p;
+  const void* d_points; const void* d_scalars; uint64_t n; void* d_partials_out;
+  int prof;                       // event marks inside front()/back() only at profile level 2 (never inside a capture)
+  hipStream_t stream;
+  uint32_t n32() const { return (uint32_t)n; }
+  uint32_t total() const { return (uint32_t)p.nw * p.B; }
+  uint32_t smax() const { return total() + (uint32_t)((uint64_t)p.nw * (n / p.seg_len)); }
+  void mark(int i) const { if (prof >= 2 || (prof == 1 && (i == ST_ACCUM || i == ST_ACCUM + 1))) (void)hipEventRecord(ws.ev[i], stream); }
+
+  // points -> records, scalars -> digits, two-level counting sort, segment schedule
+  int front() {
+    const uint32_t n32 = this->n32();
+    HIP_TRY(ctx, hipMemsetAsync(ws.d_err, 0, 1032 * sizeof(uint32_t), stream));     // flag, counters, length histogram
+    mark(ST_PREP);
+    hipLaunchKernelGGL(te::k_prep_points, dim3((n32 + 255) / 256), dim3(256), 0, stream, (const uint4*)d_points, ws.d_recs, n32);
+    mark(ST_DIGITS);
+    if (p.nw > 0) {
+      te::digits_params prm; memset(&prm, 0, sizeof prm);
+      for (int w = 0; w < p.W; w++) { const int bit = w * p.c + p.c - 1; if (bit < 320) prm.half[bit >> 5] |= 1u << (bit & 31); }
+      prm.n = n32; prm.nst = p.nst; prm.num_windows = p.W; prm.w_first = d.w_first; prm.w_step = d.w_step; prm.nw_local = p.nw;
+      const uint4* sc = (const uint4*)d_scalars;
+      switch (p.c) {
+        case 4: launch_digits<4>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+        case 5: launch_digits<5>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+        case 6: launch_digits<6>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+        case 7: launch_digits<7>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+        case 8: launch_digits<8>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+        case 9: launch_digits<9>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+        case 10: launch_digits<10>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+        case 11: launch_digits<11>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+        case 12: launch_digits<12>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+        case 13: launch_digits<13>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+        case 14: launch_digits<14>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+        case 15: launch_digits<15>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+        default: launch_digits<16>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+      }
+    }
+    te::sort_geom sg;
+    sg.n = n32; sg.nst = p.nst; sg.B = p.B; sg.logS = p.logS; sg.S = p.S; sg.P = p.P; sg.CH = p.CH; sg.chunk_len = p.chunk_len;
+    mark(ST_HIST);
+    if (p.nw > 0) hipLaunchKernelGGL(te::k_part_hist, dim3(p.CH, p.nw), dim3(1024), 0, stream, ws.d_digits, ws.d_counts1, sg);
+    mark(ST_SCAN);
+    if (p.nw > 0) hipLaunchKernelGGL(te::k_part_scan, dim3(p.nw), dim3(1024), 0, stream, ws.d_counts1, ws.d_part_start, ws.d_part_count, sg);
+    mark(ST_SCATTER);
+    if (p.nw > 0)
+      hipLaunchKernelGGL(te::k_part_scatter, dim3(p.CH, p.nw), dim3(512), 0, stream, ws.d_digits, ws.d_counts1, ws.d_part_keys, ws.d_part_idx, sg);
+    mark(ST_BSORT);
+    if (p.nw > 0) {
+      const uint32_t nslices = (p.nst + 8191u) / 8192u;
+      const uint32_t seg_threads = p.B < 1024u ? p.B : 1024u, nseg = p.B / seg_threads;
+      HIP_TRY(ctx, hipMemsetAsync(ws.d_bucket_count, 0, (size_t)p.nw * p.B * sizeof(uint32_t), stream));
+      hipLaunchKernelGGL(te::k_l2_count, dim3(nslices, p.nw), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx, ws.d_part_start,
+                         ws.d_part_count, ws.d_bucket_count, sg);
+      hipLaunchKernelGGL(te::k_bscan_a, dim3(nseg, p.nw), dim3(seg_threads), 0, stream, ws.d_bucket_count, ws.d_bucket_cursor, ws.d_seg_base,
+                         ws.d_seg_total, p.B, p.seg_len);
+      hipLaunchKernelGGL(te::k_bscan_b, dim3(nseg, p.nw), dim3(seg_threads), 0, stream, ws.d_bucket_cursor, ws.d_seg_base, ws.d_seg_total,
+                         ws.d_bucket_start, ws.d_bucket_cursor, ws.d_num_seg, p.B);
+      hipLaunchKernelGGL(te::k_l2_place, dim3(nslices, p.nw), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx, ws.d_part_start,
+                         ws.d_part_count, ws.d_bucket_cursor, ws.d_sorted, sg);
+    }
+    const uint32_t total = this->total();
+    mark(ST_ORDER);
+    if (p.nw > 0) {
+      // d_num_seg[1] = number of split buckets; size_hist zeroed together with it
+      hipLaunchKernelGGL(te::k_seg_build, dim3(1024), dim3(256), 0, stream, ws.d_seg_base, ws.d_bucket_count, ws.d_num_seg, total, p.seg_len,
+                         ws.d_seg_bucket, ws.d_seg_lenv, ws.d_size_hist, ws.d_split_list, ws.d_num_seg + 1, ws.d_large_list, ws.d_chunk_list, total);
+      if (ctx->opt_sort) {
+        hipLaunchKernelGGL(te::k_order_scan, dim3(1), dim3(1024), 0, stream, ws.d_size_hist, ws.d_size_cursor);
+        hipLaunchKernelGGL(te::k_order_scatter, dim3(256), dim3(256), 0, stream, ws.d_seg_lenv, ws.d_num_seg, ws.d_size_cursor, ws.d_order);
+      }
+    }
+    return 0;
+  }
+
+  // K3: one thread per segment (at most seg_len entries of one bucket), 7-product mixed additions
+  int accumulate() {
+    mark(ST_ACCUM);
+    if (p.nw > 0) {
+      const uint32_t n32 = this->n32(), smax = this->smax();
+      const uint32_t* order = ctx->opt_sort ? ws.d_order : nullptr;
+      hipLaunchKernelGGL(te::k_accumulate, dim3((smax + 255) / 256), dim3(256), 0, stream, ws.d_recs, ws.d_sorted, ws.d_bucket_start,
+                         ws.d_bucket_count, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv, order, ws.d_num_seg, ws.d_buckets, ws.d_seg_out,
+                         n32, p.logB, p.seg_len);
+    }
+    return 0;
+  }
+
+  // recombination of split buckets, digit marginals, weighted sums, error flag read-back
+  int back() {
+    const uint32_t total = this->total();
+    if (p.nw > 0) {
+      hipLaunchKernelGGL(te::k_seg_combine, dim3(256), dim3(256), 0, stream, ws.d_split_list, ws.d_num_seg + 1, ws.d_bucket_count, ws.d_seg_base,
+                         ws.d_seg_out, ws.d_buckets, p.seg_len);
+      // giant buckets (empty lists for well-spread digits: two near-empty launches)
+      hipLaunchKernelGGL(te::k_seg_combine_large1, dim3(512), dim3(256), 0, stream, ws.d_chunk_list, ws.d_num_seg + 1, ws.d_bucket_count, ws.d_seg_base,
+                         ws.d_seg_out, p.seg_len, total);
+      hipLaunchKernelGGL(te::k_seg_combine_large2, dim3(256), dim3(256), 0, stream, ws.d_large_list, ws.d_num_seg + 1, ws.d_bucket_count, ws.d_seg_base,
+                         ws.d_seg_out, ws.d_buckets, p.seg_len, total);
+    }
+    // digit marginals M_k[v], k = 0..3 (see K4a in kernels.hip.hpp).  Chains of folds, 4 (or 2) points per level:
+    //   rows chain  B[d3 d2 d1 d0] -fold d0-> -fold d1-> X2[d3 d2]      cols chain  B -fold d3-> -fold d2-> Y2[d1 d0]
+    //   then M3 = fold d2 of X2, M2 = fold d3 of X2, M1 = fold d0 of Y2, M0 = fold d1 of Y2.
+    const te::ete* marg[4] = {ws.d_buckets, ws.d_buckets, ws.d_buckets, ws.d_buckets};
+    if (p.nw > 0) {
+      struct chain_t { const te::ete* cur; uint32_t n; uint32_t steps[2][2]; int nsteps, step; uint32_t left; te::ete* buf[2]; int pp; };
+      const uint32_t w0 = p.dw[0], w1 = p.dw[1], w2 = p.dw[2], w3 = p.dw[3];
+      auto run_phase = [&](chain_t* ch, int nch) {
+        for (int i = 0; i < nch; i++) { ch[i].step = 0; ch[i].left = ch[i].nsteps ? ch[i].steps[0][0] : 1u; ch[i].pp = 0; }
+        for (;;) {
+          te::sum_jobs js; memset(&js, 0, sizeof js);
+          uint32_t most = 0; bool any = false;
+          for (int i = 0; i < nch; i++) {
+            chain_t& c = ch[i];
+            while (c.step < c.nsteps && c.left <= 1) { c.step++; if (c.step < c.nsteps) c.left = c.steps[c.step][0]; }
+            if (c.step >= c.nsteps) continue;
+            const uint32_t K = (c.left % 4 == 0) ? 4u : 2u, inner = c.steps[c.step][1];   // stride of the digit being folded
+            te::sum_job& j = js.j[i];
+            // fold the HIGH part of the remaining digit: groups of K adjacent sub-blocks of size inner * (left / K)
+            j.in = c.cur; j.out = c.buf[c.pp]; j.K = K; j.inner = inner * (c.left / K); j.n_out = c.n / K;
+            j.in_per_window = c.n; j.out_per_window = c.n / K;
+            c.cur = j.out; c.pp ^= 1; c.left /= K; c.n /= K;
+            most = std::max(most, j.n_out * (uint32_t)p.nw); any = true;
+          }
+          if (!any) break;
+          if (most >= 131072u) {      // enough outputs to fill the chip with one thread each: throughput-bound level
+            uint32_t blocks = (most + 255) / 256; if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(te::k_sum_groups, dim3(blocks, nch), dim3(256), 0, stream, js, (uint32_t)p.nw);
+          } else {                    // latency-bound level: four lanes per output
+            uint32_t blocks = (most * 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+            hipLaunchKernelGGL(te::k_sum_groups_team, dim3(blocks, nch), dim3(256), 0, stream, js, (uint32_t)p.nw);
+          }
+        }
+      };
+      // phase 1: X2[d3 d2] (fold the low w0 + w1 bits, contiguous) and Y2[d1 d0] (fold the high w3 + w2 bits)
+      chain_t ph1[2] = {
+          {ws.d_buckets, p.B, {{1u << (w0 + w1), 1u}, {0, 0}}, 1, 0, 0, {ws.d_red[0], ws.d_red[1]}, 0},
+          {ws.d_buckets, p.B, {{1u << (w2 + w3), 1u << (w0 + w1)}, {0, 0}}, 1, 0, 0, {ws.d_red[2], ws.d_red[3]}, 0}};
+      run_phase(ph1, 2);
+      // phase 2: from X2 (index d3 * 2^w2 + d2) and Y2 (index d1 * 2^w0 + d0)
+      chain_t ph2[4] = {
+          {ph1[1].cur, 1u << (w0 + w1), {{1u << w1, 1u << w0}, {0, 0}}, 1, 0, 0, {ws.d_red[4], ws.d_red[5]}, 0},    // M0[d0]: fold d1 (high)
+          {ph1[1].cur, 1u << (w0 + w1), {{1u << w0, 1u}, {0, 0}}, 1, 0, 0, {ws.d_red[6], ws.d_red[7]}, 0},          // M1[d1]: fold d0 (low)
+          {ph1[0].cur, 1u << (w2 + w3), {{1u << w3, 1u << w2}, {0, 0}}, 1, 0, 0, {ws.d_red[8], ws.d_red[9]}, 0},    // M2[d2]: fold d3 (high)
+          {ph1[0].cur, 1u << (w2 + w3), {{1u << w2, 1u}, {0, 0}}, 1, 0, 0, {ws.d_red[10], ws.d_red[11]}, 0}};       // M3[d3]: fold d2 (low)
+      run_phase(ph2, 4);
+      for (int k = 0; k < 4; k++) marg[k] = ph2[k].cur;
+    }
+    mark(ST_WEIGHTED);
+    if (p.nw > 0) {
+      te::ete* rows = reinterpret_cast<te::ete*>(d_partials_out) + (size_t)d.w_first * 5;
+      te::wsum_jobs wj;
+      for (int k = 0; k < 4; k++) { wj.in[k] = marg[k]; wj.N[k] = 1u << p.dw[k]; }
+      hipLaunchKernelGGL(te::k_weighted_sum, dim3(4, p.nw), dim3(64), 0, stream, wj, rows, (uint32_t)d.w_step * 5u);
+    }
+    mark(ST_COUNT);
+    HIP_TRY(ctx, hipMemcpyAsync(ws.h_err, ws.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    return 0;
+  }
+};
+
+// Captures fn (a sequence of launches on ws.stream) into an executable graph.
+template <typename F> int capture_graph(te_ctx* ctx, workset_t& ws, hipGraphExec_t& exec, F&& fn) {
+  if (exec) { (void)hipGraphExecDestroy(exec); exec = nullptr; }
+  hipGraph_t graph = nullptr;
+  HIP_TRY(ctx, hipStreamBeginCapture(ws.stream, hipStreamCaptureModeThreadLocal));
+  const int rc = fn();
+  const hipError_t e = hipStreamEndCapture(ws.stream, &graph);
+  if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  HIP_TRY(ctx, e);
+  const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  HIP_TRY(ctx, ei);
+  return 0;
 }
 
 int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, const void* d_scalars, uint64_t n,
                     void* d_partials_out, hipStream_t stream) {
   plan_t p; make_plan(ctx, d, n, p);
+  HIP_TRY(ctx, hipSetDevice(d.device));
   if (int rc = ensure_buffers(ctx, d, ws, n, p)) return rc;
   ws.plan = p; ws.n = n; ws.used = true; d.last_ws = (int)(&ws - d.ws);
-  HIP_TRY(ctx, hipSetDevice(d.device));
   // profile 1: two events around the dominant kernel only (what bench.py times live); 2: every stage boundary
   // (an event between two kernels costs ~4 us of idle stream time, 11 of them ~2 % of a 2^20 MSM)
-  const int prof = ctx->opt_profile;
-  auto mark = [&](int i) { if (prof >= 2 || (prof == 1 && (i == ST_ACCUM || i == ST_ACCUM + 1))) (void)hipEventRecord(ws.ev[i], stream); };
-  const uint32_t n32 = (uint32_t)n;
-
-  HIP_TRY(ctx, hipMemsetAsync(ws.d_err, 0, 1032 * sizeof(uint32_t), stream));     // flag, counters, length histogram
-  mark(ST_PREP);
-  {  hipLaunchKernelGGL(te::k_prep_points, dim3((n32 + 255) / 256), dim3(256), 0, stream,
-                     (const uint4*)d_points, ws.d_recs, n32);
-  }
-  mark(ST_DIGITS);
-  if (p.nw > 0) {
-    te::digits_params prm; memset(&prm, 0, sizeof prm);
-    for (int w = 0; w < p.W; w++) { const int bit = w * p.c + p.c - 1; if (bit < 320) prm.half[bit >> 5] |= 1u << (bit & 31); }
-    prm.n = n32; prm.nst = p.nst; prm.num_windows = p.W; prm.w_first = d.w_first; prm.w_step = d.w_step; prm.nw_local = p.nw;
-    const uint4* sc = (const uint4*)d_scalars;
-    switch (p.c) {
-      case 4: launch_digits<4>(sc, ws.d_digits, prm, ws.d_err, stream); break;
-      case 5: launch_digits<5>(sc, ws.d_digits, prm, ws.d_err, stream); break;
-      case 6: launch_digits<6>(sc, ws.d_digits, prm, ws.d_err, stream); break;
-      case 7: launch_digits<7>(sc, ws.d_digits, prm, ws.d_err, stream); break;
-      case 8: launch_digits<8>(sc, ws.d_digits, prm, ws.d_err, stream); break;
-      case 9: launch_digits<9>(sc, ws.d_digits, prm, ws.d_err, stream); break;
-      case 10: launch_digits<10>(sc, ws.d_digits, prm, ws.d_err, stream); break;
-      case 11: launch_digits<11>(sc, ws.d_digits, prm, ws.d_err, stream); break;
-      case 12: launch_digits<12>(sc, ws.d_digits, prm, ws.d_err, stream); break;
-      case 13: launch_digits<13>(sc, ws.d_digits, prm, ws.d_err, stream); break;
-      case 14: launch_digits<14>(sc, ws.d_digits, prm, ws.d_err, stream); break;
-      case 15: launch_digits<15>(sc, ws.d_digits, prm, ws.d_err, stream); break;
-      default: launch_digits<16>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+  msm_launch L{ctx, d, ws, p, d_points, d_scalars, n, d_partials_out, ctx->opt_profile, stream};
+  if (ctx->opt_graph && ctx->opt_profile < 2) {
+    // the graphs hold pointers and geometry: re-captured when any of them changes (including a buffer reallocation)
+    const graph_key key{d_points, d_scalars, d_partials_out, n, ws.generation, p.c, d.w_first, d.w_step, (int)p.seg_len, ctx->opt_sort};
+    if (!ws.g_front || !ws.g_back || memcmp(&key, &ws.g_key, sizeof key) != 0) {
+      msm_launch C = L; C.stream = ws.stream; C.prof = 0;
+      if (int rc = capture_graph(ctx, ws, ws.g_front, [&] { return C.front(); })) return rc;
+      if (int rc = capture_graph(ctx, ws, ws.g_back, [&] { return C.back(); })) return rc;
+      ws.g_key = key;
     }
+    HIP_TRY(ctx, hipGraphLaunch(ws.g_front, stream));
+    if (int rc = L.accumulate()) return rc;
+    L.mark(ST_TREE);
+    HIP_TRY(ctx, hipGraphLaunch(ws.g_back, stream));
+  } else {
+    if (int rc = L.front()) return rc;
+    if (int rc = L.accumulate()) return rc;
+    L.mark(ST_TREE);
+    if (int rc = L.back()) return rc;
   }
-  te::sort_geom sg;
-  sg.n = n32; sg.nst = p.nst; sg.B = p.B; sg.logS = p.logS; sg.S = p.S; sg.P = p.P; sg.CH = p.CH; sg.chunk_len = p.chunk_len;
-  mark(ST_HIST);
-  if (p.nw > 0) hipLaunchKernelGGL(te::k_part_hist, dim3(p.CH, p.nw), dim3(1024), 0, stream, ws.d_digits, ws.d_counts1, sg);
-  mark(ST_SCAN);
-  if (p.nw > 0) hipLaunchKernelGGL(te::k_part_scan, dim3(p.nw), dim3(1024), 0, stream, ws.d_counts1, ws.d_part_start, ws.d_part_count, sg);
-  mark(ST_SCATTER);
-  if (p.nw > 0)
-    hipLaunchKernelGGL(te::k_part_scatter, dim3(p.CH, p.nw), dim3(512), 0, stream, ws.d_digits, ws.d_counts1, ws.d_part_keys, ws.d_part_idx, sg);
-  mark(ST_BSORT);
-  if (p.nw > 0) {
-    const uint32_t nslices = (p.nst + 8191u) / 8192u;
-    const uint32_t seg_threads = p.B < 1024u ? p.B : 1024u, nseg = p.B / seg_threads;
-    HIP_TRY(ctx, hipMemsetAsync(ws.d_bucket_count, 0, (size_t)p.nw * p.B * sizeof(uint32_t), stream));
-    hipLaunchKernelGGL(te::k_l2_count, dim3(nslices, p.nw), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx, ws.d_part_start,
-                       ws.d_part_count, ws.d_bucket_count, sg);
-    hipLaunchKernelGGL(te::k_bscan_a, dim3(nseg, p.nw), dim3(seg_threads), 0, stream, ws.d_bucket_count, ws.d_bucket_cursor, ws.d_seg_base,
-                       ws.d_seg_total, p.B, p.seg_len);
-    hipLaunchKernelGGL(te::k_bscan_b, dim3(nseg, p.nw), dim3(seg_threads), 0, stream, ws.d_bucket_cursor, ws.d_seg_base, ws.d_seg_total,
-                       ws.d_bucket_start, ws.d_bucket_cursor, ws.d_num_seg, p.B);
-    hipLaunchKernelGGL(te::k_l2_place, dim3(nslices, p.nw), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx, ws.d_part_start,
-                       ws.d_part_count, ws.d_bucket_cursor, ws.d_sorted, sg);
-  }
-  const uint32_t total = (uint32_t)p.nw * p.B;
-  const uint32_t smax = total + (uint32_t)((uint64_t)p.nw * (n / p.seg_len));
-  mark(ST_ORDER);
-  const uint32_t* order = nullptr;
-  if (p.nw > 0) {
-    // d_num_seg[1] = number of split buckets; size_hist zeroed together with it
-    hipLaunchKernelGGL(te::k_seg_build, dim3(1024), dim3(256), 0, stream, ws.d_seg_base, ws.d_bucket_count, ws.d_num_seg, total, p.seg_len,
-                       ws.d_seg_bucket, ws.d_seg_lenv, ws.d_size_hist, ws.d_split_list, ws.d_num_seg + 1, ws.d_large_list, ws.d_chunk_list, total);
-    if (ctx->opt_sort) {
-      hipLaunchKernelGGL(te::k_order_scan, dim3(1), dim3(1024), 0, stream, ws.d_size_hist, ws.d_size_cursor);
-      hipLaunchKernelGGL(te::k_order_scatter, dim3(256), dim3(256), 0, stream, ws.d_seg_lenv, ws.d_num_seg, ws.d_size_cursor, ws.d_order);
-      order = ws.d_order;
-    }
-  }
-  mark(ST_ACCUM);
-  if (p.nw > 0) {
-    hipLaunchKernelGGL(te::k_accumulate, dim3((smax + 255) / 256), dim3(256), 0, stream, ws.d_recs, ws.d_sorted, ws.d_bucket_start,
-                       ws.d_bucket_count, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv, order, ws.d_num_seg, ws.d_buckets, ws.d_seg_out,
-                       n32, p.logB, p.seg_len);
-    hipLaunchKernelGGL(te::k_seg_combine, dim3(256), dim3(256), 0, stream, ws.d_split_list, ws.d_num_seg + 1, ws.d_bucket_count, ws.d_seg_base,
-                       ws.d_seg_out, ws.d_buckets, p.seg_len);
-    // giant buckets (empty lists for well-spread digits: two near-empty launches)
-    hipLaunchKernelGGL(te::k_seg_combine_large1, dim3(512), dim3(256), 0, stream, ws.d_chunk_list, ws.d_num_seg + 1, ws.d_bucket_count, ws.d_seg_base,
-                       ws.d_seg_out, p.seg_len, total);
-    hipLaunchKernelGGL(te::k_seg_combine_large2, dim3(256), dim3(256), 0, stream, ws.d_large_list, ws.d_num_seg + 1, ws.d_bucket_count, ws.d_seg_base,
-                       ws.d_seg_out, ws.d_buckets, p.seg_len, total);
-  }
-  mark(ST_TREE);
-  // digit marginals M_k[v], k = 0..3 (see K4a in kernels.hip.hpp).  Chains of folds, 4 (or 2) points per level:
-  //   rows chain  B[d3 d2 d1 d0] -fold d0-> -fold d1-> X2[d3 d2]      cols chain  B -fold d3-> -fold d2-> Y2[d1 d0]
-  //   then M3 = fold d2 of X2, M2 = fold d3 of X2, M1 = fold d0 of Y2, M0 = fold d1 of Y2.
-  const te::ete* marg[4] = {ws.d_buckets, ws.d_buckets, ws.d_buckets, ws.d_buckets};
-  if (p.nw > 0) {
-    struct chain_t { const te::ete* cur; uint32_t n; uint32_t steps[2][2]; int nsteps, step; uint32_t left; te::ete* buf[2]; int pp; };
-    const uint32_t w0 = p.dw[0], w1 = p.dw[1], w2 = p.dw[2], w3 = p.dw[3];
-    auto run_phase = [&](chain_t* ch, int nch) {
-      for (int i = 0; i < nch; i++) { ch[i].step = 0; ch[i].left = ch[i].nsteps ? ch[i].steps[0][0] : 1u; ch[i].pp = 0; }
-      for (;;) {
-        te::sum_jobs js; memset(&js, 0, sizeof js);
-        uint32_t most = 0; bool any = false;
-        for (int i = 0; i < nch; i++) {
-          chain_t& c = ch[i];
-          while (c.step < c.nsteps && c.left <= 1) { c.step++; if (c.step < c.nsteps) c.left = c.steps[c.step][0]; }
-          if (c.step >= c.nsteps) continue;
-          const uint32_t K = (c.left % 4 == 0) ? 4u : 2u, inner = c.steps[c.step][1];   // stride of the digit being folded
-          te::sum_job& j = js.j[i];
-          // fold the HIGH part of the remaining digit: groups of K adjacent sub-blocks of size inner * (left / K)
-          j.in = c.cur; j.out = c.buf[c.pp]; j.K = K; j.inner = inner * (c.left / K); j.n_out = c.n / K;
-          j.in_per_window = c.n; j.out_per_window = c.n / K;
-          c.cur = j.out; c.pp ^= 1; c.left /= K; c.n /= K;
-          most = std::max(most, j.n_out * (uint32_t)p.nw); any = true;
-        }
-        if (!any) break;
-        if (most >= 131072u) {      // enough outputs to fill the chip with one thread each: throughput-bound level
-          uint32_t blocks = (most + 255) / 256; if (blocks > 4096) blocks = 4096;
-          hipLaunchKernelGGL(te::k_sum_groups, dim3(blocks, nch), dim3(256), 0, stream, js, (uint32_t)p.nw);
-        } else {                    // latency-bound level: four lanes per output
-          uint32_t blocks = (most * 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
-          hipLaunchKernelGGL(te::k_sum_groups_team, dim3(blocks, nch), dim3(256), 0, stream, js, (uint32_t)p.nw);
-        }
-      }
-    };
-    // phase 1: X2[d3 d2] (fold the low w0 + w1 bits, contiguous) and Y2[d1 d0] (fold the high w3 + w2 bits)
-    chain_t ph1[2] = {
-        {ws.d_buckets, p.B, {{1u << (w0 + w1), 1u}, {0, 0}}, 1, 0, 0, {ws.d_red[0], ws.d_red[1]}, 0},
-        {ws.d_buckets, p.B, {{1u << (w2 + w3), 1u << (w0 + w1)}, {0, 0}}, 1, 0, 0, {ws.d_red[2], ws.d_red[3]}, 0}};
-    run_phase(ph1, 2);
-    // phase 2: from X2 (index d3 * 2^w2 + d2) and Y2 (index d1 * 2^w0 + d0)
-    chain_t ph2[4] = {
-        {ph1[1].cur, 1u << (w0 + w1), {{1u << w1, 1u << w0}, {0, 0}}, 1, 0, 0, {ws.d_red[4], ws.d_red[5]}, 0},    // M0[d0]: fold d1 (high)
-        {ph1[1].cur, 1u << (w0 + w1), {{1u << w0, 1u}, {0, 0}}, 1, 0, 0, {ws.d_red[6], ws.d_red[7]}, 0},          // M1[d1]: fold d0 (low)
-        {ph1[0].cur, 1u << (w2 + w3), {{1u << w3, 1u << w2}, {0, 0}}, 1, 0, 0, {ws.d_red[8], ws.d_red[9]}, 0},    // M2[d2]: fold d3 (high)
-        {ph1[0].cur, 1u << (w2 + w3), {{1u << w2, 1u}, {0, 0}}, 1, 0, 0, {ws.d_red[10], ws.d_red[11]}, 0}};       // M3[d3]: fold d2 (low)
-    run_phase(ph2, 4);
-    for (int k = 0; k < 4; k++) marg[k] = ph2[k].cur;
-  }
-  mark(ST_WEIGHTED);
-  if (p.nw > 0) {
-    te::ete* rows = reinterpret_cast<te::ete*>(d_partials_out) + (size_t)d.w_first * 5;
-    te::wsum_jobs wj;
-    for (int k = 0; k < 4; k++) { wj.in[k] = marg[k]; wj.N[k] = 1u << p.dw[k]; }
-    hipLaunchKernelGGL(te::k_weighted_sum, dim3(4, p.nw), dim3(64), 0, stream, wj, rows, (uint32_t)d.w_step * 5u);
-  }
-  mark(ST_COUNT);
-  HIP_TRY(ctx, hipMemcpyAsync(ws.h_err, ws.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   HIP_TRY(ctx, hipEventRecord(ws.ev_done, stream));
   HIP_TRY(ctx, hipGetLastError());
   return 0;
@@ -361,6 +427,8 @@ void free_dev(gpu_t& d) {
     if (ws.h_err) (void)hipHostFree(ws.h_err);
     if (ws.h_partials) (void)hipHostFree(ws.h_partials);
     if (ws.ev_done) (void)hipEventDestroy(ws.ev_done);
+    if (ws.g_front) (void)hipGraphExecDestroy(ws.g_front);
+    if (ws.g_back) (void)hipGraphExecDestroy(ws.g_back);
     for (auto& ev : ws.ev) if (ev) (void)hipEventDestroy(ev);
     if (ws.stream) (void)hipStreamDestroy(ws.stream);
   }
@@ -512,6 +580,7 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   if (!strcmp(key, "window_bits")) { if (value != 0 && (value < 4 || value > 16)) return set_err(ctx, TE_MSM_EINVAL, "window_bits must be 0 or in [4,16]"); ctx->opt_window_bits = (int)value; return 0; }
   if (!strcmp(key, "sort_buckets")) { ctx->opt_sort = value ? 1 : 0; return 0; }
   if (!strcmp(key, "profile")) { ctx->opt_profile = value < 0 ? 0 : (value > 2 ? 2 : (int)value); ctx->have_stage_ms = false; return 0; }
+  if (!strcmp(key, "graph")) { ctx->opt_graph = value ? 1 : 0; return 0; }
   if (!strcmp(key, "workset")) { if (value < 0 || value >= TE_MSM_WORKSETS) return set_err(ctx, TE_MSM_EINVAL, "workset out of range"); ctx->opt_workset = (int)value; return 0; }
   if (!strcmp(key, "segment_len")) { if (value < 1 || value > 1000000) return set_err(ctx, TE_MSM_EINVAL, "segment_len must be in [1, 1e6]"); ctx->opt_seg_len = (int)value; return 0; }
   return set_err(ctx, TE_MSM_EINVAL, "unknown option");
@@ -525,6 +594,7 @@ int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value) {
   if (!strcmp(key, "num_devices")) { *value = (int64_t)ctx->devs.size(); return 0; }
   if (!strcmp(key, "segment_len")) { *value = ctx->opt_seg_len; return 0; }
   if (!strcmp(key, "workset")) { *value = ctx->opt_workset; return 0; }
+  if (!strcmp(key, "graph")) { *value = ctx->opt_graph; return 0; }
   return set_err(ctx, TE_MSM_EINVAL, "unknown option");
 }
 
