@@ -22,6 +22,19 @@ PKG = "webgpu-msm-twisted-edwards_amd"
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 
+def measured_traffic(log2n, c, world):
+    """HBM bytes per k_accumulate launch from the committed rocprofv3 PMC passes (tools/profile_bench.sh ->
+    profiles/r01_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes).  Counters cannot be
+    read from inside the process, so the figure applies to the profiled workload only (n = 2^20, c = 16, one GPU)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    if not (log2n == 20 and c == 16 and world == 1 and os.path.exists(path)):
+        return None
+    try:
+        return json.load(open(path))["kernels"]["k_accumulate"]["hbm_bytes_per_launch"]
+    except (KeyError, ValueError):
+        return None
+
+
 def algorithmic_bytes(n, W, B):
     """whole MSM, and the share of the dominant kernel (bucket accumulation)."""
     whole = 96 * n + W * n * (64 + 4) + 2 * W * B * 128 + 64
@@ -41,7 +54,7 @@ def main():
                     help="uniform: the harness's distribution; equal: one scalar repeated (worst-case skew); small: 64-bit scalars")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--segment-len", type=int, default=0)
-    ap.add_argument("--inflight", type=int, default=2, help="MSMs in flight in pipelined mode (1..4, each on its own stream / work set)")
+    ap.add_argument("--inflight", type=int, default=4, help="MSMs in flight in pipelined mode (1..4, each on its own stream / work set)")
     ap.add_argument("--no-pipeline", action="store_true", help="N=1: await every MSM before submitting the next (latency mode)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -207,9 +220,16 @@ def main():
                                % (args.log2n, c, W, B, args.points, args.scalars),
                    "parallelism": "windows sharded over %d GPU(s), RCCL all-gather of %d B partial sums" % (world, W * 720) if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(args.log2n, c, world),
+                     "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; 2 x FETCH + WRITE)",
                      "algorithmic_bytes_per_launch": acc_bytes_rank, "kernel_ms": acc_ms,
-                     "note": "integer-multiply bound (about 1.2e8 field products per launch), see DESIGN.md"},
+                     # the timed region keeps `depth` MSMs in flight: the kernel shares the GPU with the other MSMs' kernels,
+                     # so its duration there is longer than when it has the GPU to itself (untimed single-MSM pass)
+                     "alone": {"kernel_ms": stage_ms.get("accumulate"),
+                               "achieved": acc_bytes_rank / (stage_ms["accumulate"] * 1e-3) / 1e9 if stage_ms.get("accumulate") else None,
+                               "frac": acc_bytes_rank / (stage_ms["accumulate"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if stage_ms.get("accumulate") else None},
+                     "note": "VALU-bound, not HBM-bound: 7 field products = 1650 instructions per gathered point, "
+                             "~97 % of the measured v_mad_u64_u32 issue rate (DESIGN.md section 6)"},
         "msm_algorithmic_bytes": whole_bytes,
         "msm_algorithmic_gbps": whole_bytes / (ms_per_step * 1e-3) / 1e9,
         "stage_ms_untimed_pass": stage_ms,

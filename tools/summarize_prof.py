@@ -3,6 +3,7 @@ trace) and per-kernel mean FETCH_SIZE / WRITE_SIZE (PMC passes), corrected as MI
 prescribes (FETCH_SIZE reads half of a wide coalesced stream on gfx950: reported raw and x2)."""
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
@@ -25,6 +26,7 @@ def main(root):
             continue
         print("%-60s %5d %10.1f %10.1f %10.1f %12.1f  %5.1f%%" % (k[:60], len(v), sum(v) / len(v), min(v), max(v), sum(v), 100 * sum(v) / tot))
     # pmc
+    traffic = {}
     for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         acc = defaultdict(list)
         for f in find(os.path.join(root, sub), "*counter_collection.csv"):
@@ -38,6 +40,14 @@ def main(root):
             m = sum(v) / len(v)
             extra = "  x2(gfx950 wide-read correction) = %.1f MB" % (2 * m * 1024 / 1e6) if name == "FETCH_SIZE" else ""
             print("%-60s %5d %14.1f KiB = %10.1f MB%s" % (k[:60], len(v), m, m * 1024 / 1e6, extra))
+            short = k.split("(")[0].split("::")[-1]
+            traffic.setdefault(short, {})[name] = m * 1024
+    # HBM bytes per launch as MI355X_MICROARCH.md prescribes: 2 x FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE
+    out = {k: {"fetch_bytes_raw": v.get("FETCH_SIZE"), "write_bytes": v.get("WRITE_SIZE"),
+               "hbm_bytes_per_launch": 2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0),
+               "mean_us": (sum(dur[n]) / len(dur[n])) if (n := next((d for d in dur if d.split("(")[0].split("::")[-1] == k), None)) else None}
+           for k, v in traffic.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
+    json.dump({"workload": "bench.py default (n = 2^20, c = 16, one GPU)", "kernels": out}, open(os.path.join(root, "traffic.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
