@@ -175,7 +175,7 @@ struct sort_geom {
 
 // All global loads in these kernels are 16 bytes per lane (8 u16 digits / keys, 4 u32 indices): with 2- or
 // 4-byte loads the level-2 kernel spent 160 of its 197 us just fetching 100 MB (the memory pipeline is
-// paid per load INSTRUCTION; profiles/r01_notes.md).
+// paid per load INSTRUCTION and per distinct line it touches).
 __device__ __forceinline__ void unpack8(const uint4& v, uint32_t (&d)[8]) {
   d[0] = v.x & 0xffffu; d[1] = v.x >> 16; d[2] = v.y & 0xffffu; d[3] = v.y >> 16;
   d[4] = v.z & 0xffffu; d[5] = v.z >> 16; d[6] = v.w & 0xffffu; d[7] = v.w >> 16;
