@@ -54,6 +54,8 @@ def main():
                     help="uniform: the harness's distribution; equal: one scalar repeated (worst-case skew); small: 64-bit scalars")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--segment-len", type=int, default=0)
+    ap.add_argument("--digits", choices=("signed", "unsigned"), default="signed",
+                    help="signed window digits, 2^(c-1) buckets (BASELINE config 3, the reference's shipped behaviour) or unsigned, 2^c buckets (config 2)")
     ap.add_argument("--inflight", type=int, default=4, help="MSMs in flight in pipelined mode (1..4, each on its own stream / work set)")
     ap.add_argument("--no-pipeline", action="store_true", help="N=1: await every MSM before submitting the next (latency mode)")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -103,9 +105,10 @@ def main():
     ctx.set_option("window_bits", args.window_bits)
     if args.segment_len:
         ctx.set_option("segment_len", args.segment_len)
+    ctx.set_option("signed_digits", 1 if args.digits == "signed" else 0)
     ctx.set_option("profile", 1)          # two HIP events around the dominant kernel, on the engine's stream
     c, W = ctx.plan(n)
-    B = 1 << (c - 1)
+    B = 1 << (c - 1 if args.digits == "signed" else c)
     if world > 1 or force_dist:
         # TE_BENCH_REHEARSE_WORLD=D (with TE_BENCH_FORCE_DIST=1, one rank): this rank does the work of rank 0 of D -- the
         # per-rank step of a D-GPU run without the other D-1 GPUs.  The result is a partial sum: no parity claim is made.
@@ -216,8 +219,8 @@ def main():
         "vs_baseline": None,
         "dtype": "u32",
         "data": "synthetic",
-        "config": {"workload": "n=2^%d TE-BLS12 MSM, %d-bit signed windows (%d windows x %d buckets), points=%s, scalars=%s, inputs resident in HBM"
-                               % (args.log2n, c, W, B, args.points, args.scalars),
+        "config": {"workload": "n=2^%d TE-BLS12 MSM, %d-bit %s windows (%d windows x %d buckets), points=%s, scalars=%s, inputs resident in HBM"
+                               % (args.log2n, c, args.digits, W, B, args.points, args.scalars),
                    "parallelism": "windows sharded over %d GPU(s), RCCL all-gather of %d B partial sums" % (world, W * 720) if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(args.log2n, c, world),
@@ -266,6 +269,7 @@ def main():
         # untimed cross-check of the sharded path: the same MSM on this rank's GPU alone must give the same point
         with pkg.MsmContext((dev,)) as solo:
             solo.set_option("window_bits", args.window_bits)
+            solo.set_option("signed_digits", 1 if args.digits == "signed" else 0)
             same = solo.run_device(d_pts.data_ptr(), d_sc.data_ptr(), n) == result
         flag = torch.tensor([1 if same else 0], dtype=torch.int32, device="cuda")
         if dist.get_backend() == "gloo":

@@ -69,6 +69,9 @@ int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]);
 
 /* Options (the reference hard-codes these: chunk_size submission.ts:80, dispatch table :109-142).
  *   "window_bits"   c in [4,16]; 0 = choose from n (default)
+ *   "signed_digits" 1 = signed window digits, 2^(c-1) buckets per window (default; the reference's shipped behaviour,
+ *                   miscellaneous/utils.ts:52-95); 0 = plain unsigned windows, 2^c buckets (utils.ts:34-50): same
+ *                   result, accepts any 256-bit scalar (no final-carry error)
  *   "sort_buckets"  1 = schedule buckets by descending size (default), 0 = natural order
  *   "segment_len"   a bucket longer than this is accumulated by several threads (default 64)
  *   "profile"       1 = HIP events around the dominant kernel (accumulate) only, 2 = around every stage
@@ -111,6 +114,9 @@ int te_msm_finalize(te_ctx* ctx, const uint8_t* partials, int window_bits, int n
 /* The same tail without a context (pure host code, no device needed): used when the rows were produced
  * elsewhere, e.g. gathered from other ranks.  Does not know about scalar-range errors. */
 int te_msm_finalize_host(const uint8_t* partials, int window_bits, int num_windows, uint8_t out_xy_le[64]);
+/* Same for either digit form: bucket_bits = window_bits - 1 (signed digits, what te_msm_finalize_host assumes) or
+ * window_bits (option "signed_digits" = 0). */
+int te_msm_finalize_host_ex(const uint8_t* partials, int window_bits, int bucket_bits, int num_windows, uint8_t out_xy_le[64]);
 
 /* ---- measurement / stage verification (the reference's `debug` flags, submission.ts:892-1363) --- */
 /* Per-stage device time of the last run in ms (needs option "profile" >= 1; level 1 reports "accumulate" only).  Returns the number of

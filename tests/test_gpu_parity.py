@@ -143,6 +143,53 @@ def test_every_window_size(ctx, ora, c):
     ctx.set_option("sort_buckets", 1)
 
 
+# ------------------------------------------------------------------ unsigned windows, 2^c buckets
+@pytest.mark.parametrize("c,n", [(4, 500), (8, 3000), (13, 20011), (15, 40000), (16, 70001)])
+def test_unsigned_digits(pkg, model, ora, c, n):
+    """option signed_digits = 0: plain windows (miscellaneous/utils.ts:34-50), bucket = digit - 1 of 2^c; same result as the
+    signed path and as the oracle; digits, bucket counts and the pipelined / sharded tails agree"""
+    import torch
+    pts, sc = ora.gen_points(900 + c, n), ora.gen_scalars(900 + c, n)
+    exp = ora.msm(pts, sc, threads=8)
+    with pkg.MsmContext((0,)) as u:
+        u.set_option("window_bits", c)
+        u.set_option("signed_digits", 0)
+        assert u.get_option("signed_digits") == 0
+        assert u.run(pts, sc) == exp
+        W, B = (256 + c - 1) // c, 1 << c
+        nst = (n + 7) & ~7
+        dig = np.frombuffer(u.debug_read("digits", W * nst * 2), dtype=np.uint16).reshape(W, nst)
+        assert np.all(dig[:, n:] == 0)
+        words = np.frombuffer(sc, dtype="<u8").reshape(n, 4)
+        ints = [int(words[i, 0]) | int(words[i, 1]) << 64 | int(words[i, 2]) << 128 | int(words[i, 3]) << 192 for i in range(0, n, max(1, n // 211))]
+        for j, i in enumerate(range(0, n, max(1, n // 211))):
+            assert [int(dig[w, i]) for w in range(W)] == [(ints[j] >> (c * w)) & (B - 1) for w in range(W)]
+        cnt = np.frombuffer(u.debug_read("bucket_count", W * B * 4), dtype=np.uint32).reshape(W, B)
+        for w in (0, W // 2, W - 1):
+            d = dig[w, :n].astype(np.int64)
+            assert np.array_equal(cnt[w], np.bincount(d[d != 0] - 1, minlength=B))
+        # pipelined tickets and the window-sharded tail use the same digit form
+        dp, ds = _dev(pts), _dev(sc)
+        torch.cuda.synchronize()
+        t = u.submit_device(dp.data_ptr(), ds.data_ptr(), n)
+        assert u.collect(t) == exp
+        part = torch.zeros(W * 720, dtype=torch.uint8, device="cuda")
+        u.partial_device(dp.data_ptr(), ds.data_ptr(), n, part.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        rows = part.cpu().numpy().tobytes()
+        assert u.finalize(rows, c, W) == exp
+        assert pkg.finalize_host(rows, c, W, bucket_bits=c) == exp
+    # unsigned windows accept any 256-bit scalar (no final carry): check against plain double-and-add
+    pts4 = ora.gen_points(3, 4)
+    ks = [(1 << 256) - 1, (1 << 255) + 12345, 1, 0]
+    with pkg.MsmContext((0,)) as u:
+        u.set_option("window_bits", c)
+        u.set_option("signed_digits", 0)
+        got = u.run(pts4, model.scalars_to_bytes(ks))
+    pl = [model.xy_from_bytes(pts4[64 * i:64 * i + 64]) for i in range(4)]
+    assert model.xy_from_bytes(got) == model.msm_naive(pl, ks)
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 255, 1000, 4097, 65535, 65537, 100003])
 def test_ragged_sizes(ctx, ora, n):
     pts, sc = ora.gen_points(n, n), ora.gen_scalars(n, n)

@@ -97,6 +97,8 @@ def _lib() -> ctypes.CDLL:
         L.te_msm_finalize.restype = ci
         L.te_msm_finalize_host.argtypes = [cp, ci, ci, cp]
         L.te_msm_finalize_host.restype = ci
+        L.te_msm_finalize_host_ex.argtypes = [cp, ci, ci, ci, cp]
+        L.te_msm_finalize_host_ex.restype = ci
         L.te_msm_stage_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(cp), ci]
         L.te_msm_stage_ms.restype = ci
         L.te_msm_debug_read.argtypes = [vp, cp, vp, u64]
@@ -207,12 +209,14 @@ class MsmContext:
         return buf.raw[:got]
 
 
-def finalize_host(partials: bytes, window_bits: int, num_windows: int) -> bytes:
-    """Context-free host tail (te_msm_finalize_host): Horner + affine over W rows of 720 bytes."""
+def finalize_host(partials: bytes, window_bits: int, num_windows: int, bucket_bits: int | None = None) -> bytes:
+    """Context-free host tail (te_msm_finalize_host_ex): Horner + affine over W rows of 720 bytes.
+    bucket_bits: window_bits - 1 for signed digits (default), window_bits for unsigned ones."""
     out = ctypes.create_string_buffer(64)
-    rc = _lib().te_msm_finalize_host(bytes(partials), window_bits, num_windows, out)
+    bb = window_bits - 1 if bucket_bits is None else bucket_bits
+    rc = _lib().te_msm_finalize_host_ex(bytes(partials), window_bits, bb, num_windows, out)
     if rc:
-        raise MsmError(rc, "te_msm_finalize_host failed")
+        raise MsmError(rc, "te_msm_finalize_host_ex failed")
     return out.raw
 
 

@@ -123,15 +123,16 @@ static inline Pt pdbl(const Pt& a) {
 }
 
 // partials: W rows of 720 B = [T | W0 | W1 | W2 | W3]: T = sum of the window's buckets, Wk = sum_v v * M_k[v] for digit k of
-// the bucket index (digit widths w_k = (c - 1 + 3 - k) / 4, e.g. 4,4,4,3 for c = 16).  Window value
+// the bucket index (bucket_bits = c - 1 for signed digits, c for unsigned; digit widths w_k = (bucket_bits + 3 - k) / 4,
+// e.g. 4,4,4,3 for 15 bits).  Window value
 //     V = T + W0 + 2^w0 W1 + 2^(w0+w1) W2 + 2^(w0+w1+w2) W3,      result = sum_w 2^(c*w) V_w,
 // evaluated top-down; the c doublings per window are split around the digit terms, so no doubling is added.
-static inline void horner_to_affine(const uint8_t* partials, int c, int W, uint8_t out_xy_le[64]) {
+static inline void horner_to_affine(const uint8_t* partials, int c, int bucket_bits, int W, uint8_t out_xy_le[64]) {
   const Fe d2 = {{2 * 3021, 0, 0, 0}};
   const Fe R2 = {{0x25d577bab861857bULL, 0xcc2c27b58860591fULL, 0xa7cc008fe5dc8593ULL, 0x011fdae7eff1c939ULL}};
   const Fe k2d = mul(d2, R2);
   int dw[4];
-  for (int k = 0; k < 4; k++) dw[k] = (c - 1 + 3 - k) / 4;
+  for (int k = 0; k < 4; k++) dw[k] = (bucket_bits + 3 - k) / 4;
   const int s3 = dw[0] + dw[1] + dw[2];
   Pt acc = identity();
   for (int w = W - 1; w >= 0; w--) {

@@ -17,7 +17,8 @@
 namespace te {
 
 struct digits_params {
-  uint32_t half[10];   // sum_w 2^(c*w + c-1) over ALL windows of the decomposition, 9 limbs (+1 zero)
+  uint32_t half[10];   // signed digits: sum_w 2^(c*w + c-1) over ALL windows of the decomposition, 9 limbs (+1 zero); unsigned: 0
+  uint32_t zero_digit; // stored code of digit 0: 2^(c-1) signed, 0 unsigned
   uint32_t n, nst;     // points, digit-row stride (n rounded up to a multiple of 8; pad entries hold digit 0)
   int num_windows;     // total windows W of the decomposition
   int w_first, w_step, nw_local;
@@ -80,7 +81,7 @@ __global__ void __launch_bounds__(256) k_digits(const uint4* __restrict__ scalar
   if (i0 >= prm.nst) return;
   uint32_t* __restrict__ out = reinterpret_cast<uint32_t*>(digits);
   const uint32_t half_stride = prm.nst >> 1;
-  constexpr uint32_t ZERO_DIGIT = 1u << (C - 1);
+  const uint32_t ZERO_DIGIT = prm.zero_digit;
   if (i0 >= prm.n) {                                   // padding entries: digit 0
     for (int k = 0; k < prm.nw_local; k++) out[(size_t)k * half_stride + pair] = ZERO_DIGIT | (ZERO_DIGIT << 16);
     return;
@@ -122,10 +123,10 @@ __global__ void __launch_bounds__(256) k_digits(const uint4* __restrict__ scalar
 }
 
 // ------------------------------------------------------------------------------------------------
-// bucket of a stored digit: digit = stored - B (B = 2^(c-1)); bucket = |digit| - 1 in [0, B);
-// weight of bucket j is j + 1; digit 0 contributes nothing (smvp.template.wgsl:128).
-__device__ __forceinline__ bool digit_bucket(uint32_t stored, uint32_t B, uint32_t& bucket, uint32_t& neg) {
-  const int d = (int)stored - (int)B;
+// bucket of a stored digit: digit = stored - half (half = 2^(c-1) for signed digits, 0 for unsigned ones);
+// bucket = |digit| - 1 in [0, B); weight of bucket j is j + 1; digit 0 contributes nothing (smvp.template.wgsl:128).
+__device__ __forceinline__ bool digit_bucket(uint32_t stored, uint32_t half, uint32_t& bucket, uint32_t& neg) {
+  const int d = (int)stored - (int)half;
   if (d == 0) return false;
   neg = d < 0 ? 1u : 0u;
   bucket = (uint32_t)(d < 0 ? -d : d) - 1u;
@@ -170,6 +171,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds /*
 struct sort_geom {
   uint32_t n, nst;       // entries per window; row stride of digits / part_keys / part_idx (multiple of 8, >= n)
   uint32_t B, logS, S, P, CH, chunk_len;   // chunk_len is a multiple of TE_TILE
+  uint32_t half;         // stored code of digit 0 (see digit_bucket)
 };
 #define TE_TILE 4096u
 
@@ -200,7 +202,7 @@ __global__ void __launch_bounds__(1024) k_part_hist(const uint16_t* __restrict__
 #pragma unroll
         for (int e = 0; e < 8; e++) {
           uint32_t b, neg;
-          if (digit_bucket(dd[e], g.B, b, neg)) atomicAdd(&h[wave * g.P + (b >> g.logS)], 1u);
+          if (digit_bucket(dd[e], g.half, b, neg)) atomicAdd(&h[wave * g.P + (b >> g.logS)], 1u);
         }
       }
     }
@@ -263,7 +265,7 @@ __global__ void __launch_bounds__(512) k_part_scatter(const uint16_t* __restrict
     for (int e = 0; e < 8; e++) {
       part[e] = 0xffffffffu;
       uint32_t b, neg;
-      if (i0 + (uint32_t)e < hi && digit_bucket(dd[e], g.B, b, neg)) {
+      if (i0 + (uint32_t)e < hi && digit_bucket(dd[e], g.half, b, neg)) {
         part[e] = b >> g.logS; key[e] = (b & (g.S - 1u)) | (neg << 15);
         rank[e] = atomicAdd(&tile_cnt[part[e]], 1u);
       }

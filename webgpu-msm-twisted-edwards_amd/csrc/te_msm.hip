@@ -30,7 +30,8 @@ const char* const kStageNames[ST_COUNT] = {"prep_points", "digits", "part_hist",
 
 struct plan_t {
   int c = 0, W = 0, nw = 0;           // window bits, total windows, windows of this shard
-  uint32_t B = 0, logB = 0;           // buckets per window = 2^(c-1)
+  uint32_t B = 0, logB = 0;           // buckets per window = 2^(c-1) (signed digits) or 2^c (unsigned)
+  int signed_digits = 1;
   uint32_t dw[4] = {0, 0, 0, 0};      // bits of the four digits of a bucket index (dw[0] lowest)
   uint32_t CH = 0, chunk_len = 0, nst = 0;   // level-1 chunks per window (chunk_len multiple of 4096); padded row stride
   uint32_t seg_len = 64;
@@ -82,6 +83,7 @@ struct te_ctx {
   std::string err;
   int opt_window_bits = 0;
   int opt_sort = 1;
+  int opt_signed = 1;          // signed window digits (the reference's shipped behaviour); 0 = plain unsigned windows, 2^c buckets
   int opt_profile = 0;
   int opt_seg_len = 64;        // work segment: at most this many entries of one bucket per thread
   int opt_graph = 0;           // replay the launch sequence around k_accumulate as HIP graphs
@@ -125,8 +127,9 @@ void make_plan(const te_ctx* ctx, const gpu_t& d, uint64_t n, plan_t& p) {
   p.W = (256 + p.c - 1) / p.c;
   p.nw = 0;
   for (int w = d.w_first; w < p.W; w += d.w_step) p.nw++;
-  p.B = 1u << (p.c - 1); p.logB = p.c - 1;
-  for (int k = 0; k < 4; k++) p.dw[k] = (uint32_t)(p.c - 1 + 3 - k) / 4u;       // 15 -> 4,4,4,3
+  p.signed_digits = ctx->opt_signed;
+  p.logB = (uint32_t)(p.signed_digits ? p.c - 1 : p.c); p.B = 1u << p.logB;
+  for (int k = 0; k < 4; k++) p.dw[k] = (p.logB + 3u - (uint32_t)k) / 4u;       // 15 -> 4,4,4,3
   uint32_t ch = p.nw > 0 ? 1024u / (uint32_t)p.nw : 1u;     // ~4 blocks of 512 threads per CU in k_part_scatter
   if (ch < 1) ch = 1;
   if (ch > 256) ch = 256;
@@ -215,7 +218,8 @@ struct msm_launch {
     mark(ST_DIGITS);
     if (p.nw > 0) {
       te::digits_params prm; memset(&prm, 0, sizeof prm);
-      for (int w = 0; w < p.W; w++) { const int bit = w * p.c + p.c - 1; if (bit < 320) prm.half[bit >> 5] |= 1u << (bit & 31); }
+      if (p.signed_digits) for (int w = 0; w < p.W; w++) { const int bit = w * p.c + p.c - 1; if (bit < 320) prm.half[bit >> 5] |= 1u << (bit & 31); }
+      prm.zero_digit = p.signed_digits ? 1u << (p.c - 1) : 0u;
       prm.n = n32; prm.nst = p.nst; prm.num_windows = p.W; prm.w_first = d.w_first; prm.w_step = d.w_step; prm.nw_local = p.nw;
       const uint4* sc = (const uint4*)d_scalars;
       switch (p.c) {
@@ -235,7 +239,7 @@ struct msm_launch {
       }
     }
     te::sort_geom sg;
-    sg.n = n32; sg.nst = p.nst; sg.B = p.B; sg.logS = p.logS; sg.S = p.S; sg.P = p.P; sg.CH = p.CH; sg.chunk_len = p.chunk_len;
+    sg.n = n32; sg.nst = p.nst; sg.B = p.B; sg.logS = p.logS; sg.S = p.S; sg.P = p.P; sg.CH = p.CH; sg.chunk_len = p.chunk_len; sg.half = p.signed_digits ? p.B : 0u;
     mark(ST_HIST);
     if (p.nw > 0) hipLaunchKernelGGL(te::k_part_hist, dim3(p.CH, p.nw), dim3(1024), 0, stream, ws.d_digits, ws.d_counts1, sg);
     mark(ST_SCAN);
@@ -383,7 +387,7 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, 
   msm_launch L{ctx, d, ws, p, d_points, d_scalars, n, d_partials_out, ctx->opt_profile, stream};
   if (ctx->opt_graph && ctx->opt_profile < 2) {
     // the graphs hold pointers and geometry: re-captured when any of them changes (including a buffer reallocation)
-    const graph_key key{d_points, d_scalars, d_partials_out, n, ws.generation, p.c, d.w_first, d.w_step, (int)p.seg_len, ctx->opt_sort};
+    const graph_key key{d_points, d_scalars, d_partials_out, n, ws.generation, p.c, d.w_first, d.w_step, (int)p.seg_len, ctx->opt_sort | (ctx->opt_signed << 1)};
     if (!ws.g_front || !ws.g_back || memcmp(&key, &ws.g_key, sizeof key) != 0) {
       msm_launch C = L; C.stream = ws.stream; C.prof = 0;
       if (int rc = capture_graph(ctx, ws, ws.g_front, [&] { return C.front(); })) return rc;
@@ -482,7 +486,7 @@ int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, boo
       memcpy(&merged[(size_t)w * TE_MSM_PARTIAL_BYTES], ws.h_partials + (size_t)w * TE_MSM_PARTIAL_BYTES, TE_MSM_PARTIAL_BYTES);
   }
   if (int rc = collect_stage_ms(ctx, ctx->devs[0].ws[ctx->opt_workset])) return rc;
-  te_host::horner_to_affine(merged.data(), p0.c, p0.W, out);
+  te_host::horner_to_affine(merged.data(), p0.c, (int)p0.logB, p0.W, out);
   return 0;
 }
 
@@ -571,7 +575,7 @@ int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]) {
   d.next_collect++;
   if (int rc = collect_stage_ms(ctx, ws)) return rc;
   if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
-  te_host::horner_to_affine(ws.h_partials, ws.plan.c, ws.plan.W, out_xy_le);
+  te_host::horner_to_affine(ws.h_partials, ws.plan.c, (int)ws.plan.logB, ws.plan.W, out_xy_le);
   return 0;
 }
 
@@ -579,6 +583,7 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   if (!ctx || !key) return TE_MSM_EINVAL;
   if (!strcmp(key, "window_bits")) { if (value != 0 && (value < 4 || value > 16)) return set_err(ctx, TE_MSM_EINVAL, "window_bits must be 0 or in [4,16]"); ctx->opt_window_bits = (int)value; return 0; }
   if (!strcmp(key, "sort_buckets")) { ctx->opt_sort = value ? 1 : 0; return 0; }
+  if (!strcmp(key, "signed_digits")) { ctx->opt_signed = value ? 1 : 0; return 0; }
   if (!strcmp(key, "profile")) { ctx->opt_profile = value < 0 ? 0 : (value > 2 ? 2 : (int)value); ctx->have_stage_ms = false; return 0; }
   if (!strcmp(key, "graph")) { ctx->opt_graph = value ? 1 : 0; return 0; }
   if (!strcmp(key, "workset")) { if (value < 0 || value >= TE_MSM_WORKSETS) return set_err(ctx, TE_MSM_EINVAL, "workset out of range"); ctx->opt_workset = (int)value; return 0; }
@@ -590,6 +595,7 @@ int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value) {
   if (!ctx || !key || !value) return TE_MSM_EINVAL;
   if (!strcmp(key, "window_bits")) { *value = ctx->opt_window_bits; return 0; }
   if (!strcmp(key, "sort_buckets")) { *value = ctx->opt_sort; return 0; }
+  if (!strcmp(key, "signed_digits")) { *value = ctx->opt_signed; return 0; }
   if (!strcmp(key, "profile")) { *value = ctx->opt_profile; return 0; }
   if (!strcmp(key, "num_devices")) { *value = (int64_t)ctx->devs.size(); return 0; }
   if (!strcmp(key, "segment_len")) { *value = ctx->opt_seg_len; return 0; }
@@ -643,14 +649,20 @@ int te_msm_finalize(te_ctx* ctx, const uint8_t* partials, int window_bits, int n
     if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
     if (int rc = collect_stage_ms(ctx, ws)) return rc;
   }
-  te_host::horner_to_affine(partials, window_bits, num_windows, out_xy_le);
+  te_host::horner_to_affine(partials, window_bits, ctx->opt_signed ? window_bits - 1 : window_bits, num_windows, out_xy_le);
   return 0;
 }
 
 int te_msm_finalize_host(const uint8_t* partials, int window_bits, int num_windows, uint8_t out_xy_le[64]) {
   if (!partials || !out_xy_le || window_bits < 2 || window_bits > 16 || num_windows < 1 || num_windows > 128) return TE_MSM_EINVAL;
+  return te_msm_finalize_host_ex(partials, window_bits, window_bits - 1, num_windows, out_xy_le);
+}
+
+int te_msm_finalize_host_ex(const uint8_t* partials, int window_bits, int bucket_bits, int num_windows, uint8_t out_xy_le[64]) {
+  if (!partials || !out_xy_le || window_bits < 2 || window_bits > 16 || num_windows < 1 || num_windows > 128) return TE_MSM_EINVAL;
+  if (bucket_bits != window_bits && bucket_bits != window_bits - 1) return TE_MSM_EINVAL;
   if (!te_host::tail_selftest()) return TE_MSM_ESTATE;
-  te_host::horner_to_affine(partials, window_bits, num_windows, out_xy_le);
+  te_host::horner_to_affine(partials, window_bits, bucket_bits, num_windows, out_xy_le);
   return 0;
 }
 

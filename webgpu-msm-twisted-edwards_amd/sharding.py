@@ -86,6 +86,7 @@ class ShardedPipeline:
         self.torch, self.ctx, self.n, self.dist, self.group = torch, ctx, n, dist, group
         self.world = dist.get_world_size(group)
         self.c, self.W = ctx.plan(n)
+        self.bucket_bits = self.c - 1 if ctx.get_option("signed_digits") else self.c
         nbytes = self.W * PARTIAL_BYTES
         self.gloo = dist.get_backend(group) == "gloo"
         self.part = [torch.zeros(nbytes, dtype=torch.uint8, device="cuda") for _ in range(depth)]
@@ -133,4 +134,4 @@ class ShardedPipeline:
         nbytes = self.W * PARTIAL_BYTES
         flat = self.host[slot].numpy().tobytes()
         merged = merge_partials([flat[r * nbytes:(r + 1) * nbytes] for r in range(self.world)], self.W, self.world)
-        return finalize_host(merged, self.c, self.W)
+        return finalize_host(merged, self.c, self.W, self.bucket_bits)
