@@ -118,6 +118,12 @@ int te_msm_finalize_host(const uint8_t* partials, int window_bits, int num_windo
  * window_bits (option "signed_digits" = 0). */
 int te_msm_finalize_host_ex(const uint8_t* partials, int window_bits, int bucket_bits, int num_windows, uint8_t out_xy_le[64]);
 
+/* ---- harness inputs (host code, no device needed).  The reference's harness generates its own random inputs when the
+ * ZPrize files are not used (ui/AllBenchmarks.tsx:99-131, reference/webgpu/utils.ts:81-88,118-124): seeded scalars =
+ * 256 random bits reduced mod p; points = n distinct subgroup points (a + i*b)*G, or, with fixed_point != 0, the harness's
+ * one fixed point replicated n times.  Either output pointer may be NULL. */
+int te_msm_synth_inputs(uint64_t seed, uint64_t n, int fixed_point, uint8_t* points_xy_le, uint8_t* scalars_le);
+
 /* ---- measurement / stage verification (the reference's `debug` flags, submission.ts:892-1363) --- */
 /* Per-stage device time of the last run in ms (needs option "profile" >= 1; level 1 reports "accumulate" only).  Returns the number of
  * stages written; names[i] points to static strings. */

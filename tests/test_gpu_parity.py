@@ -1,6 +1,7 @@
 """GPU parity tests: the HIP path (through the C-ABI of libtemsm.so) against the oracle, on the same
 seeded inputs, bit-exact.  Run with `-m gpu` on an MI355X.  Nothing here reads /root/reference."""
 import ctypes
+import importlib
 import os
 
 import numpy as np
@@ -332,6 +333,24 @@ def test_zprize_vectors_if_supplied(ctx, pkg, kats):
             pts, sc = td.load_test_case(pp, sp)
             out = ctx.run(pts, sc)
             assert (int.from_bytes(out[:32], "little"), int.from_bytes(out[32:], "little")) == (int(e["x"]), int(e["y"]))
+
+
+def test_full_benchmarks_protocol(pkg, ora):
+    """the reference's benchmark loop (full_benchmarks.ts:6-163) over compute_msm: table shape, and every run is a real MSM"""
+    import io
+    fb = importlib.import_module(pkg.__name__ + ".full_benchmarks")
+    buf = io.StringIO()
+    res = fb.run([10, 12], None, num_runs=2, delay_ms=1, out=buf)
+    text = buf.getvalue()
+    assert "| MSM size | 1st run | Run 1 | Run 2 | Average (incl 1st) | Average (excl 1st) |" in text
+    assert "| 2^10 |" in text and "| 2^12 |" in text
+    for power in (10, 12):
+        r = res[power]
+        assert len(r["subsequent_runs"]) == 2 and r["first_run_elapsed"] > 0
+        assert abs(r["full_average"] - (r["first_run_elapsed"] + sum(r["subsequent_runs"])) / 3) < 1e-9
+    pts, sc = pkg.synth_inputs(0x5EED0000 + 10, 1 << 10)
+    out = pkg.compute_msm(pts, sc, log_result=False)
+    assert out["x"] == int.from_bytes(ora.msm(pts, sc)[:32], "little")
 
 
 def test_node_compute_msm_entry_point(pkg, model, ora, tmp_path):

@@ -178,6 +178,17 @@ def test_host_tail_identity_and_args(pkg):
 
 
 # ---------------------------------------------------------------- C-ABI surface
+def test_synthetic_inputs_equal_the_oracle_generator(pkg, ora):
+    """te_msm_synth_inputs (product side, used by bench.py and full_benchmarks.py) == the oracle's generator, so golden
+    fixtures, tests and the bench all speak about the same inputs"""
+    for seed, n in ((1, 1), (7, 2), (3, 1000), (0x5EED0014, 4097)):
+        pts, sc = pkg.synth_inputs(seed, n)
+        assert pts == ora.gen_points(seed, n) and sc == ora.gen_scalars(seed, n)
+    assert pkg.synth_inputs(9, 3, fixed_point=True)[0] == ora.gen_points_fixed(3)
+    assert pkg.synth_inputs(9, 0) == (b"", b"")
+    assert pkg.synth_inputs(9, 4, points=False)[0] is None
+
+
 def _declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "te_msm.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
@@ -219,6 +230,13 @@ def test_product_does_not_touch_the_oracle():
                     if re.search(r"te_oracle|oracle/|from oracle|import oracle|ora_msm", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_zprize_expected_results_are_the_reference_constants(pkg, kats):
+    import importlib
+    td = importlib.import_module("webgpu-msm-twisted-edwards_amd.testdata")
+    assert {str(k): {"x": str(v["x"]), "y": str(v["y"])} for k, v in td.EXPECTED.items()} == kats["zprize_expected"]
+    assert td.expected_result(16)["x"] == int(kats["zprize_expected"]["16"]["x"]) and td.expected_result(15) is None
 
 
 def test_zprize_ingestion_format(pkg, model, tmp_path):

@@ -99,6 +99,8 @@ def _lib() -> ctypes.CDLL:
         L.te_msm_finalize_host.restype = ci
         L.te_msm_finalize_host_ex.argtypes = [cp, ci, ci, ci, cp]
         L.te_msm_finalize_host_ex.restype = ci
+        L.te_msm_synth_inputs.argtypes = [u64, u64, ci, vp, vp]
+        L.te_msm_synth_inputs.restype = ci
         L.te_msm_stage_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(cp), ci]
         L.te_msm_stage_ms.restype = ci
         L.te_msm_debug_read.argtypes = [vp, cp, vp, u64]
@@ -218,6 +220,18 @@ def finalize_host(partials: bytes, window_bits: int, num_windows: int, bucket_bi
     if rc:
         raise MsmError(rc, "te_msm_finalize_host_ex failed")
     return out.raw
+
+
+def synth_inputs(seed: int, n: int, fixed_point: bool = False, points: bool = True, scalars: bool = True):
+    """Seeded harness inputs in compute_msm's wire format (te_msm_synth_inputs): (points 64n bytes, scalars 32n bytes);
+    a part not asked for is None.  Host code only."""
+    pb = ctypes.create_string_buffer(64 * n) if points else None
+    sb = ctypes.create_string_buffer(32 * n) if scalars else None
+    rc = _lib().te_msm_synth_inputs(seed, n, 1 if fixed_point else 0, ctypes.cast(pb, ctypes.c_void_p) if pb is not None else None,
+                                    ctypes.cast(sb, ctypes.c_void_p) if sb is not None else None)
+    if rc:
+        raise MsmError(rc, "te_msm_synth_inputs failed")
+    return (pb.raw if pb is not None else None), (sb.raw if sb is not None else None)
 
 
 _DEFAULT_CTX = None

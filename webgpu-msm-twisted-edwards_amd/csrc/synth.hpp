@@ -1,0 +1,75 @@
+// synth.hpp -- deterministic synthetic inputs for the harness side of the path (host code only).
+// The reference's harness feeds compute_msm either the ZPrize files or random inputs it generates itself
+// (ui/AllBenchmarks.tsx:99-131: one fixed point replicated n times + random scalars; reference/webgpu/utils.ts:81-88,
+// 118-124 for the scalar distribution).  bench.py, full_benchmarks.py and the tests need the same thing without the
+// files: scalars = 256 random bits reduced mod p (splitmix64 stream), points P_i = (a + i*b)*G built as a chain
+// P_0 = a*G, P_{i+1} = P_i + b*G and normalised with one batched inversion -- n DISTINCT subgroup points, which the
+// harness's replicated point is not.
+#pragma once
+#include <vector>
+#include "host_tail.hpp"
+
+namespace te_host {
+
+static inline uint64_t splitmix64(uint64_t& s) {
+  uint64_t z = (s += 0x9E3779B97F4A7C15ULL);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+static inline Fe rand_mod_p(uint64_t& s) {          // plain integer in [0, p)
+  Fe r; for (int i = 0; i < 4; i++) r.l[i] = splitmix64(s);
+  return canon(r);
+}
+static const Fe R2_M = {{0x25d577bab861857bULL, 0xcc2c27b58860591fULL, 0xa7cc008fe5dc8593ULL, 0x011fdae7eff1c939ULL}};   // R^2 mod p
+static inline Fe to_mont(const Fe& raw) { return mul(raw, R2_M); }
+static inline Fe from_mont(const Fe& m) { const Fe one_raw = {{1, 0, 0, 0}}; return mul(m, one_raw); }
+
+static inline void synth_scalars(uint64_t seed, uint64_t n, uint8_t* out) {
+  uint64_t s = seed;
+  for (uint64_t i = 0; i < n; i++) { const Fe r = rand_mod_p(s); memcpy(out + 32 * i, r.l, 32); }
+}
+
+// k * P, k a plain integer below p (double-and-add over its 253 bits)
+static inline Pt pmul(const Pt& p, const Fe& k, const Fe& k2d) {
+  Pt acc = identity();
+  for (int i = 252; i >= 0; i--) {
+    acc = pdbl(acc);
+    if ((k.l[i >> 6] >> (i & 63)) & 1) acc = padd(acc, p, k2d);
+  }
+  return acc;
+}
+
+static inline void synth_points(uint64_t seed, uint64_t n, uint8_t* out) {
+  if (n == 0) return;
+  // generator of the prime-order subgroup, reference/utils/FieldMath.ts:108-109
+  const Fe gx = {{0x137e82844bbe49c5ULL, 0xe7608833a9dd83f3ULL, 0x16b294b80d905006ULL, 0x036824eb02475007ULL}};
+  const Fe gy = {{0xd50dce7d8bcda9d4ULL, 0x7f6758f4c08bc255ULL, 0x37c0a81e810abce5ULL, 0x11b1d8d5c1d897a3ULL}};
+  const Fe d2 = {{2 * 3021, 0, 0, 0}};
+  const Fe k2d = to_mont(d2);
+  Pt g; g.x = to_mont(gx); g.y = to_mont(gy); g.z = ONE_M; g.t = mul(g.x, g.y);
+  uint64_t s = seed ^ 0xA5A5A5A55A5A5A5AULL;
+  const Fe a = rand_mod_p(s), b = rand_mod_p(s);
+  const Pt q = pmul(g, b, k2d);
+  std::vector<Pt> pts(n);
+  pts[0] = pmul(g, a, k2d);
+  for (uint64_t i = 1; i < n; i++) pts[i] = padd(pts[i - 1], q, k2d);
+  std::vector<Fe> pre(n);
+  Fe acc = ONE_M;
+  for (uint64_t i = 0; i < n; i++) { pre[i] = acc; acc = mul(acc, pts[i].z); }
+  Fe iv = inv(acc);
+  for (uint64_t i = n; i-- > 0;) {
+    const Fe zi = mul(iv, pre[i]);
+    iv = mul(iv, pts[i].z);
+    const Fe x = from_mont(mul(pts[i].x, zi)), y = from_mont(mul(pts[i].y, zi));
+    memcpy(out + 64 * i, x.l, 32); memcpy(out + 64 * i + 32, y.l, 32);
+  }
+}
+
+// the harness's fixed point (ui/AllBenchmarks.tsx:107-109), replicated
+static inline void synth_points_fixed(uint64_t n, uint8_t* out) {
+  const Fe hx = {{0xd5d3b8c459b4076eULL, 0x1b5799eed0eb02d2ULL, 0x8e051509543ece5eULL, 0x062edc0d88e22612ULL}};
+  const Fe hy = {{0xb7969948a31c10c6ULL, 0x96933076821a1429ULL, 0x803b36417a89f1a0ULL, 0x11fbd6ecd3449628ULL}};
+  for (uint64_t i = 0; i < n; i++) { memcpy(out + 64 * i, hx.l, 32); memcpy(out + 64 * i + 32, hy.l, 32); }
+}
+
+}  // namespace te_host

@@ -18,6 +18,7 @@
 
 #include "../../include/te_msm.h"
 #include "host_tail.hpp"
+#include "synth.hpp"
 #include "kernels.hip.hpp"
 
 namespace {
@@ -675,6 +676,13 @@ int te_msm_stage_ms(te_ctx* ctx, float* ms, const char** names, int max_stages) 
     ms[k] = ctx->stage_ms[i]; if (names) names[k] = kStageNames[i]; k++;
   }
   return k;
+}
+
+int te_msm_synth_inputs(uint64_t seed, uint64_t n, int fixed_point, uint8_t* points_xy_le, uint8_t* scalars_le) {
+  if (n >= (1ull << 31) || !te_host::tail_selftest()) return TE_MSM_EINVAL;
+  if (scalars_le) te_host::synth_scalars(seed, n, scalars_le);
+  if (points_xy_le) { if (fixed_point) te_host::synth_points_fixed(n, points_xy_le); else te_host::synth_points(seed, n, points_xy_le); }
+  return 0;
 }
 
 int64_t te_msm_debug_read(te_ctx* ctx, const char* stage, void* dst, uint64_t cap) {
