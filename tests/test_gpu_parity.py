@@ -320,6 +320,29 @@ def test_full_size_2_20(ctx, model, ora):
     ctx.set_option("window_bits", 0)
 
 
+def test_beyond_the_harness_sizes_2_22(pkg, model, ora):
+    """n = 2^22 (four times the largest harness case): 64-bit offsets, more chunks / slices / segments than any other test;
+    bit-exact against the oracle, for the harness's fixed point against the closed form, and pipelined with 2^20 MSMs"""
+    import torch
+    n = 1 << 22
+    pts, sc = pkg.synth_inputs(0x5EED0016, n)
+    exp = ora.msm(pts, sc, c=16, threads=16)
+    with pkg.MsmContext((0,)) as big:
+        assert big.run(pts, sc) == exp
+        dp, ds = _dev(pts), _dev(sc)
+        torch.cuda.synchronize()
+        small_n = 1 << 20
+        exp_small = ora.msm(pts[:64 * small_n], sc[:32 * small_n], c=16, threads=16)
+        t0 = big.submit_device(dp.data_ptr(), ds.data_ptr(), n)
+        t1 = big.submit_device(dp.data_ptr(), ds.data_ptr(), small_n)       # a prefix of the same buffers
+        t2 = big.submit_device(dp.data_ptr(), ds.data_ptr(), n)
+        assert big.collect(t0) == exp and big.collect(t1) == exp_small and big.collect(t2) == exp
+        fixed, _ = pkg.synth_inputs(0, n, fixed_point=True, scalars=False)
+        ks = np.frombuffer(sc, dtype="<u8").reshape(n, 4).astype(object)
+        total = int(ks[:, 0].sum()) + (int(ks[:, 1].sum()) << 64) + (int(ks[:, 2].sum()) << 128) + (int(ks[:, 3].sum()) << 192)
+        assert model.xy_from_bytes(big.run(fixed, sc)) == model.scalar_mul(total % model.L, (model.HX, model.HY))
+
+
 def test_zprize_vectors_if_supplied(ctx, pkg, kats):
     """test-data/testCases.ts:11-52: replays the official vectors when TE_ZPRIZE_DATA points at them."""
     import importlib
