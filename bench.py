@@ -56,7 +56,8 @@ def main():
     ap.add_argument("--segment-len", type=int, default=0)
     ap.add_argument("--digits", choices=("signed", "unsigned"), default="signed",
                     help="signed window digits, 2^(c-1) buckets (BASELINE config 3, the reference's shipped behaviour) or unsigned, 2^c buckets (config 2)")
-    ap.add_argument("--inflight", type=int, default=4, help="MSMs in flight in pipelined mode (1..4, each on its own stream / work set)")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="MSMs in flight in pipelined mode (1..8, each on its own stream / work set); 0 = 4 on one GPU, 8 when the windows are sharded (small per-rank kernels)")
     ap.add_argument("--no-pipeline", action="store_true", help="N=1: await every MSM before submitting the next (latency mode)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -122,7 +123,7 @@ def main():
 
     pipelined = not args.no_pipeline
     sharded = world > 1 or force_dist
-    depth = max(1, min(args.inflight, pkg.WORKSETS))
+    depth = max(1, min(args.inflight or (8 if sharded else 4), pkg.WORKSETS))
     pipe = pkg.ShardedPipeline(ctx, n, dist, depth=depth) if (sharded and pipelined) else None
 
     result = None

@@ -35,7 +35,7 @@ typedef struct te_ctx te_ctx;
 
 #define TE_MSM_POINT_BYTES   64
 #define TE_MSM_SCALAR_BYTES  32
-#define TE_MSM_WORKSETS      4    /* MSMs one context can have in flight (submit/collect, partial_device) */
+#define TE_MSM_WORKSETS      8    /* MSMs one context can have in flight (submit/collect, partial_device) */
 #define TE_MSM_PARTIAL_BYTES 720  /* per window: 5 extended points x 144 B (see te_msm_partial_device) */
 
 /* Replaces get_device() + per-call buffer/pipeline creation (implementation/cuzk/gpu.ts:14-25,
@@ -117,6 +117,11 @@ int te_msm_finalize_host(const uint8_t* partials, int window_bits, int num_windo
 /* Same for either digit form: bucket_bits = window_bits - 1 (signed digits, what te_msm_finalize_host assumes) or
  * window_bits (option "signed_digits" = 0). */
 int te_msm_finalize_host_ex(const uint8_t* partials, int window_bits, int bucket_bits, int num_windows, uint8_t out_xy_le[64]);
+/* The tail for an all-gathered buffer: `gathered` holds `world` consecutive W x 720 B buffers, the r-th written by the
+ * rank that owns windows {w : w mod world == r} (te_msm_set_window_shard(r, world)); row w is taken from buffer
+ * w mod world.  Saves the caller the merge. */
+int te_msm_finalize_gathered(const uint8_t* gathered, int world, int window_bits, int bucket_bits, int num_windows,
+                             uint8_t out_xy_le[64]);
 
 /* ---- harness inputs (host code, no device needed).  The reference's harness generates its own random inputs when the
  * ZPrize files are not used (ui/AllBenchmarks.tsx:99-131, reference/webgpu/utils.ts:81-88,118-124): seeded scalars =

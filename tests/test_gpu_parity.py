@@ -404,7 +404,9 @@ def test_pipelined_submit_collect(pkg, ora):
     """MSMs in flight on rotating work sets: results in submission order, each equal to the oracle; protocol errors are
     reported"""
     import torch
-    cases = [(11, 30000), (12, 70000), (13, 5000), (14, 30000), (15, 1000), (16, 40000)]
+    sizes = [30000, 70000, 5000, 30000, 1000, 40000, 65536, 257, 12345, 50000, 3, 20000]
+    K = pkg.WORKSETS
+    cases = [(11 + i, sizes[i % len(sizes)]) for i in range(K + 2)]
     data = []
     for seed, n in cases:
         pts, sc = ora.gen_points(seed, n), ora.gen_scalars(seed, n)
@@ -412,16 +414,16 @@ def test_pipelined_submit_collect(pkg, ora):
     torch.cuda.synchronize()
     with pkg.MsmContext((0,)) as c:
         sub = lambda i: c.submit_device(data[i][0].data_ptr(), data[i][1].data_ptr(), data[i][2])
-        t = [sub(i) for i in range(pkg.WORKSETS)]
+        t = [sub(i) for i in range(K)]
         with pytest.raises(pkg.MsmError):
-            sub(4)                                                                            # every work set is busy
+            sub(K)                                                                            # every work set is busy
         with pytest.raises(pkg.MsmError):
             c.collect(t[1])                                                                   # out of order
         assert c.collect(t[0]) == data[0][3]
-        t.append(sub(4))
+        t.append(sub(K))
         assert c.collect(t[1]) == data[1][3]
-        t.append(sub(5))
-        for i in range(2, 6):
+        t.append(sub(K + 1))
+        for i in range(2, K + 2):
             assert c.collect(t[i]) == data[i][3]
         assert c.run_device(data[0][0].data_ptr(), data[0][1].data_ptr(), data[0][2]) == data[0][3]
 

@@ -161,6 +161,8 @@ def test_window_shards_merge(fpcheck, pkg, ora):
             assert fpcheck.fpc_partial_rows(pts, sc, n, c, first, step, b) == 0
             bufs.append(b.raw)
         assert pkg.finalize_host(pkg.merge_partials(bufs, W, world), c, W) == exp
+        flat = ctypes.create_string_buffer(b"".join(bufs), world * W * 720)        # what an all-gather leaves in host memory
+        assert pkg.finalize_gathered(ctypes.addressof(flat), world, c, W) == exp
 
 
 def test_final_carry_detected_by_emulation(fpcheck, model, ora):

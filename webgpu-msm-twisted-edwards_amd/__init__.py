@@ -15,6 +15,7 @@ from .binding import (  # noqa: F401
     MsmError,
     compute_msm,
     finalize_host,
+    finalize_gathered,
     synth_inputs,
     build_library,
     library_path,

@@ -13,7 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 PARTIAL_BYTES = 720
-WORKSETS = 4            # TE_MSM_WORKSETS: MSMs one context can have in flight
+WORKSETS = 8            # TE_MSM_WORKSETS: MSMs one context can have in flight
 
 
 class MsmError(RuntimeError):
@@ -99,6 +99,8 @@ def _lib() -> ctypes.CDLL:
         L.te_msm_finalize_host.restype = ci
         L.te_msm_finalize_host_ex.argtypes = [cp, ci, ci, ci, cp]
         L.te_msm_finalize_host_ex.restype = ci
+        L.te_msm_finalize_gathered.argtypes = [vp, ci, ci, ci, ci, cp]
+        L.te_msm_finalize_gathered.restype = ci
         L.te_msm_synth_inputs.argtypes = [u64, u64, ci, vp, vp]
         L.te_msm_synth_inputs.restype = ci
         L.te_msm_stage_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(cp), ci]
@@ -219,6 +221,16 @@ def finalize_host(partials: bytes, window_bits: int, num_windows: int, bucket_bi
     rc = _lib().te_msm_finalize_host_ex(bytes(partials), window_bits, bb, num_windows, out)
     if rc:
         raise MsmError(rc, "te_msm_finalize_host_ex failed")
+    return out.raw
+
+
+def finalize_gathered(gathered_ptr: int, world: int, window_bits: int, num_windows: int, bucket_bits: int | None = None) -> bytes:
+    """Host tail over an all-gathered buffer in HOST memory (te_msm_finalize_gathered); gathered_ptr is its address."""
+    out = ctypes.create_string_buffer(64)
+    bb = window_bits - 1 if bucket_bits is None else bucket_bits
+    rc = _lib().te_msm_finalize_gathered(gathered_ptr, world, window_bits, bb, num_windows, out)
+    if rc:
+        raise MsmError(rc, "te_msm_finalize_gathered failed")
     return out.raw
 
 

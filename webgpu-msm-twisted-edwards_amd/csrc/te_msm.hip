@@ -667,6 +667,16 @@ int te_msm_finalize_host_ex(const uint8_t* partials, int window_bits, int bucket
   return 0;
 }
 
+int te_msm_finalize_gathered(const uint8_t* gathered, int world, int window_bits, int bucket_bits, int num_windows,
+                             uint8_t out_xy_le[64]) {
+  if (!gathered || world < 1 || num_windows < 1 || num_windows > 128) return TE_MSM_EINVAL;
+  std::vector<uint8_t> merged((size_t)num_windows * TE_MSM_PARTIAL_BYTES);
+  for (int w = 0; w < num_windows; w++)
+    memcpy(&merged[(size_t)w * TE_MSM_PARTIAL_BYTES],
+           gathered + ((size_t)(w % world) * num_windows + w) * TE_MSM_PARTIAL_BYTES, TE_MSM_PARTIAL_BYTES);
+  return te_msm_finalize_host_ex(merged.data(), window_bits, bucket_bits, num_windows, out_xy_le);
+}
+
 int te_msm_stage_ms(te_ctx* ctx, float* ms, const char** names, int max_stages) {
   if (!ctx || !ms) return TE_MSM_EINVAL;
   if (!ctx->have_stage_ms) return set_err(ctx, TE_MSM_ESTATE, "no profiled run yet (set option profile=1)");

@@ -125,13 +125,10 @@ class ShardedPipeline:
         return t
 
     def collect(self, ticket: int) -> bytes:
-        from .binding import finalize_host
+        from .binding import finalize_gathered
         assert ticket == self.next_collect, "collect in submission order"
         slot = ticket % self.depth
         self.ev[slot].synchronize()
         self.next_collect += 1
         self.ctx.partial_wait(slot)                     # done already (the copy is ordered behind it): reports scalar-range errors
-        nbytes = self.W * PARTIAL_BYTES
-        flat = self.host[slot].numpy().tobytes()
-        merged = merge_partials([flat[r * nbytes:(r + 1) * nbytes] for r in range(self.world)], self.W, self.world)
-        return finalize_host(merged, self.c, self.W, self.bucket_bits)
+        return finalize_gathered(self.host[slot].data_ptr(), self.world, self.c, self.W, self.bucket_bits)
