@@ -17,7 +17,9 @@ _LIB = None
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "libte_oracle.so")
     src = os.path.join(_HERE, "te_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    so2, src2 = os.path.join(_HERE, "libbls377_oracle.so"), os.path.join(_HERE, "bls377_oracle.c")
+    stale2 = not os.path.exists(so2) or os.path.getmtime(so2) < os.path.getmtime(src2)
+    if force or stale2 or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
 

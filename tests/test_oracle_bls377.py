@@ -1,0 +1,74 @@
+"""BLS12-377 G1 oracle (BASELINE config 5).  The reference holds no vector for this curve ("parity unpinned"): these tests
+pin the oracle to public mathematics instead -- the BLS12 parameterisation, the curve equation, the group axioms -- and
+the C oracle to the pure-Python model."""
+import random
+
+from oracle import model377 as m
+from oracle import oracle377 as o
+
+
+def test_parameters_follow_from_the_bls12_seed():
+    x = m.SEED_X
+    assert m.R_ORDER == x ** 4 - x ** 2 + 1                      # scalar field = TE base field p (README.md:69-73)
+    assert ((x - 1) ** 2 * m.R_ORDER) % 3 == 0 and m.Q == (x - 1) ** 2 * m.R_ORDER // 3 + x
+    order = m.Q + 1 - (x + 1)                                    # #E(F_q) = q + 1 - t, t = x + 1
+    assert order == m.COFACTOR * m.R_ORDER
+    assert m.Q.bit_length() == 377 and m.R_ORDER.bit_length() == 253
+
+
+def test_generator_and_group_axioms():
+    assert m.on_curve(m.G) and m.scalar_mul(m.R_ORDER, m.G) is m.INF
+    rnd = random.Random(5)
+    a, b, c = (rnd.randrange(m.R_ORDER) for _ in range(3))
+    A, B, C = (m.scalar_mul(k, m.G) for k in (a, b, c))
+    assert m.add(m.add(A, B), C) == m.add(A, m.add(B, C)) == m.scalar_mul((a + b + c) % m.R_ORDER, m.G)
+    assert m.add(A, m.neg(A)) is m.INF and m.add(A, m.INF) == A and m.add(A, A) == m.scalar_mul(2 * a, m.G)
+    assert all(m.on_curve(p) for p in (A, B, C))
+
+
+def test_c_oracle_against_the_model():
+    rnd = random.Random(6)
+    gb = m.points_to_bytes([m.G])
+    assert o.on_curve(gb)
+    for _ in range(5):
+        k = rnd.randrange(m.R_ORDER)
+        assert o.scalar_mul(gb, k) == m.result_to_bytes(m.scalar_mul(k, m.G))
+    A, B = m.scalar_mul(11, m.G), m.scalar_mul(31, m.G)
+    ab, bb = m.points_to_bytes([A]), m.points_to_bytes([B])
+    assert o.point_add(ab, bb) == m.result_to_bytes(m.add(A, B))
+    assert o.point_add(ab, ab) == m.result_to_bytes(m.add(A, A))                          # doubling through the complete law
+    assert o.point_add(ab, m.points_to_bytes([m.neg(A)])) == bytes(96)                      # inverse -> infinity
+    assert o.point_add(ab, bytes(96)) == ab and o.point_add(bytes(96), bytes(96)) == bytes(96)
+    assert o.scalar_mul(gb, m.R_ORDER) == bytes(96)
+
+
+def test_seeded_inputs_match_the_model():
+    for seed, n in ((1, 1), (2, 17), (3, 100)):
+        assert o.gen_points(seed, n) == m.points_to_bytes(m.gen_points(seed, n))
+        assert o.gen_scalars(seed, n) == m.scalars_to_bytes(m.gen_scalars(seed, n))
+
+
+def test_msm_pipeline_naive_and_model_agree():
+    for seed, n, c in ((4, 1, 4), (5, 33, 5), (6, 200, 8), (7, 300, 13)):
+        pts, sc = o.gen_points(seed, n), o.gen_scalars(seed, n)
+        exp = o.msm_naive(pts, sc)
+        assert o.msm(pts, sc, c=c, threads=3) == exp
+        assert o.msm(pts, sc, c=16, threads=2) == exp
+        if n <= 40:
+            pl, kl = m.gen_points(seed, n), m.gen_scalars(seed, n)
+            assert exp == m.result_to_bytes(m.msm_naive(pl, kl)) == m.result_to_bytes(m.msm_pipeline(pl, kl, c))
+
+
+def test_edge_scalars_and_errors():
+    import pytest
+    pts = o.gen_points(9, 6)
+    ks = [0, 1, m.R_ORDER - 1, 1 << 15, (1 << 16) - 1, (1 << 252) + 5]
+    sc = m.scalars_to_bytes(ks)
+    pl = [m.xy_from_bytes(pts[96 * i:96 * i + 96]) for i in range(6)]
+    assert o.msm(pts, sc, c=16) == o.msm_naive(pts, sc) == m.result_to_bytes(m.msm_naive(pl, ks))
+    assert o.msm(b"", b"", c=16) == bytes(96)                                            # empty sum = infinity
+    assert o.msm(pts[:96], m.scalars_to_bytes([0]), c=16) == bytes(96)
+    with pytest.raises(ValueError):
+        o.msm(pts[:96], m.scalars_to_bytes([(1 << 256) - 1]), c=16)                       # final carry
+    with pytest.raises(ValueError):
+        o.msm(pts[:96], m.scalars_to_bytes([1 << 300]), c=16)                             # above 256 bits
