@@ -33,6 +33,16 @@ typedef struct te_ctx te_ctx;
                                      (submission/miscellaneous/utils.ts:80-83) */
 #define TE_MSM_ESTATE      (-4)   /* call order / capacity */
 
+/* Groups (option "curve").  0: the Twisted-Edwards BLS12 curve of the competition (default; everything above).
+ * 1: BLS12-377 G1, y^2 = x^3 + 1 over the 377-bit base field (README.md:57-73, BASELINE config 5): points are
+ * n x (x || y) with 48-byte little-endian coordinates (96 bytes), scalars n x 48-byte little-endian records holding
+ * values below 2^256 (README.md:325-331), the result is x || y in 96 bytes (the point at infinity as 96 zero bytes) --
+ * `out_xy_le` of te_msm_run / run_device / collect must then hold TE_MSM_RESULT_BYTES_MAX bytes.  Single device; the
+ * window-sharded building blocks (te_msm_partial_device ...) are Twisted-Edwards only. */
+#define TE_MSM_CURVE_TE_BLS12      0
+#define TE_MSM_CURVE_BLS12_377_G1  1
+#define TE_MSM_RESULT_BYTES_MAX    96
+
 #define TE_MSM_POINT_BYTES   64
 #define TE_MSM_SCALAR_BYTES  32
 #define TE_MSM_WORKSETS      8    /* MSMs one context can have in flight (submit/collect, partial_device) */
@@ -72,6 +82,7 @@ int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]);
  *   "signed_digits" 1 = signed window digits, 2^(c-1) buckets per window (default; the reference's shipped behaviour,
  *                   miscellaneous/utils.ts:52-95); 0 = plain unsigned windows, 2^c buckets (utils.ts:34-50): same
  *                   result, accepts any 256-bit scalar (no final-carry error)
+ *   "curve"         TE_MSM_CURVE_TE_BLS12 (default) or TE_MSM_CURVE_BLS12_377_G1, see above
  *   "sort_buckets"  1 = schedule buckets by descending size (default), 0 = natural order
  *   "segment_len"   a bucket longer than this is accumulated by several threads (default 64)
  *   "profile"       1 = HIP events around the dominant kernel (accumulate) only, 2 = around every stage

@@ -52,6 +52,19 @@ def fpcheck():
 
 
 @pytest.fixture(scope="session")
+def fq377check():
+    """Host build of the BLS12-377 device arithmetic with column-overflow checking (tests/csrc/fq377check.cpp)."""
+    import ctypes
+    d = os.path.join(ROOT, "tests", "csrc")
+    so, src = os.path.join(d, "libfq377check.so"), os.path.join(d, "fq377check.cpp")
+    hdr_dir = os.path.join(ROOT, "webgpu-msm-twisted-edwards_amd", "csrc")
+    deps = [src] + [os.path.join(hdr_dir, f) for f in ("fp.hpp", "fq377.hpp", "curve377.hpp", "fq377_constants.inc")]
+    if not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src])
+    return ctypes.CDLL(so)
+
+
+@pytest.fixture(scope="session")
 def kats():
     import json
     return json.load(open(os.path.join(ROOT, "tests", "golden", "reference_kats.json")))

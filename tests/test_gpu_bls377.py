@@ -1,0 +1,129 @@
+"""GPU parity for BASELINE config 5: MSM on BLS12-377 G1 through the same C-ABI (option "curve" = 1), against the
+BLS12-377 oracle (oracle/bls377_oracle.c, itself checked against the bigint model in tests/test_oracle_bls377.py).
+The reference holds no vector for this curve: parity is UNPINNED by the reference and pinned to the group law only."""
+import ctypes
+
+import pytest
+
+from oracle import model377 as m
+from oracle import oracle377 as o
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bls(pkg):
+    c = pkg.MsmContext((0,))
+    c.set_option("curve", pkg.CURVE_BLS12_377_G1)
+    yield c
+    c.close()
+
+
+def _dev(b):
+    import torch
+    return torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
+
+
+def test_records_equal_the_host_build_of_the_same_code(bls):
+    import os
+    L = ctypes.CDLL(os.path.join(os.path.dirname(__file__), "csrc", "libfq377check.so"))
+    n = 300
+    pts, sc = o.gen_points(1, n), o.gen_scalars(1, n)
+    assert bls.run(pts, sc) == o.msm(pts, sc, threads=4)
+    recs = bls.debug_read("records", n * 128)
+    for i in (0, 1, 2, 77, n - 1):
+        r = ctypes.create_string_buffer(128)
+        L.f377_prep_point(pts[96 * i:96 * i + 96], r)
+        assert recs[128 * i:128 * i + 128] == r.raw, i
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 1000, 4097, 70001])
+def test_ragged_sizes(bls, n):
+    pts, sc = o.gen_points(n, n), o.gen_scalars(n, n)
+    assert bls.run(pts, sc) == o.msm(pts, sc, threads=8)
+
+
+@pytest.mark.parametrize("c", [4, 7, 8, 11, 13, 15, 16])
+def test_window_sizes_and_digit_forms(bls, c):
+    n = 2500
+    pts, sc = o.gen_points(50 + c, n), o.gen_scalars(50 + c, n)
+    exp = o.msm(pts, sc, threads=4)
+    bls.set_option("window_bits", c)
+    for signed in (1, 0):
+        bls.set_option("signed_digits", signed)
+        assert bls.run(pts, sc) == exp
+    bls.set_option("signed_digits", 1)
+    bls.set_option("window_bits", 0)
+
+
+def test_edge_scalars_empty_and_errors(bls, pkg):
+    pts = o.gen_points(9, 8)
+    ks = [0, 1, m.R_ORDER - 1, m.R_ORDER, 1 << 15, (1 << 16) - 1, (1 << 252) + 5, (1 << 253) + 12345]
+    pl = [m.xy_from_bytes(pts[96 * i:96 * i + 96]) for i in range(8)]
+    assert bls.run(pts, m.scalars_to_bytes(ks)) == m.result_to_bytes(m.msm_naive(pl, ks))
+    assert bls.run(b"", b"") == bytes(96)                                              # empty sum: infinity
+    assert bls.run(pts[:96], m.scalars_to_bytes([0])) == bytes(96)
+    assert bls.run(pts[:192], m.scalars_to_bytes([5, m.R_ORDER - 5]) ) == m.result_to_bytes(
+        m.add(m.scalar_mul(5, pl[0]), m.scalar_mul(m.R_ORDER - 5, pl[1])))
+    same = pts[:96] * 2                                                                # P + (-P) = infinity through the buckets
+    assert bls.run(same, m.scalars_to_bytes([7, m.R_ORDER - 7])) == bytes(96)
+    bls.set_option("window_bits", 16)
+    with pytest.raises(pkg.MsmError) as e:
+        bls.run(pts[:96], m.scalars_to_bytes([(1 << 256) - 1]))                        # final carry
+    assert e.value.code == -3
+    with pytest.raises(pkg.MsmError) as e:
+        bls.run(pts[:96], m.scalars_to_bytes([1 << 300]))                              # 48-byte record above 2^256
+    assert e.value.code == -3
+    bls.set_option("window_bits", 0)
+    with pytest.raises(pkg.MsmError):
+        bls.run(pts[:96], bytes(32))                                                   # wrong record size for this curve
+
+
+def test_skew_and_split_buckets(bls):
+    """all scalars equal (every window: one bucket holds every point), and a tiny segment length"""
+    n = 6000
+    pts = o.gen_points(17, n)
+    sc = o.gen_scalars(17, 1) * n
+    assert bls.run(pts, sc) == o.msm(pts, sc, threads=8)
+    sc = o.gen_scalars(18, n)
+    exp = o.msm(pts, sc, threads=8)
+    for seg in (1, 3, 64):
+        bls.set_option("segment_len", seg)
+        assert bls.run(pts, sc) == exp
+    bls.set_option("segment_len", 64)
+
+
+def test_device_resident_and_pipelined(bls, pkg):
+    import torch
+    cases = []
+    for seed, n in ((21, 30000), (22, 5000), (23, 65536)):
+        pts, sc = o.gen_points(seed, n), o.gen_scalars(seed, n)
+        cases.append((_dev(pts), _dev(sc), n, o.msm(pts, sc, threads=8)))
+    torch.cuda.synchronize()
+    assert bls.run_device(cases[0][0].data_ptr(), cases[0][1].data_ptr(), cases[0][2]) == cases[0][3]
+    ts = [bls.submit_device(dp.data_ptr(), ds.data_ptr(), n) for dp, ds, n, _ in cases]
+    for t, (_, _, _, exp) in zip(ts, cases):
+        assert bls.collect(t) == exp
+    with pytest.raises(pkg.MsmError):                                                  # sharding blocks are Twisted-Edwards only
+        part = torch.zeros(64 * 840, dtype=torch.uint8, device="cuda")
+        bls.partial_device(cases[0][0].data_ptr(), cases[0][1].data_ptr(), cases[0][2], part.data_ptr())
+
+
+def test_one_context_serves_both_curves(pkg, ora):
+    n = 3000
+    with pkg.MsmContext((0,)) as c:
+        pts, sc = ora.gen_points(5, n), ora.gen_scalars(5, n)
+        assert c.run(pts, sc) == ora.msm(pts, sc, threads=4)
+        c.set_option("curve", pkg.CURVE_BLS12_377_G1)
+        p2, s2 = o.gen_points(5, n), o.gen_scalars(5, n)
+        assert c.run(p2, s2) == o.msm(p2, s2, threads=4)
+        c.set_option("curve", pkg.CURVE_TE_BLS12)
+        assert c.run(pts, sc) == ora.msm(pts, sc, threads=4)
+
+
+def test_full_size_2_20(bls):
+    n = 1 << 20
+    pts, sc = o.gen_points(0x5EED0014, n), o.gen_scalars(0x5EED0014, n)
+    bls.set_option("window_bits", 16)
+    assert bls.run(pts, sc) == o.msm(pts, sc, c=16, threads=16)
+    bls.set_option("window_bits", 0)

@@ -72,3 +72,99 @@ def test_edge_scalars_and_errors():
         o.msm(pts[:96], m.scalars_to_bytes([(1 << 256) - 1]), c=16)                       # final carry
     with pytest.raises(ValueError):
         o.msm(pts[:96], m.scalars_to_bytes([1 << 300]), c=16)                             # above 256 bits
+
+
+# ---------------------------------------------------------------- the product's device arithmetic, compiled for the host
+def _limb_helpers():
+    import ctypes
+    NL, LB = 14, 29
+    LM = (1 << LB) - 1
+
+    def limbs(v):
+        return (ctypes.c_uint32 * NL)(*[(v >> (LB * i)) & LM if i < NL - 1 else v >> (LB * (NL - 1)) for i in range(NL)])
+
+    def val(a):
+        return sum(int(a[i]) << (LB * i) for i in range(NL))
+    return NL, LB, LM, limbs, val
+
+
+def test_device_field_377_on_the_host(fq377check):
+    """csrc/fq377.hpp: Montgomery product (R = 2^406) exact, constants right, no 64-bit column ever overflows"""
+    import ctypes
+    NL, LB, LM, limbs, val = _limb_helpers()
+    R, Q, L = 1 << (NL * LB), m.Q, fq377check
+    rinv, rnd = pow(R, -1, Q), random.Random(1)
+    out = (ctypes.c_uint32 * NL)()
+    for _ in range(1500):
+        a, b = rnd.randrange(8 * Q), rnd.randrange(8 * Q)
+        L.f377_mont_mul(limbs(a), limbs(b), out)
+        r = val(out)
+        assert r % Q == a * b * rinv % Q and r < a * b // R + Q + 1 and all(out[i] <= LM for i in range(NL - 1))
+    # widest legal operands: one normalised, the other with limbs up to 2^30.8
+    wide = (ctypes.c_uint32 * NL)(*([int(2 ** 30.8)] * 13 + [7]))
+    norm = (ctypes.c_uint32 * NL)(*([LM] * 13 + [7]))
+    L.f377_mont_mul(norm, wide, out)
+    assert val(out) % Q == val(norm) * val(wide) * rinv % Q
+    assert L.f377_overflow_and_reset() == 0
+    c = (ctypes.c_uint32 * (7 * NL))()
+    L.f377_constants(c)
+    vals = [sum(int(c[NL * k + i]) << (LB * i) for i in range(NL)) for k in range(7)]
+    assert vals == [R % Q, R * R % Q, Q, 2 * Q, 4 * Q, 8 * Q, 16 * Q]
+    for k in range(3, 7):                               # offset forms: every lower limb >= 2^29 - 1
+        assert all(LM <= int(c[NL * k + i]) < (1 << 30) for i in range(NL - 1))
+
+
+def test_device_group_law_377_on_the_host(fq377check):
+    """csrc/curve377.hpp: complete mixed / full addition against the affine model, incl. doubling, inverses, infinity"""
+    import ctypes
+    NL, LB, LM, limbs, val = _limb_helpers()
+    Q, L = m.Q, fq377check
+    rinv = pow(1 << (NL * LB), -1, Q)
+
+    def aff(b):
+        cs = []
+        for k in range(3):
+            ws = [int.from_bytes(b[56 * k + 4 * i:56 * k + 4 * i + 4], "little") for i in range(NL)]
+            cs.append(sum(w << (LB * i) for i, w in enumerate(ws)) * rinv % Q)
+        if cs[2] == 0:
+            return None
+        zi = pow(cs[2], Q - 2, Q)
+        return (cs[0] * zi % Q, cs[1] * zi % Q)
+
+    def rec(pt):
+        r = ctypes.create_string_buffer(128)
+        L.f377_prep_point(m.points_to_bytes([pt]), r)
+        return r
+    ident = ctypes.create_string_buffer(168)
+    L.f377_identity(ident)
+    assert aff(ident.raw) is None
+    pts = m.gen_points(3, 12)
+    acc, exp, o168 = ident, None, ctypes.create_string_buffer(168)
+    for i, p in enumerate(pts):
+        neg = i % 3 == 1
+        L.f377_madd(acc, rec(p), 1 if neg else 0, o168)
+        exp = m.add(exp, m.neg(p) if neg else p)
+        acc = ctypes.create_string_buffer(o168.raw, 168)
+        assert aff(acc.raw) == exp
+    A, B = ctypes.create_string_buffer(168), ctypes.create_string_buffer(168)
+    L.f377_madd(ident, rec(pts[0]), 0, A)
+    L.f377_madd(A, rec(pts[0]), 0, B)
+    assert aff(B.raw) == m.add(pts[0], pts[0])                     # doubling through the mixed law
+    L.f377_madd(A, rec(pts[0]), 1, B)
+    assert aff(B.raw) is None                                      # P - P
+    L.f377_add(acc, acc, o168)
+    assert aff(o168.raw) == m.add(exp, exp)
+    L.f377_add(acc, A, o168)
+    assert aff(o168.raw) == m.add(exp, pts[0])
+    L.f377_add(acc, ident, o168)
+    assert aff(o168.raw) == exp
+    L.f377_add(ident, ident, o168)
+    assert aff(o168.raw) is None
+    chain = [ident]
+    for r in range(150):                                           # long mixed chains keep the limb rule
+        L.f377_madd(chain[-1], rec(pts[r % 12]), r & 1, o168)
+        chain.append(ctypes.create_string_buffer(o168.raw, 168))
+        if r % 7 == 0:
+            L.f377_add(chain[-1], chain[r // 2], o168)
+            chain[-1] = ctypes.create_string_buffer(o168.raw, 168)
+    assert L.f377_overflow_and_reset() == 0

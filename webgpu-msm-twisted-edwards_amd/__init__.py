@@ -20,6 +20,8 @@ from .binding import (  # noqa: F401
     build_library,
     library_path,
     PARTIAL_BYTES,
+    CURVE_TE_BLS12,
+    CURVE_BLS12_377_G1,
     WORKSETS,
 )
 from .sharding import ShardedPipeline, compute_msm_sharded, exchange_partials, merge_partials, window_shard_for_rank  # noqa: F401

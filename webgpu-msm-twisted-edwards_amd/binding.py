@@ -13,6 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 PARTIAL_BYTES = 720
+CURVE_TE_BLS12, CURVE_BLS12_377_G1 = 0, 1        # option "curve" (TE_MSM_CURVE_*)
 WORKSETS = 8            # TE_MSM_WORKSETS: MSMs one context can have in flight
 
 
@@ -123,6 +124,7 @@ class MsmContext:
             raise MsmError(rc, L.te_msm_last_error(None).decode())
         self._h = h
         self._L = L
+        self._sizes = (64, 32, 64)          # point, scalar, result bytes of the selected curve
 
     def close(self):
         if getattr(self, "_h", None):
@@ -145,6 +147,8 @@ class MsmContext:
     # ---- options
     def set_option(self, key: str, value: int):
         self._check(self._L.te_msm_set_option(self._h, key.encode(), int(value)))
+        if key == "curve":
+            self._sizes = (96, 48, 96) if int(value) == CURVE_BLS12_377_G1 else (64, 32, 64)
 
     def get_option(self, key: str) -> int:
         v = ctypes.c_int64()
@@ -161,18 +165,20 @@ class MsmContext:
 
     # ---- whole MSM
     def run(self, points: bytes, scalars: bytes) -> bytes:
-        """Host buffers in the reference's wire format -> 64-byte affine result (x || y, LE)."""
-        n = len(scalars) // 32
-        if len(scalars) != 32 * n or len(points) != 64 * n:
-            raise MsmError(-1, "points must be 64*n bytes and scalars 32*n bytes")
-        out = ctypes.create_string_buffer(64)
+        """Host buffers in the reference's wire format -> affine result x || y, little-endian (64 bytes; 96 for
+        BLS12-377 G1, whose points are 96 and scalar records 48 bytes)."""
+        pb, sb, rb = self._sizes
+        n = len(scalars) // sb
+        if len(scalars) != sb * n or len(points) != pb * n:
+            raise MsmError(-1, f"points must be {pb}*n bytes and scalars {sb}*n bytes")
+        out = ctypes.create_string_buffer(96)
         self._check(self._L.te_msm_run(self._h, bytes(points), bytes(scalars), n, out))
-        return out.raw
+        return out.raw[:rb]
 
     def run_device(self, d_points: int, d_scalars: int, n: int) -> bytes:
-        out = ctypes.create_string_buffer(64)
+        out = ctypes.create_string_buffer(96)
         self._check(self._L.te_msm_run_device(self._h, d_points, d_scalars, n, out))
-        return out.raw
+        return out.raw[:self._sizes[2]]
 
     # ---- pipelined form: up to WORKSETS MSMs in flight (host tail and device work of consecutive MSMs overlap)
     def submit_device(self, d_points: int, d_scalars: int, n: int) -> int:
@@ -181,9 +187,9 @@ class MsmContext:
         return t.value
 
     def collect(self, ticket: int) -> bytes:
-        out = ctypes.create_string_buffer(64)
+        out = ctypes.create_string_buffer(96)
         self._check(self._L.te_msm_collect(self._h, ticket, out))
-        return out.raw
+        return out.raw[:self._sizes[2]]
 
     # ---- window-sharded building blocks
     def partial_device(self, d_points: int, d_scalars: int, n: int, d_partials: int, stream: int = -1):

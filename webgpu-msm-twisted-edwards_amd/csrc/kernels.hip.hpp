@@ -19,6 +19,7 @@ namespace te {
 struct digits_params {
   uint32_t half[10];   // signed digits: sum_w 2^(c*w + c-1) over ALL windows of the decomposition, 9 limbs (+1 zero); unsigned: 0
   uint32_t zero_digit; // stored code of digit 0: 2^(c-1) signed, 0 unsigned
+  uint32_t sc_stride;  // scalar record size in 16-byte units: 2 (32 bytes) or 3 (48-byte records, upper 16 bytes must be zero)
   uint32_t n, nst;     // points, digit-row stride (n rounded up to a multiple of 8; pad entries hold digit 0)
   int num_windows;     // total windows W of the decomposition
   int w_first, w_step, nw_local;
@@ -88,7 +89,13 @@ __global__ void __launch_bounds__(256) k_digits(const uint4* __restrict__ scalar
   }
   const bool second = i0 + 1u < prm.n;
   const size_t j1 = second ? (size_t)i0 + 1 : (size_t)i0;       // clamped: unconditional loads
-  const uint4 a0 = scalars[2 * (size_t)i0], a1 = scalars[2 * (size_t)i0 + 1], b0 = scalars[2 * j1], b1 = scalars[2 * j1 + 1];
+  const size_t st = prm.sc_stride;
+  const uint4 a0 = scalars[st * i0], a1 = scalars[st * i0 + 1], b0 = scalars[st * j1], b1 = scalars[st * j1 + 1];
+  bool bad = false;
+  if (st == 3) {                                        // 48-byte records hold values below 2^256
+    const uint4 a2 = scalars[st * i0 + 2], b2 = scalars[st * j1 + 2];
+    bad = (a2.x | a2.y | a2.z | a2.w | b2.x | b2.y | b2.z | b2.w) != 0u;
+  }
   uint32_t s[2][10] = {{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, 0u, 0u}, {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, 0u, 0u}};
 #pragma unroll
   for (int t = 0; t < 2; t++) {
@@ -98,7 +105,6 @@ __global__ void __launch_bounds__(256) k_digits(const uint4* __restrict__ scalar
   }
   // window extraction with compile-time bit positions (runtime-indexed register arrays would spill)
   constexpr int WMAX = (255 + C) / C + 1;
-  bool bad = false;
   int next = prm.w_first, k = 0;                       // next owned window and its local index
 #pragma unroll
   for (int w = 0; w < WMAX; w++) {

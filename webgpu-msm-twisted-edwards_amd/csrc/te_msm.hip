@@ -20,6 +20,8 @@
 #include "host_tail.hpp"
 #include "synth.hpp"
 #include "kernels.hip.hpp"
+#include "host_tail377.hpp"
+#include "kernels377.hip.hpp"
 
 namespace {
 
@@ -29,7 +31,16 @@ enum { ST_PREP = 0, ST_DIGITS, ST_HIST, ST_SCAN, ST_SCATTER, ST_BSORT, ST_ORDER,
 const char* const kStageNames[ST_COUNT] = {"prep_points", "digits", "part_hist", "part_scan", "part_scatter", "bucket_sort", "order",
                                            "accumulate", "marginal_sums", "weighted_sum"};
 
+// per-curve sizes: wire format, device accumulator slot, partial row (5 points), result
+struct curve_sizes { size_t point_in, scalar_in, acc, row, result; };
+inline curve_sizes sizes_of(int curve) {
+  return curve == TE_MSM_CURVE_BLS12_377_G1 ? curve_sizes{96, 48, sizeof(te377::g1p_slot), TE377_TAIL_ROW_BYTES, 96}
+                                            : curve_sizes{TE_MSM_POINT_BYTES, TE_MSM_SCALAR_BYTES, sizeof(te::ete), TE_MSM_PARTIAL_BYTES, 64};
+}
+constexpr size_t TE_MAX_ROW_BYTES = TE377_TAIL_ROW_BYTES;
+
 struct plan_t {
+  int curve = 0;                      // TE_MSM_CURVE_*
   int c = 0, W = 0, nw = 0;           // window bits, total windows, windows of this shard
   uint32_t B = 0, logB = 0;           // buckets per window = 2^(c-1) (signed digits) or 2^c (unsigned)
   int signed_digits = 1;
@@ -84,6 +95,7 @@ struct te_ctx {
   std::string err;
   int opt_window_bits = 0;
   int opt_sort = 1;
+  int opt_curve = TE_MSM_CURVE_TE_BLS12;   // which group the point buffers are in (option "curve")
   int opt_signed = 1;          // signed window digits (the reference's shipped behaviour); 0 = plain unsigned windows, 2^c buckets
   int opt_profile = 0;
   int opt_seg_len = 64;        // work segment: at most this many entries of one bucket per thread
@@ -124,6 +136,7 @@ int auto_window_bits(uint64_t n) {
 }
 
 void make_plan(const te_ctx* ctx, const gpu_t& d, uint64_t n, plan_t& p) {
+  p.curve = ctx->opt_curve;
   p.c = ctx->opt_window_bits ? ctx->opt_window_bits : auto_window_bits(n);
   p.W = (256 + p.c - 1) / p.c;
   p.nw = 0;
@@ -158,9 +171,17 @@ template <typename T> int ensure(te_ctx* ctx, workset_t& ws, T*& ptr, size_t& ca
   return 0;
 }
 
+// point buffers: `count` accumulator slots of the plan's curve
+int ensure_points(te_ctx* ctx, workset_t& ws, te::ete*& ptr, size_t& cap_bytes, size_t count, size_t acc_bytes) {
+  uint8_t* raw = reinterpret_cast<uint8_t*>(ptr);
+  const int rc = ensure(ctx, ws, raw, cap_bytes, count * acc_bytes);
+  ptr = reinterpret_cast<te::ete*>(raw);
+  return rc;
+}
+
 int ensure_buffers(te_ctx* ctx, gpu_t& d, workset_t& ws, uint64_t n, const plan_t& p) {
   HIP_TRY(ctx, hipSetDevice(d.device));
-  const size_t nd = (size_t)p.nw * p.nst + 16, wb = (size_t)p.nw * p.B;
+  const size_t nd = (size_t)p.nw * p.nst + 16, wb = (size_t)p.nw * p.B, ab = sizes_of(p.curve).acc;
   int rc = 0;
   if ((rc = ensure(ctx, ws, ws.d_recs, ws.cap[0], (size_t)n))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_digits, ws.cap[1], nd))) return rc;
@@ -174,22 +195,22 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, workset_t& ws, uint64_t n, const plan_
   if ((rc = ensure(ctx, ws, ws.d_order, ws.cap[7], smax))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_seg_bucket, ws.cap[20], smax))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_seg_lenv, ws.cap[21], smax))) return rc;
-  if ((rc = ensure(ctx, ws, ws.d_seg_out, ws.cap[22], smax))) return rc;
+  if ((rc = ensure_points(ctx, ws, ws.d_seg_out, ws.cap[22], smax, ab))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_seg_base, ws.cap[23], wb + 1))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_split_list, ws.cap[24], wb + 1))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_large_list, ws.cap[25], wb + 1))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_chunk_list, ws.cap[26], 2 * wb + 2))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_part_start, ws.cap[6], (size_t)p.nw * p.P))) return rc;
-  if ((rc = ensure(ctx, ws, ws.d_buckets, ws.cap[8], wb))) return rc;
+  if ((rc = ensure_points(ctx, ws, ws.d_buckets, ws.cap[8], wb, ab))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_part_count, ws.cap[9], (size_t)p.nw * p.P))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_part_keys, ws.cap[14], nd))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_part_idx, ws.cap[15], nd))) return rc;
   // marginal-sum levels fold by 4 (or 2): level 1 output is at most B/2 per window, level 2 at most B/4
-  if ((rc = ensure(ctx, ws, ws.d_red[0], ws.cap[10], wb / 2 + 1))) return rc;
-  if ((rc = ensure(ctx, ws, ws.d_red[1], ws.cap[11], wb / 4 + 1))) return rc;
-  if ((rc = ensure(ctx, ws, ws.d_red[2], ws.cap[12], wb / 2 + 1))) return rc;
-  if ((rc = ensure(ctx, ws, ws.d_red[3], ws.cap[13], wb / 4 + 1))) return rc;
-  for (int i = 4; i < 12; i++) if ((rc = ensure(ctx, ws, ws.d_red[i], ws.cap[24 + i], (size_t)p.nw * 256 + 16))) return rc;
+  if ((rc = ensure_points(ctx, ws, ws.d_red[0], ws.cap[10], wb / 2 + 1, ab))) return rc;
+  if ((rc = ensure_points(ctx, ws, ws.d_red[1], ws.cap[11], wb / 4 + 1, ab))) return rc;
+  if ((rc = ensure_points(ctx, ws, ws.d_red[2], ws.cap[12], wb / 2 + 1, ab))) return rc;
+  if ((rc = ensure_points(ctx, ws, ws.d_red[3], ws.cap[13], wb / 4 + 1, ab))) return rc;
+  for (int i = 4; i < 12; i++) if ((rc = ensure_points(ctx, ws, ws.d_red[i], ws.cap[24 + i], (size_t)p.nw * 256 + 16, ab))) return rc;
   return 0;
 }
 
@@ -215,12 +236,16 @@ struct msm_launch {
     const uint32_t n32 = this->n32();
     HIP_TRY(ctx, hipMemsetAsync(ws.d_err, 0, 1032 * sizeof(uint32_t), stream));     // flag, counters, length histogram
     mark(ST_PREP);
-    hipLaunchKernelGGL(te::k_prep_points, dim3((n32 + 255) / 256), dim3(256), 0, stream, (const uint4*)d_points, ws.d_recs, n32);
+    if (p.curve == TE_MSM_CURVE_BLS12_377_G1)
+      hipLaunchKernelGGL(te377::k377_prep_points, dim3((n32 + 255) / 256), dim3(256), 0, stream, (const uint4*)d_points, ws.d_recs, n32);
+    else
+      hipLaunchKernelGGL(te::k_prep_points, dim3((n32 + 255) / 256), dim3(256), 0, stream, (const uint4*)d_points, ws.d_recs, n32);
     mark(ST_DIGITS);
     if (p.nw > 0) {
       te::digits_params prm; memset(&prm, 0, sizeof prm);
       if (p.signed_digits) for (int w = 0; w < p.W; w++) { const int bit = w * p.c + p.c - 1; if (bit < 320) prm.half[bit >> 5] |= 1u << (bit & 31); }
       prm.zero_digit = p.signed_digits ? 1u << (p.c - 1) : 0u;
+      prm.sc_stride = (uint32_t)(sizes_of(p.curve).scalar_in / 16);
       prm.n = n32; prm.nst = p.nst; prm.num_windows = p.W; prm.w_first = d.w_first; prm.w_step = d.w_step; prm.nw_local = p.nw;
       const uint4* sc = (const uint4*)d_scalars;
       switch (p.c) {
@@ -282,9 +307,14 @@ struct msm_launch {
     if (p.nw > 0) {
       const uint32_t n32 = this->n32(), smax = this->smax();
       const uint32_t* order = ctx->opt_sort ? ws.d_order : nullptr;
-      hipLaunchKernelGGL(te::k_accumulate, dim3((smax + 255) / 256), dim3(256), 0, stream, ws.d_recs, ws.d_sorted, ws.d_bucket_start,
-                         ws.d_bucket_count, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv, order, ws.d_num_seg, ws.d_buckets, ws.d_seg_out,
-                         n32, p.logB, p.seg_len);
+      if (p.curve == TE_MSM_CURVE_BLS12_377_G1)
+        hipLaunchKernelGGL(te377::k377_accumulate, dim3((smax + 255) / 256), dim3(256), 0, stream, ws.d_recs, ws.d_sorted, ws.d_bucket_start,
+                           ws.d_bucket_count, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv, order, ws.d_num_seg,
+                           reinterpret_cast<te377::g1p_slot*>(ws.d_buckets), reinterpret_cast<te377::g1p_slot*>(ws.d_seg_out), n32, p.logB, p.seg_len);
+      else
+        hipLaunchKernelGGL(te::k_accumulate, dim3((smax + 255) / 256), dim3(256), 0, stream, ws.d_recs, ws.d_sorted, ws.d_bucket_start,
+                           ws.d_bucket_count, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv, order, ws.d_num_seg, ws.d_buckets, ws.d_seg_out,
+                           n32, p.logB, p.seg_len);
     }
     return 0;
   }
@@ -292,7 +322,11 @@ struct msm_launch {
   // recombination of split buckets, digit marginals, weighted sums, error flag read-back
   int back() {
     const uint32_t total = this->total();
-    if (p.nw > 0) {
+    const bool bls = p.curve == TE_MSM_CURVE_BLS12_377_G1;
+    if (p.nw > 0 && bls) {
+      hipLaunchKernelGGL(te377::k377_seg_combine, dim3(1024), dim3(256), 0, stream, ws.d_bucket_count, ws.d_seg_base,
+                         reinterpret_cast<const te377::g1p_slot*>(ws.d_seg_out), reinterpret_cast<te377::g1p_slot*>(ws.d_buckets), total, p.seg_len);
+    } else if (p.nw > 0) {
       hipLaunchKernelGGL(te::k_seg_combine, dim3(256), dim3(256), 0, stream, ws.d_split_list, ws.d_num_seg + 1, ws.d_bucket_count, ws.d_seg_base,
                          ws.d_seg_out, ws.d_buckets, p.seg_len);
       // giant buckets (empty lists for well-spread digits: two near-empty launches)
@@ -326,7 +360,12 @@ struct msm_launch {
             most = std::max(most, j.n_out * (uint32_t)p.nw); any = true;
           }
           if (!any) break;
-          if (most >= 131072u) {      // enough outputs to fill the chip with one thread each: throughput-bound level
+          if (bls) {                  // same job tables (layout-identical structs), one lane per output at every level
+            static_assert(sizeof(te377::sum_jobs) == sizeof(te::sum_jobs), "job tables must have one layout");
+            te377::sum_jobs jb; memcpy(&jb, &js, sizeof jb);
+            uint32_t blocks = (most + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+            hipLaunchKernelGGL(te377::k377_sum_groups, dim3(blocks, nch), dim3(256), 0, stream, jb, (uint32_t)p.nw);
+          } else if (most >= 131072u) {      // enough outputs to fill the chip with one thread each: throughput-bound level
             uint32_t blocks = (most + 255) / 256; if (blocks > 4096) blocks = 4096;
             hipLaunchKernelGGL(te::k_sum_groups, dim3(blocks, nch), dim3(256), 0, stream, js, (uint32_t)p.nw);
           } else {                    // latency-bound level: four lanes per output
@@ -350,7 +389,12 @@ struct msm_launch {
       for (int k = 0; k < 4; k++) marg[k] = ph2[k].cur;
     }
     mark(ST_WEIGHTED);
-    if (p.nw > 0) {
+    if (p.nw > 0 && bls) {
+      uint32_t* rows = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(d_partials_out) + (size_t)d.w_first * TE377_TAIL_ROW_BYTES);
+      te377::wsum_jobs wj;
+      for (int k = 0; k < 4; k++) { wj.in[k] = reinterpret_cast<const te377::g1p_slot*>(marg[k]); wj.N[k] = 1u << p.dw[k]; }
+      hipLaunchKernelGGL(te377::k377_weighted_sum, dim3(4, p.nw), dim3(16), 0, stream, wj, rows, (uint32_t)d.w_step * (TE377_TAIL_ROW_BYTES / 4u));
+    } else if (p.nw > 0) {
       te::ete* rows = reinterpret_cast<te::ete*>(d_partials_out) + (size_t)d.w_first * 5;
       te::wsum_jobs wj;
       for (int k = 0; k < 4; k++) { wj.in[k] = marg[k]; wj.N[k] = 1u << p.dw[k]; }
@@ -388,7 +432,7 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, 
   msm_launch L{ctx, d, ws, p, d_points, d_scalars, n, d_partials_out, ctx->opt_profile, stream};
   if (ctx->opt_graph && ctx->opt_profile < 2) {
     // the graphs hold pointers and geometry: re-captured when any of them changes (including a buffer reallocation)
-    const graph_key key{d_points, d_scalars, d_partials_out, n, ws.generation, p.c, d.w_first, d.w_step, (int)p.seg_len, ctx->opt_sort | (ctx->opt_signed << 1)};
+    const graph_key key{d_points, d_scalars, d_partials_out, n, ws.generation, p.c, d.w_first, d.w_step, (int)p.seg_len, ctx->opt_sort | (ctx->opt_signed << 1) | (ctx->opt_curve << 2)};
     if (!ws.g_front || !ws.g_back || memcmp(&key, &ws.g_key, sizeof key) != 0) {
       msm_launch C = L; C.stream = ws.stream; C.prof = 0;
       if (int rc = capture_graph(ctx, ws, ws.g_front, [&] { return C.front(); })) return rc;
@@ -444,10 +488,15 @@ void free_dev(gpu_t& d) {
 int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, bool src_is_host, uint64_t n, uint8_t out[64]) {
   if (!ctx || !out) return TE_MSM_EINVAL;
   if (n >= (1ull << 31)) return set_err(ctx, TE_MSM_EINVAL, "n must be < 2^31");
-  if (n == 0) { memset(out, 0, 64); out[32] = 1; return 0; }       // empty sum = identity (0, 1)
+  if (n == 0) {                                                     // empty sum = identity: (0, 1), or infinity (all zero)
+    memset(out, 0, sizes_of(ctx->opt_curve).result);
+    if (ctx->opt_curve == TE_MSM_CURVE_TE_BLS12) out[32] = 1;
+    return 0;
+  }
   if (!src_points || !src_scalars) return set_err(ctx, TE_MSM_EINVAL, "null input buffer");
   const size_t nd = ctx->devs.size();
   plan_t p0; make_plan(ctx, ctx->devs[0], n, p0);
+  const curve_sizes sz = sizes_of(p0.curve);
   // stage inputs on every device
   for (size_t i = 0; i < nd; i++) {
     gpu_t& d = ctx->devs[i];
@@ -459,24 +508,24 @@ int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, boo
         if (d.d_in_points) HIP_TRY(ctx, hipFree(d.d_in_points));
         if (d.d_in_scalars) HIP_TRY(ctx, hipFree(d.d_in_scalars));
         d.d_in_points = d.d_in_scalars = nullptr;
-        HIP_TRY(ctx, hipMalloc(&d.d_in_points, n * TE_MSM_POINT_BYTES));
-        HIP_TRY(ctx, hipMalloc(&d.d_in_scalars, n * TE_MSM_SCALAR_BYTES));
+        HIP_TRY(ctx, hipMalloc(&d.d_in_points, n * 96));           // sized for the larger wire format (BLS12-377)
+        HIP_TRY(ctx, hipMalloc(&d.d_in_scalars, n * 48));
         d.cap_in = n;
       }
       if (src_is_host) {
-        HIP_TRY(ctx, hipMemcpyAsync(d.d_in_points, src_points, n * TE_MSM_POINT_BYTES, hipMemcpyHostToDevice, ws.stream));
-        HIP_TRY(ctx, hipMemcpyAsync(d.d_in_scalars, src_scalars, n * TE_MSM_SCALAR_BYTES, hipMemcpyHostToDevice, ws.stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d.d_in_points, src_points, n * sz.point_in, hipMemcpyHostToDevice, ws.stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d.d_in_scalars, src_scalars, n * sz.scalar_in, hipMemcpyHostToDevice, ws.stream));
       } else {
         // inputs live on device 0's memory: wait for nothing (caller's data is ready), copy peer-to-peer
-        HIP_TRY(ctx, hipMemcpyPeerAsync(d.d_in_points, d.device, src_points, ctx->devs[0].device, n * TE_MSM_POINT_BYTES, ws.stream));
-        HIP_TRY(ctx, hipMemcpyPeerAsync(d.d_in_scalars, d.device, src_scalars, ctx->devs[0].device, n * TE_MSM_SCALAR_BYTES, ws.stream));
+        HIP_TRY(ctx, hipMemcpyPeerAsync(d.d_in_points, d.device, src_points, ctx->devs[0].device, n * sz.point_in, ws.stream));
+        HIP_TRY(ctx, hipMemcpyPeerAsync(d.d_in_scalars, d.device, src_scalars, ctx->devs[0].device, n * sz.scalar_in, ws.stream));
       }
       dp = d.d_in_points; ds = d.d_in_scalars;
     }
     if (int rc = enqueue_partial(ctx, d, ws, dp, ds, n, ws.d_partials, ws.stream)) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ws.h_partials, ws.d_partials, (size_t)p0.W * TE_MSM_PARTIAL_BYTES, hipMemcpyDeviceToHost, ws.stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ws.h_partials, ws.d_partials, (size_t)p0.W * sz.row, hipMemcpyDeviceToHost, ws.stream));
   }
-  std::vector<uint8_t> merged((size_t)p0.W * TE_MSM_PARTIAL_BYTES, 0);
+  std::vector<uint8_t> merged((size_t)p0.W * sz.row, 0);
   for (size_t i = 0; i < nd; i++) {
     gpu_t& d = ctx->devs[i];
     workset_t& ws = d.ws[ctx->opt_workset];
@@ -484,10 +533,11 @@ int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, boo
     HIP_TRY(ctx, hipStreamSynchronize(ws.stream));
     if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
     for (int w = d.w_first; w < p0.W; w += d.w_step)
-      memcpy(&merged[(size_t)w * TE_MSM_PARTIAL_BYTES], ws.h_partials + (size_t)w * TE_MSM_PARTIAL_BYTES, TE_MSM_PARTIAL_BYTES);
+      memcpy(&merged[(size_t)w * sz.row], ws.h_partials + (size_t)w * sz.row, sz.row);
   }
   if (int rc = collect_stage_ms(ctx, ctx->devs[0].ws[ctx->opt_workset])) return rc;
-  te_host::horner_to_affine(merged.data(), p0.c, (int)p0.logB, p0.W, out);
+  if (p0.curve == TE_MSM_CURVE_BLS12_377_G1) te377_host::horner_to_affine(merged.data(), p0.c, (int)p0.logB, p0.W, out);
+  else te_host::horner_to_affine(merged.data(), p0.c, (int)p0.logB, p0.W, out);
   return 0;
 }
 
@@ -499,7 +549,7 @@ extern "C" {
 int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
   if (!out || n_dev < 1 || n_dev > 64) { g_init_error = "te_msm_init: bad arguments"; return TE_MSM_EINVAL; }
   *out = nullptr;
-  if (!te_host::tail_selftest()) { g_init_error = "te_msm_init: host tail constants self-test failed"; return TE_MSM_ESTATE; }
+  if (!te_host::tail_selftest() || !te377_host::tail_selftest()) { g_init_error = "te_msm_init: host tail constants self-test failed"; return TE_MSM_ESTATE; }
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count < 1) {
@@ -518,9 +568,9 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
       if (er == hipSuccess) er = hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking);
       if (er == hipSuccess) er = hipMalloc((void**)&ws.d_err, 2056 * sizeof(uint32_t));
       if (er == hipSuccess) { ws.d_num_seg = ws.d_err + 1; ws.d_size_hist = ws.d_err + 8; ws.d_size_cursor = ws.d_err + 1032; }
-      if (er == hipSuccess) er = hipMalloc((void**)&ws.d_partials, (size_t)TE_MAX_WINDOWS * TE_MSM_PARTIAL_BYTES);
+      if (er == hipSuccess) er = hipMalloc((void**)&ws.d_partials, (size_t)TE_MAX_WINDOWS * TE_MAX_ROW_BYTES);
       if (er == hipSuccess) er = hipHostMalloc((void**)&ws.h_err, sizeof(uint32_t), hipHostMallocDefault);
-      if (er == hipSuccess) er = hipHostMalloc((void**)&ws.h_partials, (size_t)TE_MAX_WINDOWS * TE_MSM_PARTIAL_BYTES, hipHostMallocDefault);
+      if (er == hipSuccess) er = hipHostMalloc((void**)&ws.h_partials, (size_t)TE_MAX_WINDOWS * TE_MAX_ROW_BYTES, hipHostMallocDefault);
       if (er == hipSuccess) er = hipEventCreateWithFlags(&ws.ev_done, hipEventDisableTiming);
       for (auto& evn : ws.ev) if (er == hipSuccess) er = hipEventCreate(&evn);
       if (er == hipSuccess) *ws.h_err = 0;
@@ -560,7 +610,7 @@ int te_msm_submit_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_
   workset_t& ws = d.ws[d.next_ticket % TE_MSM_WORKSETS];   // rotate work sets (and their streams): the MSMs overlap on the device
   HIP_TRY(ctx, hipSetDevice(d.device));
   if (int rc = enqueue_partial(ctx, d, ws, d_points_xy_le, d_scalars_le, n, ws.d_partials, ws.stream)) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(ws.h_partials, ws.d_partials, (size_t)ws.plan.W * TE_MSM_PARTIAL_BYTES, hipMemcpyDeviceToHost, ws.stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ws.h_partials, ws.d_partials, (size_t)ws.plan.W * sizes_of(ws.plan.curve).row, hipMemcpyDeviceToHost, ws.stream));
   HIP_TRY(ctx, hipEventRecord(ws.ev_done, ws.stream));
   *ticket = d.next_ticket++;
   return 0;
@@ -576,7 +626,8 @@ int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]) {
   d.next_collect++;
   if (int rc = collect_stage_ms(ctx, ws)) return rc;
   if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
-  te_host::horner_to_affine(ws.h_partials, ws.plan.c, (int)ws.plan.logB, ws.plan.W, out_xy_le);
+  if (ws.plan.curve == TE_MSM_CURVE_BLS12_377_G1) te377_host::horner_to_affine(ws.h_partials, ws.plan.c, (int)ws.plan.logB, ws.plan.W, out_xy_le);
+  else te_host::horner_to_affine(ws.h_partials, ws.plan.c, (int)ws.plan.logB, ws.plan.W, out_xy_le);
   return 0;
 }
 
@@ -585,6 +636,11 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   if (!strcmp(key, "window_bits")) { if (value != 0 && (value < 4 || value > 16)) return set_err(ctx, TE_MSM_EINVAL, "window_bits must be 0 or in [4,16]"); ctx->opt_window_bits = (int)value; return 0; }
   if (!strcmp(key, "sort_buckets")) { ctx->opt_sort = value ? 1 : 0; return 0; }
   if (!strcmp(key, "signed_digits")) { ctx->opt_signed = value ? 1 : 0; return 0; }
+  if (!strcmp(key, "curve")) {
+    if (value != TE_MSM_CURVE_TE_BLS12 && value != TE_MSM_CURVE_BLS12_377_G1) return set_err(ctx, TE_MSM_EINVAL, "unknown curve");
+    if (value != TE_MSM_CURVE_TE_BLS12 && ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "BLS12-377 needs a single-device context");
+    ctx->opt_curve = (int)value; return 0;
+  }
   if (!strcmp(key, "profile")) { ctx->opt_profile = value < 0 ? 0 : (value > 2 ? 2 : (int)value); ctx->have_stage_ms = false; return 0; }
   if (!strcmp(key, "graph")) { ctx->opt_graph = value ? 1 : 0; return 0; }
   if (!strcmp(key, "workset")) { if (value < 0 || value >= TE_MSM_WORKSETS) return set_err(ctx, TE_MSM_EINVAL, "workset out of range"); ctx->opt_workset = (int)value; return 0; }
@@ -597,6 +653,7 @@ int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value) {
   if (!strcmp(key, "window_bits")) { *value = ctx->opt_window_bits; return 0; }
   if (!strcmp(key, "sort_buckets")) { *value = ctx->opt_sort; return 0; }
   if (!strcmp(key, "signed_digits")) { *value = ctx->opt_signed; return 0; }
+  if (!strcmp(key, "curve")) { *value = ctx->opt_curve; return 0; }
   if (!strcmp(key, "profile")) { *value = ctx->opt_profile; return 0; }
   if (!strcmp(key, "num_devices")) { *value = (int64_t)ctx->devs.size(); return 0; }
   if (!strcmp(key, "segment_len")) { *value = ctx->opt_seg_len; return 0; }
@@ -625,6 +682,7 @@ int te_msm_partial_device(te_ctx* ctx, const void* d_points_xy_le, const void* d
   if (!ctx) return TE_MSM_EINVAL;
   if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_partial_device needs a single-device context");
   if (!d_points_xy_le || !d_scalars_le || !d_partials || n == 0 || n >= (1ull << 31)) return set_err(ctx, TE_MSM_EINVAL, "bad arguments");
+  if (ctx->opt_curve != TE_MSM_CURVE_TE_BLS12) return set_err(ctx, TE_MSM_ESTATE, "window-sharded building blocks are Twisted-Edwards only");
   gpu_t& d = ctx->devs[0];
   workset_t& ws = d.ws[ctx->opt_workset];
   HIP_TRY(ctx, hipSetDevice(d.device));
@@ -715,8 +773,8 @@ int64_t te_msm_debug_read(te_ctx* ctx, const char* stage, void* dst, uint64_t ca
   else if (!strcmp(stage, "part_count")) { src = ws.d_part_count; bytes = (uint64_t)p.nw * p.P * 4; }
   else if (!strcmp(stage, "part_keys")) { src = ws.d_part_keys; bytes = (uint64_t)p.nw * p.nst * 2; }
   else if (!strcmp(stage, "part_idx")) { src = ws.d_part_idx; bytes = (uint64_t)p.nw * p.nst * 4; }
-  else if (!strcmp(stage, "buckets")) { src = ws.d_buckets; bytes = (uint64_t)p.nw * p.B * sizeof(te::ete); }
-  else if (!strcmp(stage, "partials")) { src = ws.d_partials; bytes = (uint64_t)p.W * TE_MSM_PARTIAL_BYTES; }
+  else if (!strcmp(stage, "buckets")) { src = ws.d_buckets; bytes = (uint64_t)p.nw * p.B * sizes_of(p.curve).acc; }
+  else if (!strcmp(stage, "partials")) { src = ws.d_partials; bytes = (uint64_t)p.W * sizes_of(p.curve).row; }
   else return set_err(ctx, TE_MSM_EINVAL, "unknown stage");
   if (bytes > cap) bytes = cap;
   HIP_TRY(ctx, hipSetDevice(d.device));
