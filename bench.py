@@ -35,8 +35,10 @@ def measured_traffic(log2n, c, world):
         return None
 
 
-def algorithmic_bytes(n, W, B):
+def algorithmic_bytes(n, W, B, bls=False):
     """whole MSM, and the share of the dominant kernel (bucket accumulation)."""
+    if bls:                                               # 48-B coordinates and scalar records, 144-B projective buckets
+        return 144 * n + W * n * (96 + 4) + 2 * W * B * 144 + 96, W * n * (96 + 4) + W * B * 144
     whole = 96 * n + W * n * (64 + 4) + 2 * W * B * 128 + 64
     accumulate = W * n * (64 + 4) + W * B * 128          # gather each point + its 4-B index once, write each bucket once
     return whole, accumulate
@@ -54,6 +56,8 @@ def main():
                     help="uniform: the harness's distribution; equal: one scalar repeated (worst-case skew); small: 64-bit scalars")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--segment-len", type=int, default=0)
+    ap.add_argument("--curve", choices=("te", "bls12-377"), default="te",
+                    help="te: the Twisted-Edwards BLS12 curve (headline); bls12-377: G1 of BLS12-377, BASELINE config 5 (single GPU)")
     ap.add_argument("--digits", choices=("signed", "unsigned"), default="signed",
                     help="signed window digits, 2^(c-1) buckets (BASELINE config 3, the reference's shipped behaviour) or unsigned, 2^c buckets (config 2)")
     ap.add_argument("--inflight", type=int, default=0,
@@ -90,11 +94,15 @@ def main():
     n = 1 << args.log2n
     seed = 0x5EED0000 + args.log2n
     t0 = time.time()
-    pts, sc = pkg.synth_inputs(seed, n, fixed_point=(args.points != "chain"))      # the engine's own harness inputs
+    bls = args.curve == "bls12-377"
+    assert not (bls and (world > 1 or force_dist)), "BLS12-377 is single-GPU (window sharding is Twisted-Edwards only)"
+    sb = 48 if bls else 32
+    pts, sc = pkg.synth_inputs(seed, n, fixed_point=(args.points != "chain"),      # the engine's own harness inputs
+                               curve=pkg.CURVE_BLS12_377_G1 if bls else pkg.CURVE_TE_BLS12)
     if args.scalars == "equal":
-        sc = sc[:32] * n
+        sc = sc[:sb] * n
     elif args.scalars == "small":
-        sc = b"".join(sc[32 * i:32 * i + 8] + bytes(24) for i in range(n))
+        sc = b"".join(sc[sb * i:sb * i + 8] + bytes(sb - 8) for i in range(n))
     gen_s = time.time() - t0
     d_pts = torch.frombuffer(bytearray(pts), dtype=torch.uint8).cuda()
     d_sc = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
@@ -105,6 +113,8 @@ def main():
     if args.segment_len:
         ctx.set_option("segment_len", args.segment_len)
     ctx.set_option("signed_digits", 1 if args.digits == "signed" else 0)
+    if bls:
+        ctx.set_option("curve", pkg.CURVE_BLS12_377_G1)
     ctx.set_option("profile", 1)          # two HIP events around the dominant kernel, on the engine's stream
     c, W = ctx.plan(n)
     B = 1 << (c - 1 if args.digits == "signed" else c)
@@ -206,13 +216,13 @@ def main():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
     stage_ms = {k: v / extra for k, v in stage_acc.items()}
     ctx.set_option("profile", 1)
-    whole_bytes, acc_bytes = algorithmic_bytes(n, W, B)
+    whole_bytes, acc_bytes = algorithmic_bytes(n, W, B, bls)
     acc_bytes_rank = acc_bytes / world                    # windows are sharded
     acc_ms = acc_ms_live
     achieved = acc_bytes_rank / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
 
     out = {
-        "metric": "MSMs/sec at n=2^%d Twisted-Edwards BLS12 (latency in ms_per_step)" % args.log2n,
+        "metric": "MSMs/sec at n=2^%d %s (latency in ms_per_step)" % (args.log2n, "BLS12-377 G1" if bls else "Twisted-Edwards BLS12"),
         "value": args.steps / elapsed,
         "unit": "MSM/s",
         "n_gpus": world,
@@ -226,11 +236,11 @@ def main():
         "vs_baseline": None,
         "dtype": "u32",
         "data": "synthetic",
-        "config": {"workload": "n=2^%d TE-BLS12 MSM, %d-bit %s windows (%d windows x %d buckets), points=%s, scalars=%s, inputs resident in HBM"
-                               % (args.log2n, c, args.digits, W, B, args.points, args.scalars),
+        "config": {"workload": "n=2^%d %s MSM, %d-bit %s windows (%d windows x %d buckets), points=%s, scalars=%s, inputs resident in HBM"
+                               % (args.log2n, "BLS12-377 G1" if bls else "TE-BLS12", c, args.digits, W, B, args.points, args.scalars),
                    "parallelism": "windows sharded over %d GPU(s), RCCL all-gather of %d B partial sums" % (world, W * 720) if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(args.log2n, c, world),
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None if bls else measured_traffic(args.log2n, c, world),
                      "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; 2 x FETCH + WRITE)",
                      "algorithmic_bytes_per_launch": acc_bytes_rank, "kernel_ms": acc_ms,
                      # the timed region keeps `depth` MSMs in flight: the kernel shares the GPU with the other MSMs' kernels,
@@ -238,8 +248,9 @@ def main():
                      "alone": {"kernel_ms": stage_ms.get("accumulate"),
                                "achieved": acc_bytes_rank / (stage_ms["accumulate"] * 1e-3) / 1e9 if stage_ms.get("accumulate") else None,
                                "frac": acc_bytes_rank / (stage_ms["accumulate"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if stage_ms.get("accumulate") else None},
-                     "note": "VALU-bound, not HBM-bound: 7 field products = 1650 instructions per gathered point, "
-                             "~97 % of the measured v_mad_u64_u32 issue rate (DESIGN.md section 6)"},
+                     "note": ("VALU-bound: 11 products of 14-limb operands per gathered point (first, untuned version)" if bls else
+                              "VALU-bound, not HBM-bound: 7 field products = 1650 instructions per gathered point, "
+                              "~97 % of the measured v_mad_u64_u32 issue rate (DESIGN.md section 6)")},
         "msm_algorithmic_bytes": whole_bytes,
         "msm_algorithmic_gbps": whole_bytes / (ms_per_step * 1e-3) / 1e9,
         "stage_ms_untimed_pass": stage_ms,
@@ -256,14 +267,18 @@ def main():
         out["pcie_inclusive_ms_host_buffers"] = min(t_pcie)
         assert r_host == result
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle          # cpu_baseline leg (and result checker) only
         threads = args.cpu_threads or min(16, os.cpu_count() or 1)
         t0 = time.perf_counter()
-        exp = oracle.msm(pts, sc, c=16 if n >= 65536 else 4, bpr_mode=1, threads=threads)
+        if bls:
+            from oracle import oracle377       # cpu_baseline leg (and result checker) only
+            exp = oracle377.msm(pts, sc, c=16 if n >= 65536 else 4, threads=threads)
+        else:
+            from oracle import oracle          # cpu_baseline leg (and result checker) only
+            exp = oracle.msm(pts, sc, c=16 if n >= 65536 else 4, bpr_mode=1, threads=threads)
         cpu_s = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "MSM/s", "cores": threads, "kind": "port",
-                               "sample": "1 full MSM at n=2^%d (C restatement of the reference pipeline, oracle/te_oracle.c), %.1f s"
-                                         % (args.log2n, cpu_s)}
+                               "sample": "1 full MSM at n=2^%d (C restatement of the reference pipeline, oracle/%s), %.1f s"
+                                         % (args.log2n, "bls377_oracle.c; parity unpinned by the reference" if bls else "te_oracle.c", cpu_s)}
         out["parity"] = "bit-exact vs oracle" if exp == result else "MISMATCH vs oracle"
         if exp != result:
             print(json.dumps(out))

@@ -139,6 +139,8 @@ int te_msm_finalize_gathered(const uint8_t* gathered, int world, int window_bits
  * 256 random bits reduced mod p; points = n distinct subgroup points (a + i*b)*G, or, with fixed_point != 0, the harness's
  * one fixed point replicated n times.  Either output pointer may be NULL. */
 int te_msm_synth_inputs(uint64_t seed, uint64_t n, int fixed_point, uint8_t* points_xy_le, uint8_t* scalars_le);
+/* The same scheme for BLS12-377 G1: 96-byte points (a + i*b)*G, 48-byte scalar records (values below r). */
+int te_msm_synth_inputs_bls12_377(uint64_t seed, uint64_t n, uint8_t* points_xy_le, uint8_t* scalars_le);
 
 /* ---- measurement / stage verification (the reference's `debug` flags, submission.ts:892-1363) --- */
 /* Per-stage device time of the last run in ms (needs option "profile" >= 1; level 1 reports "accumulate" only).  Returns the number of

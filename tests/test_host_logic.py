@@ -189,6 +189,10 @@ def test_synthetic_inputs_equal_the_oracle_generator(pkg, ora):
     assert pkg.synth_inputs(9, 3, fixed_point=True)[0] == ora.gen_points_fixed(3)
     assert pkg.synth_inputs(9, 0) == (b"", b"")
     assert pkg.synth_inputs(9, 4, points=False)[0] is None
+    from oracle import oracle377
+    for seed, n in ((1, 1), (7, 2), (3, 300)):
+        pts, sc = pkg.synth_inputs(seed, n, curve=pkg.CURVE_BLS12_377_G1)
+        assert pts == oracle377.gen_points(seed, n) and sc == oracle377.gen_scalars(seed, n)
 
 
 def _declared_symbols():

@@ -104,6 +104,8 @@ def _lib() -> ctypes.CDLL:
         L.te_msm_finalize_gathered.restype = ci
         L.te_msm_synth_inputs.argtypes = [u64, u64, ci, vp, vp]
         L.te_msm_synth_inputs.restype = ci
+        L.te_msm_synth_inputs_bls12_377.argtypes = [u64, u64, vp, vp]
+        L.te_msm_synth_inputs_bls12_377.restype = ci
         L.te_msm_stage_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(cp), ci]
         L.te_msm_stage_ms.restype = ci
         L.te_msm_debug_read.argtypes = [vp, cp, vp, u64]
@@ -240,13 +242,15 @@ def finalize_gathered(gathered_ptr: int, world: int, window_bits: int, num_windo
     return out.raw
 
 
-def synth_inputs(seed: int, n: int, fixed_point: bool = False, points: bool = True, scalars: bool = True):
-    """Seeded harness inputs in compute_msm's wire format (te_msm_synth_inputs): (points 64n bytes, scalars 32n bytes);
-    a part not asked for is None.  Host code only."""
-    pb = ctypes.create_string_buffer(64 * n) if points else None
-    sb = ctypes.create_string_buffer(32 * n) if scalars else None
-    rc = _lib().te_msm_synth_inputs(seed, n, 1 if fixed_point else 0, ctypes.cast(pb, ctypes.c_void_p) if pb is not None else None,
-                                    ctypes.cast(sb, ctypes.c_void_p) if sb is not None else None)
+def synth_inputs(seed: int, n: int, fixed_point: bool = False, points: bool = True, scalars: bool = True, curve: int = CURVE_TE_BLS12):
+    """Seeded harness inputs in compute_msm's wire format (te_msm_synth_inputs): (points 64n bytes, scalars 32n bytes)
+    -- 96n / 48n bytes for curve = CURVE_BLS12_377_G1; a part not asked for is None.  Host code only."""
+    bls = curve == CURVE_BLS12_377_G1
+    pb = ctypes.create_string_buffer((96 if bls else 64) * n) if points else None
+    sb = ctypes.create_string_buffer((48 if bls else 32) * n) if scalars else None
+    pp = ctypes.cast(pb, ctypes.c_void_p) if pb is not None else None
+    sp = ctypes.cast(sb, ctypes.c_void_p) if sb is not None else None
+    rc = _lib().te_msm_synth_inputs_bls12_377(seed, n, pp, sp) if bls else _lib().te_msm_synth_inputs(seed, n, 1 if fixed_point else 0, pp, sp)
     if rc:
         raise MsmError(rc, "te_msm_synth_inputs failed")
     return (pb.raw if pb is not None else None), (sb.raw if sb is not None else None)

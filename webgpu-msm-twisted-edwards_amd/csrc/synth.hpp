@@ -8,6 +8,7 @@
 #pragma once
 #include <vector>
 #include "host_tail.hpp"
+#include "host_tail377.hpp"
 
 namespace te_host {
 
@@ -73,3 +74,43 @@ static inline void synth_points_fixed(uint64_t n, uint8_t* out) {
 }
 
 }  // namespace te_host
+
+// the same scheme on BLS12-377 G1: 48-byte scalar records (values < r), 96-byte points P_i = (a + i*b)*G
+namespace te377_host {
+
+static inline void synth_scalars(uint64_t seed, uint64_t n, uint8_t* out) {
+  uint64_t s = seed;
+  for (uint64_t i = 0; i < n; i++) { const te_host::Fe r = te_host::rand_mod_p(s); memset(out + 48 * i, 0, 48); memcpy(out + 48 * i, r.l, 32); }
+}
+static inline Pt pmul(const Pt& p, const te_host::Fe& k) {      // k < r (253 bits)
+  Pt acc = identity();
+  for (int i = 252; i >= 0; i--) { acc = padd(acc, acc); if ((k.l[i >> 6] >> (i & 63)) & 1) acc = padd(acc, p); }
+  return acc;
+}
+static inline void synth_points(uint64_t seed, uint64_t n, uint8_t* out) {
+  if (n == 0) return;
+  // generator of the order-r subgroup (the standard one of the BLS12-377 specification), plain integers
+  const Fe gx = {{0xeab9b16eb21be9efULL, 0xd5481512ffcd394eULL, 0x188282c8bd37cb5cULL, 0x85951e2caa9d41bbULL, 0xc8fc6225bf87ff54ULL, 0x008848defe740a67ULL}};
+  const Fe gy = {{0xfd82de55559c8ea6ULL, 0xc2fe3d3634a9591aULL, 0x6d182ad44fb82305ULL, 0xbd7fb348ca3e52d9ULL, 0x1f674f5d30afeec4ULL, 0x01914a69c5102effULL}};
+  const Fe R2 = {{0xb786686c9400cd22ULL, 0x0329fcaab00431b1ULL, 0x22a5f11162d6b46dULL, 0xbfdf7d03827dc3acULL, 0x837e92f041790bf9ULL, 0x006dfccb1e914b88ULL}};
+  Pt g; g.x = mul(gx, R2); g.y = mul(gy, R2); g.z = ONE_M;
+  uint64_t s = seed ^ 0xA5A5A5A55A5A5A5AULL;
+  const te_host::Fe a = te_host::rand_mod_p(s), b = te_host::rand_mod_p(s);
+  const Pt q = pmul(g, b);
+  std::vector<Pt> pts(n);
+  pts[0] = pmul(g, a);
+  for (uint64_t i = 1; i < n; i++) pts[i] = padd(pts[i - 1], q);
+  std::vector<Fe> pre(n);
+  Fe acc = ONE_M;
+  for (uint64_t i = 0; i < n; i++) { pre[i] = acc; acc = mul(acc, pts[i].z); }      // no infinity in the chain (order r)
+  Fe iv = inv(acc);
+  Fe one_raw; memset(&one_raw, 0, sizeof one_raw); one_raw.l[0] = 1;
+  for (uint64_t i = n; i-- > 0;) {
+    const Fe zi = mul(iv, pre[i]);
+    iv = mul(iv, pts[i].z);
+    const Fe x = mul(mul(pts[i].x, zi), one_raw), y = mul(mul(pts[i].y, zi), one_raw);
+    memcpy(out + 96 * i, x.l, 48); memcpy(out + 96 * i + 48, y.l, 48);
+  }
+}
+
+}  // namespace te377_host

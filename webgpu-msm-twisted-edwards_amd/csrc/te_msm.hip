@@ -753,6 +753,13 @@ int te_msm_synth_inputs(uint64_t seed, uint64_t n, int fixed_point, uint8_t* poi
   return 0;
 }
 
+int te_msm_synth_inputs_bls12_377(uint64_t seed, uint64_t n, uint8_t* points_xy_le, uint8_t* scalars_le) {
+  if (n >= (1ull << 31) || !te377_host::tail_selftest()) return TE_MSM_EINVAL;
+  if (scalars_le) te377_host::synth_scalars(seed, n, scalars_le);
+  if (points_xy_le) te377_host::synth_points(seed, n, points_xy_le);
+  return 0;
+}
+
 int64_t te_msm_debug_read(te_ctx* ctx, const char* stage, void* dst, uint64_t cap) {
   if (!ctx || !stage || !dst) return TE_MSM_EINVAL;
   gpu_t& d = ctx->devs[0];
