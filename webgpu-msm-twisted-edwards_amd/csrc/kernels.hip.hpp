@@ -488,6 +488,7 @@ __global__ void __launch_bounds__(256) k_l2_place(const uint16_t* __restrict__ p
 //   k_order_*    : counting sort of segment ids by descending length
 // also: histogram of the segment lengths (for the schedule) and the lists of split buckets (for k_seg_combine*)
 #define TE_COMBINE_SMALL 16u
+#define TE_SEG_BLOCK 2048u
 __global__ void __launch_bounds__(256) k_seg_build(const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ bucket_count,
                                                    const uint32_t* __restrict__ num_segments, uint32_t total_buckets, uint32_t seg_len,
                                                    uint32_t* __restrict__ seg_bucket, uint32_t* __restrict__ seg_lenv,
@@ -496,13 +497,33 @@ __global__ void __launch_bounds__(256) k_seg_build(const uint32_t* __restrict__ 
                                                    uint32_t* __restrict__ large_list, uint32_t* __restrict__ chunk_list /* pairs (bucket, first part) */,
                                                    uint32_t list_cap) {
   __shared__ uint32_t h[1024];
+  __shared__ uint32_t sb[TE_SEG_BLOCK + 2];           // seg_base of the buckets this block's segments belong to
+  __shared__ uint32_t g_first;
   for (uint32_t j = threadIdx.x; j < 1024u; j += 256u) h[j] = 0;
-  __syncthreads();
   const uint32_t ns = *num_segments;
-  for (uint32_t s = blockIdx.x * 256u + threadIdx.x; s < ns; s += gridDim.x * 256u) {
-    uint32_t lo = 0, hi = total_buckets;            // last bucket g with seg_base[g] <= s
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seg_base[mid] <= s) lo = mid; else hi = mid; }
-    const uint32_t part = s - seg_base[lo], cnt = bucket_count[lo];
+  // The block owns the contiguous segments [s_lo, s_hi).  Every bucket has at least one segment, so they belong to at
+  // most s_hi - s_lo + 1 consecutive buckets: one binary search in global memory finds the first, their seg_base
+  // values are staged in LDS and every thread searches there (a 19-step search in global memory per segment made this
+  // kernel 29 us of dependent loads).
+  const uint32_t per = (ns + gridDim.x - 1u) / gridDim.x;
+  const uint32_t chunk = per < TE_SEG_BLOCK ? per : TE_SEG_BLOCK;       // blocks with more than TE_SEG_BLOCK segments loop
+  for (uint32_t s_lo = blockIdx.x * per; s_lo < min(ns, (blockIdx.x + 1u) * per); s_lo += chunk) {
+    const uint32_t s_hi = min(min(ns, (blockIdx.x + 1u) * per), s_lo + chunk);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t lo = 0, hi = total_buckets;          // last bucket g with seg_base[g] <= s_lo
+      while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seg_base[mid] <= s_lo) lo = mid; else hi = mid; }
+      g_first = lo;
+    }
+    __syncthreads();
+    const uint32_t g0 = g_first, ng = min(total_buckets - g0, s_hi - s_lo + 1u);
+    for (uint32_t j = threadIdx.x; j < ng; j += 256u) sb[j] = seg_base[g0 + j];
+    __syncthreads();
+    for (uint32_t s = s_lo + threadIdx.x; s < s_hi; s += 256u) {
+    uint32_t l = 0, r = ng;                            // last staged bucket with seg_base <= s
+    while (r - l > 1) { const uint32_t mid = (l + r) >> 1; if (sb[mid] <= s) l = mid; else r = mid; }
+    const uint32_t lo = g0 + l;
+    const uint32_t part = s - sb[l], cnt = bucket_count[lo];
     const uint32_t len = cnt > part * seg_len ? min(seg_len, cnt - part * seg_len) : 0u;
     seg_bucket[s] = lo;
     seg_lenv[s] = len;
@@ -513,6 +534,7 @@ __global__ void __launch_bounds__(256) k_seg_build(const uint32_t* __restrict__ 
     else if (nparts > TE_COMBINE_SMALL) {
       if (part == 0) { const uint32_t i = atomicAdd(&split_count[1], 1u); if (i < list_cap) large_list[i] = lo; }
       if ((part & 1023u) == 0) { const uint32_t i = atomicAdd(&split_count[2], 1u); if (i < list_cap) { chunk_list[2 * i] = lo; chunk_list[2 * i + 1] = part; } }
+    }
     }
   }
   __syncthreads();
