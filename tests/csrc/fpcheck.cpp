@@ -51,7 +51,7 @@ void fpc_constants(uint32_t out[9 * 9]) {
   memcpy(out, c, sizeof c);
 }
 void fpc_constants2(uint32_t out[3 * 9]) {
-  fp c[3] = {fp_R2_HALF(), fp_D_R3(), fp_kp_offset<16>()};
+  fp c[3] = {fp_R2_HALF(), fp_NEG_D_R3(), fp_kp_offset<16>()};
   memcpy(out, c, sizeof c);
 }
 // body of k_prep_points: record in a 128-byte slot

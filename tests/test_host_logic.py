@@ -42,7 +42,7 @@ def test_field_constants(fpcheck, model):
     out2 = (ctypes.c_uint32 * 27)()
     fpcheck.fpc_constants2(out2)
     got2 = [[int(out2[9 * k + i]) for i in range(9)] for k in range(3)]
-    assert [sum(l << (LB * i) for i, l in enumerate(g)) for g in got2[:2]] == [R * R * pow(2, -1, P) % P, model.D * pow(R, 3, P) % P]
+    assert [sum(l << (LB * i) for i, l in enumerate(g)) for g in got2[:2]] == [R * R * pow(2, -1, P) % P, (-model.D * pow(R, 3, P)) % P]
     assert all(l <= LM for g in got2[:2] for l in g)
     for k, g in zip((2, 4, 8, 16), got[6:] + got2[2:]):   # offset forms: same value as K*p, every lower limb >= 2^29 - 1
         assert sum(l << (LB * i) for i, l in enumerate(g)) == k * P

@@ -17,8 +17,9 @@ namespace te {
 // Every coordinate is a mont_mul output: limb class N, value < 1.1p.  144 bytes, x | y | z | t.
 struct ete { fp x, y, z, t; };
 
-// Precomputed affine point: hm = (y - x)/2, hp = (y + x)/2, dt = d*x*y (mod p, lazily reduced: values < 1.1p,
-// class N; a negated record holds dt' = 2p - dt with limbs < 2^30).  108 bytes, stored in 128-byte slots.
+// Precomputed affine point: hm = (y - x)/2, hp = (y + x)/2, dt = -d*x*y (mod p, lazily reduced: values < 1.1p,
+// class N; a negated record holds 4p - dt with limbs < 2^30).  108 bytes, stored in 128-byte slots.
+// dt carries the MINUS sign so that in ete_madd F = Z1 - C becomes a sum and no product meets two differences.
 struct pnt { fp hm, hp, dt; };
 
 TE_HD ete ete_identity() { ete r; r.x = fp_zero(); r.y = fp_R1(); r.z = fp_R1(); r.t = fp_zero(); return r; }
@@ -36,7 +37,7 @@ TE_HD pnt pnt_cneg(const pnt& a, bool neg) {
 }
 
 // Affine (x, y) as plain integers (class N, ANY 256-bit value) -> record, in four products and nothing else:
-//   hm = (y - x + 16p) * (R^2/2) / R,   hp = (y + x) * (R^2/2) / R,   dt = (x * y / R) * (d R^3) / R.
+//   hm = (y - x + 16p) * (R^2/2) / R,   hp = (y + x) * (R^2/2) / R,   dt = (x * y / R) * (-d R^3) / R.
 // The constants fold the conversion to Montgomery form, the halving and the factor d into the products
 // (16p > 2^256 keeps y - x non-negative for non-canonical inputs).  Values: hm, hp < 1.07p, dt < 1.01p.
 TE_HD pnt pnt_from_affine_raw(const fp& x, const fp& y) {
@@ -45,25 +46,26 @@ TE_HD pnt pnt_from_affine_raw(const fp& x, const fp& y) {
   mont_mul_x<3>(a, b, o);
   pnt r;
   r.hm = o[0]; r.hp = o[1];
-  r.dt = mont_mul(o[2], fp_D_R3());
+  r.dt = mont_mul(o[2], fp_NEG_D_R3());
   return r;
 }
 
 // Mixed addition acc + b, 7 products, unified and complete (a = -1 is a square, d is not).
 // With A' = (Y1-X1)(y2-x2)/2, B' = (Y1+X1)(y2+x2)/2:  E = B'-A' = X1 y2 + Y1 x2,
 // H = B'+A' = Y1 y2 + X1 x2, C = d T1 x2 y2, F = Z1 - C, G = Z1 + C;  (X3,Y3,T3,Z3) = (EF, HG, EH, GF).
-// Limb classes: A' = D x N, B' = S x N, C = N x (<2^30);  E = norm(D) -> N so that E x F (F is D) is legal;
-// H, G are S;  HG = S x S, EH = N x S, GF = S x D (9 * 2^30 * 1.37 * 2^30 + 8 * 2^58 = 0.9 * 2^64).
+// The record holds -d x2 y2, so the product below is C' = -C and F = Z1 + C' is a SUM, G = Z1 - C' the difference.
+// Limb classes: A' = D x N, B' = S x N, C' = N x (<2^30);  E and G are D (differences in offset form), H and F are S:
+// every closing product EF, HG, EH, GF is D x S (9 * 2^30.6 * 2^30 + 8 * 2^58 = 0.9 * 2^64) -- no operand is normalised.
 // Values: everything is below 5p before a product and below 1.1p after it; nothing is reduced mod p.
 TE_HD ete ete_madd(const ete& a, const pnt& b) {
   const fp in1[3] = {fp_sub<2>(a.y, a.x), fp_add(a.y, a.x), a.t}, in2[3] = {b.hm, b.hp, b.dt};
   fp abc[3];
   mont_mul_x<3>(in1, in2, abc);
-  const fp &A = abc[0], &B = abc[1], &C = abc[2];
-  const fp E = fp_norm(fp_sub<2>(B, A));
+  const fp &A = abc[0], &B = abc[1], &Cn = abc[2];
+  const fp E = fp_sub<2>(B, A);
   const fp H = fp_add(B, A);
-  const fp F = fp_sub<2>(a.z, C);
-  const fp G = fp_add(a.z, C);
+  const fp F = fp_add(a.z, Cn);
+  const fp G = fp_sub<2>(a.z, Cn);
   const fp l[4] = {E, H, E, G}, rr[4] = {F, G, H, F};
   fp o[4];
   mont_mul_x<4>(l, rr, o);
