@@ -64,7 +64,7 @@ TE_HD g1p g1_madd(const g1p& a, const g1a& b) {
   const fq y3n = fq_norm(fq_mul3(fq_add(s[1], X1)));                            // 3 (X1 + x2 Z1)
   const fq t0x3 = fq_mul3(p[0]);                                                // 3 X1 x2           (limbs < 2^30.6)
   const fq z3n = fq_norm(fq_add(p[1], fq_mul3(Z1)));                            // Y1 y2 + 3 Z1
-  const fq t1n = fq_norm(fq_sub<2>(fq_sub<2>(fq_sub<2>(p[1], Z1), Z1), Z1));    // Y1 y2 - 3 Z1
+  const fq t1n = fq_norm(fq_sub<4>(fq_sub<4>(fq_sub<4>(p[1], Z1), Z1), Z1));    // Y1 y2 - 3 Z1   (Z1 may reach 2q: offset 4q)
   return g1_finish(t0x3, t1n, t3n, t4, y3n, z3n);
 }
 
