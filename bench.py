@@ -249,7 +249,7 @@ def main():
                                "achieved": acc_bytes_rank / (stage_ms["accumulate"] * 1e-3) / 1e9 if stage_ms.get("accumulate") else None,
                                "frac": acc_bytes_rank / (stage_ms["accumulate"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if stage_ms.get("accumulate") else None},
                      "note": ("VALU-bound: 11 products of 14-limb operands per gathered point (first, untuned version)" if bls else
-                              "VALU-bound, not HBM-bound: 7 field products = 1650 instructions per gathered point, "
+                              "VALU-bound, not HBM-bound: 7 field products = 1637 instructions per gathered point, "
                               "~97 % of the measured v_mad_u64_u32 issue rate (DESIGN.md section 6)")},
         "msm_algorithmic_bytes": whole_bytes,
         "msm_algorithmic_gbps": whole_bytes / (ms_per_step * 1e-3) / 1e9,
