@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <functional>
 
 #include "../../include/te_msm.h"
 #include "host_tail.hpp"
@@ -27,8 +28,10 @@ namespace {
 
 thread_local std::string g_init_error;
 
-enum { ST_PREP = 0, ST_DIGITS, ST_HIST, ST_SCAN, ST_SCATTER, ST_BSORT, ST_ORDER, ST_ACCUM, ST_TREE, ST_WEIGHTED, ST_COUNT };
-const char* const kStageNames[ST_COUNT] = {"prep_points", "digits", "part_hist", "part_scan", "part_scatter", "bucket_sort", "order",
+// in execution order: everything that needs only the scalars first, so that a host-buffer call can upload the points
+// (2/3 of the bytes) while those stages already run
+enum { ST_DIGITS = 0, ST_HIST, ST_SCAN, ST_SCATTER, ST_BSORT, ST_ORDER, ST_PREP, ST_ACCUM, ST_TREE, ST_WEIGHTED, ST_COUNT };
+const char* const kStageNames[ST_COUNT] = {"digits", "part_hist", "part_scan", "part_scatter", "bucket_sort", "order", "prep_points",
                                            "accumulate", "marginal_sums", "weighted_sum"};
 
 // per-curve sizes: wire format, device accumulator slot, partial row (5 points), result
@@ -56,7 +59,8 @@ struct graph_key { const void *pts, *sc, *out; uint64_t n, generation; int c, w_
 // several MSMs overlap ON THE DEVICE: the launch gaps and the latency-bound reduction tail of one are filled by the wide kernels of the
 // other (te_msm_submit_device alternates them; "workset" option for te_msm_partial_device callers).
 struct workset_t {
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr, copy_stream = nullptr;   // copy_stream: host-buffer uploads beside the compute stream
+  hipEvent_t ev_copy = nullptr;
   size_t cap[40] = {};                                  // per-buffer capacity in bytes (ensure())
   te::pnt_slot* d_recs = nullptr;
   uint16_t *d_digits = nullptr, *d_part_keys = nullptr;
@@ -231,15 +235,26 @@ struct msm_launch {
   uint32_t smax() const { return total() + (uint32_t)((uint64_t)p.nw * (n / p.seg_len)); }
   void mark(int i) const { if (prof >= 2 || (prof == 1 && (i == ST_ACCUM || i == ST_ACCUM + 1))) (void)hipEventRecord(ws.ev[i], stream); }
 
-  // points -> records, scalars -> digits, two-level counting sort, segment schedule
   int front() {
+    if (int rc = front_scalars()) return rc;
+    return front_points();
+  }
+
+  // points -> records (needs only the points; runs last of the front part)
+  int front_points() {
     const uint32_t n32 = this->n32();
-    HIP_TRY(ctx, hipMemsetAsync(ws.d_err, 0, 1032 * sizeof(uint32_t), stream));     // flag, counters, length histogram
     mark(ST_PREP);
     if (p.curve == TE_MSM_CURVE_BLS12_377_G1)
       hipLaunchKernelGGL(te377::k377_prep_points, dim3((n32 + 255) / 256), dim3(256), 0, stream, (const uint4*)d_points, ws.d_recs, n32);
     else
       hipLaunchKernelGGL(te::k_prep_points, dim3((n32 + 255) / 256), dim3(256), 0, stream, (const uint4*)d_points, ws.d_recs, n32);
+    return 0;
+  }
+
+  // scalars -> digits, two-level counting sort, segment schedule (needs only the scalars)
+  int front_scalars() {
+    const uint32_t n32 = this->n32();
+    HIP_TRY(ctx, hipMemsetAsync(ws.d_err, 0, 1032 * sizeof(uint32_t), stream));     // flag, counters, length histogram
     mark(ST_DIGITS);
     if (p.nw > 0) {
       te::digits_params prm; memset(&prm, 0, sizeof prm);
@@ -421,8 +436,10 @@ template <typename F> int capture_graph(te_ctx* ctx, workset_t& ws, hipGraphExec
   return 0;
 }
 
+// before_points (optional): called after the scalar-only stages are enqueued and before the first kernel that reads the
+// points -- te_msm_run uploads the points there, so the upload overlaps digits, sort and schedule.
 int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, const void* d_scalars, uint64_t n,
-                    void* d_partials_out, hipStream_t stream) {
+                    void* d_partials_out, hipStream_t stream, const std::function<int()>* before_points = nullptr) {
   plan_t p; make_plan(ctx, d, n, p);
   HIP_TRY(ctx, hipSetDevice(d.device));
   if (int rc = ensure_buffers(ctx, d, ws, n, p)) return rc;
@@ -430,7 +447,7 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, 
   // profile 1: two events around the dominant kernel only (what bench.py times live); 2: every stage boundary
   // (an event between two kernels costs ~4 us of idle stream time, 11 of them ~2 % of a 2^20 MSM)
   msm_launch L{ctx, d, ws, p, d_points, d_scalars, n, d_partials_out, ctx->opt_profile, stream};
-  if (ctx->opt_graph && ctx->opt_profile < 2) {
+  if (ctx->opt_graph && ctx->opt_profile < 2 && !before_points) {
     // the graphs hold pointers and geometry: re-captured when any of them changes (including a buffer reallocation)
     const graph_key key{d_points, d_scalars, d_partials_out, n, ws.generation, p.c, d.w_first, d.w_step, (int)p.seg_len, ctx->opt_sort | (ctx->opt_signed << 1) | (ctx->opt_curve << 2)};
     if (!ws.g_front || !ws.g_back || memcmp(&key, &ws.g_key, sizeof key) != 0) {
@@ -444,7 +461,9 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, 
     L.mark(ST_TREE);
     HIP_TRY(ctx, hipGraphLaunch(ws.g_back, stream));
   } else {
-    if (int rc = L.front()) return rc;
+    if (int rc = L.front_scalars()) return rc;
+    if (before_points) { if (int rc = (*before_points)()) return rc; }
+    if (int rc = L.front_points()) return rc;
     if (int rc = L.accumulate()) return rc;
     L.mark(ST_TREE);
     if (int rc = L.back()) return rc;
@@ -479,6 +498,8 @@ void free_dev(gpu_t& d) {
     if (ws.g_front) (void)hipGraphExecDestroy(ws.g_front);
     if (ws.g_back) (void)hipGraphExecDestroy(ws.g_back);
     for (auto& ev : ws.ev) if (ev) (void)hipEventDestroy(ev);
+    if (ws.ev_copy) (void)hipEventDestroy(ws.ev_copy);
+    if (ws.copy_stream) (void)hipStreamDestroy(ws.copy_stream);
     if (ws.stream) (void)hipStreamDestroy(ws.stream);
   }
   if (d.d_in_points) (void)hipFree(d.d_in_points);
@@ -513,7 +534,8 @@ int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, boo
         d.cap_in = n;
       }
       if (src_is_host) {
-        HIP_TRY(ctx, hipMemcpyAsync(d.d_in_points, src_points, n * sz.point_in, hipMemcpyHostToDevice, ws.stream));
+        // scalars first; the points follow from inside enqueue_partial (pageable copies return when the data has left
+        // the caller's buffer, so the scalar-only stages enqueued in between run while the points are still in flight)
         HIP_TRY(ctx, hipMemcpyAsync(d.d_in_scalars, src_scalars, n * sz.scalar_in, hipMemcpyHostToDevice, ws.stream));
       } else {
         // inputs live on device 0's memory: wait for nothing (caller's data is ready), copy peer-to-peer
@@ -522,7 +544,15 @@ int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, boo
       }
       dp = d.d_in_points; ds = d.d_in_scalars;
     }
-    if (int rc = enqueue_partial(ctx, d, ws, dp, ds, n, ws.d_partials, ws.stream)) return rc;
+    const std::function<int()> upload_points = [&]() -> int {
+      // on the copy stream, so that it runs beside the kernels already enqueued on ws.stream; the first kernel that reads
+      // the points waits for it
+      HIP_TRY(ctx, hipMemcpyAsync(d.d_in_points, src_points, n * sz.point_in, hipMemcpyHostToDevice, ws.copy_stream));
+      HIP_TRY(ctx, hipEventRecord(ws.ev_copy, ws.copy_stream));
+      HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ws.ev_copy, 0));
+      return 0;
+    };
+    if (int rc = enqueue_partial(ctx, d, ws, dp, ds, n, ws.d_partials, ws.stream, src_is_host ? &upload_points : nullptr)) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(ws.h_partials, ws.d_partials, (size_t)p0.W * sz.row, hipMemcpyDeviceToHost, ws.stream));
   }
   std::vector<uint8_t> merged((size_t)p0.W * sz.row, 0);
@@ -566,6 +596,8 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
     hipError_t er = hipSetDevice(d.device);
     for (workset_t& ws : d.ws) {       // the small fixed allocations of both work sets; the big buffers come with the first MSM
       if (er == hipSuccess) er = hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking);
+      if (er == hipSuccess) er = hipStreamCreateWithFlags(&ws.copy_stream, hipStreamNonBlocking);
+      if (er == hipSuccess) er = hipEventCreateWithFlags(&ws.ev_copy, hipEventDisableTiming);
       if (er == hipSuccess) er = hipMalloc((void**)&ws.d_err, 2056 * sizeof(uint32_t));
       if (er == hipSuccess) { ws.d_num_seg = ws.d_err + 1; ws.d_size_hist = ws.d_err + 8; ws.d_size_cursor = ws.d_err + 1032; }
       if (er == hipSuccess) er = hipMalloc((void**)&ws.d_partials, (size_t)TE_MAX_WINDOWS * TE_MAX_ROW_BYTES);
