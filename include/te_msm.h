@@ -91,6 +91,9 @@ int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]);
  *                   first use and re-captured when pointers, n or options change; 0 = launch every kernel (default: on
  *                   ROCm 7.2 / MI355X the replay measured ~5 % slower than plain launches).
  *                   Ignored at profile level 2.
+ *   "host_chunks"   te_msm_run (Twisted-Edwards, one device): pieces the host buffers are uploaded and processed in, so
+ *                   that PCIe transfer and device work overlap; 0 = from n (4 from 2^20 points, 2 from 2^18, else 1),
+ *                   1 = whole.  The result does not depend on it.
  *   "workset"       which of the TE_MSM_WORKSETS device work sets te_msm_run* / te_msm_partial_device use (default 0) */
 int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value);
 int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value);

@@ -428,6 +428,34 @@ def test_pipelined_submit_collect(pkg, ora):
         assert c.run_device(data[0][0].data_ptr(), data[0][1].data_ptr(), data[0][2]) == data[0][3]
 
 
+def test_host_buffers_in_pieces(pkg, model, ora):
+    """te_msm_run uploads and processes large host buffers in pieces (option host_chunks): same result for any split, a
+    scalar-range error in a late piece is reported, and a ticket in flight makes it fall back to the whole-buffer path"""
+    import torch
+    n = 100003
+    pts, sc = ora.gen_points(61, n), ora.gen_scalars(61, n)
+    exp = ora.msm(pts, sc, threads=8)
+    with pkg.MsmContext((0,)) as c:
+        for k in (1, 2, 3, 8, 0):
+            c.set_option("host_chunks", k)
+            assert c.run(pts, sc) == exp, k
+        c.set_option("host_chunks", 4)
+        c.set_option("window_bits", 16)
+        bad = bytearray(sc)
+        bad[32 * (n - 5):32 * (n - 5) + 32] = b"\xff" * 32            # lands in the last piece
+        with pytest.raises(pkg.MsmError) as e:
+            c.run(pts, bytes(bad))
+        assert e.value.code == -3
+        c.set_option("window_bits", 0)
+        dp, ds = _dev(pts), _dev(sc)
+        torch.cuda.synchronize()
+        t = c.submit_device(dp.data_ptr(), ds.data_ptr(), n)           # a ticket in flight: run() must not touch its work set
+        assert c.run(pts, sc) == exp
+        assert c.collect(t) == exp
+        c.set_option("profile", 2)                                     # stage timing refers to one whole MSM
+        assert c.run(pts, sc) == exp and "accumulate" in c.stage_ms()
+
+
 def test_two_work_sets_overlap_on_two_streams(pkg, model, ora):
     """te_msm_partial_device on alternating work sets and streams: many MSMs in flight pairwise, each equal to the oracle;
     a scalar-range error is reported by te_msm_partial_wait for the work set that saw it"""

@@ -127,7 +127,9 @@ static inline Pt pdbl(const Pt& a) {
 // e.g. 4,4,4,3 for 15 bits).  Window value
 //     V = T + W0 + 2^w0 W1 + 2^(w0+w1) W2 + 2^(w0+w1+w2) W3,      result = sum_w 2^(c*w) V_w,
 // evaluated top-down; the c doublings per window are split around the digit terms, so no doubling is added.
-static inline void horner_to_affine(const uint8_t* partials, int c, int bucket_bits, int W, uint8_t out_xy_le[64]) {
+// `sets` row buffers are summed on the fly: the rows are linear in the bucket contents, so an MSM computed in pieces
+// (te_msm_run uploads and processes a large host buffer in chunks) folds as the sum of the pieces' rows.
+static inline void horner_to_affine_multi(const uint8_t* const* partials, int sets, int c, int bucket_bits, int W, uint8_t out_xy_le[64]) {
   const Fe d2 = {{2 * 3021, 0, 0, 0}};
   const Fe R2 = {{0x25d577bab861857bULL, 0xcc2c27b58860591fULL, 0xa7cc008fe5dc8593ULL, 0x011fdae7eff1c939ULL}};
   const Fe k2d = mul(d2, R2);
@@ -135,22 +137,30 @@ static inline void horner_to_affine(const uint8_t* partials, int c, int bucket_b
   for (int k = 0; k < 4; k++) dw[k] = (bucket_bits + 3 - k) / 4;
   const int s3 = dw[0] + dw[1] + dw[2];
   Pt acc = identity();
+  auto add_slot = [&](int w, int slot) {
+    for (int s = 0; s < sets; s++) {
+      const uint8_t* row = partials[s] + (size_t)w * TE_TAIL_ROW_BYTES;
+      if (!all_zero_bytes(row, TE_TAIL_ROW_BYTES)) acc = padd(acc, load_point(row + (size_t)slot * TE_TAIL_POINT_BYTES), k2d);
+    }
+  };
   for (int w = W - 1; w >= 0; w--) {
-    const uint8_t* row = partials + (size_t)w * TE_TAIL_ROW_BYTES;
-    const bool present = !all_zero_bytes(row, TE_TAIL_ROW_BYTES);
     for (int k = 0; k < c - s3; k++) acc = pdbl(acc);
-    if (present) acc = padd(acc, load_point(row + 4 * TE_TAIL_POINT_BYTES), k2d);      // W3
+    add_slot(w, 4);                                    // W3
     for (int k = 0; k < dw[2]; k++) acc = pdbl(acc);
-    if (present) acc = padd(acc, load_point(row + 3 * TE_TAIL_POINT_BYTES), k2d);      // W2
+    add_slot(w, 3);                                    // W2
     for (int k = 0; k < dw[1]; k++) acc = pdbl(acc);
-    if (present) acc = padd(acc, load_point(row + 2 * TE_TAIL_POINT_BYTES), k2d);      // W1
+    add_slot(w, 2);                                    // W1
     for (int k = 0; k < dw[0]; k++) acc = pdbl(acc);
-    if (present) { acc = padd(acc, load_point(row + TE_TAIL_POINT_BYTES), k2d); acc = padd(acc, load_point(row), k2d); }   // W0, T
+    add_slot(w, 1);                                    // W0
+    add_slot(w, 0);                                    // T
   }
   const Fe zi = inv(acc.z);
   const Fe one_raw = {{1, 0, 0, 0}};
   const Fe x = mul(mul(acc.x, zi), one_raw), y = mul(mul(acc.y, zi), one_raw);
   memcpy(out_xy_le, x.l, 32); memcpy(out_xy_le + 32, y.l, 32);
+}
+static inline void horner_to_affine(const uint8_t* partials, int c, int bucket_bits, int W, uint8_t out_xy_le[64]) {
+  horner_to_affine_multi(&partials, 1, c, bucket_bits, W, out_xy_le);
 }
 
 static inline bool tail_selftest() {

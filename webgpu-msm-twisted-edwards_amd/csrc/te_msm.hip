@@ -103,6 +103,7 @@ struct te_ctx {
   int opt_signed = 1;          // signed window digits (the reference's shipped behaviour); 0 = plain unsigned windows, 2^c buckets
   int opt_profile = 0;
   int opt_seg_len = 64;        // work segment: at most this many entries of one bucket per thread
+  int opt_host_chunks = 0;     // te_msm_run: pieces a large host buffer is uploaded and processed in (0 = choose from n)
   int opt_graph = 0;           // replay the launch sequence around k_accumulate as HIP graphs
   int opt_workset = 0;         // work set used by te_msm_run* / te_msm_partial_device
   float stage_ms[ST_COUNT] = {};
@@ -139,9 +140,9 @@ int auto_window_bits(uint64_t n) {
   return c;
 }
 
-void make_plan(const te_ctx* ctx, const gpu_t& d, uint64_t n, plan_t& p) {
+void make_plan(const te_ctx* ctx, const gpu_t& d, uint64_t n, plan_t& p, int force_c = 0) {
   p.curve = ctx->opt_curve;
-  p.c = ctx->opt_window_bits ? ctx->opt_window_bits : auto_window_bits(n);
+  p.c = force_c ? force_c : ctx->opt_window_bits ? ctx->opt_window_bits : auto_window_bits(n);
   p.W = (256 + p.c - 1) / p.c;
   p.nw = 0;
   for (int w = d.w_first; w < p.W; w += d.w_step) p.nw++;
@@ -439,8 +440,8 @@ template <typename F> int capture_graph(te_ctx* ctx, workset_t& ws, hipGraphExec
 // before_points (optional): called after the scalar-only stages are enqueued and before the first kernel that reads the
 // points -- te_msm_run uploads the points there, so the upload overlaps digits, sort and schedule.
 int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, const void* d_scalars, uint64_t n,
-                    void* d_partials_out, hipStream_t stream, const std::function<int()>* before_points = nullptr) {
-  plan_t p; make_plan(ctx, d, n, p);
+                    void* d_partials_out, hipStream_t stream, const std::function<int()>* before_points = nullptr, int force_c = 0) {
+  plan_t p; make_plan(ctx, d, n, p, force_c);
   HIP_TRY(ctx, hipSetDevice(d.device));
   if (int rc = ensure_buffers(ctx, d, ws, n, p)) return rc;
   ws.plan = p; ws.n = n; ws.used = true; d.last_ws = (int)(&ws - d.ws);
@@ -506,6 +507,48 @@ void free_dev(gpu_t& d) {
   if (d.d_in_scalars) (void)hipFree(d.d_in_scalars);
 }
 
+// te_msm_run for a large Twisted-Edwards MSM on one device: the host buffers are uploaded and processed in K pieces, each
+// a complete MSM of n/K points on its own work set with the window size of the whole -- while piece i is on the GPU,
+// piece i+1 crosses PCIe -- and the pieces' rows are summed in the host tail.
+int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_scalars, uint64_t n, int K, uint8_t out[64]) {
+  gpu_t& d = ctx->devs[0];
+  HIP_TRY(ctx, hipSetDevice(d.device));
+  plan_t pf; make_plan(ctx, d, n, pf);
+  if (n > d.cap_in) {
+    if (d.d_in_points) HIP_TRY(ctx, hipFree(d.d_in_points));
+    if (d.d_in_scalars) HIP_TRY(ctx, hipFree(d.d_in_scalars));
+    d.d_in_points = d.d_in_scalars = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d.d_in_points, n * 96));
+    HIP_TRY(ctx, hipMalloc(&d.d_in_scalars, n * 48));
+    d.cap_in = n;
+  }
+  uint8_t* dpts = static_cast<uint8_t*>(d.d_in_points);
+  uint8_t* dscs = static_cast<uint8_t*>(d.d_in_scalars);
+  for (int i = 0; i < K; i++) {
+    workset_t& ws = d.ws[i];
+    const uint64_t lo = n * (uint64_t)i / (uint64_t)K, hi = n * (uint64_t)(i + 1) / (uint64_t)K, m = hi - lo;
+    HIP_TRY(ctx, hipMemcpyAsync(dscs + lo * TE_MSM_SCALAR_BYTES, src_scalars + lo * TE_MSM_SCALAR_BYTES, m * TE_MSM_SCALAR_BYTES, hipMemcpyHostToDevice, ws.stream));
+    const std::function<int()> upload_points = [&]() -> int {
+      HIP_TRY(ctx, hipMemcpyAsync(dpts + lo * TE_MSM_POINT_BYTES, src_points + lo * TE_MSM_POINT_BYTES, m * TE_MSM_POINT_BYTES, hipMemcpyHostToDevice, ws.copy_stream));
+      HIP_TRY(ctx, hipEventRecord(ws.ev_copy, ws.copy_stream));
+      HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ws.ev_copy, 0));
+      return 0;
+    };
+    if (int rc = enqueue_partial(ctx, d, ws, dpts + lo * TE_MSM_POINT_BYTES, dscs + lo * TE_MSM_SCALAR_BYTES, m, ws.d_partials, ws.stream, &upload_points, pf.c)) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ws.h_partials, ws.d_partials, (size_t)pf.W * TE_MSM_PARTIAL_BYTES, hipMemcpyDeviceToHost, ws.stream));
+  }
+  const uint8_t* rows[TE_MSM_WORKSETS];
+  bool bad = false;
+  for (int i = 0; i < K; i++) {
+    HIP_TRY(ctx, hipStreamSynchronize(d.ws[i].stream));
+    bad = bad || *d.ws[i].h_err != 0;
+    rows[i] = d.ws[i].h_partials;
+  }
+  if (bad) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
+  te_host::horner_to_affine_multi(rows, K, pf.c, (int)pf.logB, pf.W, out);
+  return 0;
+}
+
 int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, bool src_is_host, uint64_t n, uint8_t out[64]) {
   if (!ctx || !out) return TE_MSM_EINVAL;
   if (n >= (1ull << 31)) return set_err(ctx, TE_MSM_EINVAL, "n must be < 2^31");
@@ -516,6 +559,12 @@ int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, boo
   }
   if (!src_points || !src_scalars) return set_err(ctx, TE_MSM_EINVAL, "null input buffer");
   const size_t nd = ctx->devs.size();
+  if (src_is_host && nd == 1 && ctx->opt_curve == TE_MSM_CURVE_TE_BLS12 && !ctx->opt_profile && ctx->opt_workset == 0 &&
+      ctx->devs[0].w_step == 1 && ctx->devs[0].next_ticket == ctx->devs[0].next_collect) {
+    // no tickets in flight, no stage timing requested: every work set is free for the pieces
+    const int K = ctx->opt_host_chunks ? ctx->opt_host_chunks : (n >= (1ull << 20) ? 4 : n >= (1ull << 18) ? 2 : 1);
+    if (K > 1 && n >= (uint64_t)K) return run_host_chunked(ctx, static_cast<const uint8_t*>(src_points), static_cast<const uint8_t*>(src_scalars), n, K, out);
+  }
   plan_t p0; make_plan(ctx, ctx->devs[0], n, p0);
   const curve_sizes sz = sizes_of(p0.curve);
   // stage inputs on every device
@@ -675,6 +724,7 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   }
   if (!strcmp(key, "profile")) { ctx->opt_profile = value < 0 ? 0 : (value > 2 ? 2 : (int)value); ctx->have_stage_ms = false; return 0; }
   if (!strcmp(key, "graph")) { ctx->opt_graph = value ? 1 : 0; return 0; }
+  if (!strcmp(key, "host_chunks")) { if (value < 0 || value > TE_MSM_WORKSETS) return set_err(ctx, TE_MSM_EINVAL, "host_chunks out of range"); ctx->opt_host_chunks = (int)value; return 0; }
   if (!strcmp(key, "workset")) { if (value < 0 || value >= TE_MSM_WORKSETS) return set_err(ctx, TE_MSM_EINVAL, "workset out of range"); ctx->opt_workset = (int)value; return 0; }
   if (!strcmp(key, "segment_len")) { if (value < 1 || value > 1000000) return set_err(ctx, TE_MSM_EINVAL, "segment_len must be in [1, 1e6]"); ctx->opt_seg_len = (int)value; return 0; }
   return set_err(ctx, TE_MSM_EINVAL, "unknown option");
@@ -691,6 +741,7 @@ int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value) {
   if (!strcmp(key, "segment_len")) { *value = ctx->opt_seg_len; return 0; }
   if (!strcmp(key, "workset")) { *value = ctx->opt_workset; return 0; }
   if (!strcmp(key, "graph")) { *value = ctx->opt_graph; return 0; }
+  if (!strcmp(key, "host_chunks")) { *value = ctx->opt_host_chunks; return 0; }
   return set_err(ctx, TE_MSM_EINVAL, "unknown option");
 }
 
