@@ -428,6 +428,29 @@ def test_pipelined_submit_collect(pkg, ora):
         assert c.run_device(data[0][0].data_ptr(), data[0][1].data_ptr(), data[0][2]) == data[0][3]
 
 
+def test_random_configurations(pkg, ora):
+    """differential run over seeded random combinations of size, window bits, digit form, segment length, schedule and
+    host pieces -- every one must equal the oracle"""
+    import random
+    rnd = random.Random(20241003)
+    with pkg.MsmContext((0,)) as c:
+        for it in range(40):
+            n = rnd.choice([1, 2, 7, 64, 65, 300, 1023, 4096, 5000, 20011, 66000])
+            cfg = {"window_bits": rnd.choice([0, 4, 6, 9, 12, 14, 15, 16]), "signed_digits": rnd.choice([0, 1]),
+                   "segment_len": rnd.choice([1, 2, 5, 64, 300]), "sort_buckets": rnd.choice([0, 1]), "host_chunks": rnd.choice([0, 1, 2, 5])}
+            for k, v in cfg.items():
+                c.set_option(k, v)
+            mode = rnd.choice(["uniform", "equal", "small", "fixed_point"])
+            pts, sc = ora.gen_points(1000 + it, n), ora.gen_scalars(1000 + it, n)
+            if mode == "equal":
+                sc = sc[:32] * n
+            elif mode == "small":
+                sc = b"".join(sc[32 * i:32 * i + 3] + bytes(29) for i in range(n))
+            elif mode == "fixed_point":
+                pts = ora.gen_points_fixed(n)
+            assert c.run(pts, sc) == ora.msm(pts, sc, threads=8), (it, n, cfg, mode)
+
+
 def test_host_buffers_in_pieces(pkg, model, ora):
     """te_msm_run uploads and processes large host buffers in pieces (option host_chunks): same result for any split, a
     scalar-range error in a late piece is reported, and a ticket in flight makes it fall back to the whole-buffer path"""

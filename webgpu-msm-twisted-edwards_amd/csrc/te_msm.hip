@@ -78,6 +78,7 @@ struct workset_t {
   hipEvent_t ev_done = nullptr;
   hipEvent_t ev[ST_COUNT + 1] = {};
   plan_t plan; uint64_t n = 0; bool used = false;
+  hipStream_t last_stream = nullptr;  // stream of the previous MSM on this set: a different one must wait for it (scratch reuse)
   uint64_t generation = 0;            // bumped whenever ensure() reallocates a buffer of this set
   hipGraphExec_t g_front = nullptr, g_back = nullptr; graph_key g_key = {};
 };
@@ -444,7 +445,8 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, 
   plan_t p; make_plan(ctx, d, n, p, force_c);
   HIP_TRY(ctx, hipSetDevice(d.device));
   if (int rc = ensure_buffers(ctx, d, ws, n, p)) return rc;
-  ws.plan = p; ws.n = n; ws.used = true; d.last_ws = (int)(&ws - d.ws);
+  if (ws.used && ws.last_stream != stream) HIP_TRY(ctx, hipStreamWaitEvent(stream, ws.ev_done, 0));   // the set's buffers are still the previous MSM's
+  ws.plan = p; ws.n = n; ws.used = true; ws.last_stream = stream; d.last_ws = (int)(&ws - d.ws);
   // profile 1: two events around the dominant kernel only (what bench.py times live); 2: every stage boundary
   // (an event between two kernels costs ~4 us of idle stream time, 11 of them ~2 % of a 2^20 MSM)
   msm_launch L{ctx, d, ws, p, d_points, d_scalars, n, d_partials_out, ctx->opt_profile, stream};
