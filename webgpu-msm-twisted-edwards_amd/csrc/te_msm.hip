@@ -292,7 +292,7 @@ struct msm_launch {
       hipLaunchKernelGGL(te::k_part_scatter, dim3(p.CH, p.nw), dim3(512), 0, stream, ws.d_digits, ws.d_counts1, ws.d_part_keys, ws.d_part_idx, sg);
     mark(ST_BSORT);
     if (p.nw > 0) {
-      const uint32_t nslices = (p.nst + 8191u) / 8192u;
+      const uint32_t nslices = (p.nst + TE_SLICE - 1u) / TE_SLICE;
       const uint32_t seg_threads = p.B < 1024u ? p.B : 1024u, nseg = p.B / seg_threads;
       HIP_TRY(ctx, hipMemsetAsync(ws.d_bucket_count, 0, (size_t)p.nw * p.B * sizeof(uint32_t), stream));
       hipLaunchKernelGGL(te::k_l2_count, dim3(nslices, p.nw), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx, ws.d_part_start,
