@@ -1,9 +1,9 @@
 #!/bin/bash
-# one PMC pass over the bench workload: tools/profile_pmc.sh "<counters>" [kernel-substring]
+# one PMC pass over the bench workload: tools/profile_pmc.sh "<counters>" [kernel-substring] [extra bench.py arguments]
 REPO="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$REPO/gpurun_out/prof/pmc_x"; rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp; cd /tmp
-rocprofv3 --pmc $1 --kernel-trace --output-format csv -d "$OUT" -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT.log" 2>&1 || { tail -5 "$OUT.log"; exit 1; }
+rocprofv3 --pmc $1 --kernel-trace --output-format csv -d "$OUT" -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline ${3:-} > "$OUT.log" 2>&1 || { tail -5 "$OUT.log"; exit 1; }
 python3 - "$OUT" "${2:-k_accumulate}" <<'PY'
 import csv, glob, sys, os
 from collections import defaultdict
