@@ -428,6 +428,20 @@ def test_pipelined_submit_collect(pkg, ora):
         assert c.run_device(data[0][0].data_ptr(), data[0][1].data_ptr(), data[0][2]) == data[0][3]
 
 
+def test_many_parts_per_bucket(ctx, ora):
+    """segment length 1 with few buckets: every bucket has thousands of parts, more 1024-part chunks than buckets
+    (found by tools/soak.py: the chunk list was sized by the bucket count)"""
+    n = 158508
+    pts, sc = ora.gen_points(5, n), ora.gen_scalars(5, n)
+    ctx.set_option("window_bits", 7)
+    ctx.set_option("segment_len", 1)
+    try:
+        assert ctx.run(pts, sc) == ora.msm(pts, sc, threads=8)
+    finally:
+        ctx.set_option("window_bits", 0)
+        ctx.set_option("segment_len", 64)
+
+
 def test_random_configurations(pkg, ora):
     """differential run over seeded random combinations of size, window bits, digit form, segment length, schedule and
     host pieces -- every one must equal the oracle"""

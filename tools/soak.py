@@ -1,0 +1,53 @@
+"""Differential soak: random MSM configurations, pipelined in random order, against the oracle.  Not part of the test
+suite (minutes); run on the GPU box:  python tools/soak.py [seconds]"""
+import importlib
+import random
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+pkg = importlib.import_module("webgpu-msm-twisted-edwards_amd")
+from oracle import oracle, oracle377    # noqa: E402  (checker)
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+print('soak seed', seed0, flush=True)
+rnd = random.Random(seed0)
+t_end = time.time() + budget
+done = 0
+te = pkg.MsmContext((0,))
+bls = pkg.MsmContext((0,))
+bls.set_option("curve", pkg.CURVE_BLS12_377_G1)
+while time.time() < t_end:
+    ctx, orc, pb, sb = (te, oracle, 64, 32) if rnd.random() < 0.75 else (bls, oracle377, 96, 48)
+    opts = {}
+    for k, v in (("window_bits", rnd.choice([0, 0, 4, 7, 10, 13, 15, 16])), ("signed_digits", rnd.choice([1, 1, 0])),
+                 ("segment_len", rnd.choice([64, 64, 1, 7, 500])), ("sort_buckets", rnd.choice([1, 1, 0])), ("host_chunks", rnd.choice([0, 1, 3]))):
+        ctx.set_option(k, v)
+        opts[k] = v
+    batch = []
+    for _ in range(rnd.randint(1, pkg.WORKSETS)):
+        n = int(2 ** rnd.uniform(0, 17.5))
+        seed = rnd.randrange(1 << 30)
+        pts, sc = orc.gen_points(seed, n), orc.gen_scalars(seed, n)
+        if rnd.random() < 0.2:
+            sc = sc[:sb] * n
+        batch.append((pts, sc, n))
+    exp = [orc.msm(p, s, threads=8) for p, s, _ in batch]
+    mode = "run" if rnd.random() < 0.5 else "tickets"
+    if mode == "run":
+        got = [ctx.run(p, s) for p, s, _ in batch]
+    else:
+        dev = [(torch.frombuffer(bytearray(p), dtype=torch.uint8).cuda(), torch.frombuffer(bytearray(s), dtype=torch.uint8).cuda(), n) for p, s, n in batch]
+        torch.cuda.synchronize()
+        tickets = [ctx.submit_device(a.data_ptr(), b.data_ptr(), n) for a, b, n in dev]
+        got = [ctx.collect(t) for t in tickets]
+    if got != exp:
+        print("MISMATCH", "bls" if ctx is bls else "te", opts, mode, [(n, g == e) for (_, _, n), g, e in zip(batch, got, exp)], flush=True)
+        raise SystemExit(1)
+    done += len(batch)
+    if done % 50 < len(batch):
+        print("ok", done, flush=True)
+print("soak passed:", done, "MSMs")

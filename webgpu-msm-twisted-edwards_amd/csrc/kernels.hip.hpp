@@ -495,7 +495,7 @@ __global__ void __launch_bounds__(256) k_seg_build(const uint32_t* __restrict__ 
                                                    uint32_t* __restrict__ size_hist, uint32_t* __restrict__ split_list,
                                                    uint32_t* __restrict__ split_count /* [0] small, [1] large buckets, [2] large chunks */,
                                                    uint32_t* __restrict__ large_list, uint32_t* __restrict__ chunk_list /* pairs (bucket, first part) */,
-                                                   uint32_t list_cap) {
+                                                   uint32_t large_cap, uint32_t chunk_cap) {
   __shared__ uint32_t h[1024];
   __shared__ uint32_t sb[TE_SEG_BLOCK + 2];           // seg_base of the buckets this block's segments belong to
   __shared__ uint32_t g_first;
@@ -532,8 +532,8 @@ __global__ void __launch_bounds__(256) k_seg_build(const uint32_t* __restrict__ 
     const uint32_t nparts = (cnt + seg_len - 1u) / seg_len;
     if (nparts > 1u && nparts <= TE_COMBINE_SMALL) { if (part == 0) split_list[atomicAdd(&split_count[0], 1u)] = lo; }
     else if (nparts > TE_COMBINE_SMALL) {
-      if (part == 0) { const uint32_t i = atomicAdd(&split_count[1], 1u); if (i < list_cap) large_list[i] = lo; }
-      if ((part & 1023u) == 0) { const uint32_t i = atomicAdd(&split_count[2], 1u); if (i < list_cap) { chunk_list[2 * i] = lo; chunk_list[2 * i + 1] = part; } }
+      if (part == 0) { const uint32_t i = atomicAdd(&split_count[1], 1u); if (i < large_cap) large_list[i] = lo; }
+      if ((part & 1023u) == 0) { const uint32_t i = atomicAdd(&split_count[2], 1u); if (i < chunk_cap) { chunk_list[2 * i] = lo; chunk_list[2 * i + 1] = part; } }
     }
     }
   }

@@ -205,7 +205,8 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, workset_t& ws, uint64_t n, const plan_
   if ((rc = ensure(ctx, ws, ws.d_seg_base, ws.cap[23], wb + 1))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_split_list, ws.cap[24], wb + 1))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_large_list, ws.cap[25], wb + 1))) return rc;
-  if ((rc = ensure(ctx, ws, ws.d_chunk_list, ws.cap[26], 2 * wb + 2))) return rc;
+  // a giant bucket contributes one chunk per 1024 parts: at most one per bucket plus one per 1024 segments
+  if ((rc = ensure(ctx, ws, ws.d_chunk_list, ws.cap[26], 2 * (wb + smax / 1024 + 2)))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_part_start, ws.cap[6], (size_t)p.nw * p.P))) return rc;
   if ((rc = ensure_points(ctx, ws, ws.d_buckets, ws.cap[8], wb, ab))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_part_count, ws.cap[9], (size_t)p.nw * p.P))) return rc;
@@ -235,6 +236,7 @@ struct msm_launch {
   uint32_t n32() const { return (uint32_t)n; }
   uint32_t total() const { return (uint32_t)p.nw * p.B; }
   uint32_t smax() const { return total() + (uint32_t)((uint64_t)p.nw * (n / p.seg_len)); }
+  uint32_t chunk_cap() const { return total() + smax() / 1024u + 2u; }     // entries of d_chunk_list (pairs), see ensure_buffers
   void mark(int i) const { if (prof >= 2 || (prof == 1 && (i == ST_ACCUM || i == ST_ACCUM + 1))) (void)hipEventRecord(ws.ev[i], stream); }
 
   int front() {
@@ -309,7 +311,7 @@ struct msm_launch {
     if (p.nw > 0) {
       // d_num_seg[1] = number of split buckets; size_hist zeroed together with it
       hipLaunchKernelGGL(te::k_seg_build, dim3(1024), dim3(256), 0, stream, ws.d_seg_base, ws.d_bucket_count, ws.d_num_seg, total, p.seg_len,
-                         ws.d_seg_bucket, ws.d_seg_lenv, ws.d_size_hist, ws.d_split_list, ws.d_num_seg + 1, ws.d_large_list, ws.d_chunk_list, total);
+                         ws.d_seg_bucket, ws.d_seg_lenv, ws.d_size_hist, ws.d_split_list, ws.d_num_seg + 1, ws.d_large_list, ws.d_chunk_list, total, chunk_cap());
       if (ctx->opt_sort) {
         hipLaunchKernelGGL(te::k_order_scan, dim3(1), dim3(1024), 0, stream, ws.d_size_hist, ws.d_size_cursor);
         hipLaunchKernelGGL(te::k_order_scatter, dim3(256), dim3(256), 0, stream, ws.d_seg_lenv, ws.d_num_seg, ws.d_size_cursor, ws.d_order);
@@ -348,7 +350,7 @@ struct msm_launch {
                          ws.d_seg_out, ws.d_buckets, p.seg_len);
       // giant buckets (empty lists for well-spread digits: two near-empty launches)
       hipLaunchKernelGGL(te::k_seg_combine_large1, dim3(512), dim3(256), 0, stream, ws.d_chunk_list, ws.d_num_seg + 1, ws.d_bucket_count, ws.d_seg_base,
-                         ws.d_seg_out, p.seg_len, total);
+                         ws.d_seg_out, p.seg_len, chunk_cap());
       hipLaunchKernelGGL(te::k_seg_combine_large2, dim3(256), dim3(256), 0, stream, ws.d_large_list, ws.d_num_seg + 1, ws.d_bucket_count, ws.d_seg_base,
                          ws.d_seg_out, ws.d_buckets, p.seg_len, total);
     }
