@@ -29,16 +29,34 @@ while time.time() < t_end:
         opts[k] = v
     batch = []
     for _ in range(rnd.randint(1, pkg.WORKSETS)):
-        n = int(2 ** rnd.uniform(0, 17.5))
+        n = int(2 ** rnd.uniform(0, 20.2 if rnd.random() < 0.05 else 17.5))
         seed = rnd.randrange(1 << 30)
         pts, sc = orc.gen_points(seed, n), orc.gen_scalars(seed, n)
         if rnd.random() < 0.2:
             sc = sc[:sb] * n
         batch.append((pts, sc, n))
     exp = [orc.msm(p, s, threads=8) for p, s, _ in batch]
-    mode = "run" if rnd.random() < 0.5 else "tickets"
+    mode = rnd.choice(["run", "run", "tickets", "tickets", "shards"]) if ctx is te else rnd.choice(["run", "tickets"])
     if mode == "run":
         got = [ctx.run(p, s) for p, s, _ in batch]
+    elif mode == "shards":
+        world = rnd.choice([2, 3, 5, 8])
+        got = []
+        for p_, s_, n in batch:
+            a = torch.frombuffer(bytearray(p_), dtype=torch.uint8).cuda(); b = torch.frombuffer(bytearray(s_), dtype=torch.uint8).cuda()
+            cb, W = te.plan(n)
+            rows = []
+            for r in range(world):
+                te.set_window_shard(r, world)
+                te.set_option("workset", r % pkg.WORKSETS)
+                part = torch.zeros(W * 720, dtype=torch.uint8, device="cuda")
+                te.partial_device(a.data_ptr(), b.data_ptr(), n, part.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                te.partial_wait(r % pkg.WORKSETS)
+                rows.append(part.cpu().numpy().tobytes())
+            te.set_window_shard(0, 1)
+            te.set_option("workset", 0)
+            got.append(pkg.finalize_host(pkg.merge_partials(rows, W, world), cb, W, None if opts["signed_digits"] else cb))
     else:
         dev = [(torch.frombuffer(bytearray(p), dtype=torch.uint8).cuda(), torch.frombuffer(bytearray(s), dtype=torch.uint8).cuda(), n) for p, s, n in batch]
         torch.cuda.synchronize()
