@@ -446,6 +446,8 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, 
                     void* d_partials_out, hipStream_t stream, const std::function<int()>* before_points = nullptr, int force_c = 0) {
   plan_t p; make_plan(ctx, d, n, p, force_c);
   HIP_TRY(ctx, hipSetDevice(d.device));
+  if ((uint64_t)p.nw * p.B + (uint64_t)p.nw * (n / p.seg_len) + 1024u >= (1ull << 32))
+    return set_err(ctx, TE_MSM_EINVAL, "segment_len is too small for this n: more than 2^32 segments");
   if (int rc = ensure_buffers(ctx, d, ws, n, p)) return rc;
   if (ws.used && ws.last_stream != stream) HIP_TRY(ctx, hipStreamWaitEvent(stream, ws.ev_done, 0));   // the set's buffers are still the previous MSM's
   ws.plan = p; ws.n = n; ws.used = true; ws.last_stream = stream; d.last_ws = (int)(&ws - d.ws);
