@@ -105,8 +105,7 @@ class ShardedPipeline:
         cur = self.compute_streams[slot]
         cur.wait_stream(torch.cuda.current_stream())    # the caller's inputs are ready on its stream
         self.ctx.set_option("workset", slot)            # the slot's previous MSM was collected: its buffers are free
-        with torch.cuda.stream(cur):
-            self.part[slot].zero_()
+        with torch.cuda.stream(cur):                    # (rows of windows this rank does not own stay zero from allocation)
             self.ctx.partial_device(d_points.data_ptr(), d_scalars.data_ptr(), self.n, self.part[slot].data_ptr(), cur.cuda_stream)
             if self.gloo:                               # rehearsal path (no CUDA all_gather in gloo): blocking
                 src = self.part[slot].cpu()
