@@ -4,8 +4,9 @@
 // WebGPU wrapper it drives (implementation/cuzk/gpu.ts:14-229).  Differences that matter:
 //   * the context is persistent -- device buffers, streams and kernels survive across calls (the
 //     reference re-creates device, buffers and pipelines on every call, submission.ts:96-97,360);
-//   * every stage is enqueued on one HIP stream with no host synchronisation in between, like the
-//     reference's single command-encoder submit (gpu.ts:118);
+//   * every stage of one MSM is enqueued on one HIP stream with no host synchronisation in between, like the
+//     reference's single command-encoder submit (gpu.ts:118); several MSMs are kept in flight on separate
+//     work sets / streams so that they overlap on the device;
 //   * windows can be sharded over contexts / devices; the reference is single-device.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
