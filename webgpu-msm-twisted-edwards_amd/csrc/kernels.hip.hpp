@@ -414,7 +414,7 @@ __global__ void __launch_bounds__(1024) k_bscan_b(const uint32_t* __restrict__ l
 }
 
 // grid (nslices, nw), block 256
-__global__ void __launch_bounds__(256) k_l2_place(const uint16_t* __restrict__ part_keys, const uint32_t* __restrict__ part_idx,
+__global__ void __launch_bounds__(256, 3) k_l2_place(const uint16_t* __restrict__ part_keys, const uint32_t* __restrict__ part_idx,
                                                   const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ part_count,
                                                   uint32_t* __restrict__ bucket_cursor, uint32_t* __restrict__ sorted, sort_geom g) {
   __shared__ uint32_t cnt_s[256], lex_s[256], off_s[256], gbase_s[256];
