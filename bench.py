@@ -1,15 +1,22 @@
 """bench.py -- MSM throughput / latency of the HIP path on N GPUs of one node.
 
 A "step" is one full MSM (n = 2^20 Twisted-Edwards BLS12 points, 16-bit signed windows) over
-synthetic inputs already resident in HBM.  N = 1: te_msm_run_device (device stages + host tail).
-N > 1: the MSM's 16 windows are sharded over the ranks (one process per GPU), the 11 KB of partial
-sums are exchanged with one RCCL all-gather, and every rank runs the host tail ("scaling": "strong").
+synthetic inputs already resident in HBM.  N = 1: te_msm_submit_device / te_msm_collect (device stages + host
+tail), several MSMs in flight.  N > 1: the MSM's 16 windows are sharded over the ranks (one process per GPU), the
+11 KB of partial sums are exchanged with one RCCL all-gather per MSM, and every rank runs the host tail
+("scaling": "strong").
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+
+One JSON line on rank 0.  `value` / `ms_per_step` = pipelined throughput with inputs resident in HBM; `latency_ms` =
+one synchronous MSM from resident inputs; `host_buffers_ms` = one te_msm_run from pageable host buffers (what the
+reference's compute_msm(Buffer, Buffer) delivers, PCIe included; never `value`); `sizes` = the same three figures for
+n = 2^16..2^20 (full_benchmarks.ts:13-15 runs 16..20).
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
@@ -20,19 +27,39 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "webgpu-msm-twisted-edwards_amd"
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+KERNEL_SOURCES = ("kernels.hip.hpp", "curve.hpp", "fp.hpp")     # what decides k_accumulate's memory traffic
+
+
+def kernel_sources_sha():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, PKG, "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def measured_traffic(log2n, c, world):
     """HBM bytes per k_accumulate launch from the committed rocprofv3 PMC passes (tools/profile_bench.sh ->
-    profiles/r01_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes).  Counters cannot be
-    read from inside the process, so the figure applies to the profiled workload only (n = 2^20, c = 16, one GPU)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    if not (log2n == 20 and c == 16 and world == 1 and os.path.exists(path)):
-        return None
+    profiles/pmc_traffic.json).  Counters cannot be read from inside the process, so the figure applies to the profiled
+    workload only (n = 2^20, c = 16, one GPU) and to the kernel sources it was profiled with: the JSON records their
+    hash and the commit; when the sources have changed since, the figure is withheld (null) and flagged stale."""
+    info = {"file": os.path.relpath(TRAFFIC_JSON, ROOT), "sources_sha_now": kernel_sources_sha()}
+    if not (log2n == 20 and c == 16 and world == 1 and os.path.exists(TRAFFIC_JSON)):
+        return None, info
     try:
-        return json.load(open(path))["kernels"]["k_accumulate"]["hbm_bytes_per_launch"]
+        j = json.load(open(TRAFFIC_JSON))
+        k = j["kernels"]["k_accumulate"]
     except (KeyError, ValueError):
-        return None
+        return None, info
+    info.update({"profiled_at_commit": j.get("commit"), "sources_sha_profiled": j.get("kernel_sources_sha"),
+                 "correction": j.get("correction"), "fetch_bytes_raw": k.get("fetch_bytes_raw"), "write_bytes": k.get("write_bytes")})
+    if j.get("kernel_sources_sha") != info["sources_sha_now"]:
+        info["stale"] = True
+        info["stale_value"] = k.get("hbm_bytes_per_launch")
+        return None, info
+    info["stale"] = False
+    return k.get("hbm_bytes_per_launch"), info
 
 
 def algorithmic_bytes(n, W, B, bls=False):
@@ -55,6 +82,7 @@ def main():
     ap.add_argument("--scalars", choices=["uniform", "equal", "small"], default="uniform",
                     help="uniform: the harness's distribution; equal: one scalar repeated (worst-case skew); small: 64-bit scalars")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sizes", action="store_true", help="skip the n = 2^16..2^19 side table")
     ap.add_argument("--segment-len", type=int, default=0)
     ap.add_argument("--curve", choices=("te", "bls12-377"), default="te",
                     help="te: the Twisted-Edwards BLS12 curve (headline); bls12-377: G1 of BLS12-377, BASELINE config 5 (single GPU)")
@@ -73,37 +101,58 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     force_dist = os.environ.get("TE_BENCH_FORCE_DIST") == "1"      # rehearsal: run the N > 1 code path with one rank over RCCL
+    share = os.environ.get("TE_BENCH_SHARE_GPU") == "1"            # rehearsal on a one-GPU box: every rank on cuda:0, exchange over gloo
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d); got WORLD_SIZE=%d"
+                         % (args.gpus, args.gpus, args.gpus, world))
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if force_dist and world == 1:
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("MASTER_PORT", "29533")
-        # TE_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box): every rank uses cuda:0 and the exchange goes over gloo
-        share = os.environ.get("TE_BENCH_SHARE_GPU") == "1"
         if share:
             local_rank = 0
             dist.init_process_group("gloo")
         else:
+            if local_rank >= torch.cuda.device_count():
+                raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible (set TE_BENCH_SHARE_GPU=1 to rehearse on one GPU)"
+                                 % (rank, local_rank, torch.cuda.device_count()))
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
     dev = local_rank if world > 1 else 0
     torch.cuda.set_device(dev)
+    if world > 1 and not share:
+        # one process per GPU: no two ranks may resolve to the same physical device
+        props = torch.cuda.get_device_properties(dev)
+        tag = str(getattr(props, "uuid", None) or getattr(props, "pci_bus_id", None) or "dev%d" % dev)
+        ident = torch.tensor([int(hashlib.sha256(tag.encode()).hexdigest()[:12], 16)], dtype=torch.int64, device="cuda")
+        allid = [torch.zeros_like(ident) for _ in range(world)]
+        dist.all_gather(allid, ident)
+        ids = [int(t.item()) for t in allid]
+        if len(set(ids)) != world:
+            raise SystemExit("two ranks share a GPU (device uuids %s): --gpus %d needs %d distinct devices, or TE_BENCH_SHARE_GPU=1 for a rehearsal" % (ids, world, world))
 
     pkg = importlib.import_module(PKG)
-
-    n = 1 << args.log2n
-    seed = 0x5EED0000 + args.log2n
-    t0 = time.time()
     bls = args.curve == "bls12-377"
     assert not (bls and (world > 1 or force_dist)), "BLS12-377 is single-GPU (window sharding is Twisted-Edwards only)"
+    sharded = world > 1 or force_dist
+    pipelined = not args.no_pipeline
+    depth = max(1, min(args.inflight or (8 if sharded else 4), pkg.WORKSETS))
     sb = 48 if bls else 32
-    pts, sc = pkg.synth_inputs(seed, n, fixed_point=(args.points != "chain"),      # the engine's own harness inputs
-                               curve=pkg.CURVE_BLS12_377_G1 if bls else pkg.CURVE_TE_BLS12)
-    if args.scalars == "equal":
-        sc = sc[:sb] * n
-    elif args.scalars == "small":
-        sc = b"".join(sc[sb * i:sb * i + 8] + bytes(sb - 8) for i in range(n))
-    gen_s = time.time() - t0
+
+    def make_inputs(log2n):
+        n = 1 << log2n
+        pts, sc = pkg.synth_inputs(0x5EED0000 + log2n, n, fixed_point=(args.points != "chain"),      # the engine's own harness inputs
+                                   curve=pkg.CURVE_BLS12_377_G1 if bls else pkg.CURVE_TE_BLS12)
+        if args.scalars == "equal":
+            sc = sc[:sb] * n
+        elif args.scalars == "small":
+            sc = b"".join(sc[sb * i:sb * i + 8] + bytes(sb - 8) for i in range(n))
+        return pts, sc
+
+    n = 1 << args.log2n
+    pts, sc = make_inputs(args.log2n)
     d_pts = torch.frombuffer(bytearray(pts), dtype=torch.uint8).cuda()
     d_sc = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
     torch.cuda.synchronize()
@@ -118,7 +167,8 @@ def main():
     ctx.set_option("profile", 1)          # two HIP events around the dominant kernel, on the engine's stream
     c, W = ctx.plan(n)
     B = 1 << (c - 1 if args.digits == "signed" else c)
-    if world > 1 or force_dist:
+    rehearse = 0
+    if sharded:
         # TE_BENCH_REHEARSE_WORLD=D (with TE_BENCH_FORCE_DIST=1, one rank): this rank does the work of rank 0 of D -- the
         # per-rank step of a D-GPU run without the other D-1 GPUs.  The result is a partial sum: no parity claim is made.
         rehearse = int(os.environ.get("TE_BENCH_REHEARSE_WORLD", "0")) if (force_dist and world == 1) else 0
@@ -131,9 +181,6 @@ def main():
             return pkg.compute_msm_sharded(ctx, d_pts, d_sc, n, partials, dist, None, gather_list)
         return ctx.run_device(d_pts.data_ptr(), d_sc.data_ptr(), n)
 
-    pipelined = not args.no_pipeline
-    sharded = world > 1 or force_dist
-    depth = max(1, min(args.inflight or (8 if sharded else 4), pkg.WORKSETS))
     pipe = pkg.ShardedPipeline(ctx, n, dist, depth=depth) if (sharded and pipelined) else None
 
     result = None
@@ -160,7 +207,7 @@ def main():
 
     # latency of ONE synchronous MSM (device stages + read-back + host tail), before the timed throughput region
     lat = []
-    for _ in range(3):
+    for _ in range(5):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         step()
@@ -217,20 +264,35 @@ def main():
     stage_ms = {k: v / extra for k, v in stage_acc.items()}
     ctx.set_option("profile", 1)
     whole_bytes, acc_bytes = algorithmic_bytes(n, W, B, bls)
-    acc_bytes_rank = acc_bytes / world                    # windows are sharded
+    div = rehearse or world
+    acc_bytes_rank = acc_bytes / div                      # windows are sharded
     acc_ms = acc_ms_live
     achieved = acc_bytes_rank / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
+    traffic, traffic_info = (None, None) if bls else measured_traffic(args.log2n, c, world if not rehearse else rehearse)
+
+    # VALU-issue roofline of the dominant kernel: wave instructions per launch from the ISA listing
+    # (profiles/r02_isa_hist_k_accumulate.txt) x measured issue cost against 1024 SIMDs
+    per_point_cycles = None if bls else 6553.0            # estimated VALU issue cycles per 64 accumulated points (tools/isa_hist.py)
+    valu = None
+    if per_point_cycles and acc_ms > 0:
+        waves = (W / div) * n / 64.0
+        floor_ms = waves * per_point_cycles / 1024.0 / 2.4e6          # at the 2.4 GHz peak clock
+        valu = {"bound": "valu-issue", "floor_ms_at_2.4GHz": floor_ms, "kernel_ms": acc_ms, "frac": floor_ms / acc_ms,
+                "alone_frac": floor_ms / stage_ms["accumulate"] if stage_ms.get("accumulate") else None,
+                "note": "1134 v_mad_u64_u32 (4.49 clk each, half rate) + ~450 full-rate VALU instructions per accumulated point and wave"}
 
     out = {
-        "metric": "MSMs/sec at n=2^%d %s (latency in ms_per_step)" % (args.log2n, "BLS12-377 G1" if bls else "Twisted-Edwards BLS12"),
+        "metric": "MSMs/sec at n=2^%d %s (pipelined throughput = 1000/ms_per_step; single-MSM latency in latency_ms)" % (args.log2n, "BLS12-377 G1" if bls else "Twisted-Edwards BLS12"),
         "value": args.steps / elapsed,
         "unit": "MSM/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        "latency_ms": min(lat),
         "latency_ms_single_msm": min(lat),
-        "mode": (("pipelined: %d MSMs in flight (te_msm_submit_device / te_msm_collect)" if world == 1 else "pipelined: %d window-sharded MSMs in flight per rank") % depth) if pipelined else "synchronous: one MSM at a time",
+        "host_buffers_ms": None,
+        "mode": (("pipelined: %d MSMs in flight (te_msm_submit_device / te_msm_collect)" if world == 1 and not sharded else "pipelined: %d window-sharded MSMs in flight per rank") % depth) if pipelined else "synchronous: one MSM at a time",
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -238,35 +300,91 @@ def main():
         "data": "synthetic",
         "config": {"workload": "n=2^%d %s MSM, %d-bit %s windows (%d windows x %d buckets), points=%s, scalars=%s, inputs resident in HBM"
                                % (args.log2n, "BLS12-377 G1" if bls else "TE-BLS12", c, args.digits, W, B, args.points, args.scalars),
+                   "points_note": ("chain = n distinct subgroup points (a + i*b)*G, an arithmetic progression generated by te_msm_synth_inputs "
+                                   "(SURVEY 8d asks for seeded-random a_i*G: performance-equivalent -- every point is a distinct, "
+                                   "uniformly spread field element; tests/ use the oracle's seeded-random points)") if args.points == "chain" else "harness mode: one fixed point replicated",
                    "parallelism": "windows sharded over %d GPU(s), RCCL all-gather of %d B partial sums" % (world, W * 720) if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None if bls else measured_traffic(args.log2n, c, world),
-                     "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; 2 x FETCH + WRITE)",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_info": traffic_info,
                      "algorithmic_bytes_per_launch": acc_bytes_rank, "kernel_ms": acc_ms,
                      # the timed region keeps `depth` MSMs in flight: the kernel shares the GPU with the other MSMs' kernels,
                      # so its duration there is longer than when it has the GPU to itself (untimed single-MSM pass)
                      "alone": {"kernel_ms": stage_ms.get("accumulate"),
                                "achieved": acc_bytes_rank / (stage_ms["accumulate"] * 1e-3) / 1e9 if stage_ms.get("accumulate") else None,
                                "frac": acc_bytes_rank / (stage_ms["accumulate"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if stage_ms.get("accumulate") else None},
-                     "note": ("VALU-bound: 11 products of 14-limb operands per gathered point (first, untuned version)" if bls else
-                              "VALU-bound, not HBM-bound: 7 field products = 1637 instructions per gathered point, "
-                              "~97 % of the measured v_mad_u64_u32 issue rate (DESIGN.md section 6)")},
+                     "binding_roofline": valu,
+                     "note": ("VALU-bound: 11 products of 14-limb operands per gathered point" if bls else
+                              "the north star names the HBM roofline; the kernel is VALU-issue bound (7 field products per gathered "
+                              "point, see binding_roofline and DESIGN.md section 4)")},
         "msm_algorithmic_bytes": whole_bytes,
         "msm_algorithmic_gbps": whole_bytes / (ms_per_step * 1e-3) / 1e9,
         "stage_ms_untimed_pass": stage_ms,
         "result_x": str(int.from_bytes(result[:32], "little")),
     }
+    if sharded:
+        out["rccl_ranks"] = dist.get_world_size()
+        out["backend"] = dist.get_backend()
+        # per-rank dominant-kernel time (live, last MSM of the timed region), gathered so that rank 0 reports all of them
+        km = torch.tensor([acc_ms], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+        kms = [torch.zeros_like(km) for _ in range(world)]
+        dist.all_gather(kms, km)
+        out["per_rank_kernel_ms"] = [float(x.item()) for x in kms]
 
-    if rank == 0 and world == 1:
+    def host_buffer_ms(cx, p, s, reps=3):
+        """one te_msm_run from pageable host buffers, default options (profile 0: the chunked-upload path of te_msm_run)"""
+        prof = cx.get_option("profile")
+        cx.set_option("profile", 0)
+        ts = []
+        try:
+            for _ in range(reps):
+                t1 = time.perf_counter()
+                r = cx.run(p, s)
+                ts.append((time.perf_counter() - t1) * 1e3)
+        finally:
+            cx.set_option("profile", prof)
+        return min(ts), r
+
+    if rank == 0 and world == 1 and not sharded:
         # the boundary hands over host buffers (te_msm_run): PCIe-inclusive latency, reported but never `value`
-        t_pcie = []
-        for _ in range(2):
-            t1 = time.perf_counter()
-            r_host = ctx.run(pts, sc)
-            t_pcie.append((time.perf_counter() - t1) * 1e3)
-        out["pcie_inclusive_ms_host_buffers"] = min(t_pcie)
+        hb, r_host = host_buffer_ms(ctx, pts, sc)
+        out["host_buffers_ms"] = hb
+        out["pcie_inclusive_ms_host_buffers"] = hb
+        out["host_buffers_path"] = "te_msm_run, profile 0, host_chunks=%d (0 = automatic: 4 pieces from 2^20 points, 2 from 2^18)" % ctx.get_option("host_chunks")
+        out["host_buffers_gbps"] = (len(pts) + len(sc)) / (hb * 1e-3) / 1e9
         assert r_host == result
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["sizes"] = {str(args.log2n): {"ms_per_step": ms_per_step, "latency_ms": min(lat), "host_buffers_ms": hb, "window_bits": c}}
+        if not args.no_sizes and not bls and args.log2n == 20:
+            # the other harness sizes (full_benchmarks.ts:13-15), short runs, window size chosen by the engine
+            with pkg.MsmContext((dev,)) as sx:
+                sx.set_option("signed_digits", 1 if args.digits == "signed" else 0)
+                for lg in (16, 17, 18, 19):
+                    m = 1 << lg
+                    p2, s2 = make_inputs(lg)
+                    dp2 = torch.frombuffer(bytearray(p2), dtype=torch.uint8).cuda()
+                    ds2 = torch.frombuffer(bytearray(s2), dtype=torch.uint8).cuda()
+                    torch.cuda.synchronize()
+                    for t in [sx.submit_device(dp2.data_ptr(), ds2.data_ptr(), m) for _ in range(depth)]:
+                        ref = sx.collect(t)
+                    l2 = []
+                    for _ in range(3):
+                        t1 = time.perf_counter()
+                        assert sx.run_device(dp2.data_ptr(), ds2.data_ptr(), m) == ref
+                        l2.append((time.perf_counter() - t1) * 1e3)
+                    reps = 40
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    tk = []
+                    for _ in range(reps):
+                        tk.append(sx.submit_device(dp2.data_ptr(), ds2.data_ptr(), m))
+                        if len(tk) >= depth:
+                            sx.collect(tk.pop(0))
+                    while tk:
+                        sx.collect(tk.pop(0))
+                    per = (time.perf_counter() - t1) * 1e3 / reps
+                    hb2, r2 = host_buffer_ms(sx, p2, s2)
+                    assert r2 == ref
+                    out["sizes"][str(lg)] = {"ms_per_step": per, "latency_ms": min(l2), "host_buffers_ms": hb2, "window_bits": sx.plan(m)[0]}
+    if rank == 0 and world == 1 and not sharded and not args.no_cpu_baseline:
         threads = args.cpu_threads or min(16, os.cpu_count() or 1)
         t0 = time.perf_counter()
         if bls:

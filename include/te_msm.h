@@ -73,7 +73,10 @@ int te_msm_run_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_sca
  * tail of MSM k overlaps the device work of MSM k+1, and on the GPU the launch gaps and the latency-bound reduction tail
  * of one MSM are filled by the wide kernels of the others (the reference's full_benchmarks.ts loop awaits each call; a
  * prover calling MSMs back to back does not have to).
- * Inputs must stay valid until the ticket is collected.  Tickets must be collected in submission order. */
+ * Inputs must stay valid until the ticket is collected.  Tickets must be collected in submission order.
+ * A work set owned by an uncollected ticket is never reused underneath it: te_msm_run / te_msm_run_device move to a
+ * free work set (TE_MSM_ESTATE when all TE_MSM_WORKSETS are owned), te_msm_partial_device on such a set returns
+ * TE_MSM_ESTATE.  A ticket is consumed by te_msm_collect whether it ends in a result or in TE_MSM_ESCALAR. */
 int te_msm_submit_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_scalars_le, uint64_t n, uint64_t* ticket);
 int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]);
 
@@ -121,7 +124,9 @@ int te_msm_partial_device(te_ctx* ctx, const void* d_points_xy_le, const void* d
 int te_msm_partial_wait(te_ctx* ctx, int workset);
 /* Host tail (replaces submission.ts:362-412: de-Montgomery, sum, Horner, toAffine): folds the W rows
  * (host memory; rows of absent windows all-zero are skipped as identity) into the affine result.
- * Waits for, and reports a pending TE_MSM_ESCALAR of, the last te_msm_partial_device call of this context. */
+ * Waits for, and reports a pending TE_MSM_ESCALAR of, the last te_msm_partial_device call of this context.  The digit
+ * form (signed / unsigned) is the one that call ran with, whatever the option says now; window_bits and num_windows
+ * must be that call's (te_msm_plan), otherwise TE_MSM_ESTATE -- rows from elsewhere go to te_msm_finalize_host_ex. */
 int te_msm_finalize(te_ctx* ctx, const uint8_t* partials, int window_bits, int num_windows,
                     uint8_t out_xy_le[64]);
 

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Instruction-class histogram of one kernel in the gfx950 ISA listing (`make -C csrc asm`).
+
+usage: tools/isa_hist.py <listing.s> <kernel-substring> [--loop]
+  --loop   restrict to the hottest loop: the basic blocks between the LAST backward branch target and that branch
+           (k_accumulate's per-point loop)
+Prints the count per mnemonic and per class, with the issue cost measured by tools/ubench.hip
+(profiles/r01_ubench_instruction_rates.txt: cycles per wave instruction at 4 waves/SIMD).
+"""
+import re
+import sys
+from collections import Counter
+
+# measured issue cost (cycles / wave instruction, 4 waves per SIMD); unknown VALU mnemonics default to 4.3 (VOP3)
+COST = {"v_mad_u64_u32": 4.49, "v_add_u32": 2.62, "v_sub_u32": 2.62, "v_subrev_u32": 2.62, "v_and_b32": 2.62, "v_or_b32": 2.62, "v_xor_b32": 2.62,
+        "v_mov_b32": 2.41, "v_lshrrev_b64": 4.17, "v_lshlrev_b64": 4.17, "v_lshl_add_u64": 4.17, "v_cndmask_b32": 4.29, "v_add3_u32": 4.29,
+        "v_lshrrev_b32": 2.62, "v_lshlrev_b32": 2.62, "v_alignbit_b32": 4.28, "v_and_or_b32": 4.29, "v_lshl_or_b32": 4.29, "v_lshl_add_u32": 4.29,
+        "v_bfe_u32": 4.29, "v_add_co_u32": 4.19, "v_addc_co_u32": 4.19, "v_sub_co_u32": 4.19, "v_subb_co_u32": 4.19, "v_mul_lo_u32": 4.30,
+        "v_mul_hi_u32": 4.27}
+
+
+def kernel_body(lines, name):
+    start = None
+    for i, l in enumerate(lines):
+        if re.match(r"^_Z\w*%s\w*:" % re.escape(name), l):
+            start = i
+            break
+    if start is None:
+        raise SystemExit("kernel not found: " + name)
+    body = []
+    for l in lines[start + 1:]:
+        if l.startswith("\t.section") or l.startswith(".Lfunc_end") or l.strip().startswith("s_endpgm") and False:
+            break
+        body.append(l.rstrip("\n"))
+    return body
+
+
+def main():
+    path, name = sys.argv[1], sys.argv[2]
+    loop_only = "--loop" in sys.argv
+    lines = open(path).read().split("\n")
+    body = kernel_body(lines, name)
+    # instructions with their label context
+    labels, instrs = {}, []
+    for l in body:
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m:
+            labels[m.group(1)] = len(instrs)
+            continue
+        s = l.strip()
+        if not s or s.startswith(";") or s.startswith(".") or s.endswith(":"):
+            continue
+        instrs.append(s.split(";")[0].strip())
+    lo, hi = 0, len(instrs)
+    if loop_only:
+        best = None
+        for i, ins in enumerate(instrs):
+            m = re.match(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", ins)
+            if m and m.group(1) in labels and labels[m.group(1)] <= i:
+                span = i - labels[m.group(1)]
+                if best is None or span > best[2]:
+                    best = (labels[m.group(1)], i + 1, span)
+        if best is None:
+            raise SystemExit("no backward branch found")
+        lo, hi = best[0], best[1]
+    ops = Counter(ins.split()[0] for ins in instrs[lo:hi])
+    ops = Counter({re.sub(r"_e(32|64)$|_dpp$|_sdwa$", "", k): 0 for k in ops}) + Counter()
+    for ins in instrs[lo:hi]:
+        ops[re.sub(r"_e(32|64)$|_dpp$|_sdwa$", "", ins.split()[0])] += 1
+    total = sum(ops.values())
+    valu = {k: v for k, v in ops.items() if k.startswith("v_")}
+    cyc = sum(COST.get(k, 4.3) * v for k, v in valu.items())
+    print("kernel %s: %s, %d instructions (%d VALU, %d SALU, %d memory, %d other)" % (
+        name, "hottest loop" if loop_only else "whole kernel", total, sum(valu.values()),
+        sum(v for k, v in ops.items() if k.startswith("s_") and not k.startswith(("s_waitcnt", "s_nop", "s_cbranch", "s_branch"))),
+        sum(v for k, v in ops.items() if k.startswith(("global_", "flat_", "buffer_", "ds_", "scratch_"))),
+        sum(v for k, v in ops.items() if k.startswith(("s_waitcnt", "s_nop", "s_cbranch", "s_branch")))))
+    print("estimated VALU issue: %.0f cycles per wave pass (mads %.0f)" % (cyc, COST["v_mad_u64_u32"] * ops.get("v_mad_u64_u32", 0)))
+    for k, v in sorted(ops.items(), key=lambda kv: -kv[1]):
+        print("  %-24s %6d  %5.1f %%%s" % (k, v, 100.0 * v / total, ("   ~%.2f cyc" % COST[k]) if k in COST else ""))
+
+
+if __name__ == "__main__":
+    main()

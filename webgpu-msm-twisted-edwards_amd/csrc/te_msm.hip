@@ -79,6 +79,8 @@ struct workset_t {
   hipEvent_t ev_done = nullptr;
   hipEvent_t ev[ST_COUNT + 1] = {};
   plan_t plan; uint64_t n = 0; bool used = false;
+  uint64_t pending_ticket = 0;        // ticket of an MSM submitted on this set and not collected yet (0 = none)
+  int prof_level = 0;                 // profile level the events of the last enqueue were recorded at
   hipStream_t last_stream = nullptr;  // stream of the previous MSM on this set: a different one must wait for it (scratch reuse)
   uint64_t generation = 0;            // bumped whenever ensure() reallocates a buffer of this set
   hipGraphExec_t g_front = nullptr, g_back = nullptr; graph_key g_key = {};
@@ -452,13 +454,18 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, 
   if (int rc = ensure_buffers(ctx, d, ws, n, p)) return rc;
   if (ws.used && ws.last_stream != stream) HIP_TRY(ctx, hipStreamWaitEvent(stream, ws.ev_done, 0));   // the set's buffers are still the previous MSM's
   ws.plan = p; ws.n = n; ws.used = true; ws.last_stream = stream; d.last_ws = (int)(&ws - d.ws);
+  ws.prof_level = ctx->opt_profile;
   // profile 1: two events around the dominant kernel only (what bench.py times live); 2: every stage boundary
   // (an event between two kernels costs ~4 us of idle stream time, 11 of them ~2 % of a 2^20 MSM)
   msm_launch L{ctx, d, ws, p, d_points, d_scalars, n, d_partials_out, ctx->opt_profile, stream};
   if (ctx->opt_graph && ctx->opt_profile < 2 && !before_points) {
     // the graphs hold pointers and geometry: re-captured when any of them changes (including a buffer reallocation)
-    const graph_key key{d_points, d_scalars, d_partials_out, n, ws.generation, p.c, d.w_first, d.w_step, (int)p.seg_len, ctx->opt_sort | (ctx->opt_signed << 1) | (ctx->opt_curve << 2)};
+    graph_key key; memset(&key, 0, sizeof key);          // padding bytes take part in the memcmp below
+    key.pts = d_points; key.sc = d_scalars; key.out = d_partials_out; key.n = n; key.generation = ws.generation;
+    key.c = p.c; key.w_first = d.w_first; key.w_step = d.w_step; key.seg_len = (int)p.seg_len;
+    key.sort = ctx->opt_sort | (ctx->opt_signed << 1) | (ctx->opt_curve << 2);
     if (!ws.g_front || !ws.g_back || memcmp(&key, &ws.g_key, sizeof key) != 0) {
+      if (ws.g_front || ws.g_back) HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));   // a previous replay may still be running
       msm_launch C = L; C.stream = ws.stream; C.prof = 0;
       if (int rc = capture_graph(ctx, ws, ws.g_front, [&] { return C.front(); })) return rc;
       if (int rc = capture_graph(ctx, ws, ws.g_back, [&] { return C.back(); })) return rc;
@@ -481,14 +488,18 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, 
   return 0;
 }
 
+// Stage times of the MSM that last ran on `ws`, read from the events recorded at ITS profile level (the option may have
+// changed since).  Never fatal: a failed read leaves "no stage times" instead of losing the MSM's result.
 int collect_stage_ms(te_ctx* ctx, workset_t& ws) {
-  if (!ctx->opt_profile) return 0;
+  if (!ws.prof_level) return 0;
+  bool ok = true;
   for (int i = 0; i < ST_COUNT; i++) {
     float ms = -1.0f;
-    if (ctx->opt_profile >= 2 || i == ST_ACCUM) HIP_TRY(ctx, hipEventElapsedTime(&ms, ws.ev[i], ws.ev[i + 1]));
+    if (ws.prof_level >= 2 || i == ST_ACCUM) ok = ok && hipEventElapsedTime(&ms, ws.ev[i], ws.ev[i + 1]) == hipSuccess;
     ctx->stage_ms[i] = ms;
   }
-  ctx->have_stage_ms = true;
+  if (!ok) (void)hipGetLastError();
+  ctx->have_stage_ms = ok;
   return 0;
 }
 
@@ -572,12 +583,20 @@ int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, boo
     const int K = ctx->opt_host_chunks ? ctx->opt_host_chunks : (n >= (1ull << 20) ? 4 : n >= (1ull << 18) ? 2 : 1);
     if (K > 1 && n >= (uint64_t)K) return run_host_chunked(ctx, static_cast<const uint8_t*>(src_points), static_cast<const uint8_t*>(src_scalars), n, K, out);
   }
+  // the work set this call runs on: the selected one, unless a submitted MSM still owns it (tickets exist on
+  // single-device contexts only) -- then any free one; with every set owned by a ticket the call is refused
+  int wsel = ctx->opt_workset;
+  if (ctx->devs[0].ws[wsel].pending_ticket) {
+    wsel = -1;
+    for (int i = 0; i < TE_MSM_WORKSETS && wsel < 0; i++) if (!ctx->devs[0].ws[i].pending_ticket) wsel = i;
+    if (wsel < 0) return set_err(ctx, TE_MSM_ESTATE, "every work set holds a submitted MSM that has not been collected: te_msm_collect one first");
+  }
   plan_t p0; make_plan(ctx, ctx->devs[0], n, p0);
   const curve_sizes sz = sizes_of(p0.curve);
   // stage inputs on every device
   for (size_t i = 0; i < nd; i++) {
     gpu_t& d = ctx->devs[i];
-    workset_t& ws = d.ws[ctx->opt_workset];
+    workset_t& ws = d.ws[wsel];
     HIP_TRY(ctx, hipSetDevice(d.device));
     const void *dp = src_points, *ds = src_scalars;
     if (src_is_host || i > 0) {
@@ -614,14 +633,14 @@ int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, boo
   std::vector<uint8_t> merged((size_t)p0.W * sz.row, 0);
   for (size_t i = 0; i < nd; i++) {
     gpu_t& d = ctx->devs[i];
-    workset_t& ws = d.ws[ctx->opt_workset];
+    workset_t& ws = d.ws[wsel];
     HIP_TRY(ctx, hipSetDevice(d.device));
     HIP_TRY(ctx, hipStreamSynchronize(ws.stream));
     if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
     for (int w = d.w_first; w < p0.W; w += d.w_step)
       memcpy(&merged[(size_t)w * sz.row], ws.h_partials + (size_t)w * sz.row, sz.row);
   }
-  if (int rc = collect_stage_ms(ctx, ctx->devs[0].ws[ctx->opt_workset])) return rc;
+  (void)collect_stage_ms(ctx, ctx->devs[0].ws[wsel]);
   if (p0.curve == TE_MSM_CURVE_BLS12_377_G1) te377_host::horner_to_affine(merged.data(), p0.c, (int)p0.logB, p0.W, out);
   else te_host::horner_to_affine(merged.data(), p0.c, (int)p0.logB, p0.W, out);
   return 0;
@@ -701,6 +720,7 @@ int te_msm_submit_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_
   HIP_TRY(ctx, hipMemcpyAsync(ws.h_partials, ws.d_partials, (size_t)ws.plan.W * sizes_of(ws.plan.curve).row, hipMemcpyDeviceToHost, ws.stream));
   HIP_TRY(ctx, hipEventRecord(ws.ev_done, ws.stream));
   *ticket = d.next_ticket++;
+  ws.pending_ticket = *ticket;
   return 0;
 }
 
@@ -710,9 +730,9 @@ int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]) {
   gpu_t& d = ctx->devs[0];
   if (ticket != d.next_collect || ticket >= d.next_ticket) return set_err(ctx, TE_MSM_ESTATE, "tickets must be collected in submission order");
   workset_t& ws = d.ws[ticket % TE_MSM_WORKSETS];
-  HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));
-  d.next_collect++;
-  if (int rc = collect_stage_ms(ctx, ws)) return rc;
+  HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));     // on failure the ticket stays collectable
+  (void)collect_stage_ms(ctx, ws);
+  d.next_collect++; ws.pending_ticket = 0;           // the MSM is over, with a result or with a scalar-range error
   if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
   if (ws.plan.curve == TE_MSM_CURVE_BLS12_377_G1) te377_host::horner_to_affine(ws.h_partials, ws.plan.c, (int)ws.plan.logB, ws.plan.W, out_xy_le);
   else te_host::horner_to_affine(ws.h_partials, ws.plan.c, (int)ws.plan.logB, ws.plan.W, out_xy_le);
@@ -775,6 +795,7 @@ int te_msm_partial_device(te_ctx* ctx, const void* d_points_xy_le, const void* d
   if (ctx->opt_curve != TE_MSM_CURVE_TE_BLS12) return set_err(ctx, TE_MSM_ESTATE, "window-sharded building blocks are Twisted-Edwards only");
   gpu_t& d = ctx->devs[0];
   workset_t& ws = d.ws[ctx->opt_workset];
+  if (ws.pending_ticket) return set_err(ctx, TE_MSM_ESTATE, "the selected work set holds a submitted MSM that has not been collected");
   HIP_TRY(ctx, hipSetDevice(d.device));
   return enqueue_partial(ctx, d, ws, d_points_xy_le, d_scalars_le, n, d_partials, stream == TE_MSM_OWN_STREAM ? ws.stream : (hipStream_t)stream);
 }
@@ -793,12 +814,17 @@ int te_msm_finalize(te_ctx* ctx, const uint8_t* partials, int window_bits, int n
   if (!ctx || !partials || !out_xy_le || window_bits < 2 || window_bits > 16 || num_windows < 1 || num_windows > 128) return TE_MSM_EINVAL;
   gpu_t& d = ctx->devs[0];
   workset_t& ws = d.ws[d.last_ws];
+  int bucket_bits = ctx->opt_signed ? window_bits - 1 : window_bits;
   if (ws.used) {
     HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));
     if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
-    if (int rc = collect_stage_ms(ctx, ws)) return rc;
+    (void)collect_stage_ms(ctx, ws);
+    // the rows were produced under ws.plan: its digit form decides, not an option changed since
+    if (ws.plan.curve != TE_MSM_CURVE_TE_BLS12 || window_bits != ws.plan.c || num_windows != ws.plan.W)
+      return set_err(ctx, TE_MSM_ESTATE, "te_msm_finalize: window_bits / num_windows differ from the plan of the last te_msm_partial_device call (use te_msm_finalize_host_ex for rows produced elsewhere)");
+    bucket_bits = (int)ws.plan.logB;
   }
-  te_host::horner_to_affine(partials, window_bits, ctx->opt_signed ? window_bits - 1 : window_bits, num_windows, out_xy_le);
+  te_host::horner_to_affine(partials, window_bits, bucket_bits, num_windows, out_xy_le);
   return 0;
 }
 
