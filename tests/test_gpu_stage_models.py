@@ -234,8 +234,8 @@ def test_sharded_pipeline_over_rccl(pkg, model, ora, nccl_world1):
 
 # ------------------------------------------------------------------ work-set ownership (te_msm.hip:580)
 def test_worksets_owned_by_tickets_are_not_reused(pkg, ora):
-    """eight MSMs submitted (ticket 8 lands on work set 0), then synchronous calls: they must not overwrite a work set
-    whose ticket has not been collected"""
+    """every work set owned by a submitted MSM, then synchronous calls: they must not overwrite a work set whose ticket
+    has not been collected (te_msm_run_device used to take work set 0 regardless)"""
     import torch
     K = pkg.WORKSETS
     data = []
@@ -254,8 +254,8 @@ def test_worksets_owned_by_tickets_are_not_reused(pkg, ora):
         with pytest.raises(pkg.MsmError) as e:
             c.partial_device(last[0].data_ptr(), last[1].data_ptr(), last[2], part.data_ptr())
         assert e.value.code == -4
-        assert c.collect(t[0]) == data[0][3]                      # frees work set 1 (ticket 1)
-        # work set 0 is still owned by ticket 8: the synchronous calls move to the free set
+        assert c.collect(t[0]) == data[0][3]                      # frees one work set
+        # seven sets are still owned by tickets: the synchronous calls run on the free one
         assert c.run_device(last[0].data_ptr(), last[1].data_ptr(), last[2]) == last[3]
         assert c.run(last[4], last[5]) == last[3]
         for i in range(1, K):

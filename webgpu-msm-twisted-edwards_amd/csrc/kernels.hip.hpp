@@ -625,14 +625,20 @@ __global__ void __launch_bounds__(256, 4) k_accumulate(const pnt_slot* __restric
   const uint32_t* lst = sorted + (size_t)k * n + bucket_start[g] + part * seg_len;
   ete acc = ete_identity();
   if (cnt) {
-    uint32_t e = lst[0];
+    // Software pipeline: while the addition of entry j runs, the record of entry j+1 AND the index of entry j+2 are in
+    // flight -- nothing that is loaded in an iteration is waited for in the same iteration.  (The first version fetched
+    // index j+1 and then its record inside one iteration: an s_waitcnt on the index in front of the record loads, one
+    // memory latency exposed per addition.)
+    const uint32_t last = cnt - 1u;
+    uint32_t e = lst[0], e_n = lst[min(1u, last)];
     pnt cur = load_pnt(recs, e);
     for (uint32_t j = 0; j < cnt; j++) {
       const uint32_t e_cur = e;
       pnt nxt = cur;
-      if (j + 1 < cnt) { e = lst[j + 1]; nxt = load_pnt(recs, e); }
+      const uint32_t e_nn = lst[min(j + 2u, last)];            // unconditional, clamped
+      if (j + 1 < cnt) { e = e_n; nxt = load_pnt(recs, e); }
       acc = ete_madd(acc, pnt_cneg(cur, (e_cur >> 31) != 0u));
-      cur = nxt;
+      cur = nxt; e_n = e_nn;
     }
   }
   const bool whole = bucket_count[g] <= seg_len;
@@ -661,7 +667,7 @@ struct sum_job {
   uint32_t in_per_window, out_per_window;
 };
 struct sum_jobs { sum_job j[4]; };
-__global__ void __launch_bounds__(256) k_sum_groups(sum_jobs js, uint32_t nw) {
+__global__ void __launch_bounds__(256, 2) k_sum_groups(sum_jobs js, uint32_t nw) {
   const sum_job& j = js.j[blockIdx.y];
   const uint32_t total = j.n_out * nw;
   for (uint32_t g = blockIdx.x * 256u + threadIdx.x; g < total; g += gridDim.x * 256u) {
@@ -669,7 +675,12 @@ __global__ void __launch_bounds__(256) k_sum_groups(sum_jobs js, uint32_t nw) {
     const uint32_t outer = o / j.inner, q = o - outer * j.inner;
     const ete* src = j.in + (size_t)k * j.in_per_window + (size_t)outer * j.K * j.inner + q;
     ete acc = load_ete(src);
-    for (uint32_t t = 1; t < j.K; t++) acc = ete_add(acc, load_ete(src + (size_t)t * j.inner));
+    ete nxt = load_ete(src + (size_t)j.inner);                 // K >= 2: the next operand is in flight during the addition
+    for (uint32_t t = 1; t < j.K; t++) {
+      const ete cur = nxt;
+      if (t + 1 < j.K) nxt = load_ete(src + (size_t)(t + 1) * j.inner);
+      acc = ete_add(acc, cur);
+    }
     store_ete(j.out + (size_t)k * j.out_per_window + o, acc);
   }
 }
@@ -852,6 +863,143 @@ __global__ void __launch_bounds__(64) k_weighted_sum(wsum_jobs js, ete* __restri
     __syncthreads();
   }
   if (t == 0) store_coord(reinterpret_cast<uint32_t*>(row + 1 + dgt) + w, mine);
+}
+
+// k_seg_combine and k_seg_combine_large1 in one launch: blocks [0, quad_blocks) sum the buckets cut into 2..16 parts (one quad
+// each), the remaining blocks sum the runs of 1024 parts of giant buckets (k_seg_combine_large2 finishes those).
+__global__ void __launch_bounds__(256) k_seg_combine_all(const uint32_t* __restrict__ split_list, const uint32_t* __restrict__ counts,
+                                                         const uint32_t* __restrict__ chunk_list, const uint32_t* __restrict__ bucket_count,
+                                                         const uint32_t* __restrict__ seg_base, ete* __restrict__ seg_out, ete* __restrict__ buckets,
+                                                         uint32_t seg_len, uint32_t chunk_cap, uint32_t quad_blocks) {
+  __shared__ uint32_t lds[64 * 36];
+  const uint32_t q = threadIdx.x & 3u;
+  if (blockIdx.x < quad_blocks) {
+    const uint32_t nsplit = counts[0];
+    for (uint32_t i = (blockIdx.x * 256u + threadIdx.x) >> 2; i < nsplit; i += (quad_blocks * 256u) >> 2) {
+      const uint32_t g = split_list[i];
+      const uint32_t ns = (bucket_count[g] + seg_len - 1u) / seg_len, s0 = seg_base[g];
+      fp acc = load_coord(reinterpret_cast<const uint32_t*>(seg_out + s0) + team_word(q));
+      for (uint32_t j = 1; j < ns; j++) acc = ete_add_team(acc, load_coord(reinterpret_cast<const uint32_t*>(seg_out + s0 + j) + team_word(q)), q);
+      store_coord(reinterpret_cast<uint32_t*>(buckets + g) + team_word(q), acc);
+    }
+    return;
+  }
+  const uint32_t items = min(counts[2], chunk_cap), nb = gridDim.x - quad_blocks;
+  for (uint32_t it = blockIdx.x - quad_blocks; it < items; it += nb) {
+    const uint32_t g = chunk_list[2 * it], part = chunk_list[2 * it + 1];
+    const uint32_t ns = (bucket_count[g] + seg_len - 1u) / seg_len, cnt = min(1024u, ns - part);
+    ete* base = seg_out + seg_base[g] + part;
+    const fp r = block_sum_points(base, 1u, cnt, lds);
+    if ((threadIdx.x >> 2) == 0) store_coord(reinterpret_cast<uint32_t*>(base) + team_word(q), r);
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4 tail: everything after the wide fold levels in ONE block per window (1024 threads = 256 quads, team additions, points in
+// LDS).  Replaces the last fold levels, the four second-phase chains and k_weighted_sum -- six dependent, latency-bound
+// launches of the first version.  Bucket index j = hi * L + lo with lo = (d1 d0) of w1 + w0 bits, hi = (d3 d2) of w3 + w2 bits.
+//   in : xin[hi * rx + g], g < rx   partial row sums     X2[hi] = sum_g xin[hi * rx + g]       (H = 2^(w2+w3) values)
+//        yin[h * L + lo], h < ry    partial column sums  Y2[lo] = sum_h yin[h * L + lo]        (L = 2^(w0+w1) values)
+//   A    X2 and Y2 -> LDS (two copies each: the row and the column reductions below work in place)
+//   B    M3[d3] = sum_d2 X2, M2[d2] = sum_d3 X2, M1[d1] = sum_d0 Y2, M0[d0] = sum_d1 Y2 as binary trees, all four at once
+//   C    per digit: suffix scan S_v = sum_{u >= v} M[u], T = S_0 of digit 0, W_k = sum_{v >= 1} S_v by a tree
+//   out: row [T | W0 | W1 | W2 | W3] of the window (what te_host::horner_to_affine folds).
+struct tail_params {
+  const ete* xin; const ete* yin;
+  uint32_t rx, ry, x_per_window, y_per_window;
+  uint32_t w[4];
+  ete* rows; uint32_t row_stride;   // points
+};
+__device__ __forceinline__ uint32_t* lds_point(uint32_t* base, uint32_t idx) { return base + (size_t)idx * 36u; }
+
+__global__ void __launch_bounds__(1024) k_reduce_tail(tail_params prm) {
+  extern __shared__ uint32_t tl[];
+  const uint32_t k = blockIdx.x, i = threadIdx.x >> 2, q = threadIdx.x & 3u, wq = team_word(q), Q = blockDim.x >> 2;
+  const uint32_t w0 = prm.w[0], w1 = prm.w[1], w2 = prm.w[2], w3 = prm.w[3];
+  const uint32_t H = 1u << (w2 + w3), L = 1u << (w0 + w1);
+  uint32_t* sx = tl;                       // X2, reduced along d2 (rows)      -> M3[d3] at sx[d3 << w2]
+  uint32_t* sx2 = sx + (size_t)H * 36u;    // X2, reduced along d3 (columns)   -> M2[d2] at sx2[d2]
+  uint32_t* sy = sx2 + (size_t)H * 36u;    // Y2, reduced along d0             -> M1[d1] at sy[d1 << w0]
+  uint32_t* sy2 = sy + (size_t)L * 36u;    // Y2, reduced along d1             -> M0[d0] at sy2[d0]
+  uint32_t* sc = sy2 + (size_t)L * 36u;    // 64 points of scratch for step C
+  // ---- A
+  for (uint32_t o = i; o < H + L; o += Q) {
+    const bool isx = o < H;
+    const uint32_t lo = o - H;
+    const ete* src = isx ? prm.xin + (size_t)k * prm.x_per_window + (size_t)o * prm.rx : prm.yin + (size_t)k * prm.y_per_window + lo;
+    const uint32_t stride = isx ? 1u : L, cnt = isx ? prm.rx : prm.ry;
+    fp acc = load_coord(reinterpret_cast<const uint32_t*>(src) + wq);
+    for (uint32_t t = 1; t < cnt; t++) acc = ete_add_team(acc, load_coord(reinterpret_cast<const uint32_t*>(src + (size_t)t * stride) + wq), q);
+    store_coord(lds_point(isx ? sx : sy, isx ? o : lo) + wq, acc);
+    store_coord(lds_point(isx ? sx2 : sy2, isx ? o : lo) + wq, acc);
+  }
+  __syncthreads();
+  // ---- B: job j sums m_j inputs per output in place: item (o, t), t < m/2: in[o, t] += in[o, t + m/2]
+  {
+    uint32_t m[4] = {1u << w2, 1u << w3, 1u << w0, 1u << w1};            // inputs per output: M3, M2, M1, M0
+    const uint32_t nout[4] = {1u << w3, 1u << w2, 1u << w1, 1u << w0};
+    const uint32_t ostr[4] = {1u << w2, 1u, 1u << w0, 1u}, istr[4] = {1u, 1u << w2, 1u, 1u << w0};
+    uint32_t* const base[4] = {sx, sx2, sy, sy2};
+    for (;;) {
+      uint32_t items[4], total = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) { items[j] = m[j] > 1u ? nout[j] * (m[j] >> 1) : 0u; total += items[j]; }
+      if (total == 0) break;                                              // uniform
+      for (uint32_t it0 = 0; it0 < total; it0 += Q) {                    // uniform trip count: every quad reaches the barriers
+        const uint32_t it = it0 + i;
+        uint32_t jj = 0, rel = it;
+        bool act = it < total;
+#pragma unroll
+        for (int j = 0; j < 3; j++) if (act && jj == (uint32_t)j && rel >= items[j]) { rel -= items[j]; jj = j + 1; }
+        uint32_t a_idx = 0, b_idx = 0;
+        uint32_t* bs = sx;
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (jj == (uint32_t)j) {
+          const uint32_t half = m[j] >> 1, o = act ? rel / half : 0u, t = act ? rel - o * half : 0u;
+          a_idx = o * ostr[j] + t * istr[j]; b_idx = a_idx + half * istr[j]; bs = base[j];
+        }
+        if (!act) { a_idx = 0; b_idx = 0; }
+        const fp a = load_coord(lds_point(bs, a_idx) + wq), b = load_coord(lds_point(bs, b_idx) + wq);
+        const fp sum = ete_add_team(a, b, q);
+        if (act) store_coord(lds_point(bs, a_idx) + wq, sum);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 4; j++) if (m[j] > 1u) m[j] >>= 1;
+    }
+  }
+  // ---- C: quad i = digit * 16 + v (64 quads); the other quads only keep the barriers company
+  {
+    const uint32_t dgt = (i >> 4) & 3u, v = i & 15u;
+    const bool mineq = i < 64u;
+    const uint32_t N = 1u << (dgt == 0 ? w0 : dgt == 1 ? w1 : dgt == 2 ? w2 : w3);
+    const uint32_t* mp = dgt == 0 ? lds_point(sy2, v) : dgt == 1 ? lds_point(sy, v << w0) : dgt == 2 ? lds_point(sx2, v) : lds_point(sx, v << w2);
+    fp mine = (mineq && v < N) ? load_coord(mp + wq) : identity_coord(q);
+    __syncthreads();
+    uint32_t* slot = lds_point(sc, i & 63u);
+    for (uint32_t d = 1; d < 16u; d <<= 1) {           // inclusive suffix scan
+      if (mineq) store_coord(slot + wq, mine);
+      __syncthreads();
+      const bool act = mineq && v + d < N;
+      const fp other = act ? load_coord(lds_point(sc, (i & 63u) + d) + wq) : identity_coord(q);
+      const fp sum = ete_add_team(mine, other, q);
+      mine = fp_select(act, sum, mine);
+      __syncthreads();
+    }
+    ete* row = prm.rows + (size_t)k * prm.row_stride;
+    if (mineq && v == 0) { if (dgt == 0) store_coord(reinterpret_cast<uint32_t*>(row) + wq, mine); mine = identity_coord(q); }
+    for (uint32_t s = 8; s > 0; s >>= 1) {             // tree sum of S_1..S_{N-1} (slot 0 = identity)
+      if (mineq && v >= s && v < 2 * s) store_coord(slot + wq, mine);
+      __syncthreads();
+      const bool act = mineq && v < s && v + s < N;
+      const fp other = act ? load_coord(lds_point(sc, (i & 63u) + s) + wq) : identity_coord(q);
+      const fp sum = ete_add_team(mine, other, q);
+      mine = fp_select(act, sum, mine);
+      __syncthreads();
+    }
+    if (mineq && v == 0) store_coord(reinterpret_cast<uint32_t*>(row + 1 + dgt) + wq, mine);
+  }
 }
 
 }  // namespace te

@@ -94,6 +94,7 @@ struct gpu_t {
   int last_ws = 0;
   void *d_in_points = nullptr, *d_in_scalars = nullptr; uint64_t cap_in = 0;   // te_msm_run staging
   uint64_t next_ticket = 1, next_collect = 1;
+  int ticket_ws[TE_MSM_WORKSETS] = {};   // work set of ticket t at index t % TE_MSM_WORKSETS
 };
 
 }  // namespace
@@ -341,6 +342,53 @@ struct msm_launch {
     return 0;
   }
 
+  // K4/K5 for the Twisted-Edwards curve (see kernels.hip.hpp, K4a and k_reduce_tail).  Bucket index j = hi * L + lo:
+  //   rows chain  xin[hi * r + g]  -- the low L = 2^(w0+w1) part folded from the top, 8 (4, 2) sub-blocks at a time
+  //   cols chain  yin[h * L + lo]  -- the high H = 2^(w2+w3) part folded from the top
+  // Wide levels (both chains per launch, one thread or one quad per output) run until at most 4 partial sums per output
+  // are left; k_reduce_tail (one block per window) does the rest and writes the row.  n = 2^20, c = 16: two fold
+  // launches (32768 -> 4096 -> 512 points per window and chain) + the tail, against nine launches of the first version.
+  int back_reduce_te() {
+    const uint32_t w0 = p.dw[0], w1 = p.dw[1], w2 = p.dw[2], w3 = p.dw[3];
+    const uint32_t L = 1u << (w0 + w1), H = 1u << (w2 + w3);
+    struct chain_t { const te::ete* cur; uint32_t n, r; te::ete* buf[2]; int pp; };
+    chain_t ch[2] = {{ws.d_buckets, p.B, L, {ws.d_red[0], ws.d_red[1]}, 0}, {ws.d_buckets, p.B, H, {ws.d_red[2], ws.d_red[3]}, 0}};
+    for (;;) {
+      te::sum_jobs js; memset(&js, 0, sizeof js);
+      uint32_t most = 0; int nj = 0;
+      for (int i = 0; i < 2; i++) {
+        chain_t& c = ch[i];
+        if (c.r <= 4u) continue;
+        const uint32_t K = (c.r % 8u == 0) ? 8u : (c.r % 4u == 0) ? 4u : 2u;
+        te::sum_job& j = js.j[nj++];
+        j.in = c.cur; j.out = c.buf[c.pp]; j.K = K; j.n_out = c.n / K;
+        j.inner = i == 0 ? c.r / K : (c.r / K) * L;          // rows: sub-blocks inside one hi; cols: whole slabs of L
+        j.in_per_window = c.n; j.out_per_window = c.n / K;
+        c.cur = j.out; c.pp ^= 1; c.r /= K; c.n /= K;
+        most = std::max(most, j.n_out * (uint32_t)p.nw);
+      }
+      if (!nj) break;
+      if (most >= 65536u) {               // at least one wave per SIMD with a thread per output: throughput-bound level
+        uint32_t blocks = (most + 255) / 256; if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(te::k_sum_groups, dim3(blocks, nj), dim3(256), 0, stream, js, (uint32_t)p.nw);
+      } else {                            // latency-bound level: four lanes per output
+        uint32_t blocks = (most * 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(te::k_sum_groups_team, dim3(blocks, nj), dim3(256), 0, stream, js, (uint32_t)p.nw);
+      }
+    }
+    mark(ST_WEIGHTED);
+    te::tail_params tp;
+    tp.xin = ch[0].cur; tp.yin = ch[1].cur; tp.rx = ch[0].r; tp.ry = ch[1].r;
+    tp.x_per_window = ch[0].n; tp.y_per_window = ch[1].n;
+    tp.w[0] = w0; tp.w[1] = w1; tp.w[2] = w2; tp.w[3] = w3;
+    tp.rows = reinterpret_cast<te::ete*>(d_partials_out) + (size_t)d.w_first * 5; tp.row_stride = (uint32_t)d.w_step * 5u;
+    const size_t lds_bytes = (size_t)(2u * (H + L) + 64u) * 144u;
+    hipLaunchKernelGGL(te::k_reduce_tail, dim3(p.nw), dim3(1024), lds_bytes, stream, tp);
+    mark(ST_COUNT);
+    HIP_TRY(ctx, hipMemcpyAsync(ws.h_err, ws.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    return 0;
+  }
+
   // recombination of split buckets, digit marginals, weighted sums, error flag read-back
   int back() {
     const uint32_t total = this->total();
@@ -349,14 +397,14 @@ struct msm_launch {
       hipLaunchKernelGGL(te377::k377_seg_combine, dim3(1024), dim3(256), 0, stream, ws.d_bucket_count, ws.d_seg_base,
                          reinterpret_cast<const te377::g1p_slot*>(ws.d_seg_out), reinterpret_cast<te377::g1p_slot*>(ws.d_buckets), total, p.seg_len);
     } else if (p.nw > 0) {
-      hipLaunchKernelGGL(te::k_seg_combine, dim3(256), dim3(256), 0, stream, ws.d_split_list, ws.d_num_seg + 1, ws.d_bucket_count, ws.d_seg_base,
-                         ws.d_seg_out, ws.d_buckets, p.seg_len);
-      // giant buckets (empty lists for well-spread digits: two near-empty launches)
-      hipLaunchKernelGGL(te::k_seg_combine_large1, dim3(512), dim3(256), 0, stream, ws.d_chunk_list, ws.d_num_seg + 1, ws.d_bucket_count, ws.d_seg_base,
-                         ws.d_seg_out, p.seg_len, chunk_cap());
+      // buckets cut into 2..16 parts (quads) and the 1024-part runs of giant buckets (blocks) in one launch, then the giant
+      // buckets' second stage (empty lists for well-spread digits: a near-empty launch)
+      hipLaunchKernelGGL(te::k_seg_combine_all, dim3(256 + 512), dim3(256), 0, stream, ws.d_split_list, ws.d_num_seg + 1, ws.d_chunk_list,
+                         ws.d_bucket_count, ws.d_seg_base, ws.d_seg_out, ws.d_buckets, p.seg_len, chunk_cap(), 256u);
       hipLaunchKernelGGL(te::k_seg_combine_large2, dim3(256), dim3(256), 0, stream, ws.d_large_list, ws.d_num_seg + 1, ws.d_bucket_count, ws.d_seg_base,
                          ws.d_seg_out, ws.d_buckets, p.seg_len, total);
     }
+    if (p.nw > 0 && !bls) return back_reduce_te();
     // digit marginals M_k[v], k = 0..3 (see K4a in kernels.hip.hpp).  Chains of folds, 4 (or 2) points per level:
     //   rows chain  B[d3 d2 d1 d0] -fold d0-> -fold d1-> X2[d3 d2]      cols chain  B -fold d3-> -fold d2-> Y2[d1 d0]
     //   then M3 = fold d2 of X2, M2 = fold d3 of X2, M1 = fold d0 of Y2, M0 = fold d1 of Y2.
@@ -669,6 +717,8 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
     d.w_first = i; d.w_step = n_dev;
     if (d.device < 0 || d.device >= count) { g_init_error = "te_msm_init: device id out of range"; delete ctx; return TE_MSM_EINVAL; }
     hipError_t er = hipSetDevice(d.device);
+    if (er == hipSuccess)                // k_reduce_tail keeps up to 2 x 512 + 64 points in LDS (157 KB of the CU's 160 KB)
+      er = hipFuncSetAttribute(reinterpret_cast<const void*>(te::k_reduce_tail), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     for (workset_t& ws : d.ws) {       // the small fixed allocations of both work sets; the big buffers come with the first MSM
       if (er == hipSuccess) er = hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking);
       if (er == hipSuccess) er = hipStreamCreateWithFlags(&ws.copy_stream, hipStreamNonBlocking);
@@ -714,13 +764,20 @@ int te_msm_submit_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_
   if (!d_points_xy_le || !d_scalars_le || n == 0 || n >= (1ull << 31)) return set_err(ctx, TE_MSM_EINVAL, "bad arguments");
   gpu_t& d = ctx->devs[0];
   if (d.next_ticket - d.next_collect >= TE_MSM_WORKSETS) return set_err(ctx, TE_MSM_ESTATE, "every work set has an MSM in flight: collect one first");
-  workset_t& ws = d.ws[d.next_ticket % TE_MSM_WORKSETS];   // rotate work sets (and their streams): the MSMs overlap on the device
+  // the lowest-numbered free work set (each has its own stream: the MSMs overlap on the device).  Not ticket % sets: with
+  // fewer MSMs in flight than sets only as many sets as needed are ever touched -- no buffer allocation in the middle
+  // of a run, and a smaller footprint in the Infinity Cache.
+  int wi = 0;
+  while (wi < TE_MSM_WORKSETS && d.ws[wi].pending_ticket) wi++;
+  if (wi == TE_MSM_WORKSETS) return set_err(ctx, TE_MSM_ESTATE, "every work set has an MSM in flight: collect one first");
+  workset_t& ws = d.ws[wi];
   HIP_TRY(ctx, hipSetDevice(d.device));
   if (int rc = enqueue_partial(ctx, d, ws, d_points_xy_le, d_scalars_le, n, ws.d_partials, ws.stream)) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(ws.h_partials, ws.d_partials, (size_t)ws.plan.W * sizes_of(ws.plan.curve).row, hipMemcpyDeviceToHost, ws.stream));
   HIP_TRY(ctx, hipEventRecord(ws.ev_done, ws.stream));
   *ticket = d.next_ticket++;
   ws.pending_ticket = *ticket;
+  d.ticket_ws[*ticket % TE_MSM_WORKSETS] = wi;
   return 0;
 }
 
@@ -729,7 +786,7 @@ int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]) {
   if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_collect needs a single-device context");
   gpu_t& d = ctx->devs[0];
   if (ticket != d.next_collect || ticket >= d.next_ticket) return set_err(ctx, TE_MSM_ESTATE, "tickets must be collected in submission order");
-  workset_t& ws = d.ws[ticket % TE_MSM_WORKSETS];
+  workset_t& ws = d.ws[d.ticket_ws[ticket % TE_MSM_WORKSETS]];
   HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));     // on failure the ticket stays collectable
   (void)collect_stage_ms(ctx, ws);
   d.next_collect++; ws.pending_ticket = 0;           // the MSM is over, with a result or with a scalar-range error
