@@ -89,14 +89,22 @@ def test_stages_against_oracle(ctx, fpcheck, model, ora, n, c):
     nseg = int(np.frombuffer(ctx.debug_read("num_segments", 4), dtype=np.uint32)[0])
     per_bucket = np.maximum(1, -(-cnt.reshape(-1).astype(np.int64) // seg_len))
     assert nseg == int(per_bucket.sum())
-    seg_bucket = np.frombuffer(ctx.debug_read("seg_bucket", nseg * 4), dtype=np.uint32)
-    seg_lens = np.frombuffer(ctx.debug_read("seg_len", nseg * 4), dtype=np.uint32)
-    assert np.array_equal(seg_bucket, np.repeat(np.arange(W * B), per_bucket))
+    # segment ids: window k owns [k * capW, (k+1) * capW), capW = B + n // seg_len; ids are dense inside a level-1 partition,
+    # in bucket order, and the ids a partition does not use are marked invalid (0xffffffff)
+    cap_w = B + n // seg_len
+    ids = W * cap_w
+    seg_bucket_all = np.frombuffer(ctx.debug_read("seg_bucket", ids * 4), dtype=np.uint32)
+    seg_lens_all = np.frombuffer(ctx.debug_read("seg_len", ids * 4), dtype=np.uint32)
+    valid = seg_bucket_all != 0xFFFFFFFF
+    assert np.array_equal(valid, seg_lens_all != 0xFFFFFFFF) and int(valid.sum()) == nseg
+    seg_bucket, seg_lens = seg_bucket_all[valid], seg_lens_all[valid]
+    assert np.array_equal(seg_bucket, np.repeat(np.arange(W * B), per_bucket)), "segments are not in bucket order"
+    assert np.all(seg_bucket // B == np.nonzero(valid)[0] // cap_w), "segment id outside its window's range"
     assert np.array_equal(np.bincount(seg_bucket, weights=seg_lens, minlength=W * B).astype(np.int64), cnt.reshape(-1).astype(np.int64))
     assert seg_lens.max() <= seg_len
     order = np.frombuffer(ctx.debug_read("order", nseg * 4), dtype=np.uint32)
-    assert np.array_equal(np.sort(order), np.arange(nseg)), "order is not a permutation of the segments"
-    sizes = seg_lens[order]
+    assert np.array_equal(np.sort(order), np.nonzero(valid)[0]), "order is not a permutation of the valid segments"
+    sizes = seg_lens_all[order]
     assert np.all(sizes[:-1] >= sizes[1:]), "order is not descending"
     # K3: a sample of bucket sums == affine sums of the model
     bk = ctx.debug_read("buckets", W * B * 144)

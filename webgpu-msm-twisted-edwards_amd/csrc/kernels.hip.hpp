@@ -4,8 +4,8 @@
 //   K1 convert_point_coords_and_decompose_scalars (wgsl/cuzk/convert_point_coords_and_decompose_scalars
 //      .template.wgsl:37-123)                    -> k_prep_points + k_digits<C>
 //   K2 transpose (wgsl/cuzk/transpose.wgsl:32-76; 16 threads in total)
-//                                                -> k_part_hist / k_part_scan / k_part_scatter / k_l2_count / k_bscan / k_l2_place
-//                                                   (two-level counting sort, all stores coalesced) + k_order_*
+//                                                -> (histogram in k_digits) k_part_scatter / k_l2_count / k_seg_plan / k_l2_place
+//                                                   (two-level counting sort, all stores coalesced) + k_order_scatter
 //   K3 smvp (wgsl/cuzk/smvp.template.wgsl:58-152) -> k_accumulate (7-product mixed additions)
 //   K4/K5 bpr stage_1/2 (wgsl/cuzk/bpr.template.wgsl:73-171) + the CPU sum of 4096 points
 //      (submission.ts:362-393)                   -> k_sum_groups[_team] (digit marginals) + k_weighted_sum
@@ -23,6 +23,9 @@ struct digits_params {
   uint32_t n, nst;     // points, digit-row stride (n rounded up to a multiple of 8; pad entries hold digit 0)
   int num_windows;     // total windows W of the decomposition
   int w_first, w_step, nw_local;
+  // level-1 histogram of the sort, fused into k_digits (see K2 below): partition = bucket >> logS, P partitions per window,
+  // chunk = entry index / chunk_len (CH chunks per window)
+  uint32_t half_code, logS, P, CH, chunk_len;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -74,58 +77,83 @@ __global__ void __launch_bounds__(256) k_prep_points(const uint4* __restrict__ p
 // window everywhere performs exactly those carries.  A non-zero bit at or above c*W is the
 // reference's "final carry is 1" error (utils.ts:80-83) and sets *err.
 // digits[k * n + i] (u16) for local window k.
-// Each thread decomposes TWO consecutive scalars and stores their digits as one packed u32 per window (nst is even).
+// Each thread decomposes TWO consecutive scalars per step and stores their digits as one packed u32 per window (nst is even).
+// A block covers TE_DIG_BLOCK consecutive entries (it never straddles a level-1 chunk: chunk_len is a multiple of it) and
+// also builds the level-1 histogram of the sort for them -- counts1[window][chunk][partition] += ... -- in LDS, flushed with
+// one global atomic per non-zero counter.  (The first version re-read all digits in a separate histogram kernel.)
+#define TE_DIG_BLOCK 2048u
+#define TE_DIG_THREADS 512u
+__device__ __forceinline__ bool digit_bucket(uint32_t stored, uint32_t half, uint32_t& bucket, uint32_t& neg);
 template <int C>
-__global__ void __launch_bounds__(256) k_digits(const uint4* __restrict__ scalars, uint16_t* __restrict__ digits,
-                                                digits_params prm, uint32_t* __restrict__ err) {
-  const uint32_t pair = blockIdx.x * 256u + threadIdx.x, i0 = 2u * pair;
-  if (i0 >= prm.nst) return;
+__global__ void __launch_bounds__(TE_DIG_THREADS) k_digits(const uint4* __restrict__ scalars, uint16_t* __restrict__ digits,
+                                                digits_params prm, uint32_t* __restrict__ err, uint32_t* __restrict__ counts1) {
+  __shared__ uint32_t hist[4096];                        // [local window][partition]: nw_local * P <= 4096 for every plan
+  const uint32_t hn = (uint32_t)prm.nw_local * prm.P;
+  for (uint32_t j = threadIdx.x; j < hn; j += TE_DIG_THREADS) hist[j] = 0u;
+  __syncthreads();
   uint32_t* __restrict__ out = reinterpret_cast<uint32_t*>(digits);
   const uint32_t half_stride = prm.nst >> 1;
   const uint32_t ZERO_DIGIT = prm.zero_digit;
-  if (i0 >= prm.n) {                                   // padding entries: digit 0
-    for (int k = 0; k < prm.nw_local; k++) out[(size_t)k * half_stride + pair] = ZERO_DIGIT | (ZERO_DIGIT << 16);
-    return;
-  }
-  const bool second = i0 + 1u < prm.n;
-  const size_t j1 = second ? (size_t)i0 + 1 : (size_t)i0;       // clamped: unconditional loads
-  const size_t st = prm.sc_stride;
-  const uint4 a0 = scalars[st * i0], a1 = scalars[st * i0 + 1], b0 = scalars[st * j1], b1 = scalars[st * j1 + 1];
   bool bad = false;
-  if (st == 3) {                                        // 48-byte records hold values below 2^256
-    const uint4 a2 = scalars[st * i0 + 2], b2 = scalars[st * j1 + 2];
-    bad = (a2.x | a2.y | a2.z | a2.w | b2.x | b2.y | b2.z | b2.w) != 0u;
-  }
-  uint32_t s[2][10] = {{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, 0u, 0u}, {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, 0u, 0u}};
-#pragma unroll
-  for (int t = 0; t < 2; t++) {
-    uint64_t c = 0;
-#pragma unroll
-    for (int j = 0; j < 9; j++) { c += (uint64_t)s[t][j] + prm.half[j]; s[t][j] = (uint32_t)c; c >>= 32; }
-  }
-  // window extraction with compile-time bit positions (runtime-indexed register arrays would spill)
-  constexpr int WMAX = (255 + C) / C + 1;
-  int next = prm.w_first, k = 0;                       // next owned window and its local index
-#pragma unroll
-  for (int w = 0; w < WMAX; w++) {
-    const int bit = w * C;
-    if (bit >= 288) break;
-    const int word = bit >> 5, off = bit & 31;
-    uint32_t v[2];
+  for (uint32_t step = 0; step < TE_DIG_BLOCK / (2u * TE_DIG_THREADS); step++) {
+    const uint32_t pair = (blockIdx.x * (TE_DIG_BLOCK / (2u * TE_DIG_THREADS)) + step) * TE_DIG_THREADS + threadIdx.x, i0 = 2u * pair;
+    if (i0 >= prm.nst) break;
+    if (i0 >= prm.n) {                                   // padding entries: digit 0
+      for (int k = 0; k < prm.nw_local; k++) out[(size_t)k * half_stride + pair] = ZERO_DIGIT | (ZERO_DIGIT << 16);
+      continue;
+    }
+    const bool second = i0 + 1u < prm.n;
+    const size_t j1 = second ? (size_t)i0 + 1 : (size_t)i0;       // clamped: unconditional loads
+    const size_t st = prm.sc_stride;
+    const uint4 a0 = scalars[st * i0], a1 = scalars[st * i0 + 1], b0 = scalars[st * j1], b1 = scalars[st * j1 + 1];
+    if (st == 3) {                                        // 48-byte records hold values below 2^256
+      const uint4 a2 = scalars[st * i0 + 2], b2 = scalars[st * j1 + 2];
+      bad |= (a2.x | a2.y | a2.z | a2.w | b2.x | b2.y | b2.z | b2.w) != 0u;
+    }
+    uint32_t s[2][10] = {{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, 0u, 0u}, {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, 0u, 0u}};
 #pragma unroll
     for (int t = 0; t < 2; t++) {
-      v[t] = s[t][word] >> off;
-      if (off + C > 32 && word + 1 < 10) v[t] |= s[t][word + 1] << (32 - off);
-      v[t] &= (1u << C) - 1u;
+      uint64_t c = 0;
+#pragma unroll
+      for (int j = 0; j < 9; j++) { c += (uint64_t)s[t][j] + prm.half[j]; s[t][j] = (uint32_t)c; c >>= 32; }
     }
-    if (!second) v[1] = w < prm.num_windows ? ZERO_DIGIT : 0u;
-    if (w >= prm.num_windows) { bad |= ((v[0] | v[1]) != 0u); continue; }
-    if (w == next) {
-      if (k < prm.nw_local) out[(size_t)k * half_stride + pair] = v[0] | (v[1] << 16);
-      k++; next += prm.w_step;
+    // window extraction with compile-time bit positions (runtime-indexed register arrays would spill)
+    constexpr int WMAX = (255 + C) / C + 1;
+    int next = prm.w_first, k = 0;                       // next owned window and its local index
+#pragma unroll
+    for (int w = 0; w < WMAX; w++) {
+      const int bit = w * C;
+      if (bit >= 288) break;
+      const int word = bit >> 5, off = bit & 31;
+      uint32_t v[2];
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        v[t] = s[t][word] >> off;
+        if (off + C > 32 && word + 1 < 10) v[t] |= s[t][word + 1] << (32 - off);
+        v[t] &= (1u << C) - 1u;
+      }
+      if (!second) v[1] = w < prm.num_windows ? ZERO_DIGIT : 0u;
+      if (w >= prm.num_windows) { bad |= ((v[0] | v[1]) != 0u); continue; }
+      if (w == next) {
+        if (k < prm.nw_local) {
+          out[(size_t)k * half_stride + pair] = v[0] | (v[1] << 16);
+#pragma unroll
+          for (int t = 0; t < 2; t++) {
+            uint32_t b, neg;
+            if (digit_bucket(v[t], prm.half_code, b, neg)) atomicAdd(&hist[(uint32_t)k * prm.P + (b >> prm.logS)], 1u);
+          }
+        }
+        k++; next += prm.w_step;
+      }
     }
   }
   if (bad) atomicOr(err, 1u);
+  __syncthreads();
+  const uint32_t ch = (blockIdx.x * TE_DIG_BLOCK) / prm.chunk_len;
+  for (uint32_t j = threadIdx.x; j < hn; j += TE_DIG_THREADS) {
+    const uint32_t v = hist[j];
+    if (v) { const uint32_t k = j / prm.P, p = j - k * prm.P; atomicAdd(&counts1[((size_t)k * prm.CH + ch) * prm.P + p], v); }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -169,9 +197,9 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds /*
 // store became a 32-byte sector write, 535 MB of write traffic for 67 MB of payload --
 // profiles/r01_rocprofv3_v2_summary.txt.)
 //   level 1  partition = bucket >> logS (P = B/S partitions per window, ~n/P entries each):
-//            k_part_hist -> k_part_scan -> k_part_scatter (4096-entry tiles sorted by partition in LDS,
+//            histogram (in k_digits) -> k_part_scatter (4096-entry tiles sorted by partition in LDS,
 //            written out as contiguous runs: u16 key = bucket low bits | sign << 15, u32 index)
-//   level 2  k_l2_count -> k_bscan_a/b -> k_l2_place: blocks take fixed-size slices of the level-1 output, count per
+//   level 2  k_l2_count -> k_seg_plan -> k_l2_place: blocks take fixed-size slices of the level-1 output, count per
 //            bucket in LDS, reserve ranges with one global atomic per touched bucket, and write each bucket's run
 //            contiguously -- balanced for any digit distribution.
 struct sort_geom {
@@ -189,70 +217,50 @@ __device__ __forceinline__ void unpack8(const uint4& v, uint32_t (&d)[8]) {
   d[4] = v.z & 0xffffu; d[5] = v.z >> 16; d[6] = v.w & 0xffffu; d[7] = v.w >> 16;
 }
 
-// grid (CH, nw), block 1024.  counts1[window][partition][chunk].
-__global__ void __launch_bounds__(1024) k_part_hist(const uint16_t* __restrict__ digits, uint32_t* __restrict__ counts1, sort_geom g) {
-  __shared__ uint32_t h[16 * 512];                    // one private histogram per wave
-  const uint32_t ch = blockIdx.x, k = blockIdx.y, wave = threadIdx.x >> 6;
-  for (uint32_t j = threadIdx.x; j < 16u * g.P; j += 1024u) h[j] = 0u;
-  __syncthreads();
-  const uint32_t lo8 = (ch * g.chunk_len) >> 3, hi8 = min(g.nst, (ch + 1u) * g.chunk_len) >> 3;   // pad entries are digit 0
-  const uint4* d4 = reinterpret_cast<const uint4*>(digits + (size_t)k * g.nst);
-  for (uint32_t base = lo8; base < hi8; base += 4u * 1024u) {
-    uint4 v[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) v[j] = d4[min(base + (uint32_t)j * 1024u + threadIdx.x, hi8 - 1u)];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if (base + (uint32_t)j * 1024u + threadIdx.x < hi8) {
-        uint32_t dd[8]; unpack8(v[j], dd);
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-          uint32_t b, neg;
-          if (digit_bucket(dd[e], g.half, b, neg)) atomicAdd(&h[wave * g.P + (b >> g.logS)], 1u);
-        }
-      }
-    }
-  }
-  __syncthreads();
-  for (uint32_t p = threadIdx.x; p < g.P; p += 1024u) {
-    uint32_t t = 0;
-    for (uint32_t w = 0; w < 16u; w++) t += h[w * g.P + p];
-    counts1[((size_t)k * g.P + p) * g.CH + ch] = t;      // [window][partition][chunk]: scan order
-  }
-}
-
-// one block per window: exclusive scan of counts1 in [partition][chunk] order (in place);
-// part_start / part_count per partition.
-__global__ void __launch_bounds__(1024) k_part_scan(uint32_t* __restrict__ counts1, uint32_t* __restrict__ part_start,
-                                                    uint32_t* __restrict__ part_count, sort_geom g) {
-  __shared__ uint32_t sm[17];
-  const uint32_t k = blockIdx.x, total = g.P * g.CH;
-  uint32_t* c = counts1 + (size_t)k * total;
-  const uint32_t per = (total + 1023u) / 1024u;
-  const uint32_t lo = min(total, threadIdx.x * per), hi = min(total, lo + per);
-  uint32_t sum = 0;
-  for (uint32_t j = lo; j < hi; j++) sum += c[j];
-  uint32_t bt;
-  uint32_t run = block_excl_scan(sum, sm, bt);
-  for (uint32_t j = lo; j < hi; j++) { const uint32_t v = c[j]; c[j] = run; run += v; }
-  __syncthreads();
-  for (uint32_t p = threadIdx.x; p < g.P; p += 1024u) {
-    const uint32_t s0 = c[p * g.CH];
-    const uint32_t s1 = (p + 1 < g.P) ? c[(p + 1) * g.CH] : bt;
-    part_start[k * g.P + p] = s0; part_count[k * g.P + p] = s1 - s0;
-  }
-}
-
 // grid (CH, nw), block 512: tiles of 4096 entries, 8 consecutive entries per thread (one 16-byte load).
-__global__ void __launch_bounds__(512) k_part_scatter(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ offs1,
-                                                      uint16_t* __restrict__ part_keys, uint32_t* __restrict__ part_idx, sort_geom g) {
+// Every block first derives its write offsets from counts1[window][chunk][partition] (k_digits) itself -- partition totals
+// over all chunks, their exclusive scan, plus the counts of the earlier chunks: P x CH coalesced loads per block instead of
+// a scan kernel (one block per window, 12 us of dependent loads) between two launches.  The block of chunk 0 also writes
+// what level 2 needs: part_start / part_count, and seg_part_base, the first segment id of each partition: window k owns the
+// ids [k * capW, (k+1) * capW), capW = B + n / seg_len; inside, partition p starts at p * S + sum_{p' < p} floor(count_p' / seg_len)
+// -- an upper bound on the segments of the earlier partitions that needs no bucket counts (ids left over are marked invalid
+// by k_seg_plan).
+__global__ void __launch_bounds__(512) k_part_scatter(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ counts1,
+                                                      uint16_t* __restrict__ part_keys, uint32_t* __restrict__ part_idx,
+                                                      uint32_t* __restrict__ part_start, uint32_t* __restrict__ part_count,
+                                                      uint32_t* __restrict__ seg_part_base, uint32_t seg_len, uint32_t cap_w, sort_geom g) {
   __shared__ uint32_t st_idx[TE_TILE];
   __shared__ uint16_t st_key[TE_TILE];
   __shared__ uint16_t st_part[TE_TILE];
   __shared__ uint32_t tile_cnt[512], tile_off[512], run_base[512];
   __shared__ uint32_t sm[17];
   const uint32_t ch = blockIdx.x, k = blockIdx.y, t = threadIdx.x;
-  for (uint32_t p = t; p < g.P; p += 512u) run_base[p] = offs1[((size_t)k * g.P + p) * g.CH + ch];
+  {
+    // P is a power of two <= 256: 512 / P threads share a partition's column of counts (independent loads, eight in flight)
+    tile_cnt[t] = 0u; tile_off[t] = 0u;
+    __syncthreads();
+    {
+      const uint32_t pp = t & (g.P - 1u), grp = t / g.P, ngrp = 512u / g.P;
+      const uint32_t* c = counts1 + (size_t)k * g.CH * g.P + pp;
+      uint32_t tot = 0, pre = 0;
+#pragma unroll 8
+      for (uint32_t cc = grp; cc < g.CH; cc += ngrp) { const uint32_t v = c[(size_t)cc * g.P]; tot += v; pre += cc < ch ? v : 0u; }
+      if (tot) atomicAdd(&tile_cnt[pp], tot);
+      if (pre) atomicAdd(&tile_off[pp], pre);
+    }
+    __syncthreads();
+    const uint32_t tot = t < g.P ? tile_cnt[t] : 0u, pre = t < g.P ? tile_off[t] : 0u;
+    uint32_t bt;
+    const uint32_t start = block_excl_scan(tot, sm, bt);
+    if (t < g.P) run_base[t] = start + pre;
+    if (ch == 0) {
+      const uint32_t extra = block_excl_scan(tot / seg_len, sm, bt);
+      if (t < g.P) {
+        part_start[k * g.P + t] = start; part_count[k * g.P + t] = tot;
+        seg_part_base[k * g.P + t] = k * cap_w + t * g.S + extra;
+      }
+    }
+  }
   const uint32_t lo = ch * g.chunk_len, hi = min(g.nst, lo + g.chunk_len);
   const uint4* d4 = reinterpret_cast<const uint4*>(digits + (size_t)k * g.nst);
   const uint32_t last8 = (g.nst >> 3) - 1u;
@@ -309,7 +317,8 @@ __global__ void __launch_bounds__(512) k_part_scatter(const uint16_t* __restrict
 // 19 blocks sorted 55k entries each while the rest of the chip idled -- 200 us of tail.)
 // A slice is cut into pieces at partition boundaries; a piece touches at most S (<= 256) buckets.
 //   k_l2_count : LDS count per bucket of each piece -> global atomicAdd into bucket_count (<= S per piece)
-//   k_bscan_a/b: exclusive scan of bucket_count per window -> bucket_start, bucket_cursor
+//   k_seg_plan : per partition: bucket_start = bucket_cursor = part_start + scan of the partition's bucket counts (and the
+//                segment schedule, see below)
 //   k_l2_place : LDS count again, reserve [base, base+c) in every touched bucket with one atomicAdd on
 //                bucket_cursor, sort the piece by bucket in LDS and copy each run to its reserved range.
 #define TE_SLICE 8192u
@@ -370,46 +379,6 @@ __global__ void __launch_bounds__(256) k_l2_count(const uint16_t* __restrict__ p
     if (c0) atomicAdd(&bucket_count[(size_t)k * g.B + (size_t)p * g.S + t], c0);
     __syncthreads();
     s0 = e1; p++;
-  }
-}
-
-// exclusive scan of bucket_count per window: a = per 1024-bucket segment, b = add the bases
-// Two quantities are scanned together: the bucket sizes (-> bucket_start / bucket_cursor, per window) and the number
-// of work segments per bucket, max(1, ceil(count / seg_len)) (-> seg_base, one running index over ALL windows).
-__global__ void __launch_bounds__(1024) k_bscan_a(const uint32_t* __restrict__ bucket_count, uint32_t* __restrict__ local_excl,
-                                                  uint32_t* __restrict__ local_excl_seg, uint32_t* __restrict__ seg_total,
-                                                  uint32_t B, uint32_t seg_len) {
-  __shared__ uint32_t sm[17];
-  const uint32_t seg = blockIdx.x, k = blockIdx.y, b = seg * blockDim.x + threadIdx.x;
-  const uint32_t v = b < B ? bucket_count[(size_t)k * B + b] : 0u;
-  const uint32_t ns = b < B ? max(1u, (v + seg_len - 1u) / seg_len) : 0u;
-  uint32_t bt, bt2;
-  const uint32_t ex = block_excl_scan(v, sm, bt);
-  const uint32_t ex2 = block_excl_scan(ns, sm, bt2);
-  if (b < B) { local_excl[(size_t)k * B + b] = ex; local_excl_seg[(size_t)k * B + b] = ex2; }
-  if (threadIdx.x == 0) { seg_total[2 * (k * gridDim.x + seg)] = bt; seg_total[2 * (k * gridDim.x + seg) + 1] = bt2; }
-}
-__global__ void __launch_bounds__(1024) k_bscan_b(const uint32_t* __restrict__ local_excl, uint32_t* __restrict__ seg_base /* in: local, out: global */,
-                                                  const uint32_t* __restrict__ seg_total, uint32_t* __restrict__ bucket_start,
-                                                  uint32_t* __restrict__ bucket_cursor, uint32_t* __restrict__ num_segments, uint32_t B) {
-  __shared__ uint32_t sm[17];
-  const uint32_t seg = blockIdx.x, k = blockIdx.y, nseg = gridDim.x;
-  // block-wide sums of the earlier segments' totals (a serial loop in one thread cost 20 us of dependent loads)
-  uint32_t part = 0, part2 = 0;
-  for (uint32_t s = threadIdx.x; s < seg; s += blockDim.x) part += seg_total[2 * (k * nseg + s)];
-  const uint32_t lim2 = k * nseg + seg;
-  for (uint32_t s = threadIdx.x; s < lim2; s += blockDim.x) part2 += seg_total[2 * s + 1];      // segments are numbered across windows
-  uint32_t base, base2;
-  (void)block_excl_scan(part, sm, base);
-  (void)block_excl_scan(part2, sm, base2);
-  const uint32_t base_s = base, base2_s = base2;
-  if (threadIdx.x == 0 && k == gridDim.y - 1 && seg == nseg - 1) *num_segments = base2 + seg_total[2 * (k * nseg + seg) + 1];
-  const uint32_t b = seg * blockDim.x + threadIdx.x;
-  if (b < B) {
-    const size_t g = (size_t)k * B + b;
-    const uint32_t v = base_s + local_excl[g];
-    bucket_start[g] = v; bucket_cursor[g] = v;
-    seg_base[g] = base2_s + seg_base[g];
   }
 }
 
@@ -483,87 +452,111 @@ __global__ void __launch_bounds__(256, 3) k_l2_place(const uint16_t* __restrict_
 //  * a bucket that is much larger than the rest would otherwise be ONE thread's serial chain and set the kernel's
 //    duration on its own -- every 253-bit scalar does this: its top window has only ~4.8k occupied buckets of ~219
 //    entries (1.13 ms of serial additions against ~1 ms for everything else); skewed scalars do it in general.
-// Buckets split into several segments are summed afterwards by k_seg_combine.
-//   k_seg_build  : thread per segment -> (bucket, part) by binary search in seg_base, and its length
-//   k_order_*    : counting sort of segment ids by descending length
-// also: histogram of the segment lengths (for the schedule) and the lists of split buckets (for k_seg_combine*)
+// Buckets split into several segments are summed afterwards by k_seg_combine*.
+//   k_seg_plan     : one block per level-1 partition, one thread per bucket, after k_l2_count: bucket_start / bucket_cursor
+//                    (= part_start + scan of the partition's counts -- no scan across blocks), seg_base (= seg_part_base +
+//                    scan of the segments per bucket), the segment records (bucket, length), the histogram of the
+//                    lengths and the lists of split buckets.  Segment ids are dense inside a partition; the ids between
+//                    a partition's last segment and the next partition's base stay INVALID.
+//                    (The first version needed a two-kernel scan over all buckets plus a thread-per-segment kernel with a
+//                    binary search: three dependent launches.)
+//   k_order_scatter: counting sort of the valid segment ids by descending length; every block scans the 1024-entry
+//                    histogram itself.
 #define TE_COMBINE_SMALL 16u
-#define TE_SEG_BLOCK 2048u
-__global__ void __launch_bounds__(256) k_seg_build(const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ bucket_count,
-                                                   const uint32_t* __restrict__ num_segments, uint32_t total_buckets, uint32_t seg_len,
-                                                   uint32_t* __restrict__ seg_bucket, uint32_t* __restrict__ seg_lenv,
-                                                   uint32_t* __restrict__ size_hist, uint32_t* __restrict__ split_list,
-                                                   uint32_t* __restrict__ split_count /* [0] small, [1] large buckets, [2] large chunks */,
-                                                   uint32_t* __restrict__ large_list, uint32_t* __restrict__ chunk_list /* pairs (bucket, first part) */,
-                                                   uint32_t large_cap, uint32_t chunk_cap) {
+#define TE_SEG_INVALID 0xffffffffu
+// grid (P, nw), block S (= buckets per partition, <= 256)
+__global__ void __launch_bounds__(256) k_seg_plan(const uint32_t* __restrict__ bucket_count, const uint32_t* __restrict__ part_start,
+                                                  const uint32_t* __restrict__ part_count, const uint32_t* __restrict__ seg_part_base,
+                                                  uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ bucket_cursor,
+                                                  uint32_t* __restrict__ seg_base, uint32_t* __restrict__ seg_bucket, uint32_t* __restrict__ seg_lenv,
+                                                  uint32_t* __restrict__ size_hist, uint32_t* __restrict__ split_list,
+                                                  uint32_t* __restrict__ split_count /* [0] small, [1] large buckets, [2] large chunks */,
+                                                  uint32_t* __restrict__ large_list, uint32_t* __restrict__ chunk_list /* pairs (bucket, first part) */,
+                                                  uint32_t B, uint32_t S, uint32_t seg_len, uint32_t cap_w, uint32_t large_cap, uint32_t chunk_cap) {
   __shared__ uint32_t h[1024];
-  __shared__ uint32_t sb[TE_SEG_BLOCK + 2];           // seg_base of the buckets this block's segments belong to
-  __shared__ uint32_t g_first;
-  for (uint32_t j = threadIdx.x; j < 1024u; j += 256u) h[j] = 0;
-  const uint32_t ns = *num_segments;
-  // The block owns the contiguous segments [s_lo, s_hi).  Every bucket has at least one segment, so they belong to at
-  // most s_hi - s_lo + 1 consecutive buckets: one binary search in global memory finds the first, their seg_base
-  // values are staged in LDS and every thread searches there (a 19-step search in global memory per segment made this
-  // kernel 29 us of dependent loads).
-  const uint32_t per = (ns + gridDim.x - 1u) / gridDim.x;
-  const uint32_t chunk = per < TE_SEG_BLOCK ? per : TE_SEG_BLOCK;       // blocks with more than TE_SEG_BLOCK segments loop
-  for (uint32_t s_lo = blockIdx.x * per; s_lo < min(ns, (blockIdx.x + 1u) * per); s_lo += chunk) {
-    const uint32_t s_hi = min(min(ns, (blockIdx.x + 1u) * per), s_lo + chunk);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t lo = 0, hi = total_buckets;          // last bucket g with seg_base[g] <= s_lo
-      while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seg_base[mid] <= s_lo) lo = mid; else hi = mid; }
-      g_first = lo;
+  __shared__ uint32_t sm[17];
+  __shared__ uint32_t giant[256 * 3];                   // (bucket, first segment id, count) of the buckets cut into > 16 parts
+  __shared__ uint32_t n_giant;
+  const uint32_t p = blockIdx.x, k = blockIdx.y, t = threadIdx.x, P = gridDim.x;
+  for (uint32_t j = t; j < 1024u; j += blockDim.x) h[j] = 0u;
+  if (t == 0) n_giant = 0u;
+  const uint32_t g = k * B + p * S + t;
+  const uint32_t cnt = bucket_count[g];
+  const uint32_t nparts = max(1u, (cnt + seg_len - 1u) / seg_len);
+  uint32_t bt, bt2;
+  const uint32_t ex = block_excl_scan(cnt, sm, bt);
+  const uint32_t ex2 = block_excl_scan(nparts, sm, bt2);
+  const uint32_t bs = part_start[k * P + p] + ex, sb = seg_part_base[k * P + p] + ex2;
+  bucket_start[g] = bs; bucket_cursor[g] = bs; seg_base[g] = sb;
+  if (nparts <= TE_COMBINE_SMALL) {
+    for (uint32_t part = 0; part < nparts; part++) {
+      const uint32_t len = cnt > part * seg_len ? min(seg_len, cnt - part * seg_len) : 0u;
+      seg_bucket[sb + part] = g; seg_lenv[sb + part] = len;
+      atomicAdd(&h[min(len, 1023u)], 1u);
     }
-    __syncthreads();
-    const uint32_t g0 = g_first, ng = min(total_buckets - g0, s_hi - s_lo + 1u);
-    for (uint32_t j = threadIdx.x; j < ng; j += 256u) sb[j] = seg_base[g0 + j];
-    __syncthreads();
-    for (uint32_t s = s_lo + threadIdx.x; s < s_hi; s += 256u) {
-    uint32_t l = 0, r = ng;                            // last staged bucket with seg_base <= s
-    while (r - l > 1) { const uint32_t mid = (l + r) >> 1; if (sb[mid] <= s) l = mid; else r = mid; }
-    const uint32_t lo = g0 + l;
-    const uint32_t part = s - sb[l], cnt = bucket_count[lo];
-    const uint32_t len = cnt > part * seg_len ? min(seg_len, cnt - part * seg_len) : 0u;
-    seg_bucket[s] = lo;
-    seg_lenv[s] = len;
-    atomicAdd(&h[min(len, 1023u)], 1u);
-    // buckets cut into 2..TE_COMBINE_SMALL parts are summed by one quad; longer ones by blocks, 1024 parts at a time
-    const uint32_t nparts = (cnt + seg_len - 1u) / seg_len;
-    if (nparts > 1u && nparts <= TE_COMBINE_SMALL) { if (part == 0) split_list[atomicAdd(&split_count[0], 1u)] = lo; }
-    else if (nparts > TE_COMBINE_SMALL) {
-      if (part == 0) { const uint32_t i = atomicAdd(&split_count[1], 1u); if (i < large_cap) large_list[i] = lo; }
-      if ((part & 1023u) == 0) { const uint32_t i = atomicAdd(&split_count[2], 1u); if (i < chunk_cap) { chunk_list[2 * i] = lo; chunk_list[2 * i + 1] = part; } }
-    }
+    if (nparts > 1u) split_list[atomicAdd(&split_count[0], 1u)] = g;
+  } else {
+    const uint32_t j = atomicAdd(&n_giant, 1u);
+    giant[3 * j] = g; giant[3 * j + 1] = sb; giant[3 * j + 2] = cnt;
+    const uint32_t li = atomicAdd(&split_count[1], 1u);
+    if (li < large_cap) large_list[li] = g;
+  }
+  // ids this partition does not use: [first + segments, first + S + floor(part_count / seg_len))
+  {
+    // (the last partition also covers the rest of the window's id range, up to (k + 1) * cap_w)
+    const uint32_t first = seg_part_base[k * P + p], used = bt2;
+    const uint32_t cap = p + 1u == P ? (k + 1u) * cap_w - first : S + part_count[k * P + p] / seg_len;
+    for (uint32_t j = used + t; j < cap; j += blockDim.x) { seg_bucket[first + j] = TE_SEG_INVALID; seg_lenv[first + j] = TE_SEG_INVALID; }
+  }
+  __syncthreads();
+  // giant buckets: the whole block writes their segment records; one chunk entry per 1024 parts (k_seg_combine_large*)
+  const uint32_t ng = n_giant;
+  for (uint32_t j = 0; j < ng; j++) {
+    const uint32_t gg = giant[3 * j], sb0 = giant[3 * j + 1], c0 = giant[3 * j + 2];
+    const uint32_t np = (c0 + seg_len - 1u) / seg_len;
+    for (uint32_t part = t; part < np; part += blockDim.x) {
+      const uint32_t len = min(seg_len, c0 - part * seg_len);
+      seg_bucket[sb0 + part] = gg; seg_lenv[sb0 + part] = len;
+      atomicAdd(&h[min(len, 1023u)], 1u);
+      if ((part & 1023u) == 0) { const uint32_t ci = atomicAdd(&split_count[2], 1u); if (ci < chunk_cap) { chunk_list[2 * ci] = gg; chunk_list[2 * ci + 1] = part; } }
     }
   }
   __syncthreads();
-  for (uint32_t j = threadIdx.x; j < 1024u; j += 256u) if (h[j]) atomicAdd(&size_hist[j], h[j]);
+  for (uint32_t j = t; j < 1024u; j += blockDim.x) if (h[j]) atomicAdd(&size_hist[j], h[j]);
 }
-// one block of 1024: size_cursor[s] = number of items with size > s  (descending order start)
-__global__ void __launch_bounds__(1024) k_order_scan(const uint32_t* __restrict__ size_hist, uint32_t* __restrict__ size_cursor) {
-  __shared__ uint32_t sm[17];
-  const uint32_t s = 1023u - threadIdx.x;          // thread 0 handles the largest size
-  uint32_t bt;
-  const uint32_t ex = block_excl_scan(size_hist[s], sm, bt);
-  size_cursor[s] = ex;
-}
-__global__ void __launch_bounds__(256) k_order_scatter(const uint32_t* __restrict__ lenv, const uint32_t* __restrict__ num_items,
-                                                       uint32_t* __restrict__ size_cursor, uint32_t* __restrict__ order) {
+
+// grid 256 blocks of 256; `ids` = size of the segment id space (host-known); rel_cursor zeroed per MSM.
+// order[] receives the valid segment ids by descending length; block 0 writes their number to *num_segments.
+__global__ void __launch_bounds__(256) k_order_scatter(const uint32_t* __restrict__ lenv, uint32_t ids, const uint32_t* __restrict__ size_hist,
+                                                       uint32_t* __restrict__ rel_cursor, uint32_t* __restrict__ order, uint32_t* __restrict__ num_segments) {
   __shared__ uint32_t h[1024];
   __shared__ uint32_t base[1024];
-  const uint32_t total = *num_items;
+  __shared__ uint32_t sm[17];
+  // descending start of every length: number of segments longer than s (each block scans the histogram itself)
+  {
+    uint32_t run = 0;
+    for (uint32_t c = 0; c < 4u; c++) {
+      const uint32_t s = 1023u - (c * 256u + threadIdx.x);        // thread 0 of chunk 0 handles the largest size
+      uint32_t bt;
+      const uint32_t ex = block_excl_scan(size_hist[s], sm, bt);
+      base[s] = run + ex;
+      run += bt;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *num_segments = run;
+  }
   for (uint32_t j = threadIdx.x; j < 1024u; j += 256u) h[j] = 0;
   __syncthreads();
   // the block owns a contiguous slice so that each thread sees the same elements in both passes
-  const uint32_t per = (total + gridDim.x - 1) / gridDim.x;
-  const uint32_t lo = blockIdx.x * per, hi = min(total, lo + per);
-  for (uint32_t g = lo + threadIdx.x; g < hi; g += 256u) atomicAdd(&h[min(lenv[g], 1023u)], 1u);
+  const uint32_t per = (ids + gridDim.x - 1) / gridDim.x;
+  const uint32_t lo = blockIdx.x * per, hi = min(ids, lo + per);
+  for (uint32_t g = lo + threadIdx.x; g < hi; g += 256u) { const uint32_t l = lenv[g]; if (l != TE_SEG_INVALID) atomicAdd(&h[min(l, 1023u)], 1u); }
   __syncthreads();
-  for (uint32_t j = threadIdx.x; j < 1024u; j += 256u) { base[j] = h[j] ? atomicAdd(&size_cursor[j], h[j]) : 0u; h[j] = 0; }
+  for (uint32_t j = threadIdx.x; j < 1024u; j += 256u) { base[j] += h[j] ? atomicAdd(&rel_cursor[j], h[j]) : 0u; h[j] = 0; }
   __syncthreads();
   for (uint32_t g = lo + threadIdx.x; g < hi; g += 256u) {
-    const uint32_t s = min(lenv[g], 1023u);
+    const uint32_t l = lenv[g];
+    if (l == TE_SEG_INVALID) continue;
+    const uint32_t s = min(l, 1023u);
     const uint32_t pos = base[s] + atomicAdd(&h[s], 1u);
     order[pos] = g;
   }
@@ -614,11 +607,12 @@ __global__ void __launch_bounds__(256, 4) k_accumulate(const pnt_slot* __restric
                                                     const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ seg_bucket,
                                                     const uint32_t* __restrict__ seg_lenv, const uint32_t* __restrict__ order,
                                                     const uint32_t* __restrict__ num_segments, ete* __restrict__ buckets,
-                                                    ete* __restrict__ seg_out, uint32_t n, uint32_t logB, uint32_t seg_len) {
+                                                    ete* __restrict__ seg_out, uint32_t n, uint32_t logB, uint32_t seg_len, uint32_t ids) {
   const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
-  if (gid >= *num_segments) return;
+  if (gid >= (order ? *num_segments : ids)) return;         // the schedule lists the valid segments; without it the grid is the id space
   const uint32_t sgm = order ? order[gid] : gid;
   const uint32_t g = seg_bucket[sgm];                // g = k * B + b
+  if (g == TE_SEG_INVALID) return;
   const uint32_t k = g >> logB;
   const uint32_t part = sgm - seg_base[g];
   const uint32_t cnt = seg_lenv[sgm];
@@ -896,15 +890,21 @@ __global__ void __launch_bounds__(256) k_seg_combine_all(const uint32_t* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4 tail: everything after the wide fold levels in ONE block per window (1024 threads = 256 quads, team additions, points in
-// LDS).  Replaces the last fold levels, the four second-phase chains and k_weighted_sum -- six dependent, latency-bound
+// K4 tail: everything after the wide fold levels in ONE launch, one block per (window, digit) -- team additions, points in
+// LDS.  Replaces the last fold levels, the four second-phase chains and k_weighted_sum: six dependent, latency-bound
 // launches of the first version.  Bucket index j = hi * L + lo with lo = (d1 d0) of w1 + w0 bits, hi = (d3 d2) of w3 + w2 bits.
 //   in : xin[hi * rx + g], g < rx   partial row sums     X2[hi] = sum_g xin[hi * rx + g]       (H = 2^(w2+w3) values)
 //        yin[h * L + lo], h < ry    partial column sums  Y2[lo] = sum_h yin[h * L + lo]        (L = 2^(w0+w1) values)
-//   A    X2 and Y2 -> LDS (two copies each: the row and the column reductions below work in place)
-//   B    M3[d3] = sum_d2 X2, M2[d2] = sum_d3 X2, M1[d1] = sum_d0 Y2, M0[d0] = sum_d1 Y2 as binary trees, all four at once
-//   C    per digit: suffix scan S_v = sum_{u >= v} M[u], T = S_0 of digit 0, W_k = sum_{v >= 1} S_v by a tree
-//   out: row [T | W0 | W1 | W2 | W3] of the window (what te_host::horner_to_affine folds).
+//   block (digit, window):  digit 3: M3[d3] = sum_d2 X2    digit 2: M2[d2] = sum_d3 X2
+//                           digit 1: M1[d1] = sum_d0 Y2    digit 0: M0[d0] = sum_d1 Y2      (blocks of a window recompute X2 / Y2:
+//                           a few hundred additions, cheaper than a launch boundary between them)
+//   A    X2 or Y2 -> LDS: one quad per value, its rx (ry) <= 4 inputs loaded up front
+//   B    the digit's marginal as a binary tree in place: item (o, t), t < m/2: in[o, t] += in[o, t + m/2]
+//   C    first wave only: suffix scan S_v = sum_{u >= v} M[u] (T = S_0 of digit 0), W = sum_{v >= 1} S_v by a tree
+//   out: slot 1 + digit (and slot 0 = T from the digit-0 block) of the row [T | W0 | W1 | W2 | W3] that
+//        te_host::horner_to_affine folds.
+// One level costs ~3 us (three dependent field products per team addition on a wave that owns its SIMD), a busy CU ~5 us:
+// the blocks are kept small so that the ~15 levels of a window run on four nearly idle CUs.
 struct tail_params {
   const ete* xin; const ete* yin;
   uint32_t rx, ry, x_per_window, y_per_window;
@@ -915,90 +915,73 @@ __device__ __forceinline__ uint32_t* lds_point(uint32_t* base, uint32_t idx) { r
 
 __global__ void __launch_bounds__(1024) k_reduce_tail(tail_params prm) {
   extern __shared__ uint32_t tl[];
-  const uint32_t k = blockIdx.x, i = threadIdx.x >> 2, q = threadIdx.x & 3u, wq = team_word(q), Q = blockDim.x >> 2;
+  const uint32_t dgt = blockIdx.x, k = blockIdx.y, i = threadIdx.x >> 2, q = threadIdx.x & 3u, wq = team_word(q), Q = blockDim.x >> 2;
   const uint32_t w0 = prm.w[0], w1 = prm.w[1], w2 = prm.w[2], w3 = prm.w[3];
-  const uint32_t H = 1u << (w2 + w3), L = 1u << (w0 + w1);
-  uint32_t* sx = tl;                       // X2, reduced along d2 (rows)      -> M3[d3] at sx[d3 << w2]
-  uint32_t* sx2 = sx + (size_t)H * 36u;    // X2, reduced along d3 (columns)   -> M2[d2] at sx2[d2]
-  uint32_t* sy = sx2 + (size_t)H * 36u;    // Y2, reduced along d0             -> M1[d1] at sy[d1 << w0]
-  uint32_t* sy2 = sy + (size_t)L * 36u;    // Y2, reduced along d1             -> M0[d0] at sy2[d0]
-  uint32_t* sc = sy2 + (size_t)L * 36u;    // 64 points of scratch for step C
+  const bool isx = dgt >= 2u;
+  const uint32_t nv = isx ? 1u << (w2 + w3) : 1u << (w0 + w1);          // values of X2 (Y2)
+  uint32_t* sv = tl;                                                     // X2 / Y2, then the tree in place
+  uint32_t* sc = sv + (size_t)nv * 36u;                                  // 16 points of scratch for step C
   // ---- A
-  for (uint32_t o = i; o < H + L; o += Q) {
-    const bool isx = o < H;
-    const uint32_t lo = o - H;
-    const ete* src = isx ? prm.xin + (size_t)k * prm.x_per_window + (size_t)o * prm.rx : prm.yin + (size_t)k * prm.y_per_window + lo;
-    const uint32_t stride = isx ? 1u : L, cnt = isx ? prm.rx : prm.ry;
-    fp acc = load_coord(reinterpret_cast<const uint32_t*>(src) + wq);
-    for (uint32_t t = 1; t < cnt; t++) acc = ete_add_team(acc, load_coord(reinterpret_cast<const uint32_t*>(src + (size_t)t * stride) + wq), q);
-    store_coord(lds_point(isx ? sx : sy, isx ? o : lo) + wq, acc);
-    store_coord(lds_point(isx ? sx2 : sy2, isx ? o : lo) + wq, acc);
-  }
-  __syncthreads();
-  // ---- B: job j sums m_j inputs per output in place: item (o, t), t < m/2: in[o, t] += in[o, t + m/2]
   {
-    uint32_t m[4] = {1u << w2, 1u << w3, 1u << w0, 1u << w1};            // inputs per output: M3, M2, M1, M0
-    const uint32_t nout[4] = {1u << w3, 1u << w2, 1u << w1, 1u << w0};
-    const uint32_t ostr[4] = {1u << w2, 1u, 1u << w0, 1u}, istr[4] = {1u, 1u << w2, 1u, 1u << w0};
-    uint32_t* const base[4] = {sx, sx2, sy, sy2};
-    for (;;) {
-      uint32_t items[4], total = 0;
+    const uint32_t cnt = isx ? prm.rx : prm.ry, stride = isx ? 1u : nv;
+    for (uint32_t o = i; o < nv; o += Q) {
+      const ete* src = isx ? prm.xin + (size_t)k * prm.x_per_window + (size_t)o * prm.rx : prm.yin + (size_t)k * prm.y_per_window + o;
+      fp in[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) { items[j] = m[j] > 1u ? nout[j] * (m[j] >> 1) : 0u; total += items[j]; }
-      if (total == 0) break;                                              // uniform
-      for (uint32_t it0 = 0; it0 < total; it0 += Q) {                    // uniform trip count: every quad reaches the barriers
-        const uint32_t it = it0 + i;
-        uint32_t jj = 0, rel = it;
-        bool act = it < total;
-#pragma unroll
-        for (int j = 0; j < 3; j++) if (act && jj == (uint32_t)j && rel >= items[j]) { rel -= items[j]; jj = j + 1; }
-        uint32_t a_idx = 0, b_idx = 0;
-        uint32_t* bs = sx;
-#pragma unroll
-        for (int j = 0; j < 4; j++) if (jj == (uint32_t)j) {
-          const uint32_t half = m[j] >> 1, o = act ? rel / half : 0u, t = act ? rel - o * half : 0u;
-          a_idx = o * ostr[j] + t * istr[j]; b_idx = a_idx + half * istr[j]; bs = base[j];
-        }
-        if (!act) { a_idx = 0; b_idx = 0; }
-        const fp a = load_coord(lds_point(bs, a_idx) + wq), b = load_coord(lds_point(bs, b_idx) + wq);
-        const fp sum = ete_add_team(a, b, q);
-        if (act) store_coord(lds_point(bs, a_idx) + wq, sum);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < 4; j++) if (m[j] > 1u) m[j] >>= 1;
+      for (int t = 0; t < 4; t++) in[t] = load_coord(reinterpret_cast<const uint32_t*>(src + (size_t)min((uint32_t)t, cnt - 1u) * stride) + wq);
+      fp acc = in[0];                                                                              // cnt is uniform
+      if (cnt > 1u) acc = ete_add_team(acc, in[1], q);
+      if (cnt > 2u) acc = ete_add_team(acc, in[2], q);
+      if (cnt > 3u) acc = ete_add_team(acc, in[3], q);
+      store_coord(lds_point(sv, o) + wq, acc);
     }
   }
-  // ---- C: quad i = digit * 16 + v (64 quads); the other quads only keep the barriers company
-  {
-    const uint32_t dgt = (i >> 4) & 3u, v = i & 15u;
-    const bool mineq = i < 64u;
-    const uint32_t N = 1u << (dgt == 0 ? w0 : dgt == 1 ? w1 : dgt == 2 ? w2 : w3);
-    const uint32_t* mp = dgt == 0 ? lds_point(sy2, v) : dgt == 1 ? lds_point(sy, v << w0) : dgt == 2 ? lds_point(sx2, v) : lds_point(sx, v << w2);
-    fp mine = (mineq && v < N) ? load_coord(mp + wq) : identity_coord(q);
+  __syncthreads();
+  // ---- B: outputs nout, m inputs each; element (o, t) at o * ostr + t * istr
+  const uint32_t wd = dgt == 0 ? w0 : dgt == 1 ? w1 : dgt == 2 ? w2 : w3;       // bits of this digit
+  const uint32_t wo = dgt == 0 ? w1 : dgt == 1 ? w0 : dgt == 2 ? w3 : w2;       // bits of the digit summed away
+  const bool low = dgt == 0 || dgt == 2;                                        // this digit is the low one of its pair
+  const uint32_t nout = 1u << wd, ostr = low ? 1u : 1u << wo, istr = low ? 1u << wd : 1u;
+  for (uint32_t m = 1u << wo; m > 1u; m >>= 1) {
+    const uint32_t half = m >> 1, total = nout * half;
+    for (uint32_t it0 = 0; it0 < total; it0 += Q) {                            // uniform trip count
+      const uint32_t it = it0 + i;
+      const bool act = it < total;
+      const uint32_t o = act ? it / half : 0u, t = act ? it - o * half : 0u;
+      const uint32_t a_idx = o * ostr + t * istr, b_idx = a_idx + (act ? half * istr : 0u);
+      const fp a = load_coord(lds_point(sv, a_idx) + wq), b = load_coord(lds_point(sv, b_idx) + wq);
+      const fp sum = ete_add_team(a, b, q);
+      if (act) store_coord(lds_point(sv, a_idx) + wq, sum);
+    }
     __syncthreads();
-    uint32_t* slot = lds_point(sc, i & 63u);
+  }
+  // ---- C: the first wave alone (16 quads, quad v holds M[v]); the other waves are done
+  if (threadIdx.x >= 64u) return;
+  {
+    const uint32_t v = i, N = nout;                                            // N <= 16
+    fp mine = v < N ? load_coord(lds_point(sv, v * ostr) + wq) : identity_coord(q);
+    uint32_t* slot = lds_point(sc, v);
     for (uint32_t d = 1; d < 16u; d <<= 1) {           // inclusive suffix scan
-      if (mineq) store_coord(slot + wq, mine);
+      store_coord(slot + wq, mine);
       __syncthreads();
-      const bool act = mineq && v + d < N;
-      const fp other = act ? load_coord(lds_point(sc, (i & 63u) + d) + wq) : identity_coord(q);
+      const bool act = v + d < N;
+      const fp other = act ? load_coord(lds_point(sc, v + d) + wq) : identity_coord(q);
       const fp sum = ete_add_team(mine, other, q);
       mine = fp_select(act, sum, mine);
       __syncthreads();
     }
     ete* row = prm.rows + (size_t)k * prm.row_stride;
-    if (mineq && v == 0) { if (dgt == 0) store_coord(reinterpret_cast<uint32_t*>(row) + wq, mine); mine = identity_coord(q); }
+    if (v == 0) { if (dgt == 0) store_coord(reinterpret_cast<uint32_t*>(row) + wq, mine); mine = identity_coord(q); }
     for (uint32_t s = 8; s > 0; s >>= 1) {             // tree sum of S_1..S_{N-1} (slot 0 = identity)
-      if (mineq && v >= s && v < 2 * s) store_coord(slot + wq, mine);
+      if (v >= s && v < 2 * s) store_coord(slot + wq, mine);
       __syncthreads();
-      const bool act = mineq && v < s && v + s < N;
-      const fp other = act ? load_coord(lds_point(sc, (i & 63u) + s) + wq) : identity_coord(q);
+      const bool act = v < s && v + s < N;
+      const fp other = act ? load_coord(lds_point(sc, v + s) + wq) : identity_coord(q);
       const fp sum = ete_add_team(mine, other, q);
       mine = fp_select(act, sum, mine);
       __syncthreads();
     }
-    if (mineq && v == 0) store_coord(reinterpret_cast<uint32_t*>(row + 1 + dgt) + wq, mine);
+    if (v == 0) store_coord(reinterpret_cast<uint32_t*>(row + 1 + dgt) + wq, mine);
   }
 }
 

@@ -73,11 +73,12 @@ __global__ void __launch_bounds__(256) k377_accumulate(const pnt_slot* __restric
                                                        const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ seg_bucket,
                                                        const uint32_t* __restrict__ seg_lenv, const uint32_t* __restrict__ order,
                                                        const uint32_t* __restrict__ num_segments, g1p_slot* __restrict__ buckets,
-                                                       g1p_slot* __restrict__ seg_out, uint32_t n, uint32_t logB, uint32_t seg_len) {
+                                                       g1p_slot* __restrict__ seg_out, uint32_t n, uint32_t logB, uint32_t seg_len, uint32_t ids) {
   const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
-  if (gid >= *num_segments) return;
+  if (gid >= (order ? *num_segments : ids)) return;         // see k_accumulate
   const uint32_t sgm = order ? order[gid] : gid;
   const uint32_t g = seg_bucket[sgm];
+  if (g == TE_SEG_INVALID) return;
   const uint32_t k = g >> logB;
   const uint32_t part = sgm - seg_base[g];
   const uint32_t cnt = seg_lenv[sgm];

@@ -31,8 +31,8 @@ thread_local std::string g_init_error;
 
 // in execution order: everything that needs only the scalars first, so that a host-buffer call can upload the points
 // (2/3 of the bytes) while those stages already run
-enum { ST_DIGITS = 0, ST_HIST, ST_SCAN, ST_SCATTER, ST_BSORT, ST_ORDER, ST_PREP, ST_ACCUM, ST_TREE, ST_WEIGHTED, ST_COUNT };
-const char* const kStageNames[ST_COUNT] = {"digits", "part_hist", "part_scan", "part_scatter", "bucket_sort", "order", "prep_points",
+enum { ST_DIGITS = 0, ST_SCATTER, ST_BSORT, ST_ORDER, ST_PREP, ST_ACCUM, ST_TREE, ST_WEIGHTED, ST_COUNT };
+const char* const kStageNames[ST_COUNT] = {"digits", "part_scatter", "bucket_sort", "order", "prep_points",
                                            "accumulate", "marginal_sums", "weighted_sum"};
 
 // per-curve sizes: wire format, device accumulator slot, partial row (5 points), result
@@ -65,13 +65,15 @@ struct workset_t {
   size_t cap[40] = {};                                  // per-buffer capacity in bytes (ensure())
   te::pnt_slot* d_recs = nullptr;
   uint16_t *d_digits = nullptr, *d_part_keys = nullptr;
-  uint32_t *d_counts1 = nullptr, *d_part_start = nullptr, *d_part_count = nullptr, *d_part_idx = nullptr;
-  uint32_t *d_bucket_count = nullptr, *d_bucket_start = nullptr, *d_bucket_cursor = nullptr, *d_seg_total = nullptr, *d_sorted = nullptr;
+  uint32_t *d_counts1 = nullptr, *d_part_start = nullptr, *d_part_count = nullptr, *d_part_idx = nullptr, *d_seg_part_base = nullptr;
+  uint32_t *d_bucket_count = nullptr, *d_bucket_start = nullptr, *d_bucket_cursor = nullptr, *d_sorted = nullptr;
   uint32_t *d_seg_base = nullptr, *d_seg_bucket = nullptr, *d_seg_lenv = nullptr, *d_order = nullptr;
   uint32_t *d_split_list = nullptr, *d_large_list = nullptr, *d_chunk_list = nullptr;
   te::ete *d_seg_out = nullptr, *d_buckets = nullptr, *d_red[12] = {};   // reduction: [0..3] ping/pong of the two first-phase chains, [4..11] small
-  // one scratch block, zeroed by a single memset per MSM: [0] final-carry flag, [1] number of segments, [2..4] split /
-  // giant bucket counters, [8..1031] segment-length histogram; [1032..2055] its cursor (not zeroed)
+  // ONE zeroed block per MSM (a single memset): [0] final-carry flag, [1] number of segments, [2..4] split / giant bucket
+  // counters, [8..1031] segment-length histogram, [1032..2055] reservation cursors of the schedule, then the level-1
+  // histogram counts1[window][chunk][partition] and bucket_count[window][bucket].  d_err .. d_bucket_count point into d_zero.
+  uint32_t *d_zero = nullptr; size_t zero_words = 0;
   uint32_t *d_err = nullptr, *d_num_seg = nullptr, *d_size_hist = nullptr, *d_size_cursor = nullptr;
   uint8_t* d_partials = nullptr;      // TE_MAX_WINDOWS x 720, allocated once
   uint32_t* h_err = nullptr;          // pinned
@@ -196,11 +198,16 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, workset_t& ws, uint64_t n, const plan_
   if ((rc = ensure(ctx, ws, ws.d_recs, ws.cap[0], (size_t)n))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_digits, ws.cap[1], nd))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_sorted, ws.cap[2], nd))) return rc;
-  if ((rc = ensure(ctx, ws, ws.d_counts1, ws.cap[3], (size_t)p.nw * p.CH * p.P))) return rc;
-  if ((rc = ensure(ctx, ws, ws.d_bucket_count, ws.cap[4], wb))) return rc;
+  {
+    const size_t c1 = (size_t)p.nw * p.CH * p.P;
+    ws.zero_words = 2056 + c1 + wb;
+    if ((rc = ensure(ctx, ws, ws.d_zero, ws.cap[3], ws.zero_words))) return rc;
+    ws.d_err = ws.d_zero; ws.d_num_seg = ws.d_zero + 1; ws.d_size_hist = ws.d_zero + 8; ws.d_size_cursor = ws.d_zero + 1032;
+    ws.d_counts1 = ws.d_zero + 2056; ws.d_bucket_count = ws.d_counts1 + c1;
+  }
   if ((rc = ensure(ctx, ws, ws.d_bucket_start, ws.cap[5], wb))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_bucket_cursor, ws.cap[16], wb))) return rc;
-  if ((rc = ensure(ctx, ws, ws.d_seg_total, ws.cap[17], (size_t)p.nw * 128 + 128))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_seg_part_base, ws.cap[17], (size_t)p.nw * p.P))) return rc;
   const size_t smax = wb + (size_t)p.nw * (n / (uint64_t)p.seg_len) + 16;      // segments <= buckets + entries / seg_len
   if ((rc = ensure(ctx, ws, ws.d_order, ws.cap[7], smax))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_seg_bucket, ws.cap[20], smax))) return rc;
@@ -225,8 +232,8 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, workset_t& ws, uint64_t n, const plan_
   return 0;
 }
 
-template <int C> void launch_digits(const uint4* sc, uint16_t* dg, const te::digits_params& prm, uint32_t* err, hipStream_t s) {
-  hipLaunchKernelGGL(te::k_digits<C>, dim3((prm.nst / 2 + 255) / 256), dim3(256), 0, s, sc, dg, prm, err);
+template <int C> void launch_digits(const uint4* sc, uint16_t* dg, const te::digits_params& prm, uint32_t* err, uint32_t* counts1, hipStream_t s) {
+  hipLaunchKernelGGL(te::k_digits<C>, dim3((prm.nst + TE_DIG_BLOCK - 1u) / TE_DIG_BLOCK), dim3(TE_DIG_THREADS), 0, s, sc, dg, prm, err, counts1);
 }
 
 // One MSM's device work in three parts, so that the parts before and after the dominant kernel can be replayed as HIP
@@ -262,65 +269,55 @@ struct msm_launch {
   // scalars -> digits, two-level counting sort, segment schedule (needs only the scalars)
   int front_scalars() {
     const uint32_t n32 = this->n32();
-    HIP_TRY(ctx, hipMemsetAsync(ws.d_err, 0, 1032 * sizeof(uint32_t), stream));     // flag, counters, length histogram
+    HIP_TRY(ctx, hipMemsetAsync(ws.d_zero, 0, ws.zero_words * sizeof(uint32_t), stream));   // flags, counters, histograms, bucket counts
     mark(ST_DIGITS);
+    te::sort_geom sg;
+    sg.n = n32; sg.nst = p.nst; sg.B = p.B; sg.logS = p.logS; sg.S = p.S; sg.P = p.P; sg.CH = p.CH; sg.chunk_len = p.chunk_len; sg.half = p.signed_digits ? p.B : 0u;
     if (p.nw > 0) {
       te::digits_params prm; memset(&prm, 0, sizeof prm);
       if (p.signed_digits) for (int w = 0; w < p.W; w++) { const int bit = w * p.c + p.c - 1; if (bit < 320) prm.half[bit >> 5] |= 1u << (bit & 31); }
       prm.zero_digit = p.signed_digits ? 1u << (p.c - 1) : 0u;
       prm.sc_stride = (uint32_t)(sizes_of(p.curve).scalar_in / 16);
       prm.n = n32; prm.nst = p.nst; prm.num_windows = p.W; prm.w_first = d.w_first; prm.w_step = d.w_step; prm.nw_local = p.nw;
+      prm.half_code = sg.half; prm.logS = p.logS; prm.P = p.P; prm.CH = p.CH; prm.chunk_len = p.chunk_len;
       const uint4* sc = (const uint4*)d_scalars;
       switch (p.c) {
-        case 4: launch_digits<4>(sc, ws.d_digits, prm, ws.d_err, stream); break;
-        case 5: launch_digits<5>(sc, ws.d_digits, prm, ws.d_err, stream); break;
-        case 6: launch_digits<6>(sc, ws.d_digits, prm, ws.d_err, stream); break;
-        case 7: launch_digits<7>(sc, ws.d_digits, prm, ws.d_err, stream); break;
-        case 8: launch_digits<8>(sc, ws.d_digits, prm, ws.d_err, stream); break;
-        case 9: launch_digits<9>(sc, ws.d_digits, prm, ws.d_err, stream); break;
-        case 10: launch_digits<10>(sc, ws.d_digits, prm, ws.d_err, stream); break;
-        case 11: launch_digits<11>(sc, ws.d_digits, prm, ws.d_err, stream); break;
-        case 12: launch_digits<12>(sc, ws.d_digits, prm, ws.d_err, stream); break;
-        case 13: launch_digits<13>(sc, ws.d_digits, prm, ws.d_err, stream); break;
-        case 14: launch_digits<14>(sc, ws.d_digits, prm, ws.d_err, stream); break;
-        case 15: launch_digits<15>(sc, ws.d_digits, prm, ws.d_err, stream); break;
-        default: launch_digits<16>(sc, ws.d_digits, prm, ws.d_err, stream); break;
+        case 4: launch_digits<4>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
+        case 5: launch_digits<5>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
+        case 6: launch_digits<6>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
+        case 7: launch_digits<7>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
+        case 8: launch_digits<8>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
+        case 9: launch_digits<9>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
+        case 10: launch_digits<10>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
+        case 11: launch_digits<11>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
+        case 12: launch_digits<12>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
+        case 13: launch_digits<13>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
+        case 14: launch_digits<14>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
+        case 15: launch_digits<15>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
+        default: launch_digits<16>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
       }
     }
-    te::sort_geom sg;
-    sg.n = n32; sg.nst = p.nst; sg.B = p.B; sg.logS = p.logS; sg.S = p.S; sg.P = p.P; sg.CH = p.CH; sg.chunk_len = p.chunk_len; sg.half = p.signed_digits ? p.B : 0u;
-    mark(ST_HIST);
-    if (p.nw > 0) hipLaunchKernelGGL(te::k_part_hist, dim3(p.CH, p.nw), dim3(1024), 0, stream, ws.d_digits, ws.d_counts1, sg);
-    mark(ST_SCAN);
-    if (p.nw > 0) hipLaunchKernelGGL(te::k_part_scan, dim3(p.nw), dim3(1024), 0, stream, ws.d_counts1, ws.d_part_start, ws.d_part_count, sg);
+    const uint32_t cap_w = p.B + (uint32_t)(n / p.seg_len);        // segment ids of one window (see k_part_scatter)
     mark(ST_SCATTER);
     if (p.nw > 0)
-      hipLaunchKernelGGL(te::k_part_scatter, dim3(p.CH, p.nw), dim3(512), 0, stream, ws.d_digits, ws.d_counts1, ws.d_part_keys, ws.d_part_idx, sg);
+      hipLaunchKernelGGL(te::k_part_scatter, dim3(p.CH, p.nw), dim3(512), 0, stream, ws.d_digits, ws.d_counts1, ws.d_part_keys, ws.d_part_idx,
+                         ws.d_part_start, ws.d_part_count, ws.d_seg_part_base, p.seg_len, cap_w, sg);
     mark(ST_BSORT);
+    const uint32_t total = this->total();
     if (p.nw > 0) {
       const uint32_t nslices = (p.nst + TE_SLICE - 1u) / TE_SLICE;
-      const uint32_t seg_threads = p.B < 1024u ? p.B : 1024u, nseg = p.B / seg_threads;
-      HIP_TRY(ctx, hipMemsetAsync(ws.d_bucket_count, 0, (size_t)p.nw * p.B * sizeof(uint32_t), stream));
       hipLaunchKernelGGL(te::k_l2_count, dim3(nslices, p.nw), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx, ws.d_part_start,
                          ws.d_part_count, ws.d_bucket_count, sg);
-      hipLaunchKernelGGL(te::k_bscan_a, dim3(nseg, p.nw), dim3(seg_threads), 0, stream, ws.d_bucket_count, ws.d_bucket_cursor, ws.d_seg_base,
-                         ws.d_seg_total, p.B, p.seg_len);
-      hipLaunchKernelGGL(te::k_bscan_b, dim3(nseg, p.nw), dim3(seg_threads), 0, stream, ws.d_bucket_cursor, ws.d_seg_base, ws.d_seg_total,
-                         ws.d_bucket_start, ws.d_bucket_cursor, ws.d_num_seg, p.B);
+      // d_num_seg[1..3] = split / giant bucket counters, zeroed with the rest
+      hipLaunchKernelGGL(te::k_seg_plan, dim3(p.P, p.nw), dim3(p.S), 0, stream, ws.d_bucket_count, ws.d_part_start, ws.d_part_count, ws.d_seg_part_base,
+                         ws.d_bucket_start, ws.d_bucket_cursor, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv, ws.d_size_hist, ws.d_split_list,
+                         ws.d_num_seg + 1, ws.d_large_list, ws.d_chunk_list, p.B, p.S, p.seg_len, cap_w, total, chunk_cap());
       hipLaunchKernelGGL(te::k_l2_place, dim3(nslices, p.nw), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx, ws.d_part_start,
                          ws.d_part_count, ws.d_bucket_cursor, ws.d_sorted, sg);
     }
-    const uint32_t total = this->total();
     mark(ST_ORDER);
-    if (p.nw > 0) {
-      // d_num_seg[1] = number of split buckets; size_hist zeroed together with it
-      hipLaunchKernelGGL(te::k_seg_build, dim3(1024), dim3(256), 0, stream, ws.d_seg_base, ws.d_bucket_count, ws.d_num_seg, total, p.seg_len,
-                         ws.d_seg_bucket, ws.d_seg_lenv, ws.d_size_hist, ws.d_split_list, ws.d_num_seg + 1, ws.d_large_list, ws.d_chunk_list, total, chunk_cap());
-      if (ctx->opt_sort) {
-        hipLaunchKernelGGL(te::k_order_scan, dim3(1), dim3(1024), 0, stream, ws.d_size_hist, ws.d_size_cursor);
-        hipLaunchKernelGGL(te::k_order_scatter, dim3(256), dim3(256), 0, stream, ws.d_seg_lenv, ws.d_num_seg, ws.d_size_cursor, ws.d_order);
-      }
-    }
+    if (p.nw > 0)      // also counts the valid segments (d_num_seg[0]); with "sort_buckets" = 0 the schedule is simply not used
+      hipLaunchKernelGGL(te::k_order_scatter, dim3(256), dim3(256), 0, stream, ws.d_seg_lenv, smax(), ws.d_size_hist, ws.d_size_cursor, ws.d_order, ws.d_num_seg);
     return 0;
   }
 
@@ -333,11 +330,11 @@ struct msm_launch {
       if (p.curve == TE_MSM_CURVE_BLS12_377_G1)
         hipLaunchKernelGGL(te377::k377_accumulate, dim3((smax + 255) / 256), dim3(256), 0, stream, ws.d_recs, ws.d_sorted, ws.d_bucket_start,
                            ws.d_bucket_count, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv, order, ws.d_num_seg,
-                           reinterpret_cast<te377::g1p_slot*>(ws.d_buckets), reinterpret_cast<te377::g1p_slot*>(ws.d_seg_out), n32, p.logB, p.seg_len);
+                           reinterpret_cast<te377::g1p_slot*>(ws.d_buckets), reinterpret_cast<te377::g1p_slot*>(ws.d_seg_out), n32, p.logB, p.seg_len, smax);
       else
         hipLaunchKernelGGL(te::k_accumulate, dim3((smax + 255) / 256), dim3(256), 0, stream, ws.d_recs, ws.d_sorted, ws.d_bucket_start,
                            ws.d_bucket_count, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv, order, ws.d_num_seg, ws.d_buckets, ws.d_seg_out,
-                           n32, p.logB, p.seg_len);
+                           n32, p.logB, p.seg_len, smax);
     }
     return 0;
   }
@@ -347,7 +344,8 @@ struct msm_launch {
   //   cols chain  yin[h * L + lo]  -- the high H = 2^(w2+w3) part folded from the top
   // Wide levels (both chains per launch, one thread or one quad per output) run until at most 4 partial sums per output
   // are left; k_reduce_tail (one block per window) does the rest and writes the row.  n = 2^20, c = 16: two fold
-  // launches (32768 -> 4096 -> 512 points per window and chain) + the tail, against nine launches of the first version.
+  // launches (32768 -> 4096 -> 512 points per window and chain) + the tail (one block per window and digit), against nine
+  // launches of the first version.
   int back_reduce_te() {
     const uint32_t w0 = p.dw[0], w1 = p.dw[1], w2 = p.dw[2], w3 = p.dw[3];
     const uint32_t L = 1u << (w0 + w1), H = 1u << (w2 + w3);
@@ -382,8 +380,8 @@ struct msm_launch {
     tp.x_per_window = ch[0].n; tp.y_per_window = ch[1].n;
     tp.w[0] = w0; tp.w[1] = w1; tp.w[2] = w2; tp.w[3] = w3;
     tp.rows = reinterpret_cast<te::ete*>(d_partials_out) + (size_t)d.w_first * 5; tp.row_stride = (uint32_t)d.w_step * 5u;
-    const size_t lds_bytes = (size_t)(2u * (H + L) + 64u) * 144u;
-    hipLaunchKernelGGL(te::k_reduce_tail, dim3(p.nw), dim3(1024), lds_bytes, stream, tp);
+    const size_t lds_bytes = (size_t)(std::max(H, L) + 16u) * 144u;
+    hipLaunchKernelGGL(te::k_reduce_tail, dim3(4, p.nw), dim3(1024), lds_bytes, stream, tp);
     mark(ST_COUNT);
     HIP_TRY(ctx, hipMemcpyAsync(ws.h_err, ws.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     return 0;
@@ -554,9 +552,9 @@ int collect_stage_ms(te_ctx* ctx, workset_t& ws) {
 void free_dev(gpu_t& d) {
   (void)hipSetDevice(d.device);
   for (workset_t& ws : d.ws) {
-    void* ptrs[] = {ws.d_recs, ws.d_digits, ws.d_part_keys, ws.d_counts1, ws.d_part_start, ws.d_part_count, ws.d_part_idx, ws.d_bucket_count,
-                    ws.d_bucket_start, ws.d_bucket_cursor, ws.d_seg_total, ws.d_sorted, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv,
-                    ws.d_order, ws.d_split_list, ws.d_large_list, ws.d_chunk_list, ws.d_seg_out, ws.d_buckets, ws.d_err, ws.d_partials};
+    void* ptrs[] = {ws.d_recs, ws.d_digits, ws.d_part_keys, ws.d_zero, ws.d_part_start, ws.d_part_count, ws.d_part_idx, ws.d_seg_part_base,
+                    ws.d_bucket_start, ws.d_bucket_cursor, ws.d_sorted, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv,
+                    ws.d_order, ws.d_split_list, ws.d_large_list, ws.d_chunk_list, ws.d_seg_out, ws.d_buckets, ws.d_partials};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     for (te::ete* q : ws.d_red) if (q) (void)hipFree(q);
     if (ws.h_err) (void)hipHostFree(ws.h_err);
@@ -717,14 +715,12 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
     d.w_first = i; d.w_step = n_dev;
     if (d.device < 0 || d.device >= count) { g_init_error = "te_msm_init: device id out of range"; delete ctx; return TE_MSM_EINVAL; }
     hipError_t er = hipSetDevice(d.device);
-    if (er == hipSuccess)                // k_reduce_tail keeps up to 2 x 512 + 64 points in LDS (157 KB of the CU's 160 KB)
-      er = hipFuncSetAttribute(reinterpret_cast<const void*>(te::k_reduce_tail), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (er == hipSuccess)                // k_reduce_tail keeps up to 256 + 16 points in LDS (39 KB)
+      er = hipFuncSetAttribute(reinterpret_cast<const void*>(te::k_reduce_tail), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     for (workset_t& ws : d.ws) {       // the small fixed allocations of both work sets; the big buffers come with the first MSM
       if (er == hipSuccess) er = hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking);
       if (er == hipSuccess) er = hipStreamCreateWithFlags(&ws.copy_stream, hipStreamNonBlocking);
       if (er == hipSuccess) er = hipEventCreateWithFlags(&ws.ev_copy, hipEventDisableTiming);
-      if (er == hipSuccess) er = hipMalloc((void**)&ws.d_err, 2056 * sizeof(uint32_t));
-      if (er == hipSuccess) { ws.d_num_seg = ws.d_err + 1; ws.d_size_hist = ws.d_err + 8; ws.d_size_cursor = ws.d_err + 1032; }
       if (er == hipSuccess) er = hipMalloc((void**)&ws.d_partials, (size_t)TE_MAX_WINDOWS * TE_MAX_ROW_BYTES);
       if (er == hipSuccess) er = hipHostMalloc((void**)&ws.h_err, sizeof(uint32_t), hipHostMallocDefault);
       if (er == hipSuccess) er = hipHostMalloc((void**)&ws.h_partials, (size_t)TE_MAX_WINDOWS * TE_MAX_ROW_BYTES, hipHostMallocDefault);
