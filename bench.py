@@ -83,6 +83,7 @@ def main():
                     help="uniform: the harness's distribution; equal: one scalar repeated (worst-case skew); small: 64-bit scalars")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sizes", action="store_true", help="skip the n = 2^16..2^19 side table")
+    ap.add_argument("--no-host-buffers", action="store_true", help="skip the te_msm_run (host buffer) timing: kernel traces of one configuration only")
     ap.add_argument("--segment-len", type=int, default=0)
     ap.add_argument("--curve", choices=("te", "bls12-377"), default="te",
                     help="te: the Twisted-Edwards BLS12 curve (headline); bls12-377: G1 of BLS12-377, BASELINE config 5 (single GPU)")
@@ -344,7 +345,7 @@ def main():
             cx.set_option("profile", prof)
         return min(ts), r
 
-    if rank == 0 and world == 1 and not sharded:
+    if rank == 0 and world == 1 and not sharded and not args.no_host_buffers:
         # the boundary hands over host buffers (te_msm_run): PCIe-inclusive latency, reported but never `value`
         hb, r_host = host_buffer_ms(ctx, pts, sc)
         out["host_buffers_ms"] = hb

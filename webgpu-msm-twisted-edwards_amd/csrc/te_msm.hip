@@ -61,7 +61,7 @@ struct graph_key { const void *pts, *sc, *out; uint64_t n, generation; int c, w_
 // other (te_msm_submit_device alternates them; "workset" option for te_msm_partial_device callers).
 struct workset_t {
   hipStream_t stream = nullptr, copy_stream = nullptr;   // copy_stream: host-buffer uploads beside the compute stream
-  hipEvent_t ev_copy = nullptr;
+  hipEvent_t ev_copy = nullptr, ev_start = nullptr;
   size_t cap[40] = {};                                  // per-buffer capacity in bytes (ensure())
   te::pnt_slot* d_recs = nullptr;
   uint16_t *d_digits = nullptr, *d_part_keys = nullptr;
@@ -70,14 +70,15 @@ struct workset_t {
   uint32_t *d_seg_base = nullptr, *d_seg_bucket = nullptr, *d_seg_lenv = nullptr, *d_order = nullptr;
   uint32_t *d_split_list = nullptr, *d_large_list = nullptr, *d_chunk_list = nullptr;
   te::ete *d_seg_out = nullptr, *d_buckets = nullptr, *d_red[12] = {};   // reduction: [0..3] ping/pong of the two first-phase chains, [4..11] small
-  // ONE zeroed block per MSM (a single memset): [0] final-carry flag, [1] number of segments, [2..4] split / giant bucket
-  // counters, [8..1031] segment-length histogram, [1032..2055] reservation cursors of the schedule, then the level-1
-  // histogram counts1[window][chunk][partition] and bucket_count[window][bucket].  d_err .. d_bucket_count point into d_zero.
+  // ONE zeroed block per MSM (a single memset), words: [0] final-carry flag, [1] number of segments, [2..4] split / giant
+  // bucket counters, [Z_ROWS..) the partial rows of the MSM (so that flag and rows come back in ONE device-to-host copy),
+  // [Z_HIST..) segment-length histogram, [Z_CURSOR..) reservation cursors of the schedule, [Z_END..) the level-1 histogram
+  // counts1[window][chunk][partition], then bucket_count[window][bucket].  d_err .. d_bucket_count point into d_zero.
   uint32_t *d_zero = nullptr; size_t zero_words = 0;
   uint32_t *d_err = nullptr, *d_num_seg = nullptr, *d_size_hist = nullptr, *d_size_cursor = nullptr;
-  uint8_t* d_partials = nullptr;      // TE_MAX_WINDOWS x 720, allocated once
-  uint32_t* h_err = nullptr;          // pinned
-  uint8_t* h_partials = nullptr;      // pinned, TE_MAX_WINDOWS x 720
+  uint8_t* d_partials = nullptr;      // = d_zero + Z_ROWS: TE_MAX_WINDOWS rows
+  uint32_t* h_err = nullptr;          // pinned: mirror of d_zero[0 .. Z_ROWS + rows)
+  uint8_t* h_partials = nullptr;      // = h_err + Z_ROWS
   hipEvent_t ev_done = nullptr;
   hipEvent_t ev[ST_COUNT + 1] = {};
   plan_t plan; uint64_t n = 0; bool used = false;
@@ -88,6 +89,7 @@ struct workset_t {
   hipGraphExec_t g_front = nullptr, g_back = nullptr; graph_key g_key = {};
 };
 constexpr int TE_MAX_WINDOWS = 64;    // window_bits >= 4
+constexpr size_t Z_ROWS = 8, Z_HIST = Z_ROWS + (size_t)TE_MAX_WINDOWS * TE_MAX_ROW_BYTES / 4, Z_CURSOR = Z_HIST + 1024, Z_END = Z_CURSOR + 1024;
 
 struct gpu_t {
   int device = 0;
@@ -200,10 +202,11 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, workset_t& ws, uint64_t n, const plan_
   if ((rc = ensure(ctx, ws, ws.d_sorted, ws.cap[2], nd))) return rc;
   {
     const size_t c1 = (size_t)p.nw * p.CH * p.P;
-    ws.zero_words = 2056 + c1 + wb;
+    ws.zero_words = Z_END + c1 + wb;
     if ((rc = ensure(ctx, ws, ws.d_zero, ws.cap[3], ws.zero_words))) return rc;
-    ws.d_err = ws.d_zero; ws.d_num_seg = ws.d_zero + 1; ws.d_size_hist = ws.d_zero + 8; ws.d_size_cursor = ws.d_zero + 1032;
-    ws.d_counts1 = ws.d_zero + 2056; ws.d_bucket_count = ws.d_counts1 + c1;
+    ws.d_err = ws.d_zero; ws.d_num_seg = ws.d_zero + 1; ws.d_size_hist = ws.d_zero + Z_HIST; ws.d_size_cursor = ws.d_zero + Z_CURSOR;
+    ws.d_partials = reinterpret_cast<uint8_t*>(ws.d_zero + Z_ROWS);
+    ws.d_counts1 = ws.d_zero + Z_END; ws.d_bucket_count = ws.d_counts1 + c1;
   }
   if ((rc = ensure(ctx, ws, ws.d_bucket_start, ws.cap[5], wb))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_bucket_cursor, ws.cap[16], wb))) return rc;
@@ -244,6 +247,7 @@ struct msm_launch {
   const void* d_points; const void* d_scalars; uint64_t n; void* d_partials_out;
   int prof;                       // event marks inside front()/back() only at profile level 2 (never inside a capture)
   hipStream_t stream;
+  bool own_rows = false;          // rows go to ws.d_partials: the caller fetches flag + rows with one copy
   uint32_t n32() const { return (uint32_t)n; }
   uint32_t total() const { return (uint32_t)p.nw * p.B; }
   uint32_t smax() const { return total() + (uint32_t)((uint64_t)p.nw * (n / p.seg_len)); }
@@ -383,7 +387,7 @@ struct msm_launch {
     const size_t lds_bytes = (size_t)(std::max(H, L) + 16u) * 144u;
     hipLaunchKernelGGL(te::k_reduce_tail, dim3(4, p.nw), dim3(1024), lds_bytes, stream, tp);
     mark(ST_COUNT);
-    HIP_TRY(ctx, hipMemcpyAsync(ws.h_err, ws.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    if (!own_rows) HIP_TRY(ctx, hipMemcpyAsync(ws.h_err, ws.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     return 0;
   }
 
@@ -469,7 +473,7 @@ struct msm_launch {
       hipLaunchKernelGGL(te::k_weighted_sum, dim3(4, p.nw), dim3(64), 0, stream, wj, rows, (uint32_t)d.w_step * 5u);
     }
     mark(ST_COUNT);
-    HIP_TRY(ctx, hipMemcpyAsync(ws.h_err, ws.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    if (!own_rows) HIP_TRY(ctx, hipMemcpyAsync(ws.h_err, ws.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     return 0;
   }
 };
@@ -489,10 +493,18 @@ template <typename F> int capture_graph(te_ctx* ctx, workset_t& ws, hipGraphExec
   return 0;
 }
 
-// before_points (optional): called after the scalar-only stages are enqueued and before the first kernel that reads the
-// points -- te_msm_run uploads the points there, so the upload overlaps digits, sort and schedule.
+// d_partials_out == nullptr: the rows go to the work set's own buffer (ws.d_partials, inside the block that is zeroed per
+// MSM) and the caller fetches flag + rows with fetch_rows().
+// upload_points (optional): enqueues the host-to-device copy of the points on the given (side) stream -- te_msm_run; the
+// upload then overlaps digits, sort and schedule.
+// With an upload, the points -> records conversion follows it on the work set's side stream, beside the scalar-only
+// stages, and joins before the accumulation.  Running it there for device-resident inputs as well (side_stream) was
+// measured and is not used: for one MSM the conversion and the sort stages are both bandwidth-bound and merely slow each
+// other down (latency 1.36 -> 1.38 ms), and with several MSMs in flight every extra stream competes for the runtime's few
+// hardware queues (four by default; GPU_MAX_HW_QUEUES=8 did not help) and serialises the others: 941 -> 862 MSM/s.
 int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, const void* d_scalars, uint64_t n,
-                    void* d_partials_out, hipStream_t stream, const std::function<int()>* before_points = nullptr, int force_c = 0) {
+                    void* d_partials_out, hipStream_t stream, const std::function<int(hipStream_t)>* upload_points = nullptr, int force_c = 0,
+                    bool side_stream = false) {
   plan_t p; make_plan(ctx, d, n, p, force_c);
   HIP_TRY(ctx, hipSetDevice(d.device));
   if ((uint64_t)p.nw * p.B + (uint64_t)p.nw * (n / p.seg_len) + 1024u >= (1ull << 32))
@@ -501,10 +513,12 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, 
   if (ws.used && ws.last_stream != stream) HIP_TRY(ctx, hipStreamWaitEvent(stream, ws.ev_done, 0));   // the set's buffers are still the previous MSM's
   ws.plan = p; ws.n = n; ws.used = true; ws.last_stream = stream; d.last_ws = (int)(&ws - d.ws);
   ws.prof_level = ctx->opt_profile;
+  const bool own_rows = d_partials_out == nullptr;
+  if (own_rows) d_partials_out = ws.d_partials;
   // profile 1: two events around the dominant kernel only (what bench.py times live); 2: every stage boundary
   // (an event between two kernels costs ~4 us of idle stream time, 11 of them ~2 % of a 2^20 MSM)
-  msm_launch L{ctx, d, ws, p, d_points, d_scalars, n, d_partials_out, ctx->opt_profile, stream};
-  if (ctx->opt_graph && ctx->opt_profile < 2 && !before_points) {
+  msm_launch L{ctx, d, ws, p, d_points, d_scalars, n, d_partials_out, ctx->opt_profile, stream, own_rows};
+  if (ctx->opt_graph && ctx->opt_profile < 2 && !upload_points) {
     // the graphs hold pointers and geometry: re-captured when any of them changes (including a buffer reallocation)
     graph_key key; memset(&key, 0, sizeof key);          // padding bytes take part in the memcmp below
     key.pts = d_points; key.sc = d_scalars; key.out = d_partials_out; key.n = n; key.generation = ws.generation;
@@ -521,16 +535,35 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, 
     if (int rc = L.accumulate()) return rc;
     L.mark(ST_TREE);
     HIP_TRY(ctx, hipGraphLaunch(ws.g_back, stream));
-  } else {
+  } else if (ctx->opt_profile >= 2 || !(side_stream || upload_points)) {
     if (int rc = L.front_scalars()) return rc;
-    if (before_points) { if (int rc = (*before_points)()) return rc; }
+    if (upload_points) { if (int rc = (*upload_points)(stream)) return rc; }
     if (int rc = L.front_points()) return rc;
+    if (int rc = L.accumulate()) return rc;
+    L.mark(ST_TREE);
+    if (int rc = L.back()) return rc;
+  } else {
+    // side stream: [upload of the points] -> records; it starts behind everything already enqueued on `stream`
+    HIP_TRY(ctx, hipEventRecord(ws.ev_start, stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ws.copy_stream, ws.ev_start, 0));
+    if (upload_points) { if (int rc = (*upload_points)(ws.copy_stream)) return rc; }
+    msm_launch S = L; S.stream = ws.copy_stream;
+    if (int rc = S.front_points()) return rc;
+    HIP_TRY(ctx, hipEventRecord(ws.ev_copy, ws.copy_stream));
+    if (int rc = L.front_scalars()) return rc;
+    HIP_TRY(ctx, hipStreamWaitEvent(stream, ws.ev_copy, 0));
     if (int rc = L.accumulate()) return rc;
     L.mark(ST_TREE);
     if (int rc = L.back()) return rc;
   }
   HIP_TRY(ctx, hipEventRecord(ws.ev_done, stream));
   HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+// one device-to-host copy: final-carry flag + the W rows of the work set's own row buffer (enqueue_partial with nullptr)
+int fetch_rows(te_ctx* ctx, workset_t& ws, hipStream_t stream) {
+  HIP_TRY(ctx, hipMemcpyAsync(ws.h_err, ws.d_zero, Z_ROWS * 4 + (size_t)ws.plan.W * sizes_of(ws.plan.curve).row, hipMemcpyDeviceToHost, stream));
   return 0;
 }
 
@@ -554,16 +587,16 @@ void free_dev(gpu_t& d) {
   for (workset_t& ws : d.ws) {
     void* ptrs[] = {ws.d_recs, ws.d_digits, ws.d_part_keys, ws.d_zero, ws.d_part_start, ws.d_part_count, ws.d_part_idx, ws.d_seg_part_base,
                     ws.d_bucket_start, ws.d_bucket_cursor, ws.d_sorted, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv,
-                    ws.d_order, ws.d_split_list, ws.d_large_list, ws.d_chunk_list, ws.d_seg_out, ws.d_buckets, ws.d_partials};
+                    ws.d_order, ws.d_split_list, ws.d_large_list, ws.d_chunk_list, ws.d_seg_out, ws.d_buckets};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     for (te::ete* q : ws.d_red) if (q) (void)hipFree(q);
     if (ws.h_err) (void)hipHostFree(ws.h_err);
-    if (ws.h_partials) (void)hipHostFree(ws.h_partials);
     if (ws.ev_done) (void)hipEventDestroy(ws.ev_done);
     if (ws.g_front) (void)hipGraphExecDestroy(ws.g_front);
     if (ws.g_back) (void)hipGraphExecDestroy(ws.g_back);
     for (auto& ev : ws.ev) if (ev) (void)hipEventDestroy(ev);
     if (ws.ev_copy) (void)hipEventDestroy(ws.ev_copy);
+    if (ws.ev_start) (void)hipEventDestroy(ws.ev_start);
     if (ws.copy_stream) (void)hipStreamDestroy(ws.copy_stream);
     if (ws.stream) (void)hipStreamDestroy(ws.stream);
   }
@@ -592,14 +625,12 @@ int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_
     workset_t& ws = d.ws[i];
     const uint64_t lo = n * (uint64_t)i / (uint64_t)K, hi = n * (uint64_t)(i + 1) / (uint64_t)K, m = hi - lo;
     HIP_TRY(ctx, hipMemcpyAsync(dscs + lo * TE_MSM_SCALAR_BYTES, src_scalars + lo * TE_MSM_SCALAR_BYTES, m * TE_MSM_SCALAR_BYTES, hipMemcpyHostToDevice, ws.stream));
-    const std::function<int()> upload_points = [&]() -> int {
-      HIP_TRY(ctx, hipMemcpyAsync(dpts + lo * TE_MSM_POINT_BYTES, src_points + lo * TE_MSM_POINT_BYTES, m * TE_MSM_POINT_BYTES, hipMemcpyHostToDevice, ws.copy_stream));
-      HIP_TRY(ctx, hipEventRecord(ws.ev_copy, ws.copy_stream));
-      HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ws.ev_copy, 0));
+    const std::function<int(hipStream_t)> upload_points = [&](hipStream_t side) -> int {
+      HIP_TRY(ctx, hipMemcpyAsync(dpts + lo * TE_MSM_POINT_BYTES, src_points + lo * TE_MSM_POINT_BYTES, m * TE_MSM_POINT_BYTES, hipMemcpyHostToDevice, side));
       return 0;
     };
-    if (int rc = enqueue_partial(ctx, d, ws, dpts + lo * TE_MSM_POINT_BYTES, dscs + lo * TE_MSM_SCALAR_BYTES, m, ws.d_partials, ws.stream, &upload_points, pf.c)) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ws.h_partials, ws.d_partials, (size_t)pf.W * TE_MSM_PARTIAL_BYTES, hipMemcpyDeviceToHost, ws.stream));
+    if (int rc = enqueue_partial(ctx, d, ws, dpts + lo * TE_MSM_POINT_BYTES, dscs + lo * TE_MSM_SCALAR_BYTES, m, nullptr, ws.stream, &upload_points, pf.c)) return rc;
+    if (int rc = fetch_rows(ctx, ws, ws.stream)) return rc;
   }
   const uint8_t* rows[TE_MSM_WORKSETS];
   bool bad = false;
@@ -665,16 +696,13 @@ int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, boo
       }
       dp = d.d_in_points; ds = d.d_in_scalars;
     }
-    const std::function<int()> upload_points = [&]() -> int {
-      // on the copy stream, so that it runs beside the kernels already enqueued on ws.stream; the first kernel that reads
-      // the points waits for it
-      HIP_TRY(ctx, hipMemcpyAsync(d.d_in_points, src_points, n * sz.point_in, hipMemcpyHostToDevice, ws.copy_stream));
-      HIP_TRY(ctx, hipEventRecord(ws.ev_copy, ws.copy_stream));
-      HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ws.ev_copy, 0));
+    const std::function<int(hipStream_t)> upload_points = [&](hipStream_t side) -> int {
+      // on the side stream, beside the scalar-only kernels on ws.stream; the conversion to records follows it there
+      HIP_TRY(ctx, hipMemcpyAsync(d.d_in_points, src_points, n * sz.point_in, hipMemcpyHostToDevice, side));
       return 0;
     };
-    if (int rc = enqueue_partial(ctx, d, ws, dp, ds, n, ws.d_partials, ws.stream, src_is_host ? &upload_points : nullptr)) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ws.h_partials, ws.d_partials, (size_t)p0.W * sz.row, hipMemcpyDeviceToHost, ws.stream));
+    if (int rc = enqueue_partial(ctx, d, ws, dp, ds, n, nullptr, ws.stream, src_is_host ? &upload_points : nullptr)) return rc;
+    if (int rc = fetch_rows(ctx, ws, ws.stream)) return rc;
   }
   std::vector<uint8_t> merged((size_t)p0.W * sz.row, 0);
   for (size_t i = 0; i < nd; i++) {
@@ -721,9 +749,9 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
       if (er == hipSuccess) er = hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking);
       if (er == hipSuccess) er = hipStreamCreateWithFlags(&ws.copy_stream, hipStreamNonBlocking);
       if (er == hipSuccess) er = hipEventCreateWithFlags(&ws.ev_copy, hipEventDisableTiming);
-      if (er == hipSuccess) er = hipMalloc((void**)&ws.d_partials, (size_t)TE_MAX_WINDOWS * TE_MAX_ROW_BYTES);
-      if (er == hipSuccess) er = hipHostMalloc((void**)&ws.h_err, sizeof(uint32_t), hipHostMallocDefault);
-      if (er == hipSuccess) er = hipHostMalloc((void**)&ws.h_partials, (size_t)TE_MAX_WINDOWS * TE_MAX_ROW_BYTES, hipHostMallocDefault);
+      if (er == hipSuccess) er = hipEventCreateWithFlags(&ws.ev_start, hipEventDisableTiming);
+      if (er == hipSuccess) er = hipHostMalloc((void**)&ws.h_err, Z_ROWS * 4 + (size_t)TE_MAX_WINDOWS * TE_MAX_ROW_BYTES, hipHostMallocDefault);
+      if (er == hipSuccess) ws.h_partials = reinterpret_cast<uint8_t*>(ws.h_err + Z_ROWS);
       if (er == hipSuccess) er = hipEventCreateWithFlags(&ws.ev_done, hipEventDisableTiming);
       for (auto& evn : ws.ev) if (er == hipSuccess) er = hipEventCreate(&evn);
       if (er == hipSuccess) *ws.h_err = 0;
@@ -768,8 +796,8 @@ int te_msm_submit_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_
   if (wi == TE_MSM_WORKSETS) return set_err(ctx, TE_MSM_ESTATE, "every work set has an MSM in flight: collect one first");
   workset_t& ws = d.ws[wi];
   HIP_TRY(ctx, hipSetDevice(d.device));
-  if (int rc = enqueue_partial(ctx, d, ws, d_points_xy_le, d_scalars_le, n, ws.d_partials, ws.stream)) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(ws.h_partials, ws.d_partials, (size_t)ws.plan.W * sizes_of(ws.plan.curve).row, hipMemcpyDeviceToHost, ws.stream));
+  if (int rc = enqueue_partial(ctx, d, ws, d_points_xy_le, d_scalars_le, n, nullptr, ws.stream)) return rc;
+  if (int rc = fetch_rows(ctx, ws, ws.stream)) return rc;
   HIP_TRY(ctx, hipEventRecord(ws.ev_done, ws.stream));
   *ticket = d.next_ticket++;
   ws.pending_ticket = *ticket;
