@@ -607,7 +607,7 @@ __global__ void __launch_bounds__(256, 4) k_accumulate(const pnt_slot* __restric
                                                     const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ seg_bucket,
                                                     const uint32_t* __restrict__ seg_lenv, const uint32_t* __restrict__ order,
                                                     const uint32_t* __restrict__ num_segments, ete* __restrict__ buckets,
-                                                    ete* __restrict__ seg_out, uint32_t n, uint32_t logB, uint32_t seg_len, uint32_t ids) {
+                                                    ete* __restrict__ seg_out, uint32_t n, uint32_t logB, uint32_t seg_len, uint32_t ids, uint32_t onto) {
   const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
   if (gid >= (order ? *num_segments : ids)) return;         // the schedule lists the valid segments; without it the grid is the id space
   const uint32_t sgm = order ? order[gid] : gid;
@@ -617,7 +617,9 @@ __global__ void __launch_bounds__(256, 4) k_accumulate(const pnt_slot* __restric
   const uint32_t part = sgm - seg_base[g];
   const uint32_t cnt = seg_lenv[sgm];
   const uint32_t* lst = sorted + (size_t)k * n + bucket_start[g] + part * seg_len;
-  ete acc = ete_identity();
+  // onto: the buckets already hold the sums of earlier pieces of the same MSM (te_msm_run uploads and processes large host
+  // buffers in pieces): the first part of every bucket continues from that value instead of the neutral element
+  ete acc = (onto && part == 0u) ? load_ete(buckets + g) : ete_identity();
   if (cnt) {
     // Software pipeline: while the addition of entry j runs, the record of entry j+1 AND the index of entry j+2 are in
     // flight -- nothing that is loaded in an iteration is waited for in the same iteration.  (The first version fetched

@@ -17,6 +17,7 @@
 #include <vector>
 #include <algorithm>
 #include <functional>
+#include <chrono>
 
 #include "../../include/te_msm.h"
 #include "host_tail.hpp"
@@ -99,6 +100,7 @@ struct gpu_t {
   void *d_in_points = nullptr, *d_in_scalars = nullptr; uint64_t cap_in = 0;   // te_msm_run staging
   uint64_t next_ticket = 1, next_collect = 1;
   int ticket_ws[TE_MSM_WORKSETS] = {};   // work set of ticket t at index t % TE_MSM_WORKSETS
+  std::vector<hipEvent_t> piece_events;  // te_msm_run in pieces: "piece i has arrived"
 };
 
 }  // namespace
@@ -248,6 +250,7 @@ struct msm_launch {
   int prof;                       // event marks inside front()/back() only at profile level 2 (never inside a capture)
   hipStream_t stream;
   bool own_rows = false;          // rows go to ws.d_partials: the caller fetches flag + rows with one copy
+  bool onto = false;              // a later piece of a host-buffer MSM: keep the final-carry flag, add onto the buckets
   uint32_t n32() const { return (uint32_t)n; }
   uint32_t total() const { return (uint32_t)p.nw * p.B; }
   uint32_t smax() const { return total() + (uint32_t)((uint64_t)p.nw * (n / p.seg_len)); }
@@ -273,7 +276,8 @@ struct msm_launch {
   // scalars -> digits, two-level counting sort, segment schedule (needs only the scalars)
   int front_scalars() {
     const uint32_t n32 = this->n32();
-    HIP_TRY(ctx, hipMemsetAsync(ws.d_zero, 0, ws.zero_words * sizeof(uint32_t), stream));   // flags, counters, histograms, bucket counts
+    // flags, counters, histograms, bucket counts (a later piece of the same MSM keeps word 0, the final-carry flag)
+    HIP_TRY(ctx, hipMemsetAsync(ws.d_zero + (onto ? 1 : 0), 0, (ws.zero_words - (onto ? 1 : 0)) * sizeof(uint32_t), stream));
     mark(ST_DIGITS);
     te::sort_geom sg;
     sg.n = n32; sg.nst = p.nst; sg.B = p.B; sg.logS = p.logS; sg.S = p.S; sg.P = p.P; sg.CH = p.CH; sg.chunk_len = p.chunk_len; sg.half = p.signed_digits ? p.B : 0u;
@@ -338,7 +342,7 @@ struct msm_launch {
       else
         hipLaunchKernelGGL(te::k_accumulate, dim3((smax + 255) / 256), dim3(256), 0, stream, ws.d_recs, ws.d_sorted, ws.d_bucket_start,
                            ws.d_bucket_count, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv, order, ws.d_num_seg, ws.d_buckets, ws.d_seg_out,
-                           n32, p.logB, p.seg_len, smax);
+                           n32, p.logB, p.seg_len, smax, onto ? 1u : 0u);
     }
     return 0;
   }
@@ -393,6 +397,12 @@ struct msm_launch {
 
   // recombination of split buckets, digit marginals, weighted sums, error flag read-back
   int back() {
+    if (int rc = combine()) return rc;
+    return reduce();
+  }
+
+  // sums of the buckets that were accumulated in several parts
+  int combine() {
     const uint32_t total = this->total();
     const bool bls = p.curve == TE_MSM_CURVE_BLS12_377_G1;
     if (p.nw > 0 && bls) {
@@ -406,6 +416,12 @@ struct msm_launch {
       hipLaunchKernelGGL(te::k_seg_combine_large2, dim3(256), dim3(256), 0, stream, ws.d_large_list, ws.d_num_seg + 1, ws.d_bucket_count, ws.d_seg_base,
                          ws.d_seg_out, ws.d_buckets, p.seg_len, total);
     }
+    return 0;
+  }
+
+  // buckets -> one row per window
+  int reduce() {
+    const bool bls = p.curve == TE_MSM_CURVE_BLS12_377_G1;
     if (p.nw > 0 && !bls) return back_reduce_te();
     // digit marginals M_k[v], k = 0..3 (see K4a in kernels.hip.hpp).  Chains of folds, 4 (or 2) points per level:
     //   rows chain  B[d3 d2 d1 d0] -fold d0-> -fold d1-> X2[d3 d2]      cols chain  B -fold d3-> -fold d2-> Y2[d1 d0]
@@ -602,6 +618,7 @@ void free_dev(gpu_t& d) {
   }
   if (d.d_in_points) (void)hipFree(d.d_in_points);
   if (d.d_in_scalars) (void)hipFree(d.d_in_scalars);
+  for (hipEvent_t e : d.piece_events) (void)hipEventDestroy(e);
 }
 
 // te_msm_run for a large Twisted-Edwards MSM on one device: the host buffers are uploaded and processed in K pieces, each
@@ -609,6 +626,7 @@ void free_dev(gpu_t& d) {
 // piece i+1 crosses PCIe -- and the pieces' rows are summed in the host tail.
 int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_scalars, uint64_t n, int K, uint8_t out[64]) {
   gpu_t& d = ctx->devs[0];
+  workset_t& ws = d.ws[0];
   HIP_TRY(ctx, hipSetDevice(d.device));
   plan_t pf; make_plan(ctx, d, n, pf);
   if (n > d.cap_in) {
@@ -621,26 +639,65 @@ int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_
   }
   uint8_t* dpts = static_cast<uint8_t*>(d.d_in_points);
   uint8_t* dscs = static_cast<uint8_t*>(d.d_in_scalars);
-  for (int i = 0; i < K; i++) {
-    workset_t& ws = d.ws[i];
-    const uint64_t lo = n * (uint64_t)i / (uint64_t)K, hi = n * (uint64_t)(i + 1) / (uint64_t)K, m = hi - lo;
-    HIP_TRY(ctx, hipMemcpyAsync(dscs + lo * TE_MSM_SCALAR_BYTES, src_scalars + lo * TE_MSM_SCALAR_BYTES, m * TE_MSM_SCALAR_BYTES, hipMemcpyHostToDevice, ws.stream));
-    const std::function<int(hipStream_t)> upload_points = [&](hipStream_t side) -> int {
-      HIP_TRY(ctx, hipMemcpyAsync(dpts + lo * TE_MSM_POINT_BYTES, src_points + lo * TE_MSM_POINT_BYTES, m * TE_MSM_POINT_BYTES, hipMemcpyHostToDevice, side));
-      return 0;
-    };
-    if (int rc = enqueue_partial(ctx, d, ws, dpts + lo * TE_MSM_POINT_BYTES, dscs + lo * TE_MSM_SCALAR_BYTES, m, nullptr, ws.stream, &upload_points, pf.c)) return rc;
-    if (int rc = fetch_rows(ctx, ws, ws.stream)) return rc;
+  // Pieces of n / K points: piece i crosses PCIe on the side stream while piece i-1 is digit-decomposed, sorted, converted
+  // and ACCUMULATED ONTO THE SAME BUCKETS on the main stream; one bucket reduction at the end.  (The first version ran
+  // every piece as a complete MSM with its own reduction of all W x 2^(c-1) buckets: K reductions, which made more than
+  // four pieces a loss.)  Pageable copies return once the data has left the caller's buffer, so the host alternates
+  // between staging a piece and enqueueing the previous piece's kernels.
+  // Equal pieces.  Measured alternatives (n = 2^20, tools/host_path.py, TE_MSM_TRACE_HOST=1): linearly falling sizes and
+  // "all scalars first, then the points in pieces" both delay the first accumulation and end later (2.69 / 2.82 ms against
+  // 2.64 ms); the staging itself runs at ~55 GB/s whatever the piece size.  What limits the call is the device: every
+  // piece pays ~13 launches on a fraction of the points, so K pieces keep it busy ~(1.25 + 0.15 K) ms -- about as long as
+  // the 1.8 ms the bytes need to cross PCIe; three or four pieces are the optimum, more pieces lose.
+  auto piece_lo = [&](int i) -> uint64_t { return i >= K ? n : n * (uint64_t)i / (uint64_t)K; };     // first point of piece i
+  const uint64_t m_max = (n + (uint64_t)K - 1) / (uint64_t)K;
+  {
+    plan_t pm; make_plan(ctx, d, m_max, pm, pf.c);
+    if (int rc = ensure_buffers(ctx, d, ws, m_max, pm)) return rc;        // every buffer at its final size before the first piece
   }
-  const uint8_t* rows[TE_MSM_WORKSETS];
-  bool bad = false;
+  if (ws.used && ws.last_stream != ws.stream) HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ws.ev_done, 0));
+  HIP_TRY(ctx, hipEventRecord(ws.ev_start, ws.stream));
+  HIP_TRY(ctx, hipStreamWaitEvent(ws.copy_stream, ws.ev_start, 0));
+  const bool tr = getenv("TE_MSM_TRACE_HOST") != nullptr;
+  const auto t00 = std::chrono::steady_clock::now();
+  auto stamp = [&](const char* what, int i) { if (tr) fprintf(stderr, "[te_msm_run] %8.1f us  %s %d\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t00).count(), what, i); };
+  std::vector<hipEvent_t>& evs = d.piece_events;
+  while ((int)evs.size() < K + 1) { hipEvent_t e; HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); evs.push_back(e); }
+  plan_t p;
+  bool first = true;
+  int last_piece = K - 1;
+  while (last_piece > 0 && piece_lo(last_piece) == n) last_piece--;       // empty tail pieces (n < K (K+1) / 2)
   for (int i = 0; i < K; i++) {
-    HIP_TRY(ctx, hipStreamSynchronize(d.ws[i].stream));
-    bad = bad || *d.ws[i].h_err != 0;
-    rows[i] = d.ws[i].h_partials;
+    const uint64_t lo = piece_lo(i), hi = piece_lo(i + 1), m = hi - lo;
+    if (m == 0) continue;
+    make_plan(ctx, d, m, p, pf.c);
+    if (int rc = ensure_buffers(ctx, d, ws, m, p)) return rc;              // no reallocation: only the pointers into the zeroed block move
+    msm_launch L{ctx, d, ws, p, dpts + lo * TE_MSM_POINT_BYTES, dscs + lo * TE_MSM_SCALAR_BYTES, m, ws.d_partials, 0, ws.stream, true, !first};
+    first = false;
+    HIP_TRY(ctx, hipMemcpyAsync(dscs + lo * TE_MSM_SCALAR_BYTES, src_scalars + lo * TE_MSM_SCALAR_BYTES, m * TE_MSM_SCALAR_BYTES, hipMemcpyHostToDevice, ws.copy_stream));
+    HIP_TRY(ctx, hipEventRecord(evs[K], ws.copy_stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, evs[K], 0));
+    if (int rc = L.front_scalars()) return rc;                             // digits, sort and schedule run while the piece's points cross PCIe
+    stamp("scalars staged, scalar stages enqueued", i);
+    HIP_TRY(ctx, hipMemcpyAsync(dpts + lo * TE_MSM_POINT_BYTES, src_points + lo * TE_MSM_POINT_BYTES, m * TE_MSM_POINT_BYTES, hipMemcpyHostToDevice, ws.copy_stream));
+    stamp("points staged", i);
+    HIP_TRY(ctx, hipEventRecord(evs[i], ws.copy_stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, evs[i], 0));
+    if (int rc = L.front_points()) return rc;
+    if (int rc = L.accumulate()) return rc;
+    if (int rc = L.combine()) return rc;
+    if (i == last_piece) { if (int rc = L.reduce()) return rc; }
+    stamp("piece enqueued", i);
   }
-  if (bad) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
-  te_host::horner_to_affine_multi(rows, K, pf.c, (int)pf.logB, pf.W, out);
+  ws.plan = p; ws.n = piece_lo(last_piece + 1) - piece_lo(last_piece); ws.used = true; ws.last_stream = ws.stream; ws.prof_level = 0; d.last_ws = 0;
+  if (int rc = fetch_rows(ctx, ws, ws.stream)) return rc;
+  HIP_TRY(ctx, hipEventRecord(ws.ev_done, ws.stream));
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipStreamSynchronize(ws.stream));
+  stamp("device done", 0);
+  if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
+  te_host::horner_to_affine(ws.h_partials, pf.c, (int)pf.logB, pf.W, out);
+  stamp("host tail done", 0);
   return 0;
 }
 
@@ -657,7 +714,7 @@ int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, boo
   if (src_is_host && nd == 1 && ctx->opt_curve == TE_MSM_CURVE_TE_BLS12 && !ctx->opt_profile && ctx->opt_workset == 0 &&
       ctx->devs[0].w_step == 1 && ctx->devs[0].next_ticket == ctx->devs[0].next_collect) {
     // no tickets in flight, no stage timing requested: every work set is free for the pieces
-    const int K = ctx->opt_host_chunks ? ctx->opt_host_chunks : (n >= (1ull << 20) ? 4 : n >= (1ull << 18) ? 2 : 1);
+    const int K = ctx->opt_host_chunks ? ctx->opt_host_chunks : (n >= (1ull << 19) ? 3 : n >= (1ull << 17) ? 2 : 1);
     if (K > 1 && n >= (uint64_t)K) return run_host_chunked(ctx, static_cast<const uint8_t*>(src_points), static_cast<const uint8_t*>(src_scalars), n, K, out);
   }
   // the work set this call runs on: the selected one, unless a submitted MSM still owns it (tickets exist on
@@ -832,7 +889,7 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   }
   if (!strcmp(key, "profile")) { ctx->opt_profile = value < 0 ? 0 : (value > 2 ? 2 : (int)value); ctx->have_stage_ms = false; return 0; }
   if (!strcmp(key, "graph")) { ctx->opt_graph = value ? 1 : 0; return 0; }
-  if (!strcmp(key, "host_chunks")) { if (value < 0 || value > TE_MSM_WORKSETS) return set_err(ctx, TE_MSM_EINVAL, "host_chunks out of range"); ctx->opt_host_chunks = (int)value; return 0; }
+  if (!strcmp(key, "host_chunks")) { if (value < 0 || value > 64) return set_err(ctx, TE_MSM_EINVAL, "host_chunks out of range"); ctx->opt_host_chunks = (int)value; return 0; }
   if (!strcmp(key, "workset")) { if (value < 0 || value >= TE_MSM_WORKSETS) return set_err(ctx, TE_MSM_EINVAL, "workset out of range"); ctx->opt_workset = (int)value; return 0; }
   if (!strcmp(key, "segment_len")) { if (value < 1 || value > 1000000) return set_err(ctx, TE_MSM_EINVAL, "segment_len must be in [1, 1e6]"); ctx->opt_seg_len = (int)value; return 0; }
   return set_err(ctx, TE_MSM_EINVAL, "unknown option");
