@@ -37,8 +37,10 @@ typedef struct te_ctx te_ctx;
  * 1: BLS12-377 G1, y^2 = x^3 + 1 over the 377-bit base field (README.md:57-73, BASELINE config 5): points are
  * n x (x || y) with 48-byte little-endian coordinates (96 bytes), scalars n x 48-byte little-endian records holding
  * values below 2^256 (README.md:325-331), the result is x || y in 96 bytes (the point at infinity as 96 zero bytes) --
- * `out_xy_le` of te_msm_run / run_device / collect must then hold TE_MSM_RESULT_BYTES_MAX bytes.  Single device; the
- * window-sharded building blocks (te_msm_partial_device ...) are Twisted-Edwards only. */
+ * `out_xy_le` of te_msm_run / run_device / collect must then hold TE_MSM_RESULT_BYTES_MAX bytes.  Inputs must lie in G1 (the
+ * subgroup of prime order r, as the harness generates them): the engine works in the curve's twisted-Edwards form, whose
+ * map from y^2 = x^3 + 1 is undefined at the points of order 2 and 4.  Every entry point serves both curves; partial
+ * rows of this curve are TE_MSM_PARTIAL_BYTES_BLS12_377 bytes per window (te_msm_partial_device, te_msm_finalize*). */
 #define TE_MSM_CURVE_TE_BLS12      0
 #define TE_MSM_CURVE_BLS12_377_G1  1
 #define TE_MSM_RESULT_BYTES_MAX    96
@@ -47,6 +49,7 @@ typedef struct te_ctx te_ctx;
 #define TE_MSM_SCALAR_BYTES  32
 #define TE_MSM_WORKSETS      8    /* MSMs one context can have in flight (submit/collect, partial_device) */
 #define TE_MSM_PARTIAL_BYTES 720  /* per window: 5 extended points x 144 B (see te_msm_partial_device) */
+#define TE_MSM_PARTIAL_BYTES_BLS12_377 1120   /* the same row for BLS12-377 G1: 5 points x 224 B (14 limbs per coordinate) */
 
 /* Replaces get_device() + per-call buffer/pipeline creation (implementation/cuzk/gpu.ts:14-25,
  * submission.ts:96-97).  The context is persistent: buffers and streams live across calls.
@@ -141,6 +144,12 @@ int te_msm_finalize_host_ex(const uint8_t* partials, int window_bits, int bucket
  * w mod world.  Saves the caller the merge. */
 int te_msm_finalize_gathered(const uint8_t* gathered, int world, int window_bits, int bucket_bits, int num_windows,
                              uint8_t out_xy_le[64]);
+
+/* The two context-free tails for either curve (curve = TE_MSM_CURVE_*; rows of TE_MSM_PARTIAL_BYTES or
+ * TE_MSM_PARTIAL_BYTES_BLS12_377 bytes; out_xy_le 64 or 96 bytes). */
+int te_msm_finalize_host_curve(int curve, const uint8_t* partials, int window_bits, int bucket_bits, int num_windows, uint8_t* out_xy_le);
+int te_msm_finalize_gathered_curve(int curve, const uint8_t* gathered, int world, int window_bits, int bucket_bits, int num_windows,
+                                   uint8_t* out_xy_le);
 
 /* ---- harness inputs (host code, no device needed).  The reference's harness generates its own random inputs when the
  * ZPrize files are not used (ui/AllBenchmarks.tsx:99-131, reference/webgpu/utils.ts:81-88,118-124): seeded scalars =

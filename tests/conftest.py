@@ -42,7 +42,7 @@ def fpcheck():
     d = os.path.join(ROOT, "tests", "csrc")
     so, src = os.path.join(d, "libfpcheck.so"), os.path.join(d, "fpcheck.cpp")
     hdr_dir = os.path.join(ROOT, "webgpu-msm-twisted-edwards_amd", "csrc")
-    deps = [src] + [os.path.join(hdr_dir, f) for f in ("fp.hpp", "curve.hpp", "fp_constants.inc")]
+    deps = [src] + [os.path.join(hdr_dir, f) for f in ("fp.hpp", "fq377.hpp", "field.hpp", "curve.hpp", "fp_constants.inc")]
     if not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src])
     L = ctypes.CDLL(so)
@@ -58,7 +58,7 @@ def fq377check():
     d = os.path.join(ROOT, "tests", "csrc")
     so, src = os.path.join(d, "libfq377check.so"), os.path.join(d, "fq377check.cpp")
     hdr_dir = os.path.join(ROOT, "webgpu-msm-twisted-edwards_amd", "csrc")
-    deps = [src] + [os.path.join(hdr_dir, f) for f in ("fp.hpp", "fq377.hpp", "curve377.hpp", "fq377_constants.inc")]
+    deps = [src] + [os.path.join(hdr_dir, f) for f in ("fp.hpp", "fq377.hpp", "field.hpp", "curve.hpp", "fq377_constants.inc")]
     if not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src])
     return ctypes.CDLL(so)

@@ -24,17 +24,27 @@ def _dev(b):
     return torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
 
 
-def test_records_equal_the_host_build_of_the_same_code(bls):
-    import os
-    L = ctypes.CDLL(os.path.join(os.path.dirname(__file__), "csrc", "libfq377check.so"))
+def test_records_against_the_model_and_the_host_build(bls, fq377check):
+    """the 224-byte records are projective points of the curve's twisted-Edwards form: mapped back to y^2 = x^3 + 1 they
+    are the input points (bigint model); byte for byte they equal the host build of the same header"""
+    from test_oracle_bls377 import _edwards_consts, edwards_to_weierstrass
+    L = fq377check
     n = 300
     pts, sc = o.gen_points(1, n), o.gen_scalars(1, n)
     assert bls.run(pts, sc) == o.msm(pts, sc, threads=4)
-    recs = bls.debug_read("records", n * 128)
+    recs = bls.debug_read("records", n * 224)
+    s_, f_, d_ = _edwards_consts(L)
+    rinv = pow(1 << 406, -1, m.Q)
     for i in (0, 1, 2, 77, n - 1):
-        r = ctypes.create_string_buffer(128)
+        r = ctypes.create_string_buffer(224)
         L.f377_prep_point(pts[96 * i:96 * i + 96], r)
-        assert recs[128 * i:128 * i + 128] == r.raw, i
+        assert recs[224 * i:224 * i + 224] == r.raw, i
+        hm, hp, dt, z = (sum(int.from_bytes(r.raw[56 * k + 4 * j:56 * k + 4 * j + 4], "little") << (29 * j) for j in range(14)) * rinv % m.Q
+                         for k in range(4))
+        zi = pow(z, -1, m.Q)
+        xa, ya = (hp - hm) * zi % m.Q, (hp + hm) * zi % m.Q
+        assert edwards_to_weierstrass(xa, ya, s_, f_) == m.xy_from_bytes(pts[96 * i:96 * i + 96])
+        assert dt * zi % m.Q == -d_ * xa * ya % m.Q
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 1000, 4097, 70001])
@@ -104,9 +114,49 @@ def test_device_resident_and_pipelined(bls, pkg):
     ts = [bls.submit_device(dp.data_ptr(), ds.data_ptr(), n) for dp, ds, n, _ in cases]
     for t, (_, _, _, exp) in zip(ts, cases):
         assert bls.collect(t) == exp
-    with pytest.raises(pkg.MsmError):                                                  # sharding blocks are Twisted-Edwards only
-        part = torch.zeros(64 * 840, dtype=torch.uint8, device="cuda")
-        bls.partial_device(cases[0][0].data_ptr(), cases[0][1].data_ptr(), cases[0][2], part.data_ptr())
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_window_shards_on_one_gpu(pkg, world):
+    """window sharding for this curve: every rank's rows (1120 bytes per window) merged and folded give the oracle's point"""
+    import torch
+    n = 20000
+    pts, sc = o.gen_points(31, n), o.gen_scalars(31, n)
+    dp, ds = _dev(pts), _dev(sc)
+    exp = o.msm(pts, sc, threads=8)
+    rows, cW = [], None
+    for r in range(world):
+        with pkg.MsmContext((0,)) as c:
+            c.set_option("curve", pkg.CURVE_BLS12_377_G1)
+            c.set_window_shard(*pkg.window_shard_for_rank(r, world))
+            cbits, W = c.plan(n)
+            part = torch.zeros(W * c.row_bytes, dtype=torch.uint8, device="cuda")
+            c.partial_device(dp.data_ptr(), ds.data_ptr(), n, part.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            rows.append(part.cpu().numpy().tobytes())
+            cW = (cbits, W)
+            if r == world - 1:
+                assert c.finalize(pkg.merge_partials(rows, W, world, c.row_bytes), cbits, W) == exp
+    assert pkg.finalize_host(pkg.merge_partials(rows, cW[1], world, 1120), *cW, curve=pkg.CURVE_BLS12_377_G1) == exp
+
+
+def test_giant_buckets_and_host_pieces(bls):
+    """skew: all scalars equal (one bucket per window holds every point: thousands of parts summed by the block-level
+    combine) and window sizes whose top window has a single occupied bucket; te_msm_run in pieces"""
+    n = 120000
+    pts = o.gen_points(71, n)
+    same = o.gen_scalars(5, 1) * n
+    assert bls.run(pts, same) == o.msm(pts, same, threads=16)
+    sc = o.gen_scalars(72, n)
+    exp = o.msm(pts, sc, threads=16)
+    for c in (12, 14):
+        bls.set_option("window_bits", c)
+        assert bls.run(pts, sc) == exp
+    bls.set_option("window_bits", 0)
+    for k in (1, 3, 5):
+        bls.set_option("host_chunks", k)
+        assert bls.run(pts, sc) == exp
+    bls.set_option("host_chunks", 0)
 
 
 def test_one_context_serves_both_curves(pkg, ora):

@@ -1,6 +1,7 @@
-"""Interval-arithmetic check of the limb rule of csrc/fq377.hpp for the two group-law routines of csrc/curve377.hpp:
-the formulas are replayed on BOUNDS (largest ordinary limb, largest top limb, largest value in units of q) instead of
-values, iterated to a fixed point, and every product / subtraction must satisfy its precondition:
+"""Interval-arithmetic check of the limb rule of csrc/fq377.hpp for the 14-limb instantiation of csrc/curve.hpp (BLS12-377 G1
+in its twisted-Edwards form): record conversion, the 8-product addition, the full addition and the four-lane team addition
+are replayed on BOUNDS (largest ordinary limb, largest top limb, largest value in units of q) instead of values, iterated
+to a fixed point, and every product / subtraction must satisfy its precondition:
   * product: 14 * max(a_i) * max(b_j) + 13 * 2^58 + 2^29 < 2^64  (a 64-bit column never wraps),
   * a - b + K*q: b normalised and its top limb not above the offset's top limb (no borrow out of the number),
   * normalisation: nothing exceeds 32 bits on the way.
@@ -60,40 +61,41 @@ def mul(a, b):
     return N(a.val * b.val * Q / 2.0 ** (LB * NL) + 1.0)
 
 
-def finish(t0x3, t1n, t3n, t4, y3n, z3n):
-    p0, p1, p2 = mul(y3n, t4), mul(t3n, t1n), mul(y3n, t0x3)
-    s0, s1, s2 = mul(t1n, z3n), mul(t3n, t0x3), mul(z3n, t4)
-    return sub(p1, p0, 2), add(s0, p2), add(s2, s1)
+def close(E, H, F, G):
+    """ete_close<14>: E and G are normalised, (X3, Y3, T3, Z3) = (E F, H G, E H, G F)"""
+    En, Gn = norm(E), norm(G)
+    return mul(En, F), mul(H, Gn), mul(En, H), mul(Gn, F)          # x, y, t, z
 
 
-def g1_madd(a, bx, by):
-    X1, Y1, Z1 = (norm(c) for c in a)
-    bsum = norm(add(bx, by))
-    t0, t1, t3 = mul(X1, bx), mul(Y1, by), mul(bsum, add(X1, Y1))
-    s0, s1 = mul(Z1, by), mul(Z1, bx)
-    t3n = norm(sub(sub(t3, t0, 2), t1, 2))
-    t4 = add(s0, Y1)
-    y3n = norm(mul3(add(s1, X1)))
-    t0x3 = mul3(t0)
-    z3n = norm(add(t1, mul3(Z1)))
-    t1n = norm(sub(sub(sub(t1, Z1, 4), Z1, 4), Z1, 4))
-    return finish(t0x3, t1n, t3n, t4, y3n, z3n)
+def ete_madd(a, rec):
+    x, y, z, t = a
+    hm, hp, dt, rz = rec
+    A, Bp, Cn, D = mul(sub(y, x, 2), hm), mul(add(y, x), hp), mul(t, dt), mul(z, rz)
+    X3, Y3, T3, Z3 = close(sub(Bp, A, 2), add(Bp, A), add(D, Cn), sub(D, Cn, 2))
+    return X3, Y3, Z3, T3
 
 
-def g1_add(a, b):
-    X1, Y1, Z1 = (norm(c) for c in a)
-    X2, Y2, Z2 = (norm(c) for c in b)
-    t0, t1, t2 = mul(X1, X2), mul(Y1, Y2), mul(Z1, Z2)
-    u0 = mul(norm(add(X1, Y1)), add(X2, Y2))
-    u1 = mul(norm(add(Y1, Z1)), add(Y2, Z2))
-    u2 = mul(norm(add(X1, Z1)), add(X2, Z2))
-    t3n = norm(sub(sub(u0, t0, 2), t1, 2))
-    t4n = norm(sub(sub(u1, t1, 2), t2, 2))
-    y3n = norm(mul3(norm(sub(sub(u2, t0, 2), t2, 2))))
-    t0x3 = mul3(t0)
-    z3n = norm(add(t1, mul3(t2)))
-    t1n = norm(sub(sub(sub(t1, t2, 2), t2, 2), t2, 2))
-    return finish(t0x3, t1n, t3n, t4n, y3n, z3n)
+def ete_add(a, b):
+    x1, y1, z1, t1 = a
+    x2, y2, z2, t2 = b
+    A = mul(norm(sub(y1, x1, 2)), sub(y2, x2, 2))
+    Bp = mul(norm(add(y1, x1)), add(y2, x2))
+    C = mul(mul(t1, t2), N(1.0))                                   # times the constant 2d R (class N, < q)
+    zz = mul(z1, z2)
+    D = add(zz, zz)
+    E, H, F, G = norm(sub(Bp, A, 2)), add(Bp, A), norm(sub(D, C, 2)), norm(add(D, C))
+    return mul(E, F), mul(H, G), mul(F, G), mul(E, H)              # x, y, z, t  (the team addition forms the same products)
+
+
+def prep(x, y):
+    """pnt_from_sw377 on plain integers: any 384-bit value in class N"""
+    c = N(1.0)                                                     # every constant is a residue below q
+    sx, yM, fx = mul(x, c), mul(y, c), mul(x, c)
+    w, ny, fx1 = norm(add(sx, c)), add(sx, c), add(fx, c)
+    Xp, Yp, Zp = mul(w, fx1), mul(yM, ny), mul(yM, w)
+    hm, hp, z = mul(Zp, sub(Yp, Xp, 2)), mul(Zp, add(Yp, Xp)), mul(Zp, add(Zp, Zp))
+    dt = mul(mul(Xp, Yp), c)
+    return hm, hp, dt, z
 
 
 def _join(x, y):
@@ -101,15 +103,18 @@ def _join(x, y):
 
 
 def test_limb_rule_holds_at_the_fixed_point_of_the_bounds():
-    ol2, ot2 = offset(2)
-    rec_x, rec_y, rec_y_neg = N(1.01), N(1.01), B(ol2, ot2, 2.0)          # record: products; negated y = 2q - y
-    acc = (N(1.0), N(1.0), N(1.0))
+    ol4, ot4 = offset(4)
+    raw = B(LM, (1 << 384) >> (LB * (NL - 1)), 2.0 ** 384 / Q)             # a non-canonical 384-bit coordinate
+    rec = prep(raw, raw)
+    assert all(c.val < 1.2 for c in rec)
+    rec_neg = (rec[1], rec[0], B(ol4, ot4, 4.0), rec[3])                   # negated record: hm <-> hp, dt -> 4q - dt
+    acc = (N(1.0), N(1.0), N(1.0), N(1.0))
     for _ in range(40):                                                    # accumulate: bounds reach a fixed point
-        for by in (rec_y, rec_y_neg):
-            acc = _join(acc, g1_madd(acc, rec_x, by))
+        for r in (rec, rec_neg):
+            acc = _join(acc, ete_madd(acc, r))
     s = acc
     for _ in range(40):                                                    # reductions: sums of such accumulators
-        s = _join(s, g1_add(s, s))
-        s = _join(s, g1_add(s, acc))
-    assert all(c.lim < 1 << 31 for c in s) and all(c.val < 4.1 for c in s)
+        s = _join(s, ete_add(s, s))
+        s = _join(s, ete_add(s, acc))
+    assert all(c.lim <= LM for c in s) and all(c.val < 2.1 for c in s)
     assert 0.5 < WORST[0] < 1.0                                            # the rule is tight, not vacuous

@@ -106,65 +106,110 @@ def test_device_field_377_on_the_host(fq377check):
     L.f377_mont_mul(norm, wide, out)
     assert val(out) % Q == val(norm) * val(wide) * rinv % Q
     assert L.f377_overflow_and_reset() == 0
-    c = (ctypes.c_uint32 * (7 * NL))()
+    c = (ctypes.c_uint32 * (14 * NL))()
     L.f377_constants(c)
-    vals = [sum(int(c[NL * k + i]) << (LB * i) for i in range(NL)) for k in range(7)]
-    assert vals == [R % Q, R * R % Q, Q, 2 * Q, 4 * Q, 8 * Q, 16 * Q]
+    vals = [sum(int(c[NL * k + i]) << (LB * i) for i in range(NL)) for k in range(14)]
+    assert vals[:7] == [R % Q, R * R % Q, Q, 2 * Q, 4 * Q, 8 * Q, 16 * Q]
     for k in range(3, 7):                               # offset forms: every lower limb >= 2^29 - 1
         assert all(LM <= int(c[NL * k + i]) < (1 << 30) for i in range(NL - 1))
+    # constants of the twisted-Edwards form, pinned to their defining equations (not to a sign convention):
+    # s = 1/sqrt(3); Montgomery form B v^2 = u^3 + A u^2 + u with A = -3 s, B = s; f^2 = -(A + 2)/B; d = -(A - 2)/(A + 2)
+    k2d, neg2d, s_r2, f_r2, f_m, sp1, sm1 = vals[7:]
+    S, F, D = s_r2 * rinv * rinv % Q, f_m * rinv % Q, k2d * rinv * pow(2, -1, Q) % Q
+    A_m = -3 * S % Q
+    assert 3 * S * S % Q == 1 and F * F % Q == -(A_m + 2) * pow(S, -1, Q) % Q and D == -(A_m - 2) * pow(A_m + 2, -1, Q) % Q
+    assert neg2d == (-2 * D * R) % Q and f_r2 == F * R * R % Q and sp1 == (S + 1) * R % Q and sm1 == (S - 1) * R % Q
+    assert all(v < Q for v in vals[7:])
+
+
+def _edwards_consts(L):
+    """(s, f, d) of the Edwards form as the device header holds them"""
+    import ctypes
+    NL, LB, LM, limbs, val = _limb_helpers()
+    R = 1 << (NL * LB)
+    c = (ctypes.c_uint32 * (14 * NL))()
+    L.f377_constants(c)
+    vals = [sum(int(c[NL * k + i]) << (LB * i) for i in range(NL)) for k in range(14)]
+    rinv = pow(R, -1, m.Q)
+    return vals[9] * rinv * rinv % m.Q, vals[11] * rinv % m.Q, vals[7] * rinv * pow(2, -1, m.Q) % m.Q
+
+
+def edwards_to_weierstrass(X, Y, s, f):
+    """affine point of -X^2 + Y^2 = 1 + d X^2 Y^2 -> affine point of y^2 = x^3 + 1 (None = infinity)"""
+    Q = m.Q
+    if X == 0:
+        return None if Y == 1 else (Q - 1, 0)
+    u = (1 + Y) * pow(1 - Y, -1, Q) % Q
+    v = f * u * pow(X, -1, Q) % Q
+    return ((u * pow(s, -1, Q) - 1) % Q, v * pow(s, -1, Q) % Q)
 
 
 def test_device_group_law_377_on_the_host(fq377check):
-    """csrc/curve377.hpp: complete mixed / full addition against the affine model, incl. doubling, inverses, infinity"""
+    """csrc/curve.hpp at 14 limbs: conversion to the projective Edwards record, 8-product addition and full addition against
+    the affine short-Weierstrass model, incl. doubling, inverses and the neutral element; every column stays below 2^64"""
     import ctypes
     NL, LB, LM, limbs, val = _limb_helpers()
     Q, L = m.Q, fq377check
     rinv = pow(1 << (NL * LB), -1, Q)
+    s_, f_, d_ = _edwards_consts(L)
 
-    def aff(b):
-        cs = []
-        for k in range(3):
-            ws = [int.from_bytes(b[56 * k + 4 * i:56 * k + 4 * i + 4], "little") for i in range(NL)]
-            cs.append(sum(w << (LB * i) for i, w in enumerate(ws)) * rinv % Q)
-        if cs[2] == 0:
-            return None
-        zi = pow(cs[2], Q - 2, Q)
-        return (cs[0] * zi % Q, cs[1] * zi % Q)
+    def coords(b, k):
+        out = []
+        for j in range(k):
+            ws = [int.from_bytes(b[56 * j + 4 * i:56 * j + 4 * i + 4], "little") for i in range(NL)]
+            assert all(w <= LM for w in ws[:NL - 1]), "limb class N"
+            out.append(sum(w << (LB * i) for i, w in enumerate(ws)) * rinv % Q)
+        return out
+
+    def aff(b):                                       # extended point x | y | z | t -> Weierstrass affine
+        X, Y, Z, T = coords(b, 4)
+        zi = pow(Z, Q - 2, Q)
+        xa, ya = X * zi % Q, Y * zi % Q
+        assert (-xa * xa + ya * ya - 1 - d_ * xa * xa * ya * ya) % Q == 0, "not on the Edwards curve"
+        assert xa * ya % Q == T * zi % Q, "T = XY/Z"
+        return edwards_to_weierstrass(xa, ya, s_, f_)
 
     def rec(pt):
-        r = ctypes.create_string_buffer(128)
+        r = ctypes.create_string_buffer(224)
         L.f377_prep_point(m.points_to_bytes([pt]), r)
         return r
-    ident = ctypes.create_string_buffer(168)
+    # the record is (lambda hm, lambda hp, lambda dt, lambda z) of the extended point with hm = (Y-X)/2, hp = (Y+X)/2, dt = -d T
+    for pt in m.gen_points(5, 6):
+        hm, hp, dt, z = coords(rec(pt).raw, 4)
+        zi = pow(z, Q - 2, Q)
+        xa, ya = (hp - hm) * zi % Q, (hp + hm) * zi % Q
+        assert edwards_to_weierstrass(xa, ya, s_, f_) == pt
+        assert dt * zi % Q == -d_ * xa * ya % Q
+    ident = ctypes.create_string_buffer(224)
     L.f377_identity(ident)
     assert aff(ident.raw) is None
     pts = m.gen_points(3, 12)
-    acc, exp, o168 = ident, None, ctypes.create_string_buffer(168)
+    acc, exp, o = ident, None, ctypes.create_string_buffer(224)
     for i, p in enumerate(pts):
         neg = i % 3 == 1
-        L.f377_madd(acc, rec(p), 1 if neg else 0, o168)
+        L.f377_madd(acc, rec(p), 1 if neg else 0, o)
         exp = m.add(exp, m.neg(p) if neg else p)
-        acc = ctypes.create_string_buffer(o168.raw, 168)
+        acc = ctypes.create_string_buffer(o.raw, 224)
         assert aff(acc.raw) == exp
-    A, B = ctypes.create_string_buffer(168), ctypes.create_string_buffer(168)
+    A, B = ctypes.create_string_buffer(224), ctypes.create_string_buffer(224)
     L.f377_madd(ident, rec(pts[0]), 0, A)
     L.f377_madd(A, rec(pts[0]), 0, B)
     assert aff(B.raw) == m.add(pts[0], pts[0])                     # doubling through the mixed law
     L.f377_madd(A, rec(pts[0]), 1, B)
     assert aff(B.raw) is None                                      # P - P
-    L.f377_add(acc, acc, o168)
-    assert aff(o168.raw) == m.add(exp, exp)
-    L.f377_add(acc, A, o168)
-    assert aff(o168.raw) == m.add(exp, pts[0])
-    L.f377_add(acc, ident, o168)
-    assert aff(o168.raw) == exp
-    L.f377_add(ident, ident, o168)
-    assert aff(o168.raw) is None
+    L.f377_add(acc, acc, o)
+    assert aff(o.raw) == m.add(exp, exp)
+    L.f377_add(acc, A, o)
+    assert aff(o.raw) == m.add(exp, pts[0])
+    L.f377_add(acc, ident, o)
+    assert aff(o.raw) == exp
+    L.f377_add(ident, ident, o)
+    assert aff(o.raw) is None
     chain = [ident]
     for r in range(150):                                           # long mixed chains keep the limb rule
-        L.f377_madd(chain[-1], rec(pts[r % 12]), r & 1, o168)
-        chain.append(ctypes.create_string_buffer(o168.raw, 168))
+        L.f377_madd(chain[-1], rec(pts[r % 12]), r & 1, o)
+        chain.append(ctypes.create_string_buffer(o.raw, 224))
         if r % 7 == 0:
-            L.f377_add(chain[-1], chain[r // 2], o168)
-            chain[-1] = ctypes.create_string_buffer(o168.raw, 168)
+            L.f377_add(chain[-1], chain[r // 2], o)
+            chain[-1] = ctypes.create_string_buffer(o.raw, 224)
     assert L.f377_overflow_and_reset() == 0

@@ -20,6 +20,8 @@ from .binding import (  # noqa: F401
     build_library,
     library_path,
     PARTIAL_BYTES,
+    PARTIAL_BYTES_BLS12_377,
+    partial_bytes,
     CURVE_TE_BLS12,
     CURVE_BLS12_377_G1,
     WORKSETS,

@@ -12,7 +12,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
-PARTIAL_BYTES = 720
+PARTIAL_BYTES = 720                     # TE_MSM_PARTIAL_BYTES: one window's row, Twisted-Edwards BLS12
+PARTIAL_BYTES_BLS12_377 = 1120          # TE_MSM_PARTIAL_BYTES_BLS12_377
 CURVE_TE_BLS12, CURVE_BLS12_377_G1 = 0, 1        # option "curve" (TE_MSM_CURVE_*)
 WORKSETS = 8            # TE_MSM_WORKSETS: MSMs one context can have in flight
 
@@ -102,6 +103,10 @@ def _lib() -> ctypes.CDLL:
         L.te_msm_finalize_host_ex.restype = ci
         L.te_msm_finalize_gathered.argtypes = [vp, ci, ci, ci, ci, cp]
         L.te_msm_finalize_gathered.restype = ci
+        L.te_msm_finalize_host_curve.argtypes = [ci, cp, ci, ci, ci, cp]
+        L.te_msm_finalize_host_curve.restype = ci
+        L.te_msm_finalize_gathered_curve.argtypes = [ci, vp, ci, ci, ci, ci, cp]
+        L.te_msm_finalize_gathered_curve.restype = ci
         L.te_msm_synth_inputs.argtypes = [u64, u64, ci, vp, vp]
         L.te_msm_synth_inputs.restype = ci
         L.te_msm_synth_inputs_bls12_377.argtypes = [u64, u64, vp, vp]
@@ -127,6 +132,7 @@ class MsmContext:
         self._h = h
         self._L = L
         self._sizes = (64, 32, 64)          # point, scalar, result bytes of the selected curve
+        self.curve = CURVE_TE_BLS12
 
     def close(self):
         if getattr(self, "_h", None):
@@ -151,6 +157,12 @@ class MsmContext:
         self._check(self._L.te_msm_set_option(self._h, key.encode(), int(value)))
         if key == "curve":
             self._sizes = (96, 48, 96) if int(value) == CURVE_BLS12_377_G1 else (64, 32, 64)
+            self.curve = int(value)
+
+    @property
+    def row_bytes(self) -> int:
+        """bytes of one window's partial row under the selected curve"""
+        return partial_bytes(self.curve)
 
     def get_option(self, key: str) -> int:
         v = ctypes.c_int64()
@@ -204,9 +216,9 @@ class MsmContext:
         self._check(self._L.te_msm_partial_wait(self._h, workset))
 
     def finalize(self, partials: bytes, window_bits: int, num_windows: int) -> bytes:
-        out = ctypes.create_string_buffer(64)
+        out = ctypes.create_string_buffer(96)
         self._check(self._L.te_msm_finalize(self._h, bytes(partials), window_bits, num_windows, out))
-        return out.raw
+        return out.raw[:self._sizes[2]]
 
     # ---- measurement / stage verification
     def stage_ms(self):
@@ -221,25 +233,30 @@ class MsmContext:
         return buf.raw[:got]
 
 
-def finalize_host(partials: bytes, window_bits: int, num_windows: int, bucket_bits: int | None = None) -> bytes:
-    """Context-free host tail (te_msm_finalize_host_ex): Horner + affine over W rows of 720 bytes.
-    bucket_bits: window_bits - 1 for signed digits (default), window_bits for unsigned ones."""
-    out = ctypes.create_string_buffer(64)
-    bb = window_bits - 1 if bucket_bits is None else bucket_bits
-    rc = _lib().te_msm_finalize_host_ex(bytes(partials), window_bits, bb, num_windows, out)
-    if rc:
-        raise MsmError(rc, "te_msm_finalize_host_ex failed")
-    return out.raw
+def partial_bytes(curve: int = CURVE_TE_BLS12) -> int:
+    return PARTIAL_BYTES_BLS12_377 if curve == CURVE_BLS12_377_G1 else PARTIAL_BYTES
 
 
-def finalize_gathered(gathered_ptr: int, world: int, window_bits: int, num_windows: int, bucket_bits: int | None = None) -> bytes:
-    """Host tail over an all-gathered buffer in HOST memory (te_msm_finalize_gathered); gathered_ptr is its address."""
-    out = ctypes.create_string_buffer(64)
+def finalize_host(partials: bytes, window_bits: int, num_windows: int, bucket_bits: int | None = None, curve: int = CURVE_TE_BLS12) -> bytes:
+    """Context-free host tail (te_msm_finalize_host_curve): Horner + affine over W rows of 720 bytes (1120 for
+    curve = CURVE_BLS12_377_G1).  bucket_bits: window_bits - 1 for signed digits (default), window_bits for unsigned ones."""
+    out = ctypes.create_string_buffer(96)
     bb = window_bits - 1 if bucket_bits is None else bucket_bits
-    rc = _lib().te_msm_finalize_gathered(gathered_ptr, world, window_bits, bb, num_windows, out)
+    rc = _lib().te_msm_finalize_host_curve(curve, bytes(partials), window_bits, bb, num_windows, out)
     if rc:
-        raise MsmError(rc, "te_msm_finalize_gathered failed")
-    return out.raw
+        raise MsmError(rc, "te_msm_finalize_host_curve failed")
+    return out.raw[:96 if curve == CURVE_BLS12_377_G1 else 64]
+
+
+def finalize_gathered(gathered_ptr: int, world: int, window_bits: int, num_windows: int, bucket_bits: int | None = None,
+                      curve: int = CURVE_TE_BLS12) -> bytes:
+    """Host tail over an all-gathered buffer in HOST memory (te_msm_finalize_gathered_curve); gathered_ptr is its address."""
+    out = ctypes.create_string_buffer(96)
+    bb = window_bits - 1 if bucket_bits is None else bucket_bits
+    rc = _lib().te_msm_finalize_gathered_curve(curve, gathered_ptr, world, window_bits, bb, num_windows, out)
+    if rc:
+        raise MsmError(rc, "te_msm_finalize_gathered_curve failed")
+    return out.raw[:96 if curve == CURVE_BLS12_377_G1 else 64]
 
 
 def synth_inputs(seed: int, n: int, fixed_point: bool = False, points: bool = True, scalars: bool = True, curve: int = CURVE_TE_BLS12):

@@ -1,34 +1,46 @@
-// curve.hpp -- point arithmetic on -x^2 + y^2 = 1 + 3021 x^2 y^2 over fp (a = -1, d = 3021;
-// reference/params/AleoConstants.ts:2-4, reference/utils/FieldMath.ts:104-137).
+// curve.hpp -- point arithmetic on a twisted Edwards curve -x^2 + y^2 = 1 + d x^2 y^2 (a = -1) over fel<N>:
+//   N = 9   the Twisted-Edwards BLS12 curve of the competition, d = 3021 (reference/params/AleoConstants.ts:2-4,
+//           reference/utils/FieldMath.ts:104-137)
+//   N = 14  BLS12-377 G1 in its twisted-Edwards form (BASELINE config 5; the reference has no code for this curve,
+//           README.md:57-73,279-287).  d = -(A - 2) / (A + 2) for the Montgomery form of y^2 = x^3 + 1 (tools/gen_constants.py);
+//           d is a square there, so the addition law is complete on the subgroup of odd prime order r only -- where MSM
+//           inputs live -- not on the cofactor part.
 //
-// Replaces add_points / double_point / negate_point of the reference
-// (wgsl/curve/ec.template.wgsl:7-66, wgsl/cuzk/smvp.template.wgsl:47-56).  The reference adds two
-// full extended points with add-2008-hwcd (10 field products + T = x*y recomputed per gathered
-// point, smvp.template.wgsl:107-108).  Here the n input points are converted ONCE into a record
-// ((y-x)/2, (y+x)/2, d*x*y) and bucket accumulation is a 7-product mixed addition with no
-// reduction modulo p at all (limb-magnitude rules in fp.hpp).  Any correct group law gives the same affine result, which
-// is the only thing compared with the reference.
+// Replaces add_points / double_point / negate_point of the reference (wgsl/curve/ec.template.wgsl:7-66,
+// wgsl/cuzk/smvp.template.wgsl:47-56).  The reference adds two full extended points with add-2008-hwcd (10 field products
+// + T = x*y recomputed per gathered point, smvp.template.wgsl:107-108).  Here the n input points are converted ONCE into a
+// RECORD and bucket accumulation is a 7-product (N = 9: affine record) or 8-product (N = 14: projective record, no
+// inversion in the conversion) addition with no reduction modulo p at all (limb-magnitude rules in fp.hpp / fq377.hpp).
+// Any correct group law gives the same affine result, which is the only thing compared with the reference.
 #pragma once
-#include "fp.hpp"
+#include "field.hpp"
 
 namespace te {
 
 // Extended twisted Edwards accumulator (X : Y : Z : T), x = X/Z, y = Y/Z, T = XY/Z.
-// Every coordinate is a mont_mul output: limb class N, value < 1.1p.  144 bytes, x | y | z | t.
-struct ete { fp x, y, z, t; };
+// Every coordinate is a product output: limb class N, value < 1.1p.  4 N words, x | y | z | t.
+template <int N> struct ete_t { fel<N> x, y, z, t; };
+using ete = ete_t<9>;            // 144 bytes
 
-// Precomputed affine point: hm = (y - x)/2, hp = (y + x)/2, dt = -d*x*y (mod p, lazily reduced: values < 1.1p,
-// class N; a negated record holds 4p - dt with limbs < 2^30).  108 bytes, stored in 128-byte slots.
-// dt carries the MINUS sign so that in ete_madd F = Z1 - C becomes a sum and no product meets two differences.
-struct pnt { fp hm, hp, dt; };
+// Record of an input point, up to a common factor of its coordinates (projectively the result of an addition does not
+// depend on it):  hm ~ (Y - X)/2,  hp ~ (Y + X)/2,  dt ~ -d T,  z ~ Z  of the extended point (X : Y : Z : T).
+//   N = 9 : affine, z = 1 is not stored: ((y-x)/2, (y+x)/2, -d*x*y), 27 words in a 128-byte slot.
+//   N = 14: projective (converted from short Weierstrass without a division, see pnt_from_sw377): 56 words = 224 bytes.
+// Products of class N, values < 1.1p; a negated record holds 4p - dt with limbs < 2^30.6.
+// dt carries the MINUS sign so that F = D' + C' below is a sum and no product meets two differences.
+template <int N> struct pnt_t;
+template <> struct pnt_t<9> { fel<9> hm, hp, dt; };
+template <> struct pnt_t<14> { fel<14> hm, hp, dt, z; };
+using pnt = pnt_t<9>;
 
-TE_HD ete ete_identity() { ete r; r.x = fp_zero(); r.y = fp_R1(); r.z = fp_R1(); r.t = fp_zero(); return r; }
+template <int N> TE_HD ete_t<N> ete_identity_t() { ete_t<N> r; r.x = fe_zero<N>(); r.y = fe_one<N>(); r.z = fe_one<N>(); r.t = fe_zero<N>(); return r; }
+TE_HD ete ete_identity() { return ete_identity_t<9>(); }
 
-// -(x, y) = (-x, y): swaps (y-x)/2 and (y+x)/2, negates d*x*y.
-TE_HD pnt pnt_cneg(const pnt& a, bool neg) {
-  pnt r; const fp ndt = fp_neg<4>(a.dt);
+// -(x, y) = (-x, y): swaps hm and hp, negates dt.
+template <int N> TE_HD pnt_t<N> pnt_cneg(const pnt_t<N>& a, bool neg) {
+  pnt_t<N> r = a; const fel<N> ndt = fe_neg<4>(a.dt);
 #pragma unroll
-  for (int i = 0; i < NL; i++) {
+  for (int i = 0; i < N; i++) {
     r.hm.v[i] = neg ? a.hp.v[i] : a.hm.v[i];
     r.hp.v[i] = neg ? a.hm.v[i] : a.hp.v[i];
     r.dt.v[i] = neg ? ndt.v[i] : a.dt.v[i];
@@ -50,48 +62,84 @@ TE_HD pnt pnt_from_affine_raw(const fp& x, const fp& y) {
   return r;
 }
 
-// Mixed addition acc + b, 7 products, unified and complete (a = -1 is a square, d is not).
+// BLS12-377 G1: short-Weierstrass affine (x, y) as plain integers (class N, any 384-bit value) -> projective twisted-Edwards
+// record, 11 products and no division.  With s = 1/sqrt(3), f = sqrt(-(A+2)/B) (tools/gen_constants.py):
+//   Montgomery  u = s (x + 1), v = s y;   Edwards  X = f u / v = f (x + 1) / y,   Y = (u - 1)/(u + 1) = (s x + s - 1)/(s x + s + 1).
+//   Projective (Xp : Yp : Zp) = (f (x+1) w : (s x + s - 1) y : y w),  w = s x + s + 1;  extended (Xp Zp : Yp Zp : Zp^2 : Xp Yp);
+//   record, times 2:  hm = Zp (Yp - Xp),  hp = Zp (Yp + Xp),  dt = -2 d Xp Yp,  z = 2 Zp^2.
+// Undefined (all-zero record, the neutral element's weight is lost) for y = 0 or w = 0: points of order 2 and 4, never in G1.
+TE_HD pnt_t<14> pnt_from_sw377(const fel<14>& x, const fel<14>& y) {
+  using namespace te377;
+  const fq a1[3] = {x, y, x}, b1[3] = {fq_S_R2(), fq_R2(), fq_F_R2()};
+  fq o1[3];
+  fe_mul_x<3>(a1, b1, o1);                                 // s x, y, f x   (Montgomery form, class N)
+  const fq w = fe_norm(fe_add(o1[0], fq_SP1_MONT())), ny = fe_add(o1[0], fq_SM1_MONT()), fx1 = fe_add(o1[2], fq_F_MONT());
+  const fq a2[3] = {w, o1[1], o1[1]}, b2[3] = {fx1, ny, w};
+  fq o2[3];
+  fe_mul_x<3>(a2, b2, o2);                                 // Xp = f (x+1) w,  Yp = (s x + s - 1) y,  Zp = y w
+  const fq &Xp = o2[0], &Yp = o2[1], &Zp = o2[2];
+  const fq a3[4] = {Zp, Zp, Zp, Xp}, b3[4] = {fe_sub<2>(Yp, Xp), fe_add(Yp, Xp), fe_add(Zp, Zp), Yp};
+  fq o3[4];
+  fe_mul_x<4>(a3, b3, o3);
+  pnt_t<14> r;
+  r.hm = o3[0]; r.hp = o3[1]; r.z = o3[2];
+  r.dt = fe_mul(o3[3], fq_NEG_2D_MONT());
+  return r;
+}
+
+// the four closing products of every addition: (X3, Y3, T3, Z3) = (E F, H G, E H, G F) with E, G differences (offset form)
+// and H, F sums.  N = 9: every product is "difference x sum", 9 * 2^30.6 * 2^30 + 8 * 2^58 = 0.9 * 2^64: nothing is
+// normalised.  N = 14: one operand of every product must be normalised -- E and G are.
+template <int N> TE_HD ete_t<N> ete_close(const fel<N>& E, const fel<N>& H, const fel<N>& F, const fel<N>& G) {
+  const fel<N> En = fe_norm_if_needed(E), Gn = fe_norm_if_needed(G);
+  const fel<N> l[4] = {En, H, En, Gn}, rr[4] = {F, Gn, H, F};
+  fel<N> o[4];
+  fe_mul_x<4>(l, rr, o);
+  ete_t<N> r;
+  r.x = o[0]; r.y = o[1]; r.t = o[2]; r.z = o[3];
+  return r;
+}
+
+// Mixed addition acc + b with an affine record, 7 products, unified and complete (a = -1 is a square, d is not).
 // With A' = (Y1-X1)(y2-x2)/2, B' = (Y1+X1)(y2+x2)/2:  E = B'-A' = X1 y2 + Y1 x2,
 // H = B'+A' = Y1 y2 + X1 x2, C = d T1 x2 y2, F = Z1 - C, G = Z1 + C;  (X3,Y3,T3,Z3) = (EF, HG, EH, GF).
 // The record holds -d x2 y2, so the product below is C' = -C and F = Z1 + C' is a SUM, G = Z1 - C' the difference.
-// Limb classes: A' = D x N, B' = S x N, C' = N x (<2^30);  E and G are D (differences in offset form), H and F are S:
-// every closing product EF, HG, EH, GF is D x S (9 * 2^30.6 * 2^30 + 8 * 2^58 = 0.9 * 2^64) -- no operand is normalised.
+// Limb classes: A' = D x N, B' = S x N, C' = N x (<2^30.6);  E and G are D (differences in offset form), H and F are S.
 // Values: everything is below 5p before a product and below 1.1p after it; nothing is reduced mod p.
 TE_HD ete ete_madd(const ete& a, const pnt& b) {
   const fp in1[3] = {fp_sub<2>(a.y, a.x), fp_add(a.y, a.x), a.t}, in2[3] = {b.hm, b.hp, b.dt};
   fp abc[3];
   mont_mul_x<3>(in1, in2, abc);
   const fp &A = abc[0], &B = abc[1], &Cn = abc[2];
-  const fp E = fp_sub<2>(B, A);
-  const fp H = fp_add(B, A);
-  const fp F = fp_add(a.z, Cn);
-  const fp G = fp_sub<2>(a.z, Cn);
-  const fp l[4] = {E, H, E, G}, rr[4] = {F, G, H, F};
-  fp o[4];
-  mont_mul_x<4>(l, rr, o);
-  ete r;
-  r.x = o[0]; r.y = o[1]; r.t = o[2]; r.z = o[3];
-  return r;
+  return ete_close<9>(fp_sub<2>(B, A), fp_add(B, A), fp_add(a.z, Cn), fp_sub<2>(a.z, Cn));
+}
+// The same with a projective record: D' = Z1 z2 takes the place of Z1 -- 8 products.
+TE_HD ete_t<14> ete_madd(const ete_t<14>& a, const pnt_t<14>& b) {
+  const fel<14> in1[4] = {fe_sub<2>(a.y, a.x), fe_add(a.y, a.x), a.t, a.z}, in2[4] = {b.hm, b.hp, b.dt, b.z};
+  fel<14> p[4];
+  fe_mul_x<4>(in1, in2, p);
+  const fel<14> &A = p[0], &B = p[1], &Cn = p[2], &D = p[3];
+  return ete_close<14>(fe_sub<2>(B, A), fe_add(B, A), fe_add(D, Cn), fe_sub<2>(D, Cn));
 }
 
 // Full addition a + b of two accumulators (add-2008-hwcd-3 shape, k = 2d), 9 products.
-// (Y1-X1), F = 2 Z1Z2 - C and G = 2 Z1Z2 + C are normalised so that no product sees two wide operands.
-TE_HD ete ete_add(const ete& a, const ete& b) {
-  const fp in1[4] = {fp_norm(fp_sub<2>(a.y, a.x)), fp_add(a.y, a.x), a.t, a.z};
-  const fp in2[4] = {fp_sub<2>(b.y, b.x), fp_add(b.y, b.x), b.t, b.z};
-  fp p1[4];
-  mont_mul_x<4>(in1, in2, p1);
-  const fp &A = p1[0], &B = p1[1];
-  const fp C = mont_mul(p1[2], fp_K2D_MONT());
-  const fp D = fp_add(p1[3], p1[3]);
-  const fp E = fp_norm(fp_sub<2>(B, A));
-  const fp H = fp_add(B, A);
-  const fp F = fp_norm(fp_sub<2>(D, C));
-  const fp G = fp_norm(fp_add(D, C));
-  const fp l[4] = {E, H, E, F}, rr[4] = {F, G, H, G};
-  fp o[4];
-  mont_mul_x<4>(l, rr, o);
-  ete r;
+// One operand of each opening product and F, G, E are normalised so that no product sees two wide operands.
+template <int N> TE_HD ete_t<N> ete_add(const ete_t<N>& a, const ete_t<N>& b) {
+  const fel<N> in1[4] = {fe_norm(fe_sub<2>(a.y, a.x)), fe_norm_if_needed(fe_add(a.y, a.x)), a.t, a.z};
+  const fel<N> in2[4] = {fe_sub<2>(b.y, b.x), fe_add(b.y, b.x), b.t, b.z};
+  fel<N> p1[4];
+  fe_mul_x<4>(in1, in2, p1);
+  const fel<N> &A = p1[0], &B = p1[1];
+  const fel<N> C = fe_mul(p1[2], fe_k2d<N>());
+  const fel<N> D = fe_add(p1[3], p1[3]);
+  const fel<N> E = fe_norm(fe_sub<2>(B, A));
+  const fel<N> H = fe_add(B, A);
+  const fel<N> F = fe_norm(fe_sub<2>(D, C));
+  const fel<N> G = fe_norm(fe_add(D, C));
+  const fel<N> l[4] = {E, H, E, F}, rr[4] = {F, G, H, G};
+  fel<N> o[4];
+  fe_mul_x<4>(l, rr, o);
+  ete_t<N> r;
   r.x = o[0]; r.y = o[1]; r.t = o[2]; r.z = o[3];
   return r;
 }

@@ -41,7 +41,11 @@ constexpr int NL = 9;                     // limbs
 constexpr uint32_t LB = 29;               // bits per limb
 constexpr uint32_t LM = (1u << LB) - 1u;  // limb mask
 
-struct fp { uint32_t v[NL]; };   // little-endian limbs, 36 bytes
+// A field element in limbs: N little-endian 29-bit limbs, one per u32 word.  Both base fields of the engine use it --
+// fp (this file, N = 9) and te377::fq (fq377.hpp, N = 14); the curve and the kernels are written once for any N
+// (field.hpp gives the two fields one vocabulary).
+template <int N> struct fel { uint32_t v[N]; };
+using fp = fel<9>;               // 36 bytes
 
 // p = 0x12ab655e 9a2ca556 60b44d1e 5c37b001 59aa76fe d0000001 0a118000 00000001  (params.ts:11-13), 32-bit words
 constexpr uint32_t P_W32[8] = {0x00000001u, 0x0a118000u, 0xd0000001u, 0x59aa76feu, 0x5c37b001u, 0x60b44d1eu, 0x9a2ca556u, 0x12ab655eu};

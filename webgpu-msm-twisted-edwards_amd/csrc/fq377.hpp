@@ -23,7 +23,7 @@ constexpr int NL = 14;
 constexpr uint32_t LB = 29;
 constexpr uint32_t LM = (1u << LB) - 1u;
 
-struct fq { uint32_t v[NL]; };   // little-endian limbs, 56 bytes
+using fq = te::fel<14>;          // little-endian limbs, 56 bytes
 
 // q, 32-bit words (README.md:65-67)
 constexpr uint32_t Q_W32[12] = {0x00000001u, 0x8508c000u, 0x30000000u, 0x170b5d44u, 0xba094800u, 0x1ef3622fu,

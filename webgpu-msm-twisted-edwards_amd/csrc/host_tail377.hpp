@@ -1,15 +1,18 @@
 // host_tail377.hpp -- the CPU tail for BLS12-377 G1: the same Horner fold over per-window rows [T | W0 | W1 | W2 | W3] as
-// host_tail.hpp (which follows submission.ts:362-412), with this curve's group law.  Host arithmetic: 6 x 64-bit limbs,
-// Montgomery form R = 2^384; the device writes 14 x 29-bit limbs in Montgomery form R' = 2^406, lazily reduced.
+// host_tail.hpp (which follows submission.ts:362-412).  The device works in the twisted-Edwards form of the curve
+// (curve.hpp), so the fold uses the same extended-coordinate formulas as the other curve; the result is mapped back to
+// the short-Weierstrass affine point the caller expects.  Host arithmetic: 6 x 64-bit limbs, Montgomery form R = 2^384;
+// the device writes 14 x 29-bit limbs in Montgomery form R' = 2^406, lazily reduced.
 #pragma once
 #include <stdint.h>
 #include <string.h>
+#include "fq377.hpp"     // TE377_HOST_* constants (fq377_constants.inc)
 
 namespace te377_host {
 
 typedef unsigned __int128 u128;
 struct Fe { uint64_t l[6]; };
-struct Pt { Fe x, y, z; };       // projective (X : Y : Z); identity (0 : 1 : 0)
+struct Pt { Fe x, y, z, t; };    // extended twisted Edwards (X : Y : Z : T) of the curve's Edwards form; identity (0 : 1 : 1 : 0)
 
 static const uint64_t MOD[6] = {0x8508c00000000001ULL, 0x170b5d4430000000ULL, 0x1ef3622fba094800ULL,
                                 0x1a22d9f300f5138fULL, 0xc63b05c06ca1493bULL, 0x01ae3a4617c510eaULL};      // README.md:65-67
@@ -57,12 +60,12 @@ static inline Fe inv(const Fe& a) {            // a^(q-2)
   return acc;
 }
 static inline bool is_zero(const Fe& a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3] | a.l[4] | a.l[5]) == 0; }
-static inline Pt identity() { Pt r; memset(&r, 0, sizeof r); r.y = ONE_M; return r; }
+static inline Pt identity() { Pt r; memset(&r, 0, sizeof r); r.y = ONE_M; r.z = ONE_M; return r; }
 static inline bool all_zero_bytes(const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) if (p[i]) return false; return true; }
 
 #define TE377_TAIL_COORD_BYTES 56
-#define TE377_TAIL_POINT_BYTES 168
-#define TE377_TAIL_ROW_BYTES 840
+#define TE377_TAIL_POINT_BYTES 224
+#define TE377_TAIL_ROW_BYTES 1120
 // one coordinate: 14 u32 words holding 29-bit limbs (possibly unnormalised), value < 2^410
 static inline Fe load_coord(const uint8_t* src) {
   uint32_t l[14]; memcpy(l, src, 56);
@@ -77,47 +80,77 @@ static inline Fe load_coord(const uint8_t* src) {
   Fe lo, hi; memcpy(lo.l, w, 48); memset(&hi, 0, sizeof hi); hi.l[0] = w[6]; hi.l[1] = w[7];
   return add(mul(lo, CONV_LO), mul(hi, CONV_HI));
 }
-static inline Pt load_point(const uint8_t* src) { Pt r; r.x = load_coord(src); r.y = load_coord(src + 56); r.z = load_coord(src + 112); return r; }
+// device point: x | y | z | t, 56 bytes each
+static inline Pt load_point(const uint8_t* src) { Pt r; r.x = load_coord(src); r.y = load_coord(src + 56); r.z = load_coord(src + 112); r.t = load_coord(src + 168); return r; }
 
-// complete projective addition (Renes-Costello-Batina 2016, Algorithm 7, a = 0, b3 = 3); also doubles
-static inline Fe mul3(const Fe& a) { return add(add(a, a), a); }
-static inline Pt padd(const Pt& p, const Pt& q) {
-  const Fe t0 = mul(p.x, q.x), t1 = mul(p.y, q.y), t2 = mul(p.z, q.z);
-  const Fe t3 = sub(sub(mul(add(p.x, p.y), add(q.x, q.y)), t0), t1);
-  const Fe t4 = sub(sub(mul(add(p.y, p.z), add(q.y, q.z)), t1), t2);
-  const Fe y3 = mul3(sub(sub(mul(add(p.x, p.z), add(q.x, q.z)), t0), t2));
-  const Fe t0x3 = mul3(t0), t2x3 = mul3(t2);
-  const Fe z3 = add(t1, t2x3), t1m = sub(t1, t2x3);
-  Pt r;
-  r.x = sub(mul(t3, t1m), mul(t4, y3));
-  r.y = add(mul(t1m, z3), mul(y3, t0x3));
-  r.z = add(mul(z3, t4), mul(t0x3, t3));
+static const Fe K2D = {TE377_HOST_K2D};        // 2 d of the Edwards form (fq377_constants.inc)
+static const Fe F_M = {TE377_HOST_F};          // f = sqrt(-(A+2)/B)
+static const Fe SQRT3_M = {TE377_HOST_SQRT3};  // 1 / s
+// unified addition, a = -1, k = 2d (add-2008-hwcd-3)
+static inline Pt padd(const Pt& a, const Pt& b) {
+  const Fe A = mul(sub(a.y, a.x), sub(b.y, b.x));
+  const Fe B = mul(add(a.y, a.x), add(b.y, b.x));
+  const Fe C = mul(mul(a.t, b.t), K2D);
+  const Fe zz = mul(a.z, b.z);
+  const Fe D = add(zz, zz);
+  const Fe E = sub(B, A), F = sub(D, C), G = add(D, C), H = add(B, A);
+  Pt r; r.x = mul(E, F); r.y = mul(G, H); r.t = mul(E, H); r.z = mul(F, G);
+  return r;
+}
+// dbl-2008-hwcd, a = -1
+static inline Pt pdbl(const Pt& a) {
+  const Fe A = mul(a.x, a.x), B = mul(a.y, a.y);
+  Fe C = mul(a.z, a.z); C = add(C, C);
+  Fe zero; memset(&zero, 0, sizeof zero);
+  const Fe D = sub(zero, A);
+  const Fe xy = add(a.x, a.y);
+  const Fe E = sub(sub(mul(xy, xy), A), B);
+  const Fe G = add(D, B), F = sub(G, C), H = sub(D, B);
+  Pt r; r.x = mul(E, F); r.y = mul(G, H); r.t = mul(E, H); r.z = mul(F, G);
   return r;
 }
 
-// rows: W x 840 B = [T | W0 | W1 | W2 | W3]; see host_tail.hpp for the identity behind the fold
-static inline void horner_to_affine(const uint8_t* partials, int c, int bucket_bits, int W, uint8_t out_xy_le[96]) {
+// rows: W x 1120 B = [T | W0 | W1 | W2 | W3]; see host_tail.hpp for the identity behind the fold.  `sets` row buffers are
+// summed on the fly (an MSM computed in pieces).
+static inline void horner_to_affine_multi(const uint8_t* const* partials, int sets, int c, int bucket_bits, int W, uint8_t out_xy_le[96]) {
   int dw[4];
   for (int k = 0; k < 4; k++) dw[k] = (bucket_bits + 3 - k) / 4;
   const int s3 = dw[0] + dw[1] + dw[2];
   Pt acc = identity();
+  auto add_slot = [&](int w, int slot) {
+    for (int s = 0; s < sets; s++) {
+      const uint8_t* row = partials[s] + (size_t)w * TE377_TAIL_ROW_BYTES;
+      if (!all_zero_bytes(row, TE377_TAIL_ROW_BYTES)) acc = padd(acc, load_point(row + (size_t)slot * TE377_TAIL_POINT_BYTES));
+    }
+  };
   for (int w = W - 1; w >= 0; w--) {
-    const uint8_t* row = partials + (size_t)w * TE377_TAIL_ROW_BYTES;
-    const bool present = !all_zero_bytes(row, TE377_TAIL_ROW_BYTES);
-    for (int k = 0; k < c - s3; k++) acc = padd(acc, acc);
-    if (present) acc = padd(acc, load_point(row + 4 * TE377_TAIL_POINT_BYTES));      // W3
-    for (int k = 0; k < dw[2]; k++) acc = padd(acc, acc);
-    if (present) acc = padd(acc, load_point(row + 3 * TE377_TAIL_POINT_BYTES));      // W2
-    for (int k = 0; k < dw[1]; k++) acc = padd(acc, acc);
-    if (present) acc = padd(acc, load_point(row + 2 * TE377_TAIL_POINT_BYTES));      // W1
-    for (int k = 0; k < dw[0]; k++) acc = padd(acc, acc);
-    if (present) { acc = padd(acc, load_point(row + TE377_TAIL_POINT_BYTES)); acc = padd(acc, load_point(row)); }   // W0, T
+    for (int k = 0; k < c - s3; k++) acc = pdbl(acc);
+    add_slot(w, 4);                                    // W3
+    for (int k = 0; k < dw[2]; k++) acc = pdbl(acc);
+    add_slot(w, 3);                                    // W2
+    for (int k = 0; k < dw[1]; k++) acc = pdbl(acc);
+    add_slot(w, 2);                                    // W1
+    for (int k = 0; k < dw[0]; k++) acc = pdbl(acc);
+    add_slot(w, 1);                                    // W0
+    add_slot(w, 0);                                    // T
   }
-  if (is_zero(acc.z)) { memset(out_xy_le, 0, 96); return; }            // point at infinity
-  const Fe zi = inv(acc.z);
+  // Edwards (X : Y : Z) -> Montgomery u = (Z + Y)/(Z - Y), v = f u Z / X -> Weierstrass x = sqrt(3) u - 1, y = sqrt(3) v.
+  // X = 0: the neutral element (Y = Z; the point at infinity, 96 zero bytes) or the point of order two (Y = -Z; (-1, 0)).
   Fe one_raw; memset(&one_raw, 0, sizeof one_raw); one_raw.l[0] = 1;
-  const Fe x = mul(mul(acc.x, zi), one_raw), y = mul(mul(acc.y, zi), one_raw);
+  if (is_zero(acc.x)) {
+    memset(out_xy_le, 0, 96);
+    if (!is_zero(sub(acc.y, acc.z))) { const Fe m1 = mul(sub(Fe{{0, 0, 0, 0, 0, 0}}, ONE_M), one_raw); memcpy(out_xy_le, m1.l, 48); }
+    return;
+  }
+  const Fe zpy = add(acc.z, acc.y), zmy = sub(acc.z, acc.y);
+  const Fe di = inv(mul(zmy, acc.x));                           // 1 / ((Z - Y) X)
+  const Fe u = mul(mul(zpy, acc.x), di);                        // (Z + Y) / (Z - Y)
+  const Fe v = mul(mul(mul(zpy, acc.z), di), F_M);              // f (Z + Y) Z / ((Z - Y) X)
+  const Fe x = mul(sub(mul(u, SQRT3_M), ONE_M), one_raw), y = mul(mul(v, SQRT3_M), one_raw);
   memcpy(out_xy_le, x.l, 48); memcpy(out_xy_le + 48, y.l, 48);
+}
+static inline void horner_to_affine(const uint8_t* partials, int c, int bucket_bits, int W, uint8_t out_xy_le[96]) {
+  horner_to_affine_multi(&partials, 1, c, bucket_bits, W, out_xy_le);
 }
 
 static inline bool tail_selftest() {

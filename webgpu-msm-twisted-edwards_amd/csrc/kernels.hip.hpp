@@ -562,54 +562,89 @@ __global__ void __launch_bounds__(256) k_order_scatter(const uint32_t* __restric
   }
 }
 
+// ================================================================================================
+// From here on everything handles curve points and is written once for both base fields: N = 9 limbs (Twisted-Edwards
+// BLS12) and N = 14 limbs (BLS12-377 G1 in twisted-Edwards form).  Memory layouts, in u32 words:
+//   accumulator (ete_t<N>)   4 N words  x | y | z | t            144 B / 224 B, 16-byte accesses
+//   record (pnt_t<N>)        N = 9: 27 words in a 128-byte slot (one gather = one 128-byte line)
+//                            N = 14: 56 words = 224 bytes, slots back to back
+template <int N> struct geo {
+  static constexpr uint32_t PW = 4u * N;                    // words per accumulator
+  static constexpr uint32_t PQ = PW / 4u;                   // 16-byte pieces per accumulator
+  static constexpr uint32_t RW = N == 9 ? 27u : 4u * N;     // record words
+  static constexpr uint32_t SQ = N == 9 ? 8u : N;           // 16-byte pieces per record slot
+  static constexpr uint32_t LQ = (RW + 3u) / 4u;            // 16-byte pieces to load per record
+};
+template <int N> struct rec_slot { uint4 q[geo<N>::SQ]; };
+static_assert(sizeof(rec_slot<9>) == sizeof(pnt_slot) && sizeof(rec_slot<14>) == 224, "record slots");
+
 // ------------------------------------------------------------------------------------------------
 // K3: bucket accumulation, one thread per segment, scheduled through order[] (or natural order when
 // order == nullptr).  The next record is fetched while the current addition runs.  A bucket that is a single
-// segment is written straight to buckets[]; parts of a split bucket go to seg_out[] for k_seg_combine.
+// segment is written straight to buckets[]; parts of a split bucket go to seg_out[] for k_seg_combine*.
 // (A variant that fused level 2 of the sort into this kernel -- one block per 256 buckets, lists consumed
 // straight from LDS -- was measured at 2.8 ms against 1.4 ms: block-granular scheduling leaves < 1 wave per
 // SIMD resident on average (SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE = 0.78), far too few to hide gather latency.)
-__device__ __forceinline__ pnt load_pnt(const pnt_slot* __restrict__ recs, uint32_t entry) {
+template <int N> __device__ __forceinline__ pnt_t<N> load_pnt(const rec_slot<N>* __restrict__ recs, uint32_t entry) {
   const uint4* q = recs[entry & 0x7fffffffu].q;
-  uint4 u[7];
+  constexpr uint32_t LQ = geo<N>::LQ;
+  uint4 u[LQ];
 #pragma unroll
-  for (int j = 0; j < 7; j++) u[j] = q[j];
-  const uint32_t w[28] = {u[0].x, u[0].y, u[0].z, u[0].w, u[1].x, u[1].y, u[1].z, u[1].w, u[2].x, u[2].y, u[2].z, u[2].w,
-                          u[3].x, u[3].y, u[3].z, u[3].w, u[4].x, u[4].y, u[4].z, u[4].w, u[5].x, u[5].y, u[5].z, u[5].w,
-                          u[6].x, u[6].y, u[6].z, u[6].w};
-  pnt r;
+  for (uint32_t j = 0; j < LQ; j++) u[j] = q[j];
+  uint32_t w[4 * LQ];
 #pragma unroll
-  for (int j = 0; j < NL; j++) { r.hm.v[j] = w[j]; r.hp.v[j] = w[NL + j]; r.dt.v[j] = w[2 * NL + j]; }
+  for (uint32_t j = 0; j < LQ; j++) { w[4 * j] = u[j].x; w[4 * j + 1] = u[j].y; w[4 * j + 2] = u[j].z; w[4 * j + 3] = u[j].w; }
+  pnt_t<N> r;
+#pragma unroll
+  for (int j = 0; j < N; j++) { r.hm.v[j] = w[j]; r.hp.v[j] = w[N + j]; r.dt.v[j] = w[2 * N + j]; }
+  if constexpr (N == 14) {
+#pragma unroll
+    for (int j = 0; j < N; j++) r.z.v[j] = w[3 * N + j];
+  }
   return r;
 }
-// an extended point is 36 words = 9 x 16 bytes
-__device__ __forceinline__ void store_ete(ete* dst, const ete& a) {
-  uint32_t w[36];
+template <int N> __device__ __forceinline__ void store_pnt(rec_slot<N>* dst, const pnt_t<N>& r) {
+  uint32_t w[4 * geo<N>::SQ];
 #pragma unroll
-  for (int j = 0; j < NL; j++) { w[j] = a.x.v[j]; w[NL + j] = a.y.v[j]; w[2 * NL + j] = a.z.v[j]; w[3 * NL + j] = a.t.v[j]; }
+  for (uint32_t j = 0; j < 4 * geo<N>::SQ; j++) w[j] = 0u;
+#pragma unroll
+  for (int j = 0; j < N; j++) { w[j] = r.hm.v[j]; w[N + j] = r.hp.v[j]; w[2 * N + j] = r.dt.v[j]; }
+  if constexpr (N == 14) {
+#pragma unroll
+    for (int j = 0; j < N; j++) w[3 * N + j] = r.z.v[j];
+  }
+#pragma unroll
+  for (uint32_t j = 0; j < geo<N>::SQ; j++) dst->q[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+}
+template <int N> __device__ __forceinline__ void store_ete(ete_t<N>* dst, const ete_t<N>& a) {
+  uint32_t w[4 * N];
+#pragma unroll
+  for (int j = 0; j < N; j++) { w[j] = a.x.v[j]; w[N + j] = a.y.v[j]; w[2 * N + j] = a.z.v[j]; w[3 * N + j] = a.t.v[j]; }
   uint4* o = reinterpret_cast<uint4*>(dst);
 #pragma unroll
-  for (int j = 0; j < 9; j++) o[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+  for (int j = 0; j < N; j++) o[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
 }
-__device__ __forceinline__ ete load_ete(const ete* src) {
+template <int N> __device__ __forceinline__ ete_t<N> load_ete(const ete_t<N>* src) {
   const uint4* q = reinterpret_cast<const uint4*>(src);
-  uint32_t w[36];
+  uint32_t w[4 * N];
 #pragma unroll
-  for (int j = 0; j < 9; j++) { const uint4 u = q[j]; w[4 * j] = u.x; w[4 * j + 1] = u.y; w[4 * j + 2] = u.z; w[4 * j + 3] = u.w; }
-  ete a;
+  for (int j = 0; j < N; j++) { const uint4 u = q[j]; w[4 * j] = u.x; w[4 * j + 1] = u.y; w[4 * j + 2] = u.z; w[4 * j + 3] = u.w; }
+  ete_t<N> a;
 #pragma unroll
-  for (int j = 0; j < NL; j++) { a.x.v[j] = w[j]; a.y.v[j] = w[NL + j]; a.z.v[j] = w[2 * NL + j]; a.t.v[j] = w[3 * NL + j]; }
+  for (int j = 0; j < N; j++) { a.x.v[j] = w[j]; a.y.v[j] = w[N + j]; a.z.v[j] = w[2 * N + j]; a.t.v[j] = w[3 * N + j]; }
   return a;
 }
 
-__global__ void __launch_bounds__(256, 4) k_accumulate(const pnt_slot* __restrict__ recs, const uint32_t* __restrict__ sorted,
+// registers: N = 9 fits four waves per SIMD (128 VGPRs); N = 14 holds 56 + 2 x 56 words of points alone: two waves
+template <int N>
+__global__ void __launch_bounds__(256, N == 9 ? 4 : 2) k_accumulate(const rec_slot<N>* __restrict__ recs, const uint32_t* __restrict__ sorted,
                                                     const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ bucket_count,
                                                     const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ seg_bucket,
                                                     const uint32_t* __restrict__ seg_lenv, const uint32_t* __restrict__ order,
-                                                    const uint32_t* __restrict__ num_segments, ete* __restrict__ buckets,
-                                                    ete* __restrict__ seg_out, uint32_t n, uint32_t logB, uint32_t seg_len, uint32_t ids, uint32_t onto) {
+                                                    const uint32_t* __restrict__ num_segments, ete_t<N>* __restrict__ buckets,
+                                                    ete_t<N>* __restrict__ seg_out, uint32_t n, uint32_t logB, uint32_t seg_len, uint32_t ids, uint32_t onto) {
   const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
-  if (gid >= (order ? *num_segments : ids)) return;         // the schedule lists the valid segments; without it the grid is the id space
+  if (gid >= (order ? *num_segments : ids)) return;
   const uint32_t sgm = order ? order[gid] : gid;
   const uint32_t g = seg_bucket[sgm];                // g = k * B + b
   if (g == TE_SEG_INVALID) return;
@@ -619,7 +654,7 @@ __global__ void __launch_bounds__(256, 4) k_accumulate(const pnt_slot* __restric
   const uint32_t* lst = sorted + (size_t)k * n + bucket_start[g] + part * seg_len;
   // onto: the buckets already hold the sums of earlier pieces of the same MSM (te_msm_run uploads and processes large host
   // buffers in pieces): the first part of every bucket continues from that value instead of the neutral element
-  ete acc = (onto && part == 0u) ? load_ete(buckets + g) : ete_identity();
+  ete_t<N> acc = (onto && part == 0u) ? load_ete<N>(buckets + g) : ete_identity_t<N>();
   if (cnt) {
     // Software pipeline: while the addition of entry j runs, the record of entry j+1 AND the index of entry j+2 are in
     // flight -- nothing that is loaded in an iteration is waited for in the same iteration.  (The first version fetched
@@ -627,57 +662,53 @@ __global__ void __launch_bounds__(256, 4) k_accumulate(const pnt_slot* __restric
     // memory latency exposed per addition.)
     const uint32_t last = cnt - 1u;
     uint32_t e = lst[0], e_n = lst[min(1u, last)];
-    pnt cur = load_pnt(recs, e);
+    pnt_t<N> cur = load_pnt<N>(recs, e);
     for (uint32_t j = 0; j < cnt; j++) {
       const uint32_t e_cur = e;
-      pnt nxt = cur;
+      pnt_t<N> nxt = cur;
       const uint32_t e_nn = lst[min(j + 2u, last)];            // unconditional, clamped
-      if (j + 1 < cnt) { e = e_n; nxt = load_pnt(recs, e); }
+      if (j + 1 < cnt) { e = e_n; nxt = load_pnt<N>(recs, e); }
       acc = ete_madd(acc, pnt_cneg(cur, (e_cur >> 31) != 0u));
       cur = nxt; e_n = e_nn;
     }
   }
   const bool whole = bucket_count[g] <= seg_len;
-  store_ete(whole ? buckets + g : seg_out + sgm, acc);
+  store_ete<N>(whole ? buckets + g : seg_out + sgm, acc);
 }
-
-// sums the parts of every split bucket: one quad (team addition) per entry of the split list
-__global__ void __launch_bounds__(256) k_seg_combine(const uint32_t* __restrict__ split_list, const uint32_t* __restrict__ split_count,
-                                                     const uint32_t* __restrict__ bucket_count, const uint32_t* __restrict__ seg_base,
-                                                     const ete* __restrict__ seg_out, ete* __restrict__ buckets, uint32_t seg_len);
 
 // ------------------------------------------------------------------------------------------------
 // K4a: marginal sums.  Bucket j of a window has weight j + 1; write j in four digits j = (d3 d2 d1 d0) of w3..w0 bits
 // (15 = 3+4+4+4 for c = 16).  With M_k[v] = sum of all buckets whose digit k equals v (<= 16 values per digit):
 //     sum_j (j+1) B_j = sum_j B_j + sum_k 2^(w0+..+w(k-1)) * sum_v v * M_k[v].
 // The powers of two cost nothing: they are folded into Horner's doublings on the host.  Everything here is plain
-// sums, computed by folding one digit at a time, 4 (or 2) points per thread per level:
+// sums, computed by folding one digit at a time, 8 (4, 2) points per thread per level:
 //     out[o] = sum_{t<K} in[(outer*K + t)*inner + q],   o = outer*inner + q
 // (inner = 1 folds a contiguous digit, inner > 1 folds a higher one).  Up to four independent jobs share a launch
 // (blockIdx.y).  The first level is throughput-bound (one thread per output); the later, small levels are
 // latency-bound and use four lanes per output (k_sum_groups_team below).
-struct sum_job {
-  const ete* in; ete* out;
+template <int N> struct sum_job_t {
+  const ete_t<N>* in; ete_t<N>* out;
   uint32_t n_out;      // outputs per window (0 = no job)
   uint32_t K, inner;
   uint32_t in_per_window, out_per_window;
 };
-struct sum_jobs { sum_job j[4]; };
-__global__ void __launch_bounds__(256, 2) k_sum_groups(sum_jobs js, uint32_t nw) {
-  const sum_job& j = js.j[blockIdx.y];
+template <int N> struct sum_jobs_t { sum_job_t<N> j[4]; };
+template <int N>
+__global__ void __launch_bounds__(256, N == 9 ? 2 : 1) k_sum_groups(sum_jobs_t<N> js, uint32_t nw) {
+  const sum_job_t<N>& j = js.j[blockIdx.y];
   const uint32_t total = j.n_out * nw;
   for (uint32_t g = blockIdx.x * 256u + threadIdx.x; g < total; g += gridDim.x * 256u) {
     const uint32_t k = g / j.n_out, o = g - k * j.n_out;
     const uint32_t outer = o / j.inner, q = o - outer * j.inner;
-    const ete* src = j.in + (size_t)k * j.in_per_window + (size_t)outer * j.K * j.inner + q;
-    ete acc = load_ete(src);
-    ete nxt = load_ete(src + (size_t)j.inner);                 // K >= 2: the next operand is in flight during the addition
+    const ete_t<N>* src = j.in + (size_t)k * j.in_per_window + (size_t)outer * j.K * j.inner + q;
+    ete_t<N> acc = load_ete<N>(src);
+    ete_t<N> nxt = load_ete<N>(src + (size_t)j.inner);          // K >= 2: the next operand is in flight during the addition
     for (uint32_t t = 1; t < j.K; t++) {
-      const ete cur = nxt;
-      if (t + 1 < j.K) nxt = load_ete(src + (size_t)(t + 1) * j.inner);
-      acc = ete_add(acc, cur);
+      const ete_t<N> cur = nxt;
+      if (t + 1 < j.K) nxt = load_ete<N>(src + (size_t)(t + 1) * j.inner);
+      acc = ete_add<N>(acc, cur);
     }
-    store_ete(j.out + (size_t)k * j.out_per_window + o, acc);
+    store_ete<N>(j.out + (size_t)k * j.out_per_window + o, acc);
   }
 }
 
@@ -691,10 +722,10 @@ __global__ void __launch_bounds__(256, 2) k_sum_groups(sum_jobs js, uint32_t nw)
 //     round 3   lane0: X3 = EF              lane1: Y3 = HG              lane2: T3 = EH       lane3: Z3 = FG
 // with E = B-A, H = B+A, F = D-C, G = D+C formed on every lane after a quad broadcast (DPP quad_perm, no LDS).
 // 3 product latencies instead of 9, at 75 % lane efficiency -- the right trade when the machine is idle anyway.
-__device__ __forceinline__ fp quad_bcast(const fp& v, const int k) {     // value of lane k of my quad, k uniform constant 0..3
-  fp r;
+template <int N> __device__ __forceinline__ fel<N> quad_bcast(const fel<N>& v, const int k) {     // value of lane k of my quad, k uniform constant 0..3
+  fel<N> r;
 #pragma unroll
-  for (int i = 0; i < NL; i++) {
+  for (int i = 0; i < N; i++) {
     const int x = (int)v.v[i];
     int y;
     switch (k) {
@@ -707,176 +738,92 @@ __device__ __forceinline__ fp quad_bcast(const fp& v, const int k) {     // valu
   }
   return r;
 }
-__device__ __forceinline__ fp quad_swap1(const fp& v) {                 // lanes 0<->1, 2<->3 of every quad
-  fp r;
+template <int N> __device__ __forceinline__ fel<N> quad_swap1(const fel<N>& v) {                 // lanes 0<->1, 2<->3 of every quad
+  fel<N> r;
 #pragma unroll
-  for (int i = 0; i < NL; i++) r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)v.v[i], 0xb1, 0xf, 0xf, true);
+  for (int i = 0; i < N; i++) r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)v.v[i], 0xb1, 0xf, 0xf, true);
   return r;
 }
-__device__ __forceinline__ fp fp_select(bool c, const fp& a, const fp& b) {
-  fp r;
+template <int N> __device__ __forceinline__ fel<N> fp_select(bool c, const fel<N>& a, const fel<N>& b) {
+  fel<N> r;
 #pragma unroll
-  for (int i = 0; i < NL; i++) r.v[i] = c ? a.v[i] : b.v[i];
+  for (int i = 0; i < N; i++) r.v[i] = c ? a.v[i] : b.v[i];
   return r;
 }
 // q = lane & 3 selects the coordinate this lane holds: 0 X, 1 Y, 2 T, 3 Z.  All four lanes of a quad must call.
-__device__ __forceinline__ fp ete_add_team(const fp& m1, const fp& m2, const uint32_t q) {
-  const fp o1 = quad_swap1(m1), o2 = quad_swap1(m2);                    // lane0 sees Y, lane1 sees X (lanes 2,3: unused)
+// Limb rule for N = 14: one operand of every product is normalised (lanes 0, 1: the first-point side of round 1; E, F, G).
+template <int N> __device__ __forceinline__ fel<N> ete_add_team(const fel<N>& m1, const fel<N>& m2, const uint32_t q) {
+  const fel<N> o1 = quad_swap1<N>(m1), o2 = quad_swap1<N>(m2);          // lane0 sees Y, lane1 sees X (lanes 2,3: unused)
   // round 1 operands
-  const fp u0 = fp_norm(fp_sub<2>(o1, m1)), v0 = fp_sub<2>(o2, m2);     // lane0: Y1-X1, Y2-X2
-  const fp u1 = fp_add(m1, o1), v1 = fp_add(m2, o2);                    // lane1: Y1+X1, Y2+X2
-  const fp u = q == 0 ? u0 : (q == 1 ? u1 : m1);
-  const fp v = q == 0 ? v0 : (q == 1 ? v1 : m2);
-  const fp s1 = mont_mul(u, v);                                         // A | B | T1T2 | Z1Z2
+  const fel<N> u0 = fe_norm(fe_sub<2>(o1, m1)), v0 = fe_sub<2>(o2, m2); // lane0: Y1-X1, Y2-X2
+  const fel<N> u1 = fe_norm_if_needed(fe_add(m1, o1)), v1 = fe_add(m2, o2);   // lane1: Y1+X1, Y2+X2
+  const fel<N> u = q == 0 ? u0 : (q == 1 ? u1 : m1);
+  const fel<N> v = q == 0 ? v0 : (q == 1 ? v1 : m2);
+  const fel<N> s1 = fe_mul(u, v);                                       // A | B | T1T2 | Z1Z2
   // round 2
-  const fp s2 = mont_mul(s1, fp_K2D_MONT());                            // meaningful on lane2 only
-  const fp val = q == 2 ? s2 : (q == 3 ? fp_add(s1, s1) : s1);          // A | B | C | D
+  const fel<N> s2 = fe_mul(s1, fe_k2d<N>());                            // meaningful on lane2 only
+  const fel<N> val = q == 2 ? s2 : (q == 3 ? fe_add(s1, s1) : s1);      // A | B | C | D
   // round 3
-  const fp A = quad_bcast(val, 0), B = quad_bcast(val, 1), C = quad_bcast(val, 2), D = quad_bcast(val, 3);
-  const fp E = fp_norm(fp_sub<2>(B, A)), H = fp_add(B, A), F = fp_norm(fp_sub<2>(D, C)), G = fp_norm(fp_add(D, C));
-  const fp uu = (q == 0 || q == 2) ? E : (q == 1 ? H : F);
-  const fp vv = q == 0 ? F : (q == 2 ? H : G);
-  return mont_mul(uu, vv);                                              // X3 | Y3 | T3 | Z3
+  const fel<N> A = quad_bcast<N>(val, 0), B = quad_bcast<N>(val, 1), C = quad_bcast<N>(val, 2), D = quad_bcast<N>(val, 3);
+  const fel<N> E = fe_norm(fe_sub<2>(B, A)), H = fe_add(B, A), F = fe_norm(fe_sub<2>(D, C)), G = fe_norm(fe_add(D, C));
+  const fel<N> uu = (q == 0 || q == 2) ? E : (q == 1 ? H : F);
+  const fel<N> vv = q == 0 ? F : (q == 2 ? H : G);
+  return fe_mul(uu, vv);                                                // X3 | Y3 | T3 | Z3
 }
 // word offset of coordinate q inside a stored point (memory order x | y | z | t)
-__device__ __forceinline__ uint32_t team_word(uint32_t q) { return (q == 0 ? 0u : q == 1 ? 1u : q == 2 ? 3u : 2u) * NL; }
-__device__ __forceinline__ fp load_coord(const uint32_t* p) { fp r;
+template <int N> __device__ __forceinline__ uint32_t team_word(uint32_t q) { return (q == 0 ? 0u : q == 1 ? 1u : q == 2 ? 3u : 2u) * N; }
+template <int N> __device__ __forceinline__ fel<N> load_coord(const uint32_t* p) { fel<N> r;
 #pragma unroll
-  for (int i = 0; i < NL; i++) r.v[i] = p[i];
+  for (int i = 0; i < N; i++) r.v[i] = p[i];
   return r; }
-__device__ __forceinline__ void store_coord(uint32_t* p, const fp& a) {
+template <int N> __device__ __forceinline__ void store_coord(uint32_t* p, const fel<N>& a) {
 #pragma unroll
-  for (int i = 0; i < NL; i++) p[i] = a.v[i];
+  for (int i = 0; i < N; i++) p[i] = a.v[i];
 }
-__device__ __forceinline__ fp identity_coord(uint32_t q) { return (q == 1 || q == 3) ? fp_R1() : fp_zero(); }
-
-__global__ void __launch_bounds__(256) k_seg_combine(const uint32_t* __restrict__ split_list, const uint32_t* __restrict__ split_count,
-                                                     const uint32_t* __restrict__ bucket_count, const uint32_t* __restrict__ seg_base,
-                                                     const ete* __restrict__ seg_out, ete* __restrict__ buckets, uint32_t seg_len) {
-  const uint32_t nsplit = *split_count, q = threadIdx.x & 3u;
-  for (uint32_t i = (blockIdx.x * 256u + threadIdx.x) >> 2; i < nsplit; i += (gridDim.x * 256u) >> 2) {
-    const uint32_t g = split_list[i];
-    const uint32_t ns = (bucket_count[g] + seg_len - 1u) / seg_len, s0 = seg_base[g];
-    fp acc = load_coord(reinterpret_cast<const uint32_t*>(seg_out + s0) + team_word(q));
-    for (uint32_t j = 1; j < ns; j++) acc = ete_add_team(acc, load_coord(reinterpret_cast<const uint32_t*>(seg_out + s0 + j) + team_word(q)), q);
-    store_coord(reinterpret_cast<uint32_t*>(buckets + g) + team_word(q), acc);
-  }
-}
+template <int N> __device__ __forceinline__ fel<N> identity_coord(uint32_t q) { return (q == 1 || q == 3) ? fe_one<N>() : fe_zero<N>(); }
+template <int N> __device__ __forceinline__ const uint32_t* words(const ete_t<N>* p) { return reinterpret_cast<const uint32_t*>(p); }
+template <int N> __device__ __forceinline__ uint32_t* words(ete_t<N>* p) { return reinterpret_cast<uint32_t*>(p); }
 
 // block-wide sum of cnt points src[0], src[stride], ... by 64 quads: strided serial team additions, then an LDS tree.
-// Returns the sum in quad 0.  blockDim.x must be 256; lds holds 64 * 36 words.
-__device__ __forceinline__ fp block_sum_points(const ete* __restrict__ src, uint32_t stride, uint32_t cnt, uint32_t* lds) {
-  const uint32_t i = threadIdx.x >> 2, q = threadIdx.x & 3u, w = team_word(q);
-  fp acc = identity_coord(q);
+// Returns the sum in quad 0.  blockDim.x must be 256; lds holds 64 points.
+template <int N> __device__ __forceinline__ fel<N> block_sum_points(const ete_t<N>* __restrict__ src, uint32_t stride, uint32_t cnt, uint32_t* lds) {
+  constexpr uint32_t PW = geo<N>::PW;
+  const uint32_t i = threadIdx.x >> 2, q = threadIdx.x & 3u, w = team_word<N>(q);
+  fel<N> acc = identity_coord<N>(q);
   for (uint32_t j = i; j < cnt; j += 64u) {       // quad-uniform trip count differs between quads: DPP stays inside a quad
-    const fp e = load_coord(reinterpret_cast<const uint32_t*>(src + (size_t)j * stride) + w);
-    acc = j == i ? e : ete_add_team(acc, e, q);
+    const fel<N> e = load_coord<N>(words<N>(src + (size_t)j * stride) + w);
+    acc = j == i ? e : ete_add_team<N>(acc, e, q);
   }
   for (uint32_t s = 32; s > 0; s >>= 1) {
-    if (i >= s && i < 2 * s) store_coord(lds + (size_t)i * 36 + w, acc);
+    if (i >= s && i < 2 * s) store_coord<N>(lds + (size_t)i * PW + w, acc);
     __syncthreads();
     const bool act = i < s && i + s < cnt;
-    const fp other = act ? load_coord(lds + (size_t)(i + s) * 36 + w) : identity_coord(q);
-    const fp sum = ete_add_team(acc, other, q);
-    acc = fp_select(act, sum, acc);
+    const fel<N> other = act ? load_coord<N>(lds + (size_t)(i + s) * PW + w) : identity_coord<N>(q);
+    const fel<N> sum = ete_add_team<N>(acc, other, q);
+    acc = fp_select<N>(act, sum, acc);
     __syncthreads();
   }
   return acc;
 }
-// giant buckets (skewed scalars, or a top window with one or two occupied buckets): stage 1 sums each run of 1024 parts
-// into its first slot, stage 2 sums those slots into the bucket.  One block per work item, grid-stride.
-__global__ void __launch_bounds__(256) k_seg_combine_large1(const uint32_t* __restrict__ chunk_list, const uint32_t* __restrict__ counts,
-                                                            const uint32_t* __restrict__ bucket_count, const uint32_t* __restrict__ seg_base,
-                                                            ete* __restrict__ seg_out, uint32_t seg_len, uint32_t list_cap) {
-  __shared__ uint32_t lds[64 * 36];
-  const uint32_t items = min(counts[2], list_cap), q = threadIdx.x & 3u;
-  for (uint32_t it = blockIdx.x; it < items; it += gridDim.x) {
-    const uint32_t g = chunk_list[2 * it], part = chunk_list[2 * it + 1];
-    const uint32_t ns = (bucket_count[g] + seg_len - 1u) / seg_len, cnt = min(1024u, ns - part);
-    ete* base = seg_out + seg_base[g] + part;
-    const fp r = block_sum_points(base, 1u, cnt, lds);
-    if ((threadIdx.x >> 2) == 0) store_coord(reinterpret_cast<uint32_t*>(base) + team_word(q), r);
-    __syncthreads();
-  }
-}
-__global__ void __launch_bounds__(256) k_seg_combine_large2(const uint32_t* __restrict__ large_list, const uint32_t* __restrict__ counts,
-                                                            const uint32_t* __restrict__ bucket_count, const uint32_t* __restrict__ seg_base,
-                                                            const ete* __restrict__ seg_out, ete* __restrict__ buckets, uint32_t seg_len, uint32_t list_cap) {
-  __shared__ uint32_t lds[64 * 36];
-  const uint32_t items = min(counts[1], list_cap), q = threadIdx.x & 3u;
-  for (uint32_t it = blockIdx.x; it < items; it += gridDim.x) {
-    const uint32_t g = large_list[it];
-    const uint32_t ns = (bucket_count[g] + seg_len - 1u) / seg_len, cnt = (ns + 1023u) >> 10;
-    const fp r = block_sum_points(seg_out + seg_base[g], 1024u, cnt, lds);
-    if ((threadIdx.x >> 2) == 0) store_coord(reinterpret_cast<uint32_t*>(buckets + g) + team_word(q), r);
-    __syncthreads();
-  }
-}
-
-// k_sum_groups with a quad per output (levels where the grid is too small to fill the machine): 4 threads per output.
-__global__ void __launch_bounds__(256) k_sum_groups_team(sum_jobs js, uint32_t nw) {
-  const sum_job& j = js.j[blockIdx.y];
-  const uint32_t total = j.n_out * nw, q = threadIdx.x & 3u;
-  for (uint32_t g = (blockIdx.x * 256u + threadIdx.x) >> 2; g < total; g += (gridDim.x * 256u) >> 2) {
-    const uint32_t k = g / j.n_out, o = g - k * j.n_out;
-    const uint32_t outer = o / j.inner, qq = o - outer * j.inner;
-    const ete* src = j.in + (size_t)k * j.in_per_window + (size_t)outer * j.K * j.inner + qq;
-    fp acc = load_coord(reinterpret_cast<const uint32_t*>(src) + team_word(q));
-    for (uint32_t t = 1; t < j.K; t++)
-      acc = ete_add_team(acc, load_coord(reinterpret_cast<const uint32_t*>(src + (size_t)t * j.inner) + team_word(q)), q);
-    store_coord(reinterpret_cast<uint32_t*>(j.out + (size_t)k * j.out_per_window + o) + team_word(q), acc);
-  }
-}
-
-// K4b: the four digit sums of a window, each over N <= 16 points M[0..N):
-//   total = sum_v M[v] (digit 0 only),  weighted = sum_v v * M[v] = sum_{v >= 1} S_v,  S_v = sum_{u >= v} M[u].
-// Suffix sums by a log-step scan in LDS, then a tree sum of S_1..S_{N-1}; every addition is a team addition.
-// grid (4 digits, nw), block 64 = 16 quads; quads >= N hold the identity.  Row layout written: [T | W0 | W1 | W2 | W3].
-struct wsum_jobs { const ete* in[4]; uint32_t N[4]; };
-__global__ void __launch_bounds__(64) k_weighted_sum(wsum_jobs js, ete* __restrict__ rows, uint32_t row_stride /* points */) {
-  __shared__ uint32_t lds_w[16 * 36];
-  const uint32_t dgt = blockIdx.x, k = blockIdx.y, t = threadIdx.x >> 2, q = threadIdx.x & 3u, N = js.N[dgt];
-  const uint32_t w = team_word(q);
-  fp mine = t < N ? load_coord(reinterpret_cast<const uint32_t*>(js.in[dgt] + (size_t)k * N + t) + w) : identity_coord(q);
-  for (uint32_t d = 1; d < N; d <<= 1) {            // inclusive suffix scan
-    store_coord(lds_w + (size_t)t * 36 + w, mine);
-    __syncthreads();
-    const bool act = t + d < N;                     // uniform per quad
-    const fp other = act ? load_coord(lds_w + (size_t)(t + d) * 36 + w) : identity_coord(q);
-    const fp sum = ete_add_team(mine, other, q);    // every lane takes part (DPP needs the whole quad)
-    mine = fp_select(act, sum, mine);
-    __syncthreads();
-  }
-  ete* row = rows + (size_t)k * row_stride;
-  if (t == 0) { if (dgt == 0) store_coord(reinterpret_cast<uint32_t*>(row) + w, mine); mine = identity_coord(q); }
-  for (uint32_t s = 8; s > 0; s >>= 1) {            // tree sum of S_1..S_{N-1} (slot 0 = identity)
-    if (t >= s && t < 2 * s) store_coord(lds_w + (size_t)t * 36 + w, mine);
-    __syncthreads();
-    const bool act = t < s && t + s < N;
-    const fp other = act ? load_coord(lds_w + (size_t)(t + s) * 36 + w) : identity_coord(q);
-    const fp sum = ete_add_team(mine, other, q);
-    mine = fp_select(act, sum, mine);
-    __syncthreads();
-  }
-  if (t == 0) store_coord(reinterpret_cast<uint32_t*>(row + 1 + dgt) + w, mine);
-}
-
-// k_seg_combine and k_seg_combine_large1 in one launch: blocks [0, quad_blocks) sum the buckets cut into 2..16 parts (one quad
-// each), the remaining blocks sum the runs of 1024 parts of giant buckets (k_seg_combine_large2 finishes those).
+// sums the parts of split buckets.  Blocks [0, quad_blocks) sum the buckets cut into 2..16 parts, one quad (team addition)
+// per entry of the split list; the remaining blocks sum the runs of 1024 parts of GIANT buckets (skewed scalars, or a top
+// window with one or two occupied buckets) into the first slot of each run; k_seg_combine_large2 then sums those slots
+// into the bucket.  One block per work item, grid-stride.
+template <int N>
 __global__ void __launch_bounds__(256) k_seg_combine_all(const uint32_t* __restrict__ split_list, const uint32_t* __restrict__ counts,
                                                          const uint32_t* __restrict__ chunk_list, const uint32_t* __restrict__ bucket_count,
-                                                         const uint32_t* __restrict__ seg_base, ete* __restrict__ seg_out, ete* __restrict__ buckets,
+                                                         const uint32_t* __restrict__ seg_base, ete_t<N>* __restrict__ seg_out, ete_t<N>* __restrict__ buckets,
                                                          uint32_t seg_len, uint32_t chunk_cap, uint32_t quad_blocks) {
-  __shared__ uint32_t lds[64 * 36];
-  const uint32_t q = threadIdx.x & 3u;
+  __shared__ uint32_t lds[64 * geo<N>::PW];
+  const uint32_t q = threadIdx.x & 3u, wq = team_word<N>(q);
   if (blockIdx.x < quad_blocks) {
     const uint32_t nsplit = counts[0];
     for (uint32_t i = (blockIdx.x * 256u + threadIdx.x) >> 2; i < nsplit; i += (quad_blocks * 256u) >> 2) {
       const uint32_t g = split_list[i];
       const uint32_t ns = (bucket_count[g] + seg_len - 1u) / seg_len, s0 = seg_base[g];
-      fp acc = load_coord(reinterpret_cast<const uint32_t*>(seg_out + s0) + team_word(q));
-      for (uint32_t j = 1; j < ns; j++) acc = ete_add_team(acc, load_coord(reinterpret_cast<const uint32_t*>(seg_out + s0 + j) + team_word(q)), q);
-      store_coord(reinterpret_cast<uint32_t*>(buckets + g) + team_word(q), acc);
+      fel<N> acc = load_coord<N>(words<N>(seg_out + s0) + wq);
+      for (uint32_t j = 1; j < ns; j++) acc = ete_add_team<N>(acc, load_coord<N>(words<N>(seg_out + s0 + j) + wq), q);
+      store_coord<N>(words<N>(buckets + g) + wq, acc);
     }
     return;
   }
@@ -884,17 +831,48 @@ __global__ void __launch_bounds__(256) k_seg_combine_all(const uint32_t* __restr
   for (uint32_t it = blockIdx.x - quad_blocks; it < items; it += nb) {
     const uint32_t g = chunk_list[2 * it], part = chunk_list[2 * it + 1];
     const uint32_t ns = (bucket_count[g] + seg_len - 1u) / seg_len, cnt = min(1024u, ns - part);
-    ete* base = seg_out + seg_base[g] + part;
-    const fp r = block_sum_points(base, 1u, cnt, lds);
-    if ((threadIdx.x >> 2) == 0) store_coord(reinterpret_cast<uint32_t*>(base) + team_word(q), r);
+    ete_t<N>* base = seg_out + seg_base[g] + part;
+    const fel<N> r = block_sum_points<N>(base, 1u, cnt, lds);
+    if ((threadIdx.x >> 2) == 0) store_coord<N>(words<N>(base) + wq, r);
     __syncthreads();
+  }
+}
+template <int N>
+__global__ void __launch_bounds__(256) k_seg_combine_large2(const uint32_t* __restrict__ large_list, const uint32_t* __restrict__ counts,
+                                                            const uint32_t* __restrict__ bucket_count, const uint32_t* __restrict__ seg_base,
+                                                            const ete_t<N>* __restrict__ seg_out, ete_t<N>* __restrict__ buckets, uint32_t seg_len, uint32_t list_cap) {
+  __shared__ uint32_t lds[64 * geo<N>::PW];
+  const uint32_t items = min(counts[1], list_cap), q = threadIdx.x & 3u;
+  for (uint32_t it = blockIdx.x; it < items; it += gridDim.x) {
+    const uint32_t g = large_list[it];
+    const uint32_t ns = (bucket_count[g] + seg_len - 1u) / seg_len, cnt = (ns + 1023u) >> 10;
+    const fel<N> r = block_sum_points<N>(seg_out + seg_base[g], 1024u, cnt, lds);
+    if ((threadIdx.x >> 2) == 0) store_coord<N>(words<N>(buckets + g) + team_word<N>(q), r);
+    __syncthreads();
+  }
+}
+
+// k_sum_groups with a quad per output (levels where the grid is too small to fill the machine): 4 threads per output.
+template <int N>
+__global__ void __launch_bounds__(256) k_sum_groups_team(sum_jobs_t<N> js, uint32_t nw) {
+  const sum_job_t<N>& j = js.j[blockIdx.y];
+  const uint32_t total = j.n_out * nw, q = threadIdx.x & 3u, wq = team_word<N>(q);
+  for (uint32_t g = (blockIdx.x * 256u + threadIdx.x) >> 2; g < total; g += (gridDim.x * 256u) >> 2) {
+    const uint32_t k = g / j.n_out, o = g - k * j.n_out;
+    const uint32_t outer = o / j.inner, qq = o - outer * j.inner;
+    const ete_t<N>* src = j.in + (size_t)k * j.in_per_window + (size_t)outer * j.K * j.inner + qq;
+    fel<N> acc = load_coord<N>(words<N>(src) + wq);
+    for (uint32_t t = 1; t < j.K; t++)
+      acc = ete_add_team<N>(acc, load_coord<N>(words<N>(src + (size_t)t * j.inner) + wq), q);
+    store_coord<N>(words<N>(j.out + (size_t)k * j.out_per_window + o) + wq, acc);
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // K4 tail: everything after the wide fold levels in ONE launch, one block per (window, digit) -- team additions, points in
-// LDS.  Replaces the last fold levels, the four second-phase chains and k_weighted_sum: six dependent, latency-bound
-// launches of the first version.  Bucket index j = hi * L + lo with lo = (d1 d0) of w1 + w0 bits, hi = (d3 d2) of w3 + w2 bits.
+// LDS.  Replaces the last fold levels, the four second-phase chains and the weighted-sum kernel: six dependent,
+// latency-bound launches of the first version.  Bucket index j = hi * L + lo with lo = (d1 d0) of w1 + w0 bits, hi = (d3 d2)
+// of w3 + w2 bits.
 //   in : xin[hi * rx + g], g < rx   partial row sums     X2[hi] = sum_g xin[hi * rx + g]       (H = 2^(w2+w3) values)
 //        yin[h * L + lo], h < ry    partial column sums  Y2[lo] = sum_h yin[h * L + lo]        (L = 2^(w0+w1) values)
 //   block (digit, window):  digit 3: M3[d3] = sum_d2 X2    digit 2: M2[d2] = sum_d3 X2
@@ -903,39 +881,40 @@ __global__ void __launch_bounds__(256) k_seg_combine_all(const uint32_t* __restr
 //   A    X2 or Y2 -> LDS: one quad per value, its rx (ry) <= 4 inputs loaded up front
 //   B    the digit's marginal as a binary tree in place: item (o, t), t < m/2: in[o, t] += in[o, t + m/2]
 //   C    first wave only: suffix scan S_v = sum_{u >= v} M[u] (T = S_0 of digit 0), W = sum_{v >= 1} S_v by a tree
-//   out: slot 1 + digit (and slot 0 = T from the digit-0 block) of the row [T | W0 | W1 | W2 | W3] that
-//        te_host::horner_to_affine folds.
+//   out: slot 1 + digit (and slot 0 = T from the digit-0 block) of the row [T | W0 | W1 | W2 | W3] that the host tail folds
+//        (te_host::horner_to_affine / te377_host::horner_to_affine).
 // One level costs ~3 us (three dependent field products per team addition on a wave that owns its SIMD), a busy CU ~5 us:
 // the blocks are kept small so that the ~15 levels of a window run on four nearly idle CUs.
-struct tail_params {
-  const ete* xin; const ete* yin;
+template <int N> struct tail_params_t {
+  const ete_t<N>* xin; const ete_t<N>* yin;
   uint32_t rx, ry, x_per_window, y_per_window;
   uint32_t w[4];
-  ete* rows; uint32_t row_stride;   // points
+  ete_t<N>* rows; uint32_t row_stride;   // points
 };
-__device__ __forceinline__ uint32_t* lds_point(uint32_t* base, uint32_t idx) { return base + (size_t)idx * 36u; }
+template <int N> __device__ __forceinline__ uint32_t* lds_point(uint32_t* base, uint32_t idx) { return base + (size_t)idx * geo<N>::PW; }
 
-__global__ void __launch_bounds__(1024) k_reduce_tail(tail_params prm) {
+template <int N>
+__global__ void __launch_bounds__(1024) k_reduce_tail(tail_params_t<N> prm) {
   extern __shared__ uint32_t tl[];
-  const uint32_t dgt = blockIdx.x, k = blockIdx.y, i = threadIdx.x >> 2, q = threadIdx.x & 3u, wq = team_word(q), Q = blockDim.x >> 2;
+  const uint32_t dgt = blockIdx.x, k = blockIdx.y, i = threadIdx.x >> 2, q = threadIdx.x & 3u, wq = team_word<N>(q), Q = blockDim.x >> 2;
   const uint32_t w0 = prm.w[0], w1 = prm.w[1], w2 = prm.w[2], w3 = prm.w[3];
   const bool isx = dgt >= 2u;
   const uint32_t nv = isx ? 1u << (w2 + w3) : 1u << (w0 + w1);          // values of X2 (Y2)
   uint32_t* sv = tl;                                                     // X2 / Y2, then the tree in place
-  uint32_t* sc = sv + (size_t)nv * 36u;                                  // 16 points of scratch for step C
+  uint32_t* sc = sv + (size_t)nv * geo<N>::PW;                           // 16 points of scratch for step C
   // ---- A
   {
     const uint32_t cnt = isx ? prm.rx : prm.ry, stride = isx ? 1u : nv;
     for (uint32_t o = i; o < nv; o += Q) {
-      const ete* src = isx ? prm.xin + (size_t)k * prm.x_per_window + (size_t)o * prm.rx : prm.yin + (size_t)k * prm.y_per_window + o;
-      fp in[4];
+      const ete_t<N>* src = isx ? prm.xin + (size_t)k * prm.x_per_window + (size_t)o * prm.rx : prm.yin + (size_t)k * prm.y_per_window + o;
+      fel<N> in[4];
 #pragma unroll
-      for (int t = 0; t < 4; t++) in[t] = load_coord(reinterpret_cast<const uint32_t*>(src + (size_t)min((uint32_t)t, cnt - 1u) * stride) + wq);
-      fp acc = in[0];                                                                              // cnt is uniform
-      if (cnt > 1u) acc = ete_add_team(acc, in[1], q);
-      if (cnt > 2u) acc = ete_add_team(acc, in[2], q);
-      if (cnt > 3u) acc = ete_add_team(acc, in[3], q);
-      store_coord(lds_point(sv, o) + wq, acc);
+      for (int t = 0; t < 4; t++) in[t] = load_coord<N>(words<N>(src + (size_t)min((uint32_t)t, cnt - 1u) * stride) + wq);
+      fel<N> acc = in[0];                                                                          // cnt is uniform
+      if (cnt > 1u) acc = ete_add_team<N>(acc, in[1], q);
+      if (cnt > 2u) acc = ete_add_team<N>(acc, in[2], q);
+      if (cnt > 3u) acc = ete_add_team<N>(acc, in[3], q);
+      store_coord<N>(lds_point<N>(sv, o) + wq, acc);
     }
   }
   __syncthreads();
@@ -951,40 +930,54 @@ __global__ void __launch_bounds__(1024) k_reduce_tail(tail_params prm) {
       const bool act = it < total;
       const uint32_t o = act ? it / half : 0u, t = act ? it - o * half : 0u;
       const uint32_t a_idx = o * ostr + t * istr, b_idx = a_idx + (act ? half * istr : 0u);
-      const fp a = load_coord(lds_point(sv, a_idx) + wq), b = load_coord(lds_point(sv, b_idx) + wq);
-      const fp sum = ete_add_team(a, b, q);
-      if (act) store_coord(lds_point(sv, a_idx) + wq, sum);
+      const fel<N> a = load_coord<N>(lds_point<N>(sv, a_idx) + wq), b = load_coord<N>(lds_point<N>(sv, b_idx) + wq);
+      const fel<N> sum = ete_add_team<N>(a, b, q);
+      if (act) store_coord<N>(lds_point<N>(sv, a_idx) + wq, sum);
     }
     __syncthreads();
   }
   // ---- C: the first wave alone (16 quads, quad v holds M[v]); the other waves are done
   if (threadIdx.x >= 64u) return;
   {
-    const uint32_t v = i, N = nout;                                            // N <= 16
-    fp mine = v < N ? load_coord(lds_point(sv, v * ostr) + wq) : identity_coord(q);
-    uint32_t* slot = lds_point(sc, v);
+    const uint32_t v = i, Nv = nout;                                           // Nv <= 16
+    fel<N> mine = v < Nv ? load_coord<N>(lds_point<N>(sv, v * ostr) + wq) : identity_coord<N>(q);
+    uint32_t* slot = lds_point<N>(sc, v);
     for (uint32_t d = 1; d < 16u; d <<= 1) {           // inclusive suffix scan
-      store_coord(slot + wq, mine);
+      store_coord<N>(slot + wq, mine);
       __syncthreads();
-      const bool act = v + d < N;
-      const fp other = act ? load_coord(lds_point(sc, v + d) + wq) : identity_coord(q);
-      const fp sum = ete_add_team(mine, other, q);
-      mine = fp_select(act, sum, mine);
+      const bool act = v + d < Nv;
+      const fel<N> other = act ? load_coord<N>(lds_point<N>(sc, v + d) + wq) : identity_coord<N>(q);
+      const fel<N> sum = ete_add_team<N>(mine, other, q);
+      mine = fp_select<N>(act, sum, mine);
       __syncthreads();
     }
-    ete* row = prm.rows + (size_t)k * prm.row_stride;
-    if (v == 0) { if (dgt == 0) store_coord(reinterpret_cast<uint32_t*>(row) + wq, mine); mine = identity_coord(q); }
+    ete_t<N>* row = prm.rows + (size_t)k * prm.row_stride;
+    if (v == 0) { if (dgt == 0) store_coord<N>(words<N>(row) + wq, mine); mine = identity_coord<N>(q); }
     for (uint32_t s = 8; s > 0; s >>= 1) {             // tree sum of S_1..S_{N-1} (slot 0 = identity)
-      if (v >= s && v < 2 * s) store_coord(slot + wq, mine);
+      if (v >= s && v < 2 * s) store_coord<N>(slot + wq, mine);
       __syncthreads();
-      const bool act = v < s && v + s < N;
-      const fp other = act ? load_coord(lds_point(sc, v + s) + wq) : identity_coord(q);
-      const fp sum = ete_add_team(mine, other, q);
-      mine = fp_select(act, sum, mine);
+      const bool act = v < s && v + s < Nv;
+      const fel<N> other = act ? load_coord<N>(lds_point<N>(sc, v + s) + wq) : identity_coord<N>(q);
+      const fel<N> sum = ete_add_team<N>(mine, other, q);
+      mine = fp_select<N>(act, sum, mine);
       __syncthreads();
     }
-    if (v == 0) store_coord(reinterpret_cast<uint32_t*>(row + 1 + dgt) + wq, mine);
+    if (v == 0) store_coord<N>(words<N>(row + 1 + dgt) + wq, mine);
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1a for BLS12-377 G1: short-Weierstrass affine (x, y), 48-byte little-endian each -> projective twisted-Edwards record
+// (curve.hpp, pnt_from_sw377), one lane per point; loads and stores are 16 bytes per lane.
+__global__ void __launch_bounds__(256) k_prep_points377(const uint4* __restrict__ pts, rec_slot<14>* __restrict__ recs, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  uint4 u[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) u[j] = pts[6 * (size_t)i + j];
+  const uint32_t xw[12] = {u[0].x, u[0].y, u[0].z, u[0].w, u[1].x, u[1].y, u[1].z, u[1].w, u[2].x, u[2].y, u[2].z, u[2].w};
+  const uint32_t yw[12] = {u[3].x, u[3].y, u[3].z, u[3].w, u[4].x, u[4].y, u[4].z, u[4].w, u[5].x, u[5].y, u[5].z, u[5].w};
+  store_pnt<14>(recs + i, pnt_from_sw377(te377::fq_from_words32(xw), te377::fq_from_words32(yw)));
 }
 
 }  // namespace te

@@ -82,9 +82,26 @@ static inline void synth_scalars(uint64_t seed, uint64_t n, uint8_t* out) {
   uint64_t s = seed;
   for (uint64_t i = 0; i < n; i++) { const te_host::Fe r = te_host::rand_mod_p(s); memset(out + 48 * i, 0, 48); memcpy(out + 48 * i, r.l, 32); }
 }
-static inline Pt pmul(const Pt& p, const te_host::Fe& k) {      // k < r (253 bits)
-  Pt acc = identity();
-  for (int i = 252; i >= 0; i--) { acc = padd(acc, acc); if ((k.l[i >> 6] >> (i & 63)) & 1) acc = padd(acc, p); }
+// The harness points are generated on the short-Weierstrass model the wire format uses (the engine's own Edwards form is
+// an internal matter): complete projective addition of Renes-Costello-Batina 2016, Algorithm 7, a = 0, b3 = 3; also doubles.
+struct SwPt { Fe x, y, z; };     // (X : Y : Z); the point at infinity is (0 : 1 : 0)
+static inline Fe mul3(const Fe& a) { return add(add(a, a), a); }
+static inline SwPt sw_add(const SwPt& p, const SwPt& q) {
+  const Fe t0 = mul(p.x, q.x), t1 = mul(p.y, q.y), t2 = mul(p.z, q.z);
+  const Fe t3 = sub(sub(mul(add(p.x, p.y), add(q.x, q.y)), t0), t1);
+  const Fe t4 = sub(sub(mul(add(p.y, p.z), add(q.y, q.z)), t1), t2);
+  const Fe y3 = mul3(sub(sub(mul(add(p.x, p.z), add(q.x, q.z)), t0), t2));
+  const Fe t0x3 = mul3(t0), t2x3 = mul3(t2);
+  const Fe z3 = add(t1, t2x3), t1m = sub(t1, t2x3);
+  SwPt r;
+  r.x = sub(mul(t3, t1m), mul(t4, y3));
+  r.y = add(mul(t1m, z3), mul(y3, t0x3));
+  r.z = add(mul(z3, t4), mul(t0x3, t3));
+  return r;
+}
+static inline SwPt sw_mul(const SwPt& p, const te_host::Fe& k) {      // k < r (253 bits)
+  SwPt acc; memset(&acc, 0, sizeof acc); acc.y = ONE_M;
+  for (int i = 252; i >= 0; i--) { acc = sw_add(acc, acc); if ((k.l[i >> 6] >> (i & 63)) & 1) acc = sw_add(acc, p); }
   return acc;
 }
 static inline void synth_points(uint64_t seed, uint64_t n, uint8_t* out) {
@@ -93,13 +110,13 @@ static inline void synth_points(uint64_t seed, uint64_t n, uint8_t* out) {
   const Fe gx = {{0xeab9b16eb21be9efULL, 0xd5481512ffcd394eULL, 0x188282c8bd37cb5cULL, 0x85951e2caa9d41bbULL, 0xc8fc6225bf87ff54ULL, 0x008848defe740a67ULL}};
   const Fe gy = {{0xfd82de55559c8ea6ULL, 0xc2fe3d3634a9591aULL, 0x6d182ad44fb82305ULL, 0xbd7fb348ca3e52d9ULL, 0x1f674f5d30afeec4ULL, 0x01914a69c5102effULL}};
   const Fe R2 = {{0xb786686c9400cd22ULL, 0x0329fcaab00431b1ULL, 0x22a5f11162d6b46dULL, 0xbfdf7d03827dc3acULL, 0x837e92f041790bf9ULL, 0x006dfccb1e914b88ULL}};
-  Pt g; g.x = mul(gx, R2); g.y = mul(gy, R2); g.z = ONE_M;
+  SwPt g; g.x = mul(gx, R2); g.y = mul(gy, R2); g.z = ONE_M;
   uint64_t s = seed ^ 0xA5A5A5A55A5A5A5AULL;
   const te_host::Fe a = te_host::rand_mod_p(s), b = te_host::rand_mod_p(s);
-  const Pt q = pmul(g, b);
-  std::vector<Pt> pts(n);
-  pts[0] = pmul(g, a);
-  for (uint64_t i = 1; i < n; i++) pts[i] = padd(pts[i - 1], q);
+  const SwPt q = sw_mul(g, b);
+  std::vector<SwPt> pts(n);
+  pts[0] = sw_mul(g, a);
+  for (uint64_t i = 1; i < n; i++) pts[i] = sw_add(pts[i - 1], q);
   std::vector<Fe> pre(n);
   Fe acc = ONE_M;
   for (uint64_t i = 0; i < n; i++) { pre[i] = acc; acc = mul(acc, pts[i].z); }      // no infinity in the chain (order r)

@@ -24,7 +24,6 @@
 #include "synth.hpp"
 #include "kernels.hip.hpp"
 #include "host_tail377.hpp"
-#include "kernels377.hip.hpp"
 
 namespace {
 
@@ -36,12 +35,13 @@ enum { ST_DIGITS = 0, ST_SCATTER, ST_BSORT, ST_ORDER, ST_PREP, ST_ACCUM, ST_TREE
 const char* const kStageNames[ST_COUNT] = {"digits", "part_scatter", "bucket_sort", "order", "prep_points",
                                            "accumulate", "marginal_sums", "weighted_sum"};
 
-// per-curve sizes: wire format, device accumulator slot, partial row (5 points), result
-struct curve_sizes { size_t point_in, scalar_in, acc, row, result; };
+// per-curve sizes: wire format, device accumulator, record slot, partial row (5 points), result
+struct curve_sizes { size_t point_in, scalar_in, acc, rec, row, result; };
 inline curve_sizes sizes_of(int curve) {
-  return curve == TE_MSM_CURVE_BLS12_377_G1 ? curve_sizes{96, 48, sizeof(te377::g1p_slot), TE377_TAIL_ROW_BYTES, 96}
-                                            : curve_sizes{TE_MSM_POINT_BYTES, TE_MSM_SCALAR_BYTES, sizeof(te::ete), TE_MSM_PARTIAL_BYTES, 64};
+  return curve == TE_MSM_CURVE_BLS12_377_G1 ? curve_sizes{96, 48, sizeof(te::ete_t<14>), sizeof(te::rec_slot<14>), TE377_TAIL_ROW_BYTES, 96}
+                                            : curve_sizes{TE_MSM_POINT_BYTES, TE_MSM_SCALAR_BYTES, sizeof(te::ete), sizeof(te::rec_slot<9>), TE_MSM_PARTIAL_BYTES, 64};
 }
+static_assert(TE377_TAIL_ROW_BYTES == TE_MSM_PARTIAL_BYTES_BLS12_377 && sizeof(te::ete_t<14>) * 5 == TE377_TAIL_ROW_BYTES, "row layout");
 constexpr size_t TE_MAX_ROW_BYTES = TE377_TAIL_ROW_BYTES;
 
 struct plan_t {
@@ -64,13 +64,13 @@ struct workset_t {
   hipStream_t stream = nullptr, copy_stream = nullptr;   // copy_stream: host-buffer uploads beside the compute stream
   hipEvent_t ev_copy = nullptr, ev_start = nullptr;
   size_t cap[40] = {};                                  // per-buffer capacity in bytes (ensure())
-  te::pnt_slot* d_recs = nullptr;
+  uint8_t* d_recs = nullptr;          // record slots of the plan's curve (te::rec_slot<N>)
   uint16_t *d_digits = nullptr, *d_part_keys = nullptr;
   uint32_t *d_counts1 = nullptr, *d_part_start = nullptr, *d_part_count = nullptr, *d_part_idx = nullptr, *d_seg_part_base = nullptr;
   uint32_t *d_bucket_count = nullptr, *d_bucket_start = nullptr, *d_bucket_cursor = nullptr, *d_sorted = nullptr;
   uint32_t *d_seg_base = nullptr, *d_seg_bucket = nullptr, *d_seg_lenv = nullptr, *d_order = nullptr;
   uint32_t *d_split_list = nullptr, *d_large_list = nullptr, *d_chunk_list = nullptr;
-  te::ete *d_seg_out = nullptr, *d_buckets = nullptr, *d_red[12] = {};   // reduction: [0..3] ping/pong of the two first-phase chains, [4..11] small
+  uint8_t *d_seg_out = nullptr, *d_buckets = nullptr, *d_red[4] = {};   // accumulators of the plan's curve (te::ete_t<N>); d_red: ping/pong of the two fold chains
   // ONE zeroed block per MSM (a single memset), words: [0] final-carry flag, [1] number of segments, [2..4] split / giant
   // bucket counters, [Z_ROWS..) the partial rows of the MSM (so that flag and rows come back in ONE device-to-host copy),
   // [Z_HIST..) segment-length histogram, [Z_CURSOR..) reservation cursors of the schedule, [Z_END..) the level-1 histogram
@@ -187,19 +187,11 @@ template <typename T> int ensure(te_ctx* ctx, workset_t& ws, T*& ptr, size_t& ca
   return 0;
 }
 
-// point buffers: `count` accumulator slots of the plan's curve
-int ensure_points(te_ctx* ctx, workset_t& ws, te::ete*& ptr, size_t& cap_bytes, size_t count, size_t acc_bytes) {
-  uint8_t* raw = reinterpret_cast<uint8_t*>(ptr);
-  const int rc = ensure(ctx, ws, raw, cap_bytes, count * acc_bytes);
-  ptr = reinterpret_cast<te::ete*>(raw);
-  return rc;
-}
-
 int ensure_buffers(te_ctx* ctx, gpu_t& d, workset_t& ws, uint64_t n, const plan_t& p) {
   HIP_TRY(ctx, hipSetDevice(d.device));
   const size_t nd = (size_t)p.nw * p.nst + 16, wb = (size_t)p.nw * p.B, ab = sizes_of(p.curve).acc;
   int rc = 0;
-  if ((rc = ensure(ctx, ws, ws.d_recs, ws.cap[0], (size_t)n))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_recs, ws.cap[0], (size_t)n * sizes_of(p.curve).rec))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_digits, ws.cap[1], nd))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_sorted, ws.cap[2], nd))) return rc;
   {
@@ -217,23 +209,22 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, workset_t& ws, uint64_t n, const plan_
   if ((rc = ensure(ctx, ws, ws.d_order, ws.cap[7], smax))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_seg_bucket, ws.cap[20], smax))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_seg_lenv, ws.cap[21], smax))) return rc;
-  if ((rc = ensure_points(ctx, ws, ws.d_seg_out, ws.cap[22], smax, ab))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_seg_out, ws.cap[22], smax * ab))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_seg_base, ws.cap[23], wb + 1))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_split_list, ws.cap[24], wb + 1))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_large_list, ws.cap[25], wb + 1))) return rc;
   // a giant bucket contributes one chunk per 1024 parts: at most one per bucket plus one per 1024 segments
   if ((rc = ensure(ctx, ws, ws.d_chunk_list, ws.cap[26], 2 * (wb + smax / 1024 + 2)))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_part_start, ws.cap[6], (size_t)p.nw * p.P))) return rc;
-  if ((rc = ensure_points(ctx, ws, ws.d_buckets, ws.cap[8], wb, ab))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_buckets, ws.cap[8], wb * ab))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_part_count, ws.cap[9], (size_t)p.nw * p.P))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_part_keys, ws.cap[14], nd))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_part_idx, ws.cap[15], nd))) return rc;
-  // marginal-sum levels fold by 4 (or 2): level 1 output is at most B/2 per window, level 2 at most B/4
-  if ((rc = ensure_points(ctx, ws, ws.d_red[0], ws.cap[10], wb / 2 + 1, ab))) return rc;
-  if ((rc = ensure_points(ctx, ws, ws.d_red[1], ws.cap[11], wb / 4 + 1, ab))) return rc;
-  if ((rc = ensure_points(ctx, ws, ws.d_red[2], ws.cap[12], wb / 2 + 1, ab))) return rc;
-  if ((rc = ensure_points(ctx, ws, ws.d_red[3], ws.cap[13], wb / 4 + 1, ab))) return rc;
-  for (int i = 4; i < 12; i++) if ((rc = ensure_points(ctx, ws, ws.d_red[i], ws.cap[24 + i], (size_t)p.nw * 256 + 16, ab))) return rc;
+  // fold levels (by 8, 4 or 2): the first output is at most B/2 per window, the second at most B/4
+  if ((rc = ensure(ctx, ws, ws.d_red[0], ws.cap[10], (wb / 2 + 1) * ab))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_red[1], ws.cap[11], (wb / 4 + 1) * ab))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_red[2], ws.cap[12], (wb / 2 + 1) * ab))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_red[3], ws.cap[13], (wb / 4 + 1) * ab))) return rc;
   return 0;
 }
 
@@ -267,9 +258,9 @@ struct msm_launch {
     const uint32_t n32 = this->n32();
     mark(ST_PREP);
     if (p.curve == TE_MSM_CURVE_BLS12_377_G1)
-      hipLaunchKernelGGL(te377::k377_prep_points, dim3((n32 + 255) / 256), dim3(256), 0, stream, (const uint4*)d_points, ws.d_recs, n32);
+      hipLaunchKernelGGL(te::k_prep_points377, dim3((n32 + 255) / 256), dim3(256), 0, stream, (const uint4*)d_points, reinterpret_cast<te::rec_slot<14>*>(ws.d_recs), n32);
     else
-      hipLaunchKernelGGL(te::k_prep_points, dim3((n32 + 255) / 256), dim3(256), 0, stream, (const uint4*)d_points, ws.d_recs, n32);
+      hipLaunchKernelGGL(te::k_prep_points, dim3((n32 + 255) / 256), dim3(256), 0, stream, (const uint4*)d_points, reinterpret_cast<te::pnt_slot*>(ws.d_recs), n32);
     return 0;
   }
 
@@ -329,168 +320,95 @@ struct msm_launch {
     return 0;
   }
 
-  // K3: one thread per segment (at most seg_len entries of one bucket), 7-product mixed additions
-  int accumulate() {
+  bool bls() const { return p.curve == TE_MSM_CURVE_BLS12_377_G1; }
+
+  // K3: one thread per segment (at most seg_len entries of one bucket): 7-product mixed additions (8 for BLS12-377)
+  template <int N> int accumulate_t() {
     mark(ST_ACCUM);
     if (p.nw > 0) {
       const uint32_t n32 = this->n32(), smax = this->smax();
       const uint32_t* order = ctx->opt_sort ? ws.d_order : nullptr;
-      if (p.curve == TE_MSM_CURVE_BLS12_377_G1)
-        hipLaunchKernelGGL(te377::k377_accumulate, dim3((smax + 255) / 256), dim3(256), 0, stream, ws.d_recs, ws.d_sorted, ws.d_bucket_start,
-                           ws.d_bucket_count, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv, order, ws.d_num_seg,
-                           reinterpret_cast<te377::g1p_slot*>(ws.d_buckets), reinterpret_cast<te377::g1p_slot*>(ws.d_seg_out), n32, p.logB, p.seg_len, smax);
-      else
-        hipLaunchKernelGGL(te::k_accumulate, dim3((smax + 255) / 256), dim3(256), 0, stream, ws.d_recs, ws.d_sorted, ws.d_bucket_start,
-                           ws.d_bucket_count, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv, order, ws.d_num_seg, ws.d_buckets, ws.d_seg_out,
-                           n32, p.logB, p.seg_len, smax, onto ? 1u : 0u);
+      hipLaunchKernelGGL(te::k_accumulate<N>, dim3((smax + 255) / 256), dim3(256), 0, stream, reinterpret_cast<const te::rec_slot<N>*>(ws.d_recs), ws.d_sorted,
+                         ws.d_bucket_start, ws.d_bucket_count, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv, order, ws.d_num_seg,
+                         reinterpret_cast<te::ete_t<N>*>(ws.d_buckets), reinterpret_cast<te::ete_t<N>*>(ws.d_seg_out), n32, p.logB, p.seg_len, smax, onto ? 1u : 0u);
     }
     return 0;
   }
+  int accumulate() { return bls() ? accumulate_t<14>() : accumulate_t<9>(); }
 
-  // K4/K5 for the Twisted-Edwards curve (see kernels.hip.hpp, K4a and k_reduce_tail).  Bucket index j = hi * L + lo:
+  // sums of the buckets that were accumulated in several parts: buckets cut into 2..16 parts (quads) and the 1024-part runs
+  // of giant buckets (blocks) in one launch, then the giant buckets' second stage (empty lists for well-spread digits: a
+  // near-empty launch)
+  template <int N> int combine_t() {
+    if (p.nw <= 0) return 0;
+    using E = te::ete_t<N>;
+    hipLaunchKernelGGL(te::k_seg_combine_all<N>, dim3(256 + 512), dim3(256), 0, stream, ws.d_split_list, ws.d_num_seg + 1, ws.d_chunk_list,
+                       ws.d_bucket_count, ws.d_seg_base, reinterpret_cast<E*>(ws.d_seg_out), reinterpret_cast<E*>(ws.d_buckets), p.seg_len, chunk_cap(), 256u);
+    hipLaunchKernelGGL(te::k_seg_combine_large2<N>, dim3(256), dim3(256), 0, stream, ws.d_large_list, ws.d_num_seg + 1, ws.d_bucket_count, ws.d_seg_base,
+                       reinterpret_cast<const E*>(ws.d_seg_out), reinterpret_cast<E*>(ws.d_buckets), p.seg_len, total());
+    return 0;
+  }
+  int combine() { return bls() ? combine_t<14>() : combine_t<9>(); }
+
+  // K4/K5: buckets -> one row per window (see kernels.hip.hpp, K4a and k_reduce_tail).  Bucket index j = hi * L + lo:
   //   rows chain  xin[hi * r + g]  -- the low L = 2^(w0+w1) part folded from the top, 8 (4, 2) sub-blocks at a time
   //   cols chain  yin[h * L + lo]  -- the high H = 2^(w2+w3) part folded from the top
   // Wide levels (both chains per launch, one thread or one quad per output) run until at most 4 partial sums per output
-  // are left; k_reduce_tail (one block per window) does the rest and writes the row.  n = 2^20, c = 16: two fold
-  // launches (32768 -> 4096 -> 512 points per window and chain) + the tail (one block per window and digit), against nine
-  // launches of the first version.
-  int back_reduce_te() {
-    const uint32_t w0 = p.dw[0], w1 = p.dw[1], w2 = p.dw[2], w3 = p.dw[3];
-    const uint32_t L = 1u << (w0 + w1), H = 1u << (w2 + w3);
-    struct chain_t { const te::ete* cur; uint32_t n, r; te::ete* buf[2]; int pp; };
-    chain_t ch[2] = {{ws.d_buckets, p.B, L, {ws.d_red[0], ws.d_red[1]}, 0}, {ws.d_buckets, p.B, H, {ws.d_red[2], ws.d_red[3]}, 0}};
-    for (;;) {
-      te::sum_jobs js; memset(&js, 0, sizeof js);
-      uint32_t most = 0; int nj = 0;
-      for (int i = 0; i < 2; i++) {
-        chain_t& c = ch[i];
-        if (c.r <= 4u) continue;
-        const uint32_t K = (c.r % 8u == 0) ? 8u : (c.r % 4u == 0) ? 4u : 2u;
-        te::sum_job& j = js.j[nj++];
-        j.in = c.cur; j.out = c.buf[c.pp]; j.K = K; j.n_out = c.n / K;
-        j.inner = i == 0 ? c.r / K : (c.r / K) * L;          // rows: sub-blocks inside one hi; cols: whole slabs of L
-        j.in_per_window = c.n; j.out_per_window = c.n / K;
-        c.cur = j.out; c.pp ^= 1; c.r /= K; c.n /= K;
-        most = std::max(most, j.n_out * (uint32_t)p.nw);
+  // are left; k_reduce_tail (one block per window and digit) does the rest and writes the row.  n = 2^20, c = 16: two fold
+  // launches (32768 -> 4096 -> 512 points per window and chain) + the tail, against nine launches of the first version.
+  template <int N> int reduce_t() {
+    if (p.nw > 0) {
+      using E = te::ete_t<N>;
+      const uint32_t w0 = p.dw[0], w1 = p.dw[1], w2 = p.dw[2], w3 = p.dw[3];
+      const uint32_t L = 1u << (w0 + w1), H = 1u << (w2 + w3);
+      struct chain_t { const E* cur; uint32_t n, r; E* buf[2]; int pp; };
+      E* const bk = reinterpret_cast<E*>(ws.d_buckets);
+      chain_t ch[2] = {{bk, p.B, L, {reinterpret_cast<E*>(ws.d_red[0]), reinterpret_cast<E*>(ws.d_red[1])}, 0},
+                       {bk, p.B, H, {reinterpret_cast<E*>(ws.d_red[2]), reinterpret_cast<E*>(ws.d_red[3])}, 0}};
+      for (;;) {
+        te::sum_jobs_t<N> js; memset(&js, 0, sizeof js);
+        uint32_t most = 0; int nj = 0;
+        for (int i = 0; i < 2; i++) {
+          chain_t& c = ch[i];
+          if (c.r <= 4u) continue;
+          const uint32_t K = (c.r % 8u == 0) ? 8u : (c.r % 4u == 0) ? 4u : 2u;
+          te::sum_job_t<N>& j = js.j[nj++];
+          j.in = c.cur; j.out = c.buf[c.pp]; j.K = K; j.n_out = c.n / K;
+          j.inner = i == 0 ? c.r / K : (c.r / K) * L;          // rows: sub-blocks inside one hi; cols: whole slabs of L
+          j.in_per_window = c.n; j.out_per_window = c.n / K;
+          c.cur = j.out; c.pp ^= 1; c.r /= K; c.n /= K;
+          most = std::max(most, j.n_out * (uint32_t)p.nw);
+        }
+        if (!nj) break;
+        if (most >= 65536u) {               // at least one wave per SIMD with a thread per output: throughput-bound level
+          uint32_t blocks = (most + 255) / 256; if (blocks > 4096) blocks = 4096;
+          hipLaunchKernelGGL(te::k_sum_groups<N>, dim3(blocks, nj), dim3(256), 0, stream, js, (uint32_t)p.nw);
+        } else {                            // latency-bound level: four lanes per output
+          uint32_t blocks = (most * 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+          hipLaunchKernelGGL(te::k_sum_groups_team<N>, dim3(blocks, nj), dim3(256), 0, stream, js, (uint32_t)p.nw);
+        }
       }
-      if (!nj) break;
-      if (most >= 65536u) {               // at least one wave per SIMD with a thread per output: throughput-bound level
-        uint32_t blocks = (most + 255) / 256; if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(te::k_sum_groups, dim3(blocks, nj), dim3(256), 0, stream, js, (uint32_t)p.nw);
-      } else {                            // latency-bound level: four lanes per output
-        uint32_t blocks = (most * 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(te::k_sum_groups_team, dim3(blocks, nj), dim3(256), 0, stream, js, (uint32_t)p.nw);
-      }
+      mark(ST_WEIGHTED);
+      te::tail_params_t<N> tp;
+      tp.xin = ch[0].cur; tp.yin = ch[1].cur; tp.rx = ch[0].r; tp.ry = ch[1].r;
+      tp.x_per_window = ch[0].n; tp.y_per_window = ch[1].n;
+      tp.w[0] = w0; tp.w[1] = w1; tp.w[2] = w2; tp.w[3] = w3;
+      tp.rows = reinterpret_cast<E*>(d_partials_out) + (size_t)d.w_first * 5; tp.row_stride = (uint32_t)d.w_step * 5u;
+      const size_t lds_bytes = (size_t)(std::max(H, L) + 16u) * sizeof(E);
+      hipLaunchKernelGGL(te::k_reduce_tail<N>, dim3(4, p.nw), dim3(1024), lds_bytes, stream, tp);
+    } else {
+      mark(ST_WEIGHTED);
     }
-    mark(ST_WEIGHTED);
-    te::tail_params tp;
-    tp.xin = ch[0].cur; tp.yin = ch[1].cur; tp.rx = ch[0].r; tp.ry = ch[1].r;
-    tp.x_per_window = ch[0].n; tp.y_per_window = ch[1].n;
-    tp.w[0] = w0; tp.w[1] = w1; tp.w[2] = w2; tp.w[3] = w3;
-    tp.rows = reinterpret_cast<te::ete*>(d_partials_out) + (size_t)d.w_first * 5; tp.row_stride = (uint32_t)d.w_step * 5u;
-    const size_t lds_bytes = (size_t)(std::max(H, L) + 16u) * 144u;
-    hipLaunchKernelGGL(te::k_reduce_tail, dim3(4, p.nw), dim3(1024), lds_bytes, stream, tp);
     mark(ST_COUNT);
     if (!own_rows) HIP_TRY(ctx, hipMemcpyAsync(ws.h_err, ws.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     return 0;
   }
+  int reduce() { return bls() ? reduce_t<14>() : reduce_t<9>(); }
 
   // recombination of split buckets, digit marginals, weighted sums, error flag read-back
   int back() {
     if (int rc = combine()) return rc;
     return reduce();
-  }
-
-  // sums of the buckets that were accumulated in several parts
-  int combine() {
-    const uint32_t total = this->total();
-    const bool bls = p.curve == TE_MSM_CURVE_BLS12_377_G1;
-    if (p.nw > 0 && bls) {
-      hipLaunchKernelGGL(te377::k377_seg_combine, dim3(1024), dim3(256), 0, stream, ws.d_bucket_count, ws.d_seg_base,
-                         reinterpret_cast<const te377::g1p_slot*>(ws.d_seg_out), reinterpret_cast<te377::g1p_slot*>(ws.d_buckets), total, p.seg_len);
-    } else if (p.nw > 0) {
-      // buckets cut into 2..16 parts (quads) and the 1024-part runs of giant buckets (blocks) in one launch, then the giant
-      // buckets' second stage (empty lists for well-spread digits: a near-empty launch)
-      hipLaunchKernelGGL(te::k_seg_combine_all, dim3(256 + 512), dim3(256), 0, stream, ws.d_split_list, ws.d_num_seg + 1, ws.d_chunk_list,
-                         ws.d_bucket_count, ws.d_seg_base, ws.d_seg_out, ws.d_buckets, p.seg_len, chunk_cap(), 256u);
-      hipLaunchKernelGGL(te::k_seg_combine_large2, dim3(256), dim3(256), 0, stream, ws.d_large_list, ws.d_num_seg + 1, ws.d_bucket_count, ws.d_seg_base,
-                         ws.d_seg_out, ws.d_buckets, p.seg_len, total);
-    }
-    return 0;
-  }
-
-  // buckets -> one row per window
-  int reduce() {
-    const bool bls = p.curve == TE_MSM_CURVE_BLS12_377_G1;
-    if (p.nw > 0 && !bls) return back_reduce_te();
-    // digit marginals M_k[v], k = 0..3 (see K4a in kernels.hip.hpp).  Chains of folds, 4 (or 2) points per level:
-    //   rows chain  B[d3 d2 d1 d0] -fold d0-> -fold d1-> X2[d3 d2]      cols chain  B -fold d3-> -fold d2-> Y2[d1 d0]
-    //   then M3 = fold d2 of X2, M2 = fold d3 of X2, M1 = fold d0 of Y2, M0 = fold d1 of Y2.
-    const te::ete* marg[4] = {ws.d_buckets, ws.d_buckets, ws.d_buckets, ws.d_buckets};
-    if (p.nw > 0) {
-      struct chain_t { const te::ete* cur; uint32_t n; uint32_t steps[2][2]; int nsteps, step; uint32_t left; te::ete* buf[2]; int pp; };
-      const uint32_t w0 = p.dw[0], w1 = p.dw[1], w2 = p.dw[2], w3 = p.dw[3];
-      auto run_phase = [&](chain_t* ch, int nch) {
-        for (int i = 0; i < nch; i++) { ch[i].step = 0; ch[i].left = ch[i].nsteps ? ch[i].steps[0][0] : 1u; ch[i].pp = 0; }
-        for (;;) {
-          te::sum_jobs js; memset(&js, 0, sizeof js);
-          uint32_t most = 0; bool any = false;
-          for (int i = 0; i < nch; i++) {
-            chain_t& c = ch[i];
-            while (c.step < c.nsteps && c.left <= 1) { c.step++; if (c.step < c.nsteps) c.left = c.steps[c.step][0]; }
-            if (c.step >= c.nsteps) continue;
-            const uint32_t K = (c.left % 4 == 0) ? 4u : 2u, inner = c.steps[c.step][1];   // stride of the digit being folded
-            te::sum_job& j = js.j[i];
-            // fold the HIGH part of the remaining digit: groups of K adjacent sub-blocks of size inner * (left / K)
-            j.in = c.cur; j.out = c.buf[c.pp]; j.K = K; j.inner = inner * (c.left / K); j.n_out = c.n / K;
-            j.in_per_window = c.n; j.out_per_window = c.n / K;
-            c.cur = j.out; c.pp ^= 1; c.left /= K; c.n /= K;
-            most = std::max(most, j.n_out * (uint32_t)p.nw); any = true;
-          }
-          if (!any) break;
-          if (bls) {                  // same job tables (layout-identical structs), one lane per output at every level
-            static_assert(sizeof(te377::sum_jobs) == sizeof(te::sum_jobs), "job tables must have one layout");
-            te377::sum_jobs jb; memcpy(&jb, &js, sizeof jb);
-            uint32_t blocks = (most + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
-            hipLaunchKernelGGL(te377::k377_sum_groups, dim3(blocks, nch), dim3(256), 0, stream, jb, (uint32_t)p.nw);
-          } else if (most >= 131072u) {      // enough outputs to fill the chip with one thread each: throughput-bound level
-            uint32_t blocks = (most + 255) / 256; if (blocks > 4096) blocks = 4096;
-            hipLaunchKernelGGL(te::k_sum_groups, dim3(blocks, nch), dim3(256), 0, stream, js, (uint32_t)p.nw);
-          } else {                    // latency-bound level: four lanes per output
-            uint32_t blocks = (most * 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
-            hipLaunchKernelGGL(te::k_sum_groups_team, dim3(blocks, nch), dim3(256), 0, stream, js, (uint32_t)p.nw);
-          }
-        }
-      };
-      // phase 1: X2[d3 d2] (fold the low w0 + w1 bits, contiguous) and Y2[d1 d0] (fold the high w3 + w2 bits)
-      chain_t ph1[2] = {
-          {ws.d_buckets, p.B, {{1u << (w0 + w1), 1u}, {0, 0}}, 1, 0, 0, {ws.d_red[0], ws.d_red[1]}, 0},
-          {ws.d_buckets, p.B, {{1u << (w2 + w3), 1u << (w0 + w1)}, {0, 0}}, 1, 0, 0, {ws.d_red[2], ws.d_red[3]}, 0}};
-      run_phase(ph1, 2);
-      // phase 2: from X2 (index d3 * 2^w2 + d2) and Y2 (index d1 * 2^w0 + d0)
-      chain_t ph2[4] = {
-          {ph1[1].cur, 1u << (w0 + w1), {{1u << w1, 1u << w0}, {0, 0}}, 1, 0, 0, {ws.d_red[4], ws.d_red[5]}, 0},    // M0[d0]: fold d1 (high)
-          {ph1[1].cur, 1u << (w0 + w1), {{1u << w0, 1u}, {0, 0}}, 1, 0, 0, {ws.d_red[6], ws.d_red[7]}, 0},          // M1[d1]: fold d0 (low)
-          {ph1[0].cur, 1u << (w2 + w3), {{1u << w3, 1u << w2}, {0, 0}}, 1, 0, 0, {ws.d_red[8], ws.d_red[9]}, 0},    // M2[d2]: fold d3 (high)
-          {ph1[0].cur, 1u << (w2 + w3), {{1u << w2, 1u}, {0, 0}}, 1, 0, 0, {ws.d_red[10], ws.d_red[11]}, 0}};       // M3[d3]: fold d2 (low)
-      run_phase(ph2, 4);
-      for (int k = 0; k < 4; k++) marg[k] = ph2[k].cur;
-    }
-    mark(ST_WEIGHTED);
-    if (p.nw > 0 && bls) {
-      uint32_t* rows = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(d_partials_out) + (size_t)d.w_first * TE377_TAIL_ROW_BYTES);
-      te377::wsum_jobs wj;
-      for (int k = 0; k < 4; k++) { wj.in[k] = reinterpret_cast<const te377::g1p_slot*>(marg[k]); wj.N[k] = 1u << p.dw[k]; }
-      hipLaunchKernelGGL(te377::k377_weighted_sum, dim3(4, p.nw), dim3(16), 0, stream, wj, rows, (uint32_t)d.w_step * (TE377_TAIL_ROW_BYTES / 4u));
-    } else if (p.nw > 0) {
-      te::ete* rows = reinterpret_cast<te::ete*>(d_partials_out) + (size_t)d.w_first * 5;
-      te::wsum_jobs wj;
-      for (int k = 0; k < 4; k++) { wj.in[k] = marg[k]; wj.N[k] = 1u << p.dw[k]; }
-      hipLaunchKernelGGL(te::k_weighted_sum, dim3(4, p.nw), dim3(64), 0, stream, wj, rows, (uint32_t)d.w_step * 5u);
-    }
-    mark(ST_COUNT);
-    if (!own_rows) HIP_TRY(ctx, hipMemcpyAsync(ws.h_err, ws.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    return 0;
   }
 };
 
@@ -605,7 +523,7 @@ void free_dev(gpu_t& d) {
                     ws.d_bucket_start, ws.d_bucket_cursor, ws.d_sorted, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv,
                     ws.d_order, ws.d_split_list, ws.d_large_list, ws.d_chunk_list, ws.d_seg_out, ws.d_buckets};
     for (void* q : ptrs) if (q) (void)hipFree(q);
-    for (te::ete* q : ws.d_red) if (q) (void)hipFree(q);
+    for (uint8_t* q : ws.d_red) if (q) (void)hipFree(q);
     if (ws.h_err) (void)hipHostFree(ws.h_err);
     if (ws.ev_done) (void)hipEventDestroy(ws.ev_done);
     if (ws.g_front) (void)hipGraphExecDestroy(ws.g_front);
@@ -629,6 +547,7 @@ int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_
   workset_t& ws = d.ws[0];
   HIP_TRY(ctx, hipSetDevice(d.device));
   plan_t pf; make_plan(ctx, d, n, pf);
+  const curve_sizes sz = sizes_of(pf.curve);
   if (n > d.cap_in) {
     if (d.d_in_points) HIP_TRY(ctx, hipFree(d.d_in_points));
     if (d.d_in_scalars) HIP_TRY(ctx, hipFree(d.d_in_scalars));
@@ -672,14 +591,14 @@ int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_
     if (m == 0) continue;
     make_plan(ctx, d, m, p, pf.c);
     if (int rc = ensure_buffers(ctx, d, ws, m, p)) return rc;              // no reallocation: only the pointers into the zeroed block move
-    msm_launch L{ctx, d, ws, p, dpts + lo * TE_MSM_POINT_BYTES, dscs + lo * TE_MSM_SCALAR_BYTES, m, ws.d_partials, 0, ws.stream, true, !first};
+    msm_launch L{ctx, d, ws, p, dpts + lo * sz.point_in, dscs + lo * sz.scalar_in, m, ws.d_partials, 0, ws.stream, true, !first};
     first = false;
-    HIP_TRY(ctx, hipMemcpyAsync(dscs + lo * TE_MSM_SCALAR_BYTES, src_scalars + lo * TE_MSM_SCALAR_BYTES, m * TE_MSM_SCALAR_BYTES, hipMemcpyHostToDevice, ws.copy_stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dscs + lo * sz.scalar_in, src_scalars + lo * sz.scalar_in, m * sz.scalar_in, hipMemcpyHostToDevice, ws.copy_stream));
     HIP_TRY(ctx, hipEventRecord(evs[K], ws.copy_stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, evs[K], 0));
     if (int rc = L.front_scalars()) return rc;                             // digits, sort and schedule run while the piece's points cross PCIe
     stamp("scalars staged, scalar stages enqueued", i);
-    HIP_TRY(ctx, hipMemcpyAsync(dpts + lo * TE_MSM_POINT_BYTES, src_points + lo * TE_MSM_POINT_BYTES, m * TE_MSM_POINT_BYTES, hipMemcpyHostToDevice, ws.copy_stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dpts + lo * sz.point_in, src_points + lo * sz.point_in, m * sz.point_in, hipMemcpyHostToDevice, ws.copy_stream));
     stamp("points staged", i);
     HIP_TRY(ctx, hipEventRecord(evs[i], ws.copy_stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, evs[i], 0));
@@ -696,7 +615,8 @@ int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_
   HIP_TRY(ctx, hipStreamSynchronize(ws.stream));
   stamp("device done", 0);
   if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
-  te_host::horner_to_affine(ws.h_partials, pf.c, (int)pf.logB, pf.W, out);
+  if (pf.curve == TE_MSM_CURVE_BLS12_377_G1) te377_host::horner_to_affine(ws.h_partials, pf.c, (int)pf.logB, pf.W, out);
+  else te_host::horner_to_affine(ws.h_partials, pf.c, (int)pf.logB, pf.W, out);
   stamp("host tail done", 0);
   return 0;
 }
@@ -711,7 +631,7 @@ int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, boo
   }
   if (!src_points || !src_scalars) return set_err(ctx, TE_MSM_EINVAL, "null input buffer");
   const size_t nd = ctx->devs.size();
-  if (src_is_host && nd == 1 && ctx->opt_curve == TE_MSM_CURVE_TE_BLS12 && !ctx->opt_profile && ctx->opt_workset == 0 &&
+  if (src_is_host && nd == 1 && !ctx->opt_profile && ctx->opt_workset == 0 &&
       ctx->devs[0].w_step == 1 && ctx->devs[0].next_ticket == ctx->devs[0].next_collect) {
     // no tickets in flight, no stage timing requested: every work set is free for the pieces
     const int K = ctx->opt_host_chunks ? ctx->opt_host_chunks : (n >= (1ull << 19) ? 3 : n >= (1ull << 17) ? 2 : 1);
@@ -800,8 +720,10 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
     d.w_first = i; d.w_step = n_dev;
     if (d.device < 0 || d.device >= count) { g_init_error = "te_msm_init: device id out of range"; delete ctx; return TE_MSM_EINVAL; }
     hipError_t er = hipSetDevice(d.device);
-    if (er == hipSuccess)                // k_reduce_tail keeps up to 256 + 16 points in LDS (39 KB)
-      er = hipFuncSetAttribute(reinterpret_cast<const void*>(te::k_reduce_tail), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    if (er == hipSuccess)                // k_reduce_tail keeps up to 256 + 16 points in LDS (39 KB / 61 KB)
+      er = hipFuncSetAttribute(reinterpret_cast<const void*>(te::k_reduce_tail<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    if (er == hipSuccess)
+      er = hipFuncSetAttribute(reinterpret_cast<const void*>(te::k_reduce_tail<14>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     for (workset_t& ws : d.ws) {       // the small fixed allocations of both work sets; the big buffers come with the first MSM
       if (er == hipSuccess) er = hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking);
       if (er == hipSuccess) er = hipStreamCreateWithFlags(&ws.copy_stream, hipStreamNonBlocking);
@@ -884,7 +806,6 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   if (!strcmp(key, "signed_digits")) { ctx->opt_signed = value ? 1 : 0; return 0; }
   if (!strcmp(key, "curve")) {
     if (value != TE_MSM_CURVE_TE_BLS12 && value != TE_MSM_CURVE_BLS12_377_G1) return set_err(ctx, TE_MSM_EINVAL, "unknown curve");
-    if (value != TE_MSM_CURVE_TE_BLS12 && ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "BLS12-377 needs a single-device context");
     ctx->opt_curve = (int)value; return 0;
   }
   if (!strcmp(key, "profile")) { ctx->opt_profile = value < 0 ? 0 : (value > 2 ? 2 : (int)value); ctx->have_stage_ms = false; return 0; }
@@ -930,7 +851,6 @@ int te_msm_partial_device(te_ctx* ctx, const void* d_points_xy_le, const void* d
   if (!ctx) return TE_MSM_EINVAL;
   if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_partial_device needs a single-device context");
   if (!d_points_xy_le || !d_scalars_le || !d_partials || n == 0 || n >= (1ull << 31)) return set_err(ctx, TE_MSM_EINVAL, "bad arguments");
-  if (ctx->opt_curve != TE_MSM_CURVE_TE_BLS12) return set_err(ctx, TE_MSM_ESTATE, "window-sharded building blocks are Twisted-Edwards only");
   gpu_t& d = ctx->devs[0];
   workset_t& ws = d.ws[ctx->opt_workset];
   if (ws.pending_ticket) return set_err(ctx, TE_MSM_ESTATE, "the selected work set holds a submitted MSM that has not been collected");
@@ -958,9 +878,12 @@ int te_msm_finalize(te_ctx* ctx, const uint8_t* partials, int window_bits, int n
     if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
     (void)collect_stage_ms(ctx, ws);
     // the rows were produced under ws.plan: its digit form decides, not an option changed since
-    if (ws.plan.curve != TE_MSM_CURVE_TE_BLS12 || window_bits != ws.plan.c || num_windows != ws.plan.W)
+    if (window_bits != ws.plan.c || num_windows != ws.plan.W)
       return set_err(ctx, TE_MSM_ESTATE, "te_msm_finalize: window_bits / num_windows differ from the plan of the last te_msm_partial_device call (use te_msm_finalize_host_ex for rows produced elsewhere)");
     bucket_bits = (int)ws.plan.logB;
+    if (ws.plan.curve == TE_MSM_CURVE_BLS12_377_G1) { te377_host::horner_to_affine(partials, window_bits, bucket_bits, num_windows, out_xy_le); return 0; }
+  } else if (ctx->opt_curve == TE_MSM_CURVE_BLS12_377_G1) {
+    te377_host::horner_to_affine(partials, window_bits, bucket_bits, num_windows, out_xy_le); return 0;
   }
   te_host::horner_to_affine(partials, window_bits, bucket_bits, num_windows, out_xy_le);
   return 0;
@@ -987,6 +910,27 @@ int te_msm_finalize_gathered(const uint8_t* gathered, int world, int window_bits
     memcpy(&merged[(size_t)w * TE_MSM_PARTIAL_BYTES],
            gathered + ((size_t)(w % world) * num_windows + w) * TE_MSM_PARTIAL_BYTES, TE_MSM_PARTIAL_BYTES);
   return te_msm_finalize_host_ex(merged.data(), window_bits, bucket_bits, num_windows, out_xy_le);
+}
+
+int te_msm_finalize_host_curve(int curve, const uint8_t* partials, int window_bits, int bucket_bits, int num_windows, uint8_t* out_xy_le) {
+  if (curve == TE_MSM_CURVE_TE_BLS12) return te_msm_finalize_host_ex(partials, window_bits, bucket_bits, num_windows, out_xy_le);
+  if (curve != TE_MSM_CURVE_BLS12_377_G1) return TE_MSM_EINVAL;
+  if (!partials || !out_xy_le || window_bits < 2 || window_bits > 16 || num_windows < 1 || num_windows > 128) return TE_MSM_EINVAL;
+  if (bucket_bits != window_bits && bucket_bits != window_bits - 1) return TE_MSM_EINVAL;
+  if (!te377_host::tail_selftest()) return TE_MSM_ESTATE;
+  te377_host::horner_to_affine(partials, window_bits, bucket_bits, num_windows, out_xy_le);
+  return 0;
+}
+
+int te_msm_finalize_gathered_curve(int curve, const uint8_t* gathered, int world, int window_bits, int bucket_bits, int num_windows,
+                                   uint8_t* out_xy_le) {
+  if (!gathered || world < 1 || num_windows < 1 || num_windows > 128) return TE_MSM_EINVAL;
+  if (curve != TE_MSM_CURVE_TE_BLS12 && curve != TE_MSM_CURVE_BLS12_377_G1) return TE_MSM_EINVAL;
+  const size_t row = sizes_of(curve).row;
+  std::vector<uint8_t> merged((size_t)num_windows * row);
+  for (int w = 0; w < num_windows; w++)
+    memcpy(&merged[(size_t)w * row], gathered + ((size_t)(w % world) * num_windows + w) * row, row);
+  return te_msm_finalize_host_curve(curve, merged.data(), window_bits, bucket_bits, num_windows, out_xy_le);
 }
 
 int te_msm_stage_ms(te_ctx* ctx, float* ms, const char** names, int max_stages) {
@@ -1021,7 +965,7 @@ int64_t te_msm_debug_read(te_ctx* ctx, const char* stage, void* dst, uint64_t ca
   if (!ws.used) return set_err(ctx, TE_MSM_ESTATE, "no run yet");
   const plan_t& p = ws.plan; const uint64_t n = ws.n;
   const void* src = nullptr; uint64_t bytes = 0;
-  if (!strcmp(stage, "records")) { src = ws.d_recs; bytes = n * sizeof(te::pnt_slot); }
+  if (!strcmp(stage, "records")) { src = ws.d_recs; bytes = n * sizes_of(p.curve).rec; }
   else if (!strcmp(stage, "digits")) { src = ws.d_digits; bytes = (uint64_t)p.nw * p.nst * 2; }   // row stride nst = n rounded up to 8
   else if (!strcmp(stage, "bucket_count")) { src = ws.d_bucket_count; bytes = (uint64_t)p.nw * p.B * 4; }
   else if (!strcmp(stage, "bucket_start")) { src = ws.d_bucket_start; bytes = (uint64_t)p.nw * p.B * 4; }

@@ -18,16 +18,17 @@ def window_shard_for_rank(rank: int, world: int):
     return rank, world
 
 
-def merge_partials(rows_per_rank, num_windows: int, world: int) -> bytes:
-    """rows_per_rank[r] is rank r's full W x 720 B buffer (only its own rows non-zero)."""
-    out = bytearray(num_windows * PARTIAL_BYTES)
+def merge_partials(rows_per_rank, num_windows: int, world: int, row_bytes: int = PARTIAL_BYTES) -> bytes:
+    """rows_per_rank[r] is rank r's full W x row_bytes buffer (only its own rows non-zero); row_bytes = 720, or 1120 for
+    BLS12-377 G1."""
+    out = bytearray(num_windows * row_bytes)
     for w in range(num_windows):
         r = w % world
-        out[w * PARTIAL_BYTES:(w + 1) * PARTIAL_BYTES] = rows_per_rank[r][w * PARTIAL_BYTES:(w + 1) * PARTIAL_BYTES]
+        out[w * row_bytes:(w + 1) * row_bytes] = rows_per_rank[r][w * row_bytes:(w + 1) * row_bytes]
     return bytes(out)
 
 
-def exchange_partials(partials, num_windows: int, dist=None, group=None, gather_list=None) -> bytes:
+def exchange_partials(partials, num_windows: int, dist=None, group=None, gather_list=None, row_bytes: int = PARTIAL_BYTES) -> bytes:
     """All-gathers every rank's W x 720 B tensor (CUDA tensor -> RCCL, CPU tensor -> gloo) and returns
     the merged rows as bytes.  `partials` must be complete on the current stream when called."""
     import torch
@@ -41,7 +42,7 @@ def exchange_partials(partials, num_windows: int, dist=None, group=None, gather_
         dist.all_gather(gather_list, partials, group=group)
         if partials.is_cuda:
             torch.cuda.current_stream().synchronize()
-        return merge_partials([g.cpu().numpy().tobytes() for g in gather_list], num_windows, world)
+        return merge_partials([g.cpu().numpy().tobytes() for g in gather_list], num_windows, world, row_bytes)
     if partials.is_cuda:
         torch.cuda.current_stream().synchronize()
     return partials.cpu().numpy().tobytes()
@@ -52,7 +53,7 @@ def compute_msm_sharded(ctx, d_points, d_scalars, n: int, partials, dist=None, g
 
     ctx        MsmContext whose window shard is (rank, world)
     d_points / d_scalars   torch uint8 CUDA tensors holding the FULL inputs on this rank's GPU
-    partials   torch uint8 CUDA tensor of W*720 bytes (scratch, overwritten)
+    partials   torch uint8 CUDA tensor of W * ctx.row_bytes bytes (720 per window, 1120 for BLS12-377 G1; scratch, overwritten)
     dist       torch.distributed (initialised) or None for a single rank
     Returns the 64-byte affine result (identical on every rank).  All device work is enqueued on
     torch's current stream so that the collective is ordered behind it.
@@ -63,7 +64,7 @@ def compute_msm_sharded(ctx, d_points, d_scalars, n: int, partials, dist=None, g
     partials.zero_()
     ctx.partial_device(d_points.data_ptr(), d_scalars.data_ptr(), n, partials.data_ptr(),
                        torch.cuda.current_stream().cuda_stream)
-    merged = exchange_partials(partials, W, dist, group, gather_list)
+    merged = exchange_partials(partials, W, dist, group, gather_list, ctx.row_bytes)
     return ctx.finalize(merged, c, W)
 
 
@@ -87,7 +88,8 @@ class ShardedPipeline:
         self.world = dist.get_world_size(group)
         self.c, self.W = ctx.plan(n)
         self.bucket_bits = self.c - 1 if ctx.get_option("signed_digits") else self.c
-        nbytes = self.W * PARTIAL_BYTES
+        self.curve = ctx.curve
+        nbytes = self.W * ctx.row_bytes
         self.gloo = dist.get_backend(group) == "gloo"
         self.part = [torch.zeros(nbytes, dtype=torch.uint8, device="cuda") for _ in range(depth)]
         gdev = "cpu" if self.gloo else "cuda"
@@ -130,4 +132,4 @@ class ShardedPipeline:
         self.ev[slot].synchronize()
         self.next_collect += 1
         self.ctx.partial_wait(slot)                     # done already (the copy is ordered behind it): reports scalar-range errors
-        return finalize_gathered(self.host[slot].data_ptr(), self.world, self.c, self.W, self.bucket_bits)
+        return finalize_gathered(self.host[slot].data_ptr(), self.world, self.c, self.W, self.bucket_bits, self.curve)
