@@ -91,11 +91,9 @@ def prep(x, y):
     """pnt_from_sw377 on plain integers: any 384-bit value in class N"""
     c = N(1.0)                                                     # every constant is a residue below q
     sx, yM, fx = mul(x, c), mul(y, c), mul(x, c)
-    w, ny, fx1 = norm(add(sx, c)), add(sx, c), add(fx, c)
-    Xp, Yp, Zp = mul(w, fx1), mul(yM, ny), mul(yM, w)
-    hm, hp, z = mul(Zp, sub(Yp, Xp, 2)), mul(Zp, add(Yp, Xp)), mul(Zp, add(Zp, Zp))
-    dt = mul(mul(Xp, Yp), c)
-    return hm, hp, dt, z
+    w, bb, aa = norm(add(sx, c)), add(sx, c), norm(add(fx, c))
+    X, Y, Z, T = mul(w, aa), mul(yM, bb), mul(yM, w), mul(aa, bb)
+    return norm(sub(Y, X, 2)), norm(add(Y, X)), mul(T, c), norm(add(Z, Z))      # hm, hp, dt, z
 
 
 def _join(x, y):
@@ -106,7 +104,7 @@ def test_limb_rule_holds_at_the_fixed_point_of_the_bounds():
     ol4, ot4 = offset(4)
     raw = B(LM, (1 << 384) >> (LB * (NL - 1)), 2.0 ** 384 / Q)             # a non-canonical 384-bit coordinate
     rec = prep(raw, raw)
-    assert all(c.val < 1.2 for c in rec)
+    assert all(c.val < 4.1 for c in rec)
     rec_neg = (rec[1], rec[0], B(ol4, ot4, 4.0), rec[3])                   # negated record: hm <-> hp, dt -> 4q - dt
     acc = (N(1.0), N(1.0), N(1.0), N(1.0))
     for _ in range(40):                                                    # accumulate: bounds reach a fixed point

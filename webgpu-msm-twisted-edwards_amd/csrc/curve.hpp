@@ -63,27 +63,26 @@ TE_HD pnt pnt_from_affine_raw(const fp& x, const fp& y) {
 }
 
 // BLS12-377 G1: short-Weierstrass affine (x, y) as plain integers (class N, any 384-bit value) -> projective twisted-Edwards
-// record, 11 products and no division.  With s = 1/sqrt(3), f = sqrt(-(A+2)/B) (tools/gen_constants.py):
+// record, 8 products and no division.  With s = 1/sqrt(3), f = sqrt(-(A+2)/B) (tools/gen_constants.py):
 //   Montgomery  u = s (x + 1), v = s y;   Edwards  X = f u / v = f (x + 1) / y,   Y = (u - 1)/(u + 1) = (s x + s - 1)/(s x + s + 1).
-//   Projective (Xp : Yp : Zp) = (f (x+1) w : (s x + s - 1) y : y w),  w = s x + s + 1;  extended (Xp Zp : Yp Zp : Zp^2 : Xp Yp);
-//   record, times 2:  hm = Zp (Yp - Xp),  hp = Zp (Yp + Xp),  dt = -2 d Xp Yp,  z = 2 Zp^2.
+//   With a = f (x + 1), b = s x + s - 1, w = s x + s + 1:  X = a / y, Y = b / w, and the extended point is simply
+//   (X : Y : Z : T) = (a w : b y : y w : a b)   (X Y / Z = a b).
+//   record, times 2:  hm = Y - X,  hp = Y + X,  dt = -2 d T,  z = 2 Z.
 // Undefined (all-zero record, the neutral element's weight is lost) for y = 0 or w = 0: points of order 2 and 4, never in G1.
 TE_HD pnt_t<14> pnt_from_sw377(const fel<14>& x, const fel<14>& y) {
   using namespace te377;
   const fq a1[3] = {x, y, x}, b1[3] = {fq_S_R2(), fq_R2(), fq_F_R2()};
   fq o1[3];
-  fe_mul_x<3>(a1, b1, o1);                                 // s x, y, f x   (Montgomery form, class N)
-  const fq w = fe_norm(fe_add(o1[0], fq_SP1_MONT())), ny = fe_add(o1[0], fq_SM1_MONT()), fx1 = fe_add(o1[2], fq_F_MONT());
-  const fq a2[3] = {w, o1[1], o1[1]}, b2[3] = {fx1, ny, w};
-  fq o2[3];
-  fe_mul_x<3>(a2, b2, o2);                                 // Xp = f (x+1) w,  Yp = (s x + s - 1) y,  Zp = y w
-  const fq &Xp = o2[0], &Yp = o2[1], &Zp = o2[2];
-  const fq a3[4] = {Zp, Zp, Zp, Xp}, b3[4] = {fe_sub<2>(Yp, Xp), fe_add(Yp, Xp), fe_add(Zp, Zp), Yp};
-  fq o3[4];
-  fe_mul_x<4>(a3, b3, o3);
+  fe_mul_x<3>(a1, b1, o1);                                   // s x, y, f x   (Montgomery form, class N)
+  const fq w = fe_norm(fe_add(o1[0], fq_SP1_MONT())), bb = fe_add(o1[0], fq_SM1_MONT()), aa = fe_norm(fe_add(o1[2], fq_F_MONT()));
+  const fq a2[4] = {w, o1[1], o1[1], aa}, b2[4] = {aa, bb, w, bb};
+  fq o2[4];
+  fe_mul_x<4>(a2, b2, o2);                                   // X = a w,  Y = b y,  Z = y w,  T = a b
   pnt_t<14> r;
-  r.hm = o3[0]; r.hp = o3[1]; r.z = o3[2];
-  r.dt = fe_mul(o3[3], fq_NEG_2D_MONT());
+  r.hm = fe_norm(fe_sub<2>(o2[1], o2[0]));
+  r.hp = fe_norm(fe_add(o2[1], o2[0]));
+  r.z = fe_norm(fe_add(o2[2], o2[2]));
+  r.dt = fe_mul(o2[3], fq_NEG_2D_MONT());
   return r;
 }
 
