@@ -12,7 +12,7 @@ from collections import defaultdict
 rows = []
 for f in glob.glob(os.path.join(sys.argv[1], "trace", "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].split("::")[-1]))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0]))
 rows.sort()
 # steady state: between two k_accumulate launches inside the pipelined (timed) loop -- the middle of the launch sequence
 acc_starts = [r[0] for r in rows if r[2] == "k_accumulate"]

@@ -48,7 +48,7 @@ def main(root):
             m = sum(v) / len(v)
             extra = "  x2(gfx950 wide-read correction) = %.1f MB" % (2 * m * 1024 / 1e6) if name == "FETCH_SIZE" else ""
             print("%-60s %5d %14.1f KiB = %10.1f MB%s" % (k[:60], len(v), m, m * 1024 / 1e6, extra))
-            short = k.split("(")[0].split("::")[-1]
+            short = k.split("(")[0].split("::")[-1].split("<")[0]
             traffic.setdefault(short, {})[name] = m * 1024
     # HBM bytes per launch: FETCH_SIZE x factor + WRITE_SIZE.  MI355X_MICROARCH.md prescribes factor 2 for wide coalesced
     # streaming reads on gfx950 and calibration for anything else; tools/calibrate_fetch.sh measures the factor for
@@ -56,7 +56,7 @@ def main(root):
     factor = float(os.environ.get("TE_FETCH_FACTOR", "2.0"))
     out = {k: {"fetch_bytes_raw": v.get("FETCH_SIZE"), "write_bytes": v.get("WRITE_SIZE"),
                "hbm_bytes_per_launch": factor * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0),
-               "mean_us": (sum(dur[n]) / len(dur[n])) if (n := next((d for d in dur if d.split("(")[0].split("::")[-1] == k), None)) else None}
+               "mean_us": (sum(dur[n]) / len(dur[n])) if (n := next((d for d in dur if d.split("(")[0].split("::")[-1].split("<")[0] == k), None)) else None}
            for k, v in traffic.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
     import hashlib
     h = hashlib.sha256()
