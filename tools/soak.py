@@ -24,7 +24,7 @@ while time.time() < t_end:
     ctx, orc, pb, sb = (te, oracle, 64, 32) if rnd.random() < 0.75 else (bls, oracle377, 96, 48)
     opts = {}
     for k, v in (("window_bits", rnd.choice([0, 0, 4, 7, 10, 13, 15, 16])), ("signed_digits", rnd.choice([1, 1, 0])),
-                 ("segment_len", rnd.choice([64, 64, 1, 7, 500])), ("sort_buckets", rnd.choice([1, 1, 0])), ("host_chunks", rnd.choice([0, 1, 3])),
+                 ("segment_len", rnd.choice([64, 64, 1, 7, 500])), ("sort_buckets", rnd.choice([1, 1, 0])), ("host_chunks", rnd.choice([0, 1, 3, 5])),
                  ("graph", rnd.choice([0, 0, 1])), ("profile", rnd.choice([0, 0, 1, 2]))):
         ctx.set_option(k, v)
         opts[k] = v
@@ -37,7 +37,7 @@ while time.time() < t_end:
             sc = sc[:sb] * n
         batch.append((pts, sc, n))
     exp = [orc.msm(p, s, threads=8) for p, s, _ in batch]
-    mode = rnd.choice(["run", "run", "tickets", "tickets", "shards"]) if ctx is te else rnd.choice(["run", "tickets"])
+    mode = rnd.choice(["run", "run", "tickets", "tickets", "shards"])
     if mode == "run":
         got = [ctx.run(p, s) for p, s, _ in batch]
     elif mode == "shards":
@@ -45,19 +45,19 @@ while time.time() < t_end:
         got = []
         for p_, s_, n in batch:
             a = torch.frombuffer(bytearray(p_), dtype=torch.uint8).cuda(); b = torch.frombuffer(bytearray(s_), dtype=torch.uint8).cuda()
-            cb, W = te.plan(n)
+            cb, W = ctx.plan(n)
             rows = []
             for r in range(world):
-                te.set_window_shard(r, world)
-                te.set_option("workset", r % pkg.WORKSETS)
-                part = torch.zeros(W * 720, dtype=torch.uint8, device="cuda")
-                te.partial_device(a.data_ptr(), b.data_ptr(), n, part.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                ctx.set_window_shard(r, world)
+                ctx.set_option("workset", r % pkg.WORKSETS)
+                part = torch.zeros(W * ctx.row_bytes, dtype=torch.uint8, device="cuda")
+                ctx.partial_device(a.data_ptr(), b.data_ptr(), n, part.data_ptr(), torch.cuda.current_stream().cuda_stream)
                 torch.cuda.synchronize()
-                te.partial_wait(r % pkg.WORKSETS)
+                ctx.partial_wait(r % pkg.WORKSETS)
                 rows.append(part.cpu().numpy().tobytes())
-            te.set_window_shard(0, 1)
-            te.set_option("workset", 0)
-            got.append(pkg.finalize_host(pkg.merge_partials(rows, W, world), cb, W, None if opts["signed_digits"] else cb))
+            ctx.set_window_shard(0, 1)
+            ctx.set_option("workset", 0)
+            got.append(pkg.finalize_host(pkg.merge_partials(rows, W, world, ctx.row_bytes), cb, W, None if opts["signed_digits"] else cb, curve=ctx.curve))
     else:
         dev = [(torch.frombuffer(bytearray(p), dtype=torch.uint8).cuda(), torch.frombuffer(bytearray(s), dtype=torch.uint8).cuda(), n) for p, s, n in batch]
         torch.cuda.synchronize()
