@@ -39,13 +39,13 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-def measured_traffic(log2n, c, world):
+def measured_traffic(log2n, c, world, default_workload=True):
     """HBM bytes per k_accumulate launch from the committed rocprofv3 PMC passes (tools/profile_bench.sh ->
     profiles/pmc_traffic.json).  Counters cannot be read from inside the process, so the figure applies to the profiled
     workload only (n = 2^20, c = 16, one GPU) and to the kernel sources it was profiled with: the JSON records their
     hash and the commit; when the sources have changed since, the figure is withheld (null) and flagged stale."""
     info = {"file": os.path.relpath(TRAFFIC_JSON, ROOT), "sources_sha_now": kernel_sources_sha()}
-    if not (log2n == 20 and c == 16 and world == 1 and os.path.exists(TRAFFIC_JSON)):
+    if not (log2n == 20 and c == 16 and world == 1 and default_workload and os.path.exists(TRAFFIC_JSON)):
         return None, info
     try:
         j = json.load(open(TRAFFIC_JSON))
@@ -269,7 +269,9 @@ def main():
     acc_bytes_rank = acc_bytes / div                      # windows are sharded
     acc_ms = acc_ms_live
     achieved = acc_bytes_rank / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
-    traffic, traffic_info = (None, None) if bls else measured_traffic(args.log2n, c, world if not rehearse else rehearse)
+    traffic, traffic_info = (None, None) if bls else measured_traffic(
+        args.log2n, c, world if not rehearse else rehearse,
+        args.digits == "signed" and args.scalars == "uniform" and args.points == "chain" and not args.segment_len)
 
     # VALU-issue roofline of the dominant kernel: wave instructions per launch from the ISA listing
     # (profiles/r02_isa_hist_k_accumulate.txt) x measured issue cost against 1024 SIMDs
