@@ -2,6 +2,7 @@
 // 14 limbs) for the CPU test-suite: the same code the GPU runs, with every column sum checked against 2^64
 // (g_fq377_overflow).  Not a CPU fallback.
 #include <string.h>
+#include <vector>
 #define TE377_CHECK_COLUMNS 1
 #include "../../webgpu-msm-twisted-edwards_amd/csrc/curve.hpp"
 
@@ -36,5 +37,54 @@ void f377_madd(const uint8_t acc[224], const uint8_t rec[224], int neg, uint8_t 
 }
 void f377_add(const uint8_t a_[224], const uint8_t b_[224], uint8_t out[224]) {
   ete_t<14> a, b; memcpy(&a, a_, 224); memcpy(&b, b_, 224); const ete_t<14> r = ete_add<14>(a, b); memcpy(out, &r, 224);
+}
+
+// Emulation of the device stages with the device arithmetic, for the windows w = first + k*step: digits -> buckets ->
+// digit marginals -> weighted sums -> rows [T | W0 | W1 | W2 | W3] of 1120 bytes (rows of other windows untouched): what the
+// host tail te377_host::horner_to_affine consumes.  Scalars are 48-byte records; returns -3 on a final carry.
+int f377_partial_rows(const uint8_t* points, const uint8_t* scalars, uint64_t n, int c, int first, int step, uint8_t* partials) {
+  const int W = (256 + c - 1) / c;
+  const uint32_t B = 1u << (c - 1);
+  std::vector<pnt_t<14>> recs(n);
+  for (uint64_t i = 0; i < n; i++) f377_prep_point(points + 96 * i, reinterpret_cast<uint8_t*>(&recs[i]));
+  uint32_t half[10] = {0};
+  for (int w = 0; w < W; w++) { int bit = w * c + c - 1; if (bit < 320) half[bit >> 5] |= 1u << (bit & 31); }
+  std::vector<std::vector<uint32_t>> dig(W, std::vector<uint32_t>(n));
+  for (uint64_t i = 0; i < n; i++) {
+    uint32_t s[11] = {0}; memcpy(s, scalars + 48 * i, 32);
+    uint64_t cy = 0;
+    for (int j = 0; j < 10; j++) { cy += (uint64_t)s[j] + half[j]; s[j] = (uint32_t)cy; cy >>= 32; }
+    for (int w = 0; w <= W; w++) {
+      const int bit = w * c; if (bit >= 320) break;
+      const int word = bit >> 5, off = bit & 31;
+      uint64_t two = (uint64_t)s[word] | ((uint64_t)s[word + 1] << 32);
+      uint32_t v = (uint32_t)(two >> off) & ((1u << c) - 1u);
+      if (w == W) { if (v) return -3; } else dig[w][i] = v;
+    }
+  }
+  for (int w = first; w < W; w += step) {
+    std::vector<ete_t<14>> bk(B, ete_identity_t<14>());
+    for (uint64_t i = 0; i < n; i++) {
+      const int d = (int)dig[w][i] - (int)B;
+      if (d == 0) continue;
+      const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+      bk[b] = ete_madd(bk[b], pnt_cneg(recs[i], d < 0));
+    }
+    uint32_t dw[4], sh[4]; uint32_t acc_sh = 0;
+    for (int k = 0; k < 4; k++) { dw[k] = (uint32_t)(c - 1 + 3 - k) / 4u; sh[k] = acc_sh; acc_sh += dw[k]; }
+    ete_t<14> T = ete_identity_t<14>(), Wk[4];
+    for (uint32_t j = 0; j < B; j++) T = ete_add<14>(T, bk[j]);
+    for (int k = 0; k < 4; k++) {
+      const uint32_t N = 1u << dw[k];
+      std::vector<ete_t<14>> M(N, ete_identity_t<14>());
+      for (uint32_t j = 0; j < B; j++) { ete_t<14>& m = M[(j >> sh[k]) & (N - 1u)]; m = ete_add<14>(m, bk[j]); }
+      ete_t<14> run = ete_identity_t<14>(); Wk[k] = ete_identity_t<14>();
+      for (uint32_t v = N; v-- > 1;) { run = ete_add<14>(run, M[v]); Wk[k] = ete_add<14>(Wk[k], run); }
+    }
+    uint8_t* row = partials + (size_t)w * 1120;
+    memcpy(row, &T, 224);
+    for (int k = 0; k < 4; k++) memcpy(row + 224 * (1 + k), &Wk[k], 224);
+  }
+  return 0;
 }
 }

@@ -213,3 +213,36 @@ def test_device_group_law_377_on_the_host(fq377check):
             L.f377_add(chain[-1], chain[r // 2], o)
             chain[-1] = ctypes.create_string_buffer(o.raw, 224)
     assert L.f377_overflow_and_reset() == 0
+
+
+def test_emulated_stages_plus_host_tail_377(fq377check):
+    """digits -> buckets -> marginals -> weighted sums with the device arithmetic on the host, then the PRODUCT's host tail
+    (Horner in the Edwards form + the map back to y^2 = x^3 + 1, te_msm_finalize_host_curve / _gathered_curve): the oracle's
+    point, for whole rows, for rows merged from window shards, for P + (-P) (infinity) and with no column above 2^64"""
+    import ctypes
+    import importlib
+    pkg = importlib.import_module("webgpu-msm-twisted-edwards_amd")
+    L = fq377check
+    L.f377_partial_rows.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+    for n, c in ((1, 4), (33, 5), (200, 9)):
+        W = (256 + c - 1) // c
+        pts, sc = o.gen_points(70 + n, n), o.gen_scalars(70 + n, n)
+        exp = o.msm(pts, sc)
+        buf = ctypes.create_string_buffer(W * 1120)
+        assert L.f377_partial_rows(pts, sc, n, c, 0, 1, buf) == 0
+        assert pkg.finalize_host(buf.raw, c, W, curve=pkg.CURVE_BLS12_377_G1) == exp
+        world = 3
+        bufs = []
+        for r in range(world):
+            b = ctypes.create_string_buffer(W * 1120)
+            assert L.f377_partial_rows(pts, sc, n, c, r, world, b) == 0
+            bufs.append(b.raw)
+        assert pkg.finalize_host(pkg.merge_partials(bufs, W, world, 1120), c, W, curve=pkg.CURVE_BLS12_377_G1) == exp
+        flat = ctypes.create_string_buffer(b"".join(bufs), world * W * 1120)
+        assert pkg.finalize_gathered(ctypes.addressof(flat), world, c, W, curve=pkg.CURVE_BLS12_377_G1) == exp
+    p1 = o.gen_points(5, 1)
+    buf = ctypes.create_string_buffer(64 * 1120)
+    assert L.f377_partial_rows(p1 * 2, m.scalars_to_bytes([7, m.R_ORDER - 7]), 2, 4, 0, 1, buf) == 0
+    assert pkg.finalize_host(buf.raw, 4, 64, curve=pkg.CURVE_BLS12_377_G1) == bytes(96)
+    assert L.f377_partial_rows(p1, m.scalars_to_bytes([(1 << 256) - 1]), 1, 16, 0, 1, buf) == -3
+    assert L.f377_overflow_and_reset() == 0

@@ -2,7 +2,7 @@
 # usage: tools/sweep.sh "<flag>" v1 v2 ...   -> one summary line per value of bench.py <flag> <value>
 flag="$1"; shift
 for v in "$@"; do
-  python bench.py --steps 10 --warmup 2 --no-cpu-baseline $flag $v 2>/dev/null | tail -1 > /tmp/sweep.json
+  python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-sizes --no-host-buffers $flag $v 2>/dev/null | tail -1 > /tmp/sweep.json
   python - "$flag" "$v" <<'PY'
 import json, sys
 d = json.load(open("/tmp/sweep.json"))

@@ -5,9 +5,9 @@ out=gpurun_out/sweep_seg.txt; : > $out
 run() {  # label, env D, log2n, seg
   local D=$1 lg=$2 seg=$3
   if [ "$D" = "1" ]; then
-    timeout -k 5 100 python bench.py --steps 60 --warmup 5 --inflight 4 --no-cpu-baseline --log2n $lg --window-bits 0 --segment-len $seg > gpurun_out/_s.log 2>&1 || { echo "FAILED D=$D lg=$lg seg=$seg" >> $out; return 1; }
+    timeout -k 5 100 python bench.py --steps 60 --warmup 5 --inflight 4 --no-cpu-baseline --no-sizes --no-host-buffers --log2n $lg --window-bits 0 --segment-len $seg > gpurun_out/_s.log 2>&1 || { echo "FAILED D=$D lg=$lg seg=$seg" >> $out; return 1; }
   else
-    TE_BENCH_FORCE_DIST=1 TE_BENCH_REHEARSE_WORLD=$D timeout -k 5 100 python bench.py --steps 100 --warmup 5 --inflight 4 --no-cpu-baseline --log2n $lg --segment-len $seg > gpurun_out/_s.log 2>&1 || { echo "FAILED D=$D lg=$lg seg=$seg" >> $out; return 1; }
+    TE_BENCH_FORCE_DIST=1 TE_BENCH_REHEARSE_WORLD=$D timeout -k 5 100 python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-sizes --no-host-buffers --log2n $lg --segment-len $seg > gpurun_out/_s.log 2>&1 || { echo "FAILED D=$D lg=$lg seg=$seg" >> $out; return 1; }
   fi
   python - "$D" "$lg" "$seg" <<'PY' >> $out
 import json, sys

@@ -8,7 +8,7 @@
 //                                                   (two-level counting sort, all stores coalesced) + k_order_scatter
 //   K3 smvp (wgsl/cuzk/smvp.template.wgsl:58-152) -> k_accumulate (7-product mixed additions)
 //   K4/K5 bpr stage_1/2 (wgsl/cuzk/bpr.template.wgsl:73-171) + the CPU sum of 4096 points
-//      (submission.ts:362-393)                   -> k_sum_groups[_team] (digit marginals) + k_weighted_sum
+//      (submission.ts:362-393)                   -> k_sum_groups[_team] (fold levels) + k_reduce_tail (digit marginals, weighted sums)
 // Window w of this context is  w = w_first + k * w_step  for local index k (multi-GPU window sharding).
 #pragma once
 #include <hip/hip_runtime.h>
