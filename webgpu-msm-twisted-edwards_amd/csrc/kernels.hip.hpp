@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(256, 3) k_l2_place(const uint16_t* __restrict_
         const uint32_t pos = e0 + (uint32_t)e;
         if (pos >= head && pos < total) {
           const uint32_t b = kv[e] & 0x7fffu;
-          const uint32_t slot = atomicAdd(&off_s[b], 1u);
+          const uint32_t slot = atomicAdd(&off_s[b], 1u);      // (keeping the ranks of the counting round instead was measured: no gain, 168 VGPRs)
           list[slot] = iv[e] | ((kv[e] >> 15) << 31); list_b[slot] = (uint8_t)b;
         }
       }
@@ -464,6 +464,9 @@ __global__ void __launch_bounds__(256, 3) k_l2_place(const uint16_t* __restrict_
 //                    histogram itself.
 #define TE_COMBINE_SMALL 16u
 #define TE_SEG_INVALID 0xffffffffu
+// The histogram of segment lengths is kept in TE_HIST_COPIES copies (block b adds to copy b mod copies; k_order_scatter sums
+// them): 2048 blocks adding to the same ~60 hot addresses cost 28 us of serialised atomics with a single copy.
+#define TE_HIST_COPIES 32u
 // grid (P, nw), block S (= buckets per partition, <= 256)
 __global__ void __launch_bounds__(256) k_seg_plan(const uint32_t* __restrict__ bucket_count, const uint32_t* __restrict__ part_start,
                                                   const uint32_t* __restrict__ part_count, const uint32_t* __restrict__ seg_part_base,
@@ -522,7 +525,8 @@ __global__ void __launch_bounds__(256) k_seg_plan(const uint32_t* __restrict__ b
     }
   }
   __syncthreads();
-  for (uint32_t j = t; j < 1024u; j += blockDim.x) if (h[j]) atomicAdd(&size_hist[j], h[j]);
+  uint32_t* my_hist = size_hist + ((blockIdx.y * gridDim.x + blockIdx.x) % TE_HIST_COPIES) * 1024u;
+  for (uint32_t j = t; j < 1024u; j += blockDim.x) if (h[j]) atomicAdd(&my_hist[j], h[j]);
 }
 
 // grid 256 blocks of 256; `ids` = size of the segment id space (host-known); rel_cursor zeroed per MSM.
@@ -537,8 +541,11 @@ __global__ void __launch_bounds__(256) k_order_scatter(const uint32_t* __restric
     uint32_t run = 0;
     for (uint32_t c = 0; c < 4u; c++) {
       const uint32_t s = 1023u - (c * 256u + threadIdx.x);        // thread 0 of chunk 0 handles the largest size
+      uint32_t cnt_s = 0;
+#pragma unroll 8
+      for (uint32_t r = 0; r < TE_HIST_COPIES; r++) cnt_s += size_hist[r * 1024u + s];
       uint32_t bt;
-      const uint32_t ex = block_excl_scan(size_hist[s], sm, bt);
+      const uint32_t ex = block_excl_scan(cnt_s, sm, bt);
       base[s] = run + ex;
       run += bt;
     }

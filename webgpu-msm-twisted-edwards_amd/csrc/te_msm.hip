@@ -73,7 +73,7 @@ struct workset_t {
   uint8_t *d_seg_out = nullptr, *d_buckets = nullptr, *d_red[4] = {};   // accumulators of the plan's curve (te::ete_t<N>); d_red: ping/pong of the two fold chains
   // ONE zeroed block per MSM (a single memset), words: [0] final-carry flag, [1] number of segments, [2..4] split / giant
   // bucket counters, [Z_ROWS..) the partial rows of the MSM (so that flag and rows come back in ONE device-to-host copy),
-  // [Z_HIST..) segment-length histogram, [Z_CURSOR..) reservation cursors of the schedule, [Z_END..) the level-1 histogram
+  // [Z_HIST..) segment-length histogram (TE_HIST_COPIES copies), [Z_CURSOR..) reservation cursors of the schedule, [Z_END..) the level-1 histogram
   // counts1[window][chunk][partition], then bucket_count[window][bucket].  d_err .. d_bucket_count point into d_zero.
   uint32_t *d_zero = nullptr; size_t zero_words = 0;
   uint32_t *d_err = nullptr, *d_num_seg = nullptr, *d_size_hist = nullptr, *d_size_cursor = nullptr;
@@ -90,7 +90,7 @@ struct workset_t {
   hipGraphExec_t g_front = nullptr, g_back = nullptr; graph_key g_key = {};
 };
 constexpr int TE_MAX_WINDOWS = 64;    // window_bits >= 4
-constexpr size_t Z_ROWS = 8, Z_HIST = Z_ROWS + (size_t)TE_MAX_WINDOWS * TE_MAX_ROW_BYTES / 4, Z_CURSOR = Z_HIST + 1024, Z_END = Z_CURSOR + 1024;
+constexpr size_t Z_ROWS = 8, Z_HIST = Z_ROWS + (size_t)TE_MAX_WINDOWS * TE_MAX_ROW_BYTES / 4, Z_CURSOR = Z_HIST + 1024 * TE_HIST_COPIES, Z_END = Z_CURSOR + 1024;
 
 struct gpu_t {
   int device = 0;
