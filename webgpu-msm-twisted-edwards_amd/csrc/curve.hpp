@@ -121,6 +121,30 @@ TE_HD ete_t<14> ete_madd(const ete_t<14>& a, const pnt_t<14>& b) {
   return ete_close<14>(fe_sub<2>(B, A), fe_add(B, A), fe_add(D, Cn), fe_sub<2>(D, Cn));
 }
 
+// neutral element + b without the products whose result is known: with (X1 : Y1 : Z1 : T1) = (0 : 1 : 1 : 0) the mixed addition
+// has A' = hm, B' = hp, C' = 0, D' = z2, i.e. (X3, Y3, T3, Z3) = (E z2, H z2, E H, z2^2) with E = hp - hm, H = hp + hm: three
+// products for an affine record (z2 = 1: E and H only pass through a product by one to become class N below 2p), four for a
+// projective one, instead of 7 / 8.  Every segment of k_accumulate starts with this step (one in ~31 additions).
+TE_HD ete ete_from_pnt(const pnt& b) {
+  const fp one = fp_R1();
+  const fp E = fp_sub<2>(b.hp, b.hm), H = fp_add(b.hp, b.hm);
+  const fp l[3] = {E, H, E}, rr[3] = {one, one, H};
+  fp o[3];
+  mont_mul_x<3>(l, rr, o);
+  ete r;
+  r.x = o[0]; r.y = o[1]; r.t = o[2]; r.z = one;
+  return r;
+}
+TE_HD ete_t<14> ete_from_pnt(const pnt_t<14>& b) {
+  const fel<14> En = fe_norm(fe_sub<2>(b.hp, b.hm)), H = fe_add(b.hp, b.hm);
+  const fel<14> l[4] = {En, H, En, b.z}, rr[4] = {b.z, b.z, H, b.z};
+  fel<14> o[4];
+  fe_mul_x<4>(l, rr, o);
+  ete_t<14> r;
+  r.x = o[0]; r.y = o[1]; r.t = o[2]; r.z = o[3];
+  return r;
+}
+
 // Full addition a + b of two accumulators (add-2008-hwcd-3 shape, k = 2d), 9 products.
 // One operand of each opening product and F, G, E are normalised so that no product sees two wide operands.
 template <int N> TE_HD ete_t<N> ete_add(const ete_t<N>& a, const ete_t<N>& b) {

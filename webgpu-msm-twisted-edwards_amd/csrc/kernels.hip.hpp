@@ -668,9 +668,18 @@ __global__ void __launch_bounds__(256, N == 9 ? 4 : 2) k_accumulate(const rec_sl
     // index j+1 and then its record inside one iteration: an s_waitcnt on the index in front of the record loads, one
     // memory latency exposed per addition.)
     const uint32_t last = cnt - 1u;
+    uint32_t j0 = 0;
     uint32_t e = lst[0], e_n = lst[min(1u, last)];
     pnt_t<N> cur = load_pnt<N>(recs, e);
-    for (uint32_t j = 0; j < cnt; j++) {
+    if (!(onto && part == 0u)) {
+      // first entry: neutral element + P needs 3 (4) products, not 7 (8) -- except where the segment continues a bucket
+      const pnt_t<N> first = pnt_cneg(cur, (e >> 31) != 0u);
+      e = e_n; e_n = lst[min(2u, last)];
+      cur = load_pnt<N>(recs, e);
+      acc = ete_from_pnt(first);
+      j0 = 1;
+    }
+    for (uint32_t j = j0; j < cnt; j++) {
       const uint32_t e_cur = e;
       pnt_t<N> nxt = cur;
       const uint32_t e_nn = lst[min(j + 2u, last)];            // unconditional, clamped
