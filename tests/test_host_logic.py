@@ -77,6 +77,15 @@ def test_mont_mul_values_and_limb_classes(fpcheck, model):
     for _ in range(500):
         check([rnd.randrange(d_max + 1) for _ in range(8)] + [rnd.randrange(1 << 22)],
               [rnd.randrange(s_max + 1) for _ in range(8)] + [rnd.randrange(1 << 22)])
+    # carry-folded quotient (fp.hpp): columns whose value is 0 or -1 modulo 2^29, zero operands, sparse operands
+    zero, one = [0] * NL, [1] + [0] * (NL - 1)
+    for la in (zero, one, [0, 1] + [0] * 7, [1 << 28] + [0] * 8, [LM] * NL, [0] * 8 + [1 << 22], list(limbs(P)), list(limbs(P - 1)), list(limbs(R % P)), list(limbs(R * R % P))):
+        for lb in (zero, one, [2] + [0] * 8, [LM] * 8 + [1 << 22], list(limbs(P)), list(limbs(P + 1)), list(limbs(R % P)), list(limbs(pow(R, 2, P))), [1 << 30] * 8 + [0]):
+            check(la, lb)
+    for _ in range(300):                                  # a_0 * b_0 = 0 (mod 2^29): column 0 takes q_0 = 2^29
+        la, lb = list(limbs(rnd.randrange(4 * P))), list(limbs(rnd.randrange(4 * P)))
+        la[0] &= ~((1 << rnd.randrange(1, 29)) - 1); lb[0] = (lb[0] << 20) & LM
+        check(la, lb)
 
 
 def test_field_helpers(fpcheck, model):

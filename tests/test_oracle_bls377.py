@@ -100,6 +100,11 @@ def test_device_field_377_on_the_host(fq377check):
         L.f377_mont_mul(limbs(a), limbs(b), out)
         r = val(out)
         assert r % Q == a * b * rinv % Q and r < a * b // R + Q + 1 and all(out[i] <= LM for i in range(NL - 1))
+    for a in (0, 1, Q, Q - 1, R % Q, 1 << 29, (1 << 29) - 1, 1 << 377):    # carry-folded quotient: zero / sparse columns
+        for b in (0, 1, 2, Q, Q + 1, R % Q, R * R % Q, (1 << 58) - (1 << 29)):
+            L.f377_mont_mul(limbs(a), limbs(b), out)
+            r = val(out)
+            assert r % Q == a * b * rinv % Q and r < a * b // R + Q + 1 and all(out[i] <= LM for i in range(NL - 1))
     # widest legal operands: one normalised, the other with limbs up to 2^30.8
     wide = (ctypes.c_uint32 * NL)(*([int(2 ** 30.8)] * 13 + [7]))
     norm = (ctypes.c_uint32 * NL)(*([LM] * 13 + [7]))

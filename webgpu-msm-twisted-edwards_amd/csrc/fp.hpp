@@ -71,34 +71,30 @@ template <int K> TE_HD fp fp_kp_offset();
 
 // ---------------------------------------------------------------------------------------------
 // Montgomery product a*b/R mod p (plus a multiple of p), product scanning, R = 2^261.
-// p = 1 (mod 2^29), so -p^-1 mod 2^29 = 2^29 - 1: the quotient digit of a column is q = (-acc) & mask, and adding
-// q*p[0] = q clears the low 29 bits.  Takes operands whose limb magnitudes satisfy the rule above; returns class N
-// with value < a*b/R + p.
-// p[0] = 1 as a value the optimiser cannot see through: "acc += q * one" is then one v_mad_u64_u32 like every
-// other term, instead of a zero-extension (v_mov) plus a 64-bit add.
-TE_HD uint32_t opaque_one() {
-#if defined(__HIP_DEVICE_COMPILE__)
-  uint32_t one;
-  asm("s_mov_b32 %0, 1" : "=s"(one));
-  return one;
-#else
-  return 1u;
-#endif
-}
-
+// p = 1 (mod 2^29), so -p^-1 mod 2^29 = 2^29 - 1: the quotient digit of a column with value V is q = -V mod 2^29, and
+// adding q*p[0] = q only clears the low 29 bits and carries into the next column.  Takes operands whose limb magnitudes
+// satisfy the rule above; returns class N with value <= a*b/R + p.
+//
+// CARRY-FOLDED QUOTIENT.  That q*p[0] term is never computed.  Column 0 takes q_0 = 2^29 - (V_0 mod 2^29), in [1, 2^29]
+// (2^29 instead of 0 when V_0 = 0 mod 2^29: as good a multiple), so V_0 + q_0 carries exactly (V_0 >> 29) + 1.  From
+// column 1 on the accumulator holds W_i = V_i - 1, i.e. it leaves that "+ 1" out:  q_i = ~W_i mod 2^29 is then the
+// standard digit -V_i mod 2^29, and the carry of V_i + q_i is again exactly (W_i >> 29) + 1 (if the low bits of W_i
+// are all ones, q_i = 0 and V_i itself carries; otherwise V_i + q_i rounds W_i up to the next multiple of 2^29).  So
+// the next accumulator is W_{i+1} = (products of column i+1) + (W_i >> 29) with no correction, nine columns long, and
+// the one outstanding "+ 1" is added when the first result column (9) is complete.  Per product: 9 mads and 9
+// subtractions fewer (~W & mask is one v_bitop3), one 64-bit add more; the result is the standard Montgomery product
+// except that 0 * b comes out as p rather than 0 (the same residue; nothing on the device compares representatives).
 TE_HD fp mont_mul(const fp& a, const fp& b) {
   uint32_t q[NL];
   fp r;
   uint64_t acc = 0;
-  const uint32_t one = opaque_one();
 #pragma unroll
   for (int k = 0; k < NL; k++) {
 #pragma unroll
     for (int i = 0; i <= k; i++) acc += (uint64_t)a.v[i] * b.v[k - i];
 #pragma unroll
     for (int i = 0; i < k; i++) acc += (uint64_t)q[i] * p_limb(k - i);
-    q[k] = (0u - (uint32_t)acc) & LM;
-    acc += (uint64_t)q[k] * one;       // + q*p[0]: the low 29 bits are now zero
+    q[k] = k == 0 ? (1u << LB) - ((uint32_t)acc & LM) : ~(uint32_t)acc & LM;
     acc >>= LB;
   }
 #pragma unroll
@@ -107,6 +103,7 @@ TE_HD fp mont_mul(const fp& a, const fp& b) {
     for (int i = k - (NL - 1); i < NL; i++) acc += (uint64_t)a.v[i] * b.v[k - i];
 #pragma unroll
     for (int i = k - (NL - 1); i < NL; i++) acc += (uint64_t)q[i] * p_limb(k - i);
+    if (k == NL) acc += 1u;
     r.v[k - NL] = (uint32_t)acc & LM;
     acc >>= LB;
   }
@@ -125,11 +122,11 @@ TE_HD void chain(uint64_t& acc) {
 #endif
 }
 
-// M independent products in lockstep (r[m] = mont_mul(a[m], b[m])) for throughput-bound code: 162 mads + 43 other
+// M independent products in lockstep (r[m] = mont_mul(a[m], b[m])) for throughput-bound code: 153 mads + ~45 other
 // instructions per product.  The M chains are interleaved in program order, so a chain() marker is never directly
 // followed by a use of its register (the compiler pads that pattern with an s_nop).
 template <int M, int K>
-TE_HD void mont_mul_x_col(const fp (&a)[M], const fp (&b)[M], fp (&r)[M], uint64_t (&acc)[M], uint32_t (&q)[M][NL], uint32_t one) {
+TE_HD void mont_mul_x_col(const fp (&a)[M], const fp (&b)[M], fp (&r)[M], uint64_t (&acc)[M], uint32_t (&q)[M][NL]) {
   constexpr int lo = K < NL ? 0 : K - (NL - 1), hi = K < NL ? K : NL - 1, qhi = K < NL ? K - 1 : NL - 1;
 #pragma unroll
   for (int i = lo; i <= hi; i++) {
@@ -142,22 +139,26 @@ TE_HD void mont_mul_x_col(const fp (&a)[M], const fp (&b)[M], fp (&r)[M], uint64
     for (int m = 0; m < M; m++) { acc[m] += (uint64_t)q[m][i] * p_limb(K - i); chain(acc[m]); }
   }
   if constexpr (K < NL) {
+    // q*p[0] stays implicit (CARRY-FOLDED QUOTIENT above)
 #pragma unroll
-    for (int m = 0; m < M; m++) q[m][K] = (0u - (uint32_t)acc[m]) & LM;
+    for (int m = 0; m < M; m++) q[m][K] = K == 0 ? (1u << LB) - ((uint32_t)acc[m] & LM) : ~(uint32_t)acc[m] & LM;
 #pragma unroll
-    for (int m = 0; m < M; m++) { acc[m] += (uint64_t)q[m][K] * one; acc[m] >>= LB; }
+    for (int m = 0; m < M; m++) acc[m] >>= LB;
   } else {
 #pragma unroll
-    for (int m = 0; m < M; m++) { r[m].v[K - NL] = (uint32_t)acc[m] & LM; acc[m] >>= LB; }
+    for (int m = 0; m < M; m++) {
+      if constexpr (K == NL) acc[m] += 1u;          // the carry the quotient columns left implicit
+      r[m].v[K - NL] = (uint32_t)acc[m] & LM; acc[m] >>= LB;
+    }
   }
-  if constexpr (K + 1 < 2 * NL - 1) mont_mul_x_col<M, K + 1>(a, b, r, acc, q, one);
+  if constexpr (K + 1 < 2 * NL - 1) mont_mul_x_col<M, K + 1>(a, b, r, acc, q);
 }
 template <int M> TE_HD void mont_mul_x(const fp (&a)[M], const fp (&b)[M], fp (&r)[M]) {
   uint32_t q[M][NL];
   uint64_t acc[M];
 #pragma unroll
   for (int m = 0; m < M; m++) acc[m] = 0;
-  mont_mul_x_col<M, 0>(a, b, r, acc, q, opaque_one());
+  mont_mul_x_col<M, 0>(a, b, r, acc, q);
 #pragma unroll
   for (int m = 0; m < M; m++) r[m].v[NL - 1] = (uint32_t)acc[m];
 }

@@ -12,12 +12,11 @@
 // curve377.hpp normalises one side.  The checker build verifies every column against 2^64 (tests/csrc/fq377check.cpp).
 #pragma once
 #include <stdint.h>
-#include "fp.hpp"      // TE_HD, chain(), opaque_one()
+#include "fp.hpp"      // TE_HD, chain()
 
 namespace te377 {
 
 using te::chain;
-using te::opaque_one;
 
 constexpr int NL = 14;
 constexpr uint32_t LB = 29;
@@ -63,7 +62,7 @@ struct col_acc {
 // M independent Montgomery products in lockstep, r[m] = a[m] * b[m] / R (mod q, plus a multiple of q), class N, value
 // < a*b/R + q.  See fp.hpp mont_mul_x for the scheduling rationale.
 template <int M, int K>
-TE_HD void mont_mul_x_col(const fq (&a)[M], const fq (&b)[M], fq (&r)[M], uint64_t (&acc)[M], uint32_t (&q)[M][NL], uint32_t one) {
+TE_HD void mont_mul_x_col(const fq (&a)[M], const fq (&b)[M], fq (&r)[M], uint64_t (&acc)[M], uint32_t (&q)[M][NL]) {
   constexpr int lo = K < NL ? 0 : K - (NL - 1), hi = K < NL ? K : NL - 1, qhi = K < NL ? K - 1 : NL - 1;
 #pragma unroll
   for (int i = lo; i <= hi; i++) {
@@ -77,14 +76,17 @@ TE_HD void mont_mul_x_col(const fq (&a)[M], const fq (&b)[M], fq (&r)[M], uint64
   }
   if constexpr (K < NL) {
 #pragma unroll
-    for (int m = 0; m < M; m++) q[m][K] = (0u - (uint32_t)acc[m]) & LM;
+    for (int m = 0; m < M; m++) q[m][K] = K == 0 ? (1u << LB) - ((uint32_t)acc[m] & LM) : ~(uint32_t)acc[m] & LM;
 #pragma unroll
-    for (int m = 0; m < M; m++) { acc[m] += (uint64_t)q[m][K] * one; acc[m] >>= LB; }
+    for (int m = 0; m < M; m++) acc[m] >>= LB;       // q*q_limb(0) = q stays implicit: fp.hpp, CARRY-FOLDED QUOTIENT
   } else {
 #pragma unroll
-    for (int m = 0; m < M; m++) { r[m].v[K - NL] = (uint32_t)acc[m] & LM; acc[m] >>= LB; }
+    for (int m = 0; m < M; m++) {
+      if constexpr (K == NL) acc[m] += 1u;
+      r[m].v[K - NL] = (uint32_t)acc[m] & LM; acc[m] >>= LB;
+    }
   }
-  if constexpr (K + 1 < 2 * NL - 1) mont_mul_x_col<M, K + 1>(a, b, r, acc, q, one);
+  if constexpr (K + 1 < 2 * NL - 1) mont_mul_x_col<M, K + 1>(a, b, r, acc, q);
 }
 template <int M> TE_HD void mont_mul_x(const fq (&a)[M], const fq (&b)[M], fq (&r)[M]) {
 #if defined(TE377_CHECK_COLUMNS)
@@ -93,13 +95,13 @@ template <int M> TE_HD void mont_mul_x(const fq (&a)[M], const fq (&b)[M], fq (&
     for (int k = 0; k < NL; k++) {
       for (int i = 0; i <= k; i++) c.mad(a[m].v[i], b[m].v[k - i]);
       for (int i = 0; i < k; i++) c.mad(q[i], q_limb(k - i));
-      q[k] = (0u - (uint32_t)c.acc) & LM;
-      c.mad(q[k], 1u);
+      q[k] = k == 0 ? (1u << LB) - ((uint32_t)c.acc & LM) : ~(uint32_t)c.acc & LM;
       c.shift();
     }
     for (int k = NL; k < 2 * NL - 1; k++) {
       for (int i = k - (NL - 1); i < NL; i++) c.mad(a[m].v[i], b[m].v[k - i]);
       for (int i = k - (NL - 1); i < NL; i++) c.mad(q[i], q_limb(k - i));
+      if (k == NL) c.mad(1u, 1u);
       r[m].v[k - NL] = (uint32_t)c.acc & LM;
       c.shift();
     }
@@ -110,7 +112,7 @@ template <int M> TE_HD void mont_mul_x(const fq (&a)[M], const fq (&b)[M], fq (&
   uint64_t acc[M];
 #pragma unroll
   for (int m = 0; m < M; m++) acc[m] = 0;
-  mont_mul_x_col<M, 0>(a, b, r, acc, q, opaque_one());
+  mont_mul_x_col<M, 0>(a, b, r, acc, q);
 #pragma unroll
   for (int m = 0; m < M; m++) r[m].v[NL - 1] = (uint32_t)acc[m];
 #endif
