@@ -91,6 +91,9 @@ def main():
                     help="signed window digits, 2^(c-1) buckets (BASELINE config 3, the reference's shipped behaviour) or unsigned, 2^c buckets (config 2)")
     ap.add_argument("--inflight", type=int, default=0,
                     help="MSMs in flight in pipelined mode (1..8, each on its own stream / work set); 0 = 4 on one GPU, 8 when the windows are sharded (small per-rank kernels)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="window-sharded runs: MSMs per launch sequence (te_msm_partial_device_batch); 0 = as many as make a rank's sequence "
+                         "carry a whole MSM's worth of windows (D ranks -> D, at most 8; 1 below D = 4); 1 = one MSM per sequence")
     ap.add_argument("--no-pipeline", action="store_true", help="N=1: await every MSM before submitting the next (latency mode)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -182,7 +185,17 @@ def main():
             return pkg.compute_msm_sharded(ctx, d_pts, d_sc, n, partials, dist, None, gather_list)
         return ctx.run_device(d_pts.data_ptr(), d_sc.data_ptr(), n)
 
-    pipe = pkg.ShardedPipeline(ctx, n, dist, depth=depth) if (sharded and pipelined) else None
+    # a rank of D owns ~W/D windows of every MSM: too little work for a launch sequence of its own (the reduction tail and the
+    # sort are latency-bound), so D MSMs share one (their windows are sorted, accumulated and reduced together)
+    batch = 1
+    if sharded and pipelined:
+        own = len(range(rank if not rehearse else 0, W, rehearse or world))
+        batch = args.batch or max(1, min(pkg.MAX_BATCH, W // max(own, 1)))
+        if not args.batch and batch < 4:               # measured (profiles/r02_rehearsal_per_rank_step.txt): pays from D = 4 on
+            batch = 1
+        if batch > 1 and not args.inflight:
+            depth = 4
+    pipe = pkg.ShardedPipeline(ctx, n, dist, depth=depth, batch=batch) if (sharded and pipelined) else None
 
     result = None
     for _ in range(args.warmup):
@@ -190,8 +203,8 @@ def main():
     # warm-up of the pipelined form as well: every work set allocates its device buffers on first use, which must not
     # fall into the timed region (one untimed round over all of them)
     if pipelined and sharded:
-        for t in [pipe.submit(d_pts, d_sc) for _ in range(depth)]:
-            result = pipe.collect(t)
+        for t in [pipe.submit_batch([(d_pts, d_sc)] * batch) for _ in range(depth)]:
+            result = pipe.collect_batch(t)[-1]
     elif pipelined:
         for t in [ctx.submit_device(d_pts.data_ptr(), d_sc.data_ptr(), n) for _ in range(depth)]:
             result = ctx.collect(t)
@@ -215,21 +228,24 @@ def main():
         lat.append((time.perf_counter() - t1) * 1e3)
     stage_acc.clear()
 
+    last = 1                                           # MSMs in the last launch sequence (window-sharded batches)
     sync()
     t0 = time.perf_counter()
     if pipelined and sharded:
         # the same with window shards: all-gather, read-back and host tail of MSM i overlap the device work of MSM i+1
-        tickets = []
-        for i in range(args.steps):
-            tickets.append(pipe.submit(d_pts, d_sc))
+        tickets, sent = [], 0
+        while sent < args.steps:
+            last = min(batch, args.steps - sent)
+            tickets.append(pipe.submit_batch([(d_pts, d_sc)] * last))
+            sent += last
             if len(tickets) >= depth:
-                result = pipe.collect(tickets.pop(0))
+                result = pipe.collect_batch(tickets.pop(0))[-1]
         while tickets:
-            result = pipe.collect(tickets.pop(0))
+            result = pipe.collect_batch(tickets.pop(0))[-1]
         torch.cuda.synchronize()
-        note_stage()                                   # events of the last MSM: a sample, not the mean
+        note_stage()                                   # events of the last launch sequence (`last` MSMs): a sample, not the mean
         for k in list(stage_acc):
-            stage_acc[k] *= args.steps
+            stage_acc[k] *= args.steps / last          # -> per MSM after the division by steps below
     elif pipelined:
         # K independent MSMs back to back, `depth` in flight on as many streams: host tail and device work of consecutive
         # MSMs overlap, and on the GPU the gaps and latency-bound tail of one are filled by the wide kernels of another
@@ -295,7 +311,7 @@ def main():
         "latency_ms": min(lat),
         "latency_ms_single_msm": min(lat),
         "host_buffers_ms": None,
-        "mode": (("pipelined: %d MSMs in flight (te_msm_submit_device / te_msm_collect)" if world == 1 and not sharded else "pipelined: %d window-sharded MSMs in flight per rank") % depth) if pipelined else "synchronous: one MSM at a time",
+        "mode": (("pipelined: %d MSMs in flight (te_msm_submit_device / te_msm_collect)" if world == 1 and not sharded else ("pipelined: %%d launch sequences of %d window-sharded MSM(s) each in flight per rank" % batch)) % depth) if pipelined else "synchronous: one MSM at a time",
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -310,14 +326,14 @@ def main():
                                   % (world, "RCCL" if (world > 1 and dist.get_backend() == "nccl") else "gloo (rehearsal: ranks share one GPU)", W * 720) if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_info": traffic_info,
-                     "algorithmic_bytes_per_launch": acc_bytes_rank, "kernel_ms": acc_ms,
+                     "algorithmic_bytes_per_launch": acc_bytes_rank * last, "kernel_ms": acc_ms * last, "msms_per_launch": last,
                      # the timed region keeps `depth` MSMs in flight: the kernel shares the GPU with the other MSMs' kernels,
                      # so its duration there is longer than when it has the GPU to itself (untimed single-MSM pass)
                      "alone": {"kernel_ms": stage_ms.get("accumulate"),
                                "achieved": acc_bytes_rank / (stage_ms["accumulate"] * 1e-3) / 1e9 if stage_ms.get("accumulate") else None,
                                "frac": acc_bytes_rank / (stage_ms["accumulate"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if stage_ms.get("accumulate") else None},
                      "binding_roofline": valu,
-                     "note": ("VALU-bound: 11 products of 14-limb operands per gathered point" if bls else
+                     "note": ("VALU-bound: 8 products of 14-limb operands per gathered point" if bls else
                               "the north star names the HBM roofline; the kernel is VALU-issue bound (7 field products per gathered "
                               "point, see binding_roofline and DESIGN.md section 4)")},
         "msm_algorithmic_bytes": whole_bytes,

@@ -120,6 +120,16 @@ int te_msm_plan(te_ctx* ctx, uint64_t n, int* window_bits, int* num_windows);
 #define TE_MSM_OWN_STREAM ((void*)(intptr_t)-1)
 int te_msm_partial_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_scalars_le, uint64_t n,
                           void* d_partials, void* stream);
+/* `count` (1..TE_MSM_MAX_BATCH) MSMs of the same n in ONE sequence of launches: MSM m reads d_points_xy_le[m] /
+ * d_scalars_le[m] (arrays of device pointers, in host memory, read before the call returns) and its W rows go to
+ * d_partials + m * W * row bytes.  The windows of the batch are sorted, accumulated and reduced together, as if they were
+ * count x (windows of this shard) windows of one MSM: what a rank of a D-GPU window-sharded job needs, because its W/D windows per
+ * MSM are too little work for a launch sequence of their own (measured at D = 8: 0.26 ms per MSM one by one).  There is no reference
+ * counterpart: the reference awaits one compute_msm at a time (full_benchmarks.ts:97-110).  A scalar out of range anywhere
+ * in the batch fails the whole batch (te_msm_partial_wait).  Same work set and stream rules as te_msm_partial_device. */
+#define TE_MSM_MAX_BATCH 8
+int te_msm_partial_device_batch(te_ctx* ctx, const void* const* d_points_xy_le, const void* const* d_scalars_le, uint64_t n,
+                                int count, void* d_partials, void* stream);
 /* A context owns TE_MSM_WORKSETS device work sets (option "workset" selects the one te_msm_partial_device uses), so a
  * caller can keep that many MSMs in flight on as many streams: their kernels overlap on the GPU.  te_msm_partial_wait blocks until the
  * last te_msm_partial_device call on that work set has finished and returns its status (TE_MSM_ESCALAR if a scalar was

@@ -296,6 +296,67 @@ def test_window_shards_on_one_gpu(pkg, ora, world):
     assert pkg.finalize_host(pkg.merge_partials(rows, cW[1], world), *cW) == exp
 
 
+@pytest.mark.parametrize("world,count,n,opts", [(1, 3, 5000, {}), (4, 5, 30000, {}), (8, 8, 20000, {"window_bits": 16}),
+                                                (2, 2, 3000, {"signed_digits": 0, "window_bits": 9}), (3, 4, 777, {"segment_len": 5})])
+def test_batches_of_window_sharded_msms(pkg, ora, world, count, n, opts):
+    """te_msm_partial_device_batch: `count` MSMs with different inputs share one launch sequence per rank; every MSM's rows,
+    merged over the ranks, finalize to the oracle's result -- also when a scalar buffer repeats, and batch 1 = the plain call"""
+    import torch
+    ins = [(ora.gen_points(900 + m, n), ora.gen_scalars(950 + m, n)) for m in range(count)]
+    ins[-1] = (ins[-1][0], ins[0][1])                                    # same scalars, other points
+    dev = [(_dev(p), _dev(s)) for p, s in ins]
+    exp = [ora.msm(p, s, threads=8) for p, s in ins]
+    per_rank = []
+    for r in range(world):
+        with pkg.MsmContext((0,)) as c:
+            for k, v in opts.items():
+                c.set_option(k, v)
+            c.set_window_shard(*pkg.window_shard_for_rank(r, world))
+            cbits, W = c.plan(n)
+            part = torch.zeros(count * W * 720, dtype=torch.uint8, device="cuda")
+            c.partial_device_batch([p.data_ptr() for p, _ in dev], [s.data_ptr() for _, s in dev], n, part.data_ptr(),
+                                   torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            c.partial_wait(0)
+            per_rank.append(part.cpu().numpy().tobytes())
+            if r == 0:                                                   # a batch of one is te_msm_partial_device
+                one = torch.zeros(W * 720, dtype=torch.uint8, device="cuda")
+                c.partial_device_batch([dev[1][0].data_ptr()], [dev[1][1].data_ptr()], n, one.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                blk = W * 720
+                mine = [w for w in range(W) if w % world == 0]
+                got1, ref1 = one.cpu().numpy().tobytes(), per_rank[0][blk:2 * blk]
+                # rows are lazily reduced sums: compare as points through the host tail, window by window
+                for w in mine:
+                    z = bytearray(blk); z[w * 720:(w + 1) * 720] = got1[w * 720:(w + 1) * 720]
+                    y = bytearray(blk); y[w * 720:(w + 1) * 720] = ref1[w * 720:(w + 1) * 720]
+                    bb = cbits - 1 if c.get_option("signed_digits") else cbits
+                    assert pkg.finalize_host(bytes(z), cbits, W, bb) == pkg.finalize_host(bytes(y), cbits, W, bb)
+    bb = cbits - 1 if opts.get("signed_digits", 1) else cbits
+    blk = W * 720
+    for m in range(count):
+        merged = pkg.merge_partials([rows[m * blk:(m + 1) * blk] for rows in per_rank], W, world)
+        assert pkg.finalize_host(merged, cbits, W, bb) == exp[m], f"MSM {m} of the batch"
+
+
+def test_batch_argument_checks(pkg, ora):
+    import torch
+    n = 100
+    dp, ds = _dev(ora.gen_points(1, n)), _dev(ora.gen_scalars(1, n))
+    with pkg.MsmContext((0,)) as c:
+        _, W = c.plan(n)
+        part = torch.zeros(9 * W * 720, dtype=torch.uint8, device="cuda")
+        with pytest.raises(pkg.MsmError):
+            c.partial_device_batch([dp.data_ptr()] * 9, [ds.data_ptr()] * 9, n, part.data_ptr())
+        with pytest.raises(pkg.MsmError):
+            c.partial_device_batch([dp.data_ptr(), 0], [ds.data_ptr()] * 2, n, part.data_ptr())
+        bad = bytearray(ora.gen_scalars(2, n)); bad[-32:] = b"\xff" * 32          # a scalar above the decomposition's range
+        db = _dev(bytes(bad))
+        c.partial_device_batch([dp.data_ptr()] * 3, [ds.data_ptr(), db.data_ptr(), ds.data_ptr()], n, part.data_ptr())
+        with pytest.raises(pkg.MsmError):
+            c.partial_wait(0)
+
+
 def test_multi_device_context_same_gpu(pkg, ora):
     """n_dev = 2 with the same device id twice: exercises the in-process window sharding."""
     n = 20000

@@ -210,6 +210,13 @@ def test_sharded_pipeline_over_rccl(pkg, model, ora, nccl_world1):
             while tickets:
                 got.append(pipe.collect(tickets.pop(0)))
             assert got == [e for _, _, e in cases]
+            # launch sequences of up to three MSMs (te_msm_partial_device_batch), two in flight; the last batch is short
+            bp = pkg.ShardedPipeline(ctx, n, dist, depth=2, batch=3)
+            t0 = bp.submit_batch([(dp, ds) for dp, ds, _ in cases[:3]])
+            t1 = bp.submit_batch([(dp, ds) for dp, ds, _ in cases[3:]])
+            assert bp.collect_batch(t0) + bp.collect_batch(t1) == [e for _, _, e in cases]
+            t2 = bp.submit(cases[2][0], cases[2][1])
+            assert bp.collect(t2) == cases[2][2]
             # the synchronous form over the same backend
             part = torch.zeros(pipe.W * pkg.PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
             assert pkg.compute_msm_sharded(ctx, cases[0][0], cases[0][1], n, part, dist) == cases[0][2]

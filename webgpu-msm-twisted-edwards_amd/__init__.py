@@ -25,5 +25,6 @@ from .binding import (  # noqa: F401
     CURVE_TE_BLS12,
     CURVE_BLS12_377_G1,
     WORKSETS,
+    MAX_BATCH,
 )
 from .sharding import ShardedPipeline, compute_msm_sharded, exchange_partials, merge_partials, window_shard_for_rank  # noqa: F401

@@ -16,6 +16,7 @@ PARTIAL_BYTES = 720                     # TE_MSM_PARTIAL_BYTES: one window's row
 PARTIAL_BYTES_BLS12_377 = 1120          # TE_MSM_PARTIAL_BYTES_BLS12_377
 CURVE_TE_BLS12, CURVE_BLS12_377_G1 = 0, 1        # option "curve" (TE_MSM_CURVE_*)
 WORKSETS = 8            # TE_MSM_WORKSETS: MSMs one context can have in flight
+MAX_BATCH = 8           # TE_MSM_MAX_BATCH: MSMs one te_msm_partial_device_batch call takes
 
 
 class MsmError(RuntimeError):
@@ -93,6 +94,8 @@ def _lib() -> ctypes.CDLL:
         L.te_msm_plan.restype = ci
         L.te_msm_partial_device.argtypes = [vp, vp, vp, u64, vp, vp]
         L.te_msm_partial_device.restype = ci
+        L.te_msm_partial_device_batch.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), u64, ci, vp, vp]
+        L.te_msm_partial_device_batch.restype = ci
         L.te_msm_partial_wait.argtypes = [vp, ci]
         L.te_msm_partial_wait.restype = ci
         L.te_msm_finalize.argtypes = [vp, cp, ci, ci, cp]
@@ -210,6 +213,15 @@ class MsmContext:
         """stream: a hipStream_t handle (0 = HIP's default stream, as torch.cuda.current_stream().cuda_stream
         reports for torch's default stream); -1 = the context's private stream (TE_MSM_OWN_STREAM)."""
         self._check(self._L.te_msm_partial_device(self._h, d_points, d_scalars, n, d_partials, ctypes.c_void_p(stream)))
+
+    def partial_device_batch(self, d_points, d_scalars, n: int, d_partials: int, stream: int = -1):
+        """len(d_points) MSMs of n points each (device pointers as ints) in one sequence of launches; MSM m's W rows land at
+        d_partials + m * W * row_bytes (te_msm_partial_device_batch)."""
+        count = len(d_points)
+        if count != len(d_scalars) or not 1 <= count <= MAX_BATCH:
+            raise MsmError(-1, "batch of %d point buffers and %d scalar buffers (1..%d of each)" % (count, len(d_scalars), MAX_BATCH))
+        pv, sv = (ctypes.c_void_p * count)(*d_points), (ctypes.c_void_p * count)(*d_scalars)
+        self._check(self._L.te_msm_partial_device_batch(self._h, pv, sv, n, count, d_partials, ctypes.c_void_p(stream)))
 
     def partial_wait(self, workset: int = 0):
         """Blocks until the last partial_device call on that work set is done; raises on a scalar-range error."""

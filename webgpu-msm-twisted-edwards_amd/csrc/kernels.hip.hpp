@@ -649,13 +649,15 @@ __global__ void __launch_bounds__(256, N == 9 ? 4 : 2) k_accumulate(const rec_sl
                                                     const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ seg_bucket,
                                                     const uint32_t* __restrict__ seg_lenv, const uint32_t* __restrict__ order,
                                                     const uint32_t* __restrict__ num_segments, ete_t<N>* __restrict__ buckets,
-                                                    ete_t<N>* __restrict__ seg_out, uint32_t n, uint32_t logB, uint32_t seg_len, uint32_t ids, uint32_t onto) {
+                                                    ete_t<N>* __restrict__ seg_out, uint32_t n, uint32_t logB, uint32_t seg_len, uint32_t ids, uint32_t onto,
+                                                    uint32_t win_per_msm) {
   const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
   if (gid >= (order ? *num_segments : ids)) return;
   const uint32_t sgm = order ? order[gid] : gid;
   const uint32_t g = seg_bucket[sgm];                // g = k * B + b
   if (g == TE_SEG_INVALID) return;
   const uint32_t k = g >> logB;
+  recs += (size_t)(k / win_per_msm) * n;             // a batch of MSMs (te_msm_partial_device_batch): window k belongs to MSM k / win_per_msm
   const uint32_t part = sgm - seg_base[g];
   const uint32_t cnt = seg_lenv[sgm];
   const uint32_t* lst = sorted + (size_t)k * n + bucket_start[g] + part * seg_len;
@@ -906,6 +908,7 @@ template <int N> struct tail_params_t {
   uint32_t rx, ry, x_per_window, y_per_window;
   uint32_t w[4];
   ete_t<N>* rows; uint32_t row_stride;   // points
+  uint32_t win_per_msm, msm_stride;      // batch: window k of the launch is window k % win_per_msm of MSM k / win_per_msm, whose rows start msm_stride points further
 };
 template <int N> __device__ __forceinline__ uint32_t* lds_point(uint32_t* base, uint32_t idx) { return base + (size_t)idx * geo<N>::PW; }
 
@@ -967,7 +970,7 @@ __global__ void __launch_bounds__(1024) k_reduce_tail(tail_params_t<N> prm) {
       mine = fp_select<N>(act, sum, mine);
       __syncthreads();
     }
-    ete_t<N>* row = prm.rows + (size_t)k * prm.row_stride;
+    ete_t<N>* row = prm.rows + (size_t)(k / prm.win_per_msm) * prm.msm_stride + (size_t)(k % prm.win_per_msm) * prm.row_stride;
     if (v == 0) { if (dgt == 0) store_coord<N>(words<N>(row) + wq, mine); mine = identity_coord<N>(q); }
     for (uint32_t s = 8; s > 0; s >>= 1) {             // tree sum of S_1..S_{N-1} (slot 0 = identity)
       if (v >= s && v < 2 * s) store_coord<N>(slot + wq, mine);

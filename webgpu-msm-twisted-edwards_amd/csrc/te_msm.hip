@@ -46,7 +46,8 @@ constexpr size_t TE_MAX_ROW_BYTES = TE377_TAIL_ROW_BYTES;
 
 struct plan_t {
   int curve = 0;                      // TE_MSM_CURVE_*
-  int c = 0, W = 0, nw = 0;           // window bits, total windows, windows of this shard
+  int c = 0, W = 0, nw = 0;           // window bits, total windows, windows of this launch sequence (shard windows x batch)
+  int nw1 = 0, batch = 1;             // windows of this shard per MSM; MSMs that share the launch sequence (te_msm_partial_device_batch)
   uint32_t B = 0, logB = 0;           // buckets per window = 2^(c-1) (signed digits) or 2^c (unsigned)
   int signed_digits = 1;
   uint32_t dw[4] = {0, 0, 0, 0};      // bits of the four digits of a bucket index (dw[0] lowest)
@@ -151,12 +152,13 @@ int auto_window_bits(uint64_t n) {
   return c;
 }
 
-void make_plan(const te_ctx* ctx, const gpu_t& d, uint64_t n, plan_t& p, int force_c = 0) {
+void make_plan(const te_ctx* ctx, const gpu_t& d, uint64_t n, plan_t& p, int force_c = 0, int batch = 1) {
   p.curve = ctx->opt_curve;
   p.c = force_c ? force_c : ctx->opt_window_bits ? ctx->opt_window_bits : auto_window_bits(n);
   p.W = (256 + p.c - 1) / p.c;
   p.nw = 0;
   for (int w = d.w_first; w < p.W; w += d.w_step) p.nw++;
+  p.nw1 = p.nw; p.batch = batch; p.nw *= batch;
   p.signed_digits = ctx->opt_signed;
   p.logB = (uint32_t)(p.signed_digits ? p.c - 1 : p.c); p.B = 1u << p.logB;
   for (int k = 0; k < 4; k++) p.dw[k] = (p.logB + 3u - (uint32_t)k) / 4u;       // 15 -> 4,4,4,3
@@ -191,7 +193,7 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, workset_t& ws, uint64_t n, const plan_
   HIP_TRY(ctx, hipSetDevice(d.device));
   const size_t nd = (size_t)p.nw * p.nst + 16, wb = (size_t)p.nw * p.B, ab = sizes_of(p.curve).acc;
   int rc = 0;
-  if ((rc = ensure(ctx, ws, ws.d_recs, ws.cap[0], (size_t)n * sizes_of(p.curve).rec))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_recs, ws.cap[0], (size_t)n * sizes_of(p.curve).rec * (size_t)p.batch))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_digits, ws.cap[1], nd))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_sorted, ws.cap[2], nd))) return rc;
   {
@@ -237,7 +239,7 @@ template <int C> void launch_digits(const uint4* sc, uint16_t* dg, const te::dig
 // per-rank step of a window-sharded one) while k_accumulate stays an ordinary launch bracketed by timing events.
 struct msm_launch {
   te_ctx* ctx; gpu_t& d; workset_t& ws; plan_t p;
-  const void* d_points; const void* d_scalars; uint64_t n; void* d_partials_out;
+  const void* d_points; const void* d_scalars; uint64_t n; void* d_partials_out;   // batch > 1: d_points / d_scalars are arrays of p.batch device pointers (on the host)
   int prof;                       // event marks inside front()/back() only at profile level 2 (never inside a capture)
   hipStream_t stream;
   bool own_rows = false;          // rows go to ws.d_partials: the caller fetches flag + rows with one copy
@@ -246,6 +248,8 @@ struct msm_launch {
   uint32_t total() const { return (uint32_t)p.nw * p.B; }
   uint32_t smax() const { return total() + (uint32_t)((uint64_t)p.nw * (n / p.seg_len)); }
   uint32_t chunk_cap() const { return total() + smax() / 1024u + 2u; }     // entries of d_chunk_list (pairs), see ensure_buffers
+  const void* points_of(int m) const { return p.batch > 1 ? static_cast<const void* const*>(d_points)[m] : d_points; }
+  const void* scalars_of(int m) const { return p.batch > 1 ? static_cast<const void* const*>(d_scalars)[m] : d_scalars; }
   void mark(int i) const { if (prof >= 2 || (prof == 1 && (i == ST_ACCUM || i == ST_ACCUM + 1))) (void)hipEventRecord(ws.ev[i], stream); }
 
   int front() {
@@ -257,10 +261,13 @@ struct msm_launch {
   int front_points() {
     const uint32_t n32 = this->n32();
     mark(ST_PREP);
-    if (p.curve == TE_MSM_CURVE_BLS12_377_G1)
-      hipLaunchKernelGGL(te::k_prep_points377, dim3((n32 + 255) / 256), dim3(256), 0, stream, (const uint4*)d_points, reinterpret_cast<te::rec_slot<14>*>(ws.d_recs), n32);
-    else
-      hipLaunchKernelGGL(te::k_prep_points, dim3((n32 + 255) / 256), dim3(256), 0, stream, (const uint4*)d_points, reinterpret_cast<te::pnt_slot*>(ws.d_recs), n32);
+    for (int m = 0; m < p.batch; m++) {                 // records of MSM m: slots [m * n, (m + 1) * n)
+      uint8_t* recs = ws.d_recs + (size_t)m * n * sizes_of(p.curve).rec;
+      if (p.curve == TE_MSM_CURVE_BLS12_377_G1)
+        hipLaunchKernelGGL(te::k_prep_points377, dim3((n32 + 255) / 256), dim3(256), 0, stream, (const uint4*)points_of(m), reinterpret_cast<te::rec_slot<14>*>(recs), n32);
+      else
+        hipLaunchKernelGGL(te::k_prep_points, dim3((n32 + 255) / 256), dim3(256), 0, stream, (const uint4*)points_of(m), reinterpret_cast<te::pnt_slot*>(recs), n32);
+    }
     return 0;
   }
 
@@ -277,23 +284,27 @@ struct msm_launch {
       if (p.signed_digits) for (int w = 0; w < p.W; w++) { const int bit = w * p.c + p.c - 1; if (bit < 320) prm.half[bit >> 5] |= 1u << (bit & 31); }
       prm.zero_digit = p.signed_digits ? 1u << (p.c - 1) : 0u;
       prm.sc_stride = (uint32_t)(sizes_of(p.curve).scalar_in / 16);
-      prm.n = n32; prm.nst = p.nst; prm.num_windows = p.W; prm.w_first = d.w_first; prm.w_step = d.w_step; prm.nw_local = p.nw;
+      prm.n = n32; prm.nst = p.nst; prm.num_windows = p.W; prm.w_first = d.w_first; prm.w_step = d.w_step; prm.nw_local = p.nw1;
       prm.half_code = sg.half; prm.logS = p.logS; prm.P = p.P; prm.CH = p.CH; prm.chunk_len = p.chunk_len;
-      const uint4* sc = (const uint4*)d_scalars;
-      switch (p.c) {
-        case 4: launch_digits<4>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
-        case 5: launch_digits<5>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
-        case 6: launch_digits<6>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
-        case 7: launch_digits<7>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
-        case 8: launch_digits<8>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
-        case 9: launch_digits<9>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
-        case 10: launch_digits<10>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
-        case 11: launch_digits<11>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
-        case 12: launch_digits<12>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
-        case 13: launch_digits<13>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
-        case 14: launch_digits<14>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
-        case 15: launch_digits<15>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
-        default: launch_digits<16>(sc, ws.d_digits, prm, ws.d_err, ws.d_counts1, stream); break;
+      for (int m = 0; m < p.batch; m++) {                // MSM m fills digit rows and level-1 counts [m * nw1, (m + 1) * nw1)
+        const uint4* sc = (const uint4*)scalars_of(m);
+        uint16_t* dg = ws.d_digits + (size_t)m * p.nw1 * p.nst;
+        uint32_t* c1 = ws.d_counts1 + (size_t)m * p.nw1 * p.CH * p.P;
+        switch (p.c) {
+          case 4: launch_digits<4>(sc, dg, prm, ws.d_err, c1, stream); break;
+          case 5: launch_digits<5>(sc, dg, prm, ws.d_err, c1, stream); break;
+          case 6: launch_digits<6>(sc, dg, prm, ws.d_err, c1, stream); break;
+          case 7: launch_digits<7>(sc, dg, prm, ws.d_err, c1, stream); break;
+          case 8: launch_digits<8>(sc, dg, prm, ws.d_err, c1, stream); break;
+          case 9: launch_digits<9>(sc, dg, prm, ws.d_err, c1, stream); break;
+          case 10: launch_digits<10>(sc, dg, prm, ws.d_err, c1, stream); break;
+          case 11: launch_digits<11>(sc, dg, prm, ws.d_err, c1, stream); break;
+          case 12: launch_digits<12>(sc, dg, prm, ws.d_err, c1, stream); break;
+          case 13: launch_digits<13>(sc, dg, prm, ws.d_err, c1, stream); break;
+          case 14: launch_digits<14>(sc, dg, prm, ws.d_err, c1, stream); break;
+          case 15: launch_digits<15>(sc, dg, prm, ws.d_err, c1, stream); break;
+          default: launch_digits<16>(sc, dg, prm, ws.d_err, c1, stream); break;
+        }
       }
     }
     const uint32_t cap_w = p.B + (uint32_t)(n / p.seg_len);        // segment ids of one window (see k_part_scatter)
@@ -330,7 +341,8 @@ struct msm_launch {
       const uint32_t* order = ctx->opt_sort ? ws.d_order : nullptr;
       hipLaunchKernelGGL(te::k_accumulate<N>, dim3((smax + 255) / 256), dim3(256), 0, stream, reinterpret_cast<const te::rec_slot<N>*>(ws.d_recs), ws.d_sorted,
                          ws.d_bucket_start, ws.d_bucket_count, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv, order, ws.d_num_seg,
-                         reinterpret_cast<te::ete_t<N>*>(ws.d_buckets), reinterpret_cast<te::ete_t<N>*>(ws.d_seg_out), n32, p.logB, p.seg_len, smax, onto ? 1u : 0u);
+                         reinterpret_cast<te::ete_t<N>*>(ws.d_buckets), reinterpret_cast<te::ete_t<N>*>(ws.d_seg_out), n32, p.logB, p.seg_len, smax, onto ? 1u : 0u,
+                         (uint32_t)p.nw1);
     }
     return 0;
   }
@@ -394,6 +406,7 @@ struct msm_launch {
       tp.x_per_window = ch[0].n; tp.y_per_window = ch[1].n;
       tp.w[0] = w0; tp.w[1] = w1; tp.w[2] = w2; tp.w[3] = w3;
       tp.rows = reinterpret_cast<E*>(d_partials_out) + (size_t)d.w_first * 5; tp.row_stride = (uint32_t)d.w_step * 5u;
+      tp.win_per_msm = (uint32_t)p.nw1; tp.msm_stride = (uint32_t)p.W * 5u;          // batch: MSM m's W rows follow MSM m-1's
       const size_t lds_bytes = (size_t)(std::max(H, L) + 16u) * sizeof(E);
       hipLaunchKernelGGL(te::k_reduce_tail<N>, dim3(4, p.nw), dim3(1024), lds_bytes, stream, tp);
     } else {
@@ -438,8 +451,9 @@ template <typename F> int capture_graph(te_ctx* ctx, workset_t& ws, hipGraphExec
 // hardware queues (four by default; GPU_MAX_HW_QUEUES=8 did not help) and serialises the others: 941 -> 862 MSM/s.
 int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, const void* d_scalars, uint64_t n,
                     void* d_partials_out, hipStream_t stream, const std::function<int(hipStream_t)>* upload_points = nullptr, int force_c = 0,
-                    bool side_stream = false) {
-  plan_t p; make_plan(ctx, d, n, p, force_c);
+                    bool side_stream = false, int batch = 1) {
+  plan_t p; make_plan(ctx, d, n, p, force_c, batch);
+  if (batch > 1 && (uint64_t)p.nw * p.nst >= (1ull << 31)) return set_err(ctx, TE_MSM_EINVAL, "batch too large for this n: windows x points must stay below 2^31");
   HIP_TRY(ctx, hipSetDevice(d.device));
   if ((uint64_t)p.nw * p.B + (uint64_t)p.nw * (n / p.seg_len) + 1024u >= (1ull << 32))
     return set_err(ctx, TE_MSM_EINVAL, "segment_len is too small for this n: more than 2^32 segments");
@@ -452,7 +466,7 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, 
   // profile 1: two events around the dominant kernel only (what bench.py times live); 2: every stage boundary
   // (an event between two kernels costs ~4 us of idle stream time, 11 of them ~2 % of a 2^20 MSM)
   msm_launch L{ctx, d, ws, p, d_points, d_scalars, n, d_partials_out, ctx->opt_profile, stream, own_rows};
-  if (ctx->opt_graph && ctx->opt_profile < 2 && !upload_points) {
+  if (ctx->opt_graph && ctx->opt_profile < 2 && !upload_points && batch == 1) {
     // the graphs hold pointers and geometry: re-captured when any of them changes (including a buffer reallocation)
     graph_key key; memset(&key, 0, sizeof key);          // padding bytes take part in the memcmp below
     key.pts = d_points; key.sc = d_scalars; key.out = d_partials_out; key.n = n; key.generation = ws.generation;
@@ -856,6 +870,23 @@ int te_msm_partial_device(te_ctx* ctx, const void* d_points_xy_le, const void* d
   if (ws.pending_ticket) return set_err(ctx, TE_MSM_ESTATE, "the selected work set holds a submitted MSM that has not been collected");
   HIP_TRY(ctx, hipSetDevice(d.device));
   return enqueue_partial(ctx, d, ws, d_points_xy_le, d_scalars_le, n, d_partials, stream == TE_MSM_OWN_STREAM ? ws.stream : (hipStream_t)stream);
+}
+
+int te_msm_partial_device_batch(te_ctx* ctx, const void* const* d_points_xy_le, const void* const* d_scalars_le, uint64_t n, int count,
+                                void* d_partials, void* stream) {
+  if (!ctx) return TE_MSM_EINVAL;
+  if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_partial_device_batch needs a single-device context");
+  if (!d_points_xy_le || !d_scalars_le || !d_partials || n == 0 || n >= (1ull << 31) || count < 1 || count > TE_MSM_MAX_BATCH)
+    return set_err(ctx, TE_MSM_EINVAL, "bad arguments");
+  for (int m = 0; m < count; m++) if (!d_points_xy_le[m] || !d_scalars_le[m]) return set_err(ctx, TE_MSM_EINVAL, "bad arguments");
+  gpu_t& d = ctx->devs[0];
+  workset_t& ws = d.ws[ctx->opt_workset];
+  if (ws.pending_ticket) return set_err(ctx, TE_MSM_ESTATE, "the selected work set holds a submitted MSM that has not been collected");
+  HIP_TRY(ctx, hipSetDevice(d.device));
+  hipStream_t st = stream == TE_MSM_OWN_STREAM ? ws.stream : (hipStream_t)stream;
+  if (count == 1) return enqueue_partial(ctx, d, ws, d_points_xy_le[0], d_scalars_le[0], n, d_partials, st);
+  // the pointer arrays are only read while the launches are enqueued
+  return enqueue_partial(ctx, d, ws, d_points_xy_le, d_scalars_le, n, d_partials, st, nullptr, 0, false, count);
 }
 
 int te_msm_partial_wait(te_ctx* ctx, int workset) {

@@ -69,46 +69,61 @@ def compute_msm_sharded(ctx, d_points, d_scalars, n: int, partials, dist=None, g
 
 
 class ShardedPipeline:
-    """Window-sharded MSMs with `depth` in flight per rank, each on its own stream and device work set: the all-gather,
-    the 11 KiB read-back and the host tail of MSM i overlap the device work of the following ones (the multi-GPU
-    counterpart of te_msm_submit_device / te_msm_collect).
+    """Window-sharded MSMs with `depth` launch sequences in flight per rank, each on its own stream and device work set: the
+    all-gather, the read-back and the host tail of one overlap the device work of the following ones (the multi-GPU
+    counterpart of te_msm_submit_device / te_msm_collect).  With batch > 1 a launch sequence carries up to `batch` MSMs
+    (te_msm_partial_device_batch): a rank's W/D windows per MSM are too little work for kernels of their own, so the windows
+    of several MSMs are sorted, accumulated and reduced together and their rows travel in one all-gather.
 
         pipe = ShardedPipeline(ctx, n, dist)          # ctx: MsmContext with window shard (rank, world)
         t = pipe.submit(d_points, d_scalars); ...; xy = pipe.collect(t)      # collect in submission order
+        t = pipe.submit_batch([(p0, s0), (p1, s1)]); ...; [xy0, xy1] = pipe.collect_batch(t)
     """
 
-    def __init__(self, ctx, n: int, dist, group=None, depth: int = 2):
+    def __init__(self, ctx, n: int, dist, group=None, depth: int = 2, batch: int = 1):
         import torch
-        from .binding import WORKSETS
+        from .binding import WORKSETS, MAX_BATCH
 
-        assert 1 <= depth <= WORKSETS
-        self.depth = depth
+        assert 1 <= depth <= WORKSETS and 1 <= batch <= MAX_BATCH
+        self.depth, self.batch = depth, batch
 
         self.torch, self.ctx, self.n, self.dist, self.group = torch, ctx, n, dist, group
         self.world = dist.get_world_size(group)
         self.c, self.W = ctx.plan(n)
         self.bucket_bits = self.c - 1 if ctx.get_option("signed_digits") else self.c
         self.curve = ctx.curve
-        nbytes = self.W * ctx.row_bytes
+        self.row_block = self.W * ctx.row_bytes                      # one MSM's rows
+        nbytes = batch * self.row_block
         self.gloo = dist.get_backend(group) == "gloo"
         self.part = [torch.zeros(nbytes, dtype=torch.uint8, device="cuda") for _ in range(depth)]
         gdev = "cpu" if self.gloo else "cuda"
         self.gathered = [torch.zeros(self.world * nbytes, dtype=torch.uint8, device=gdev) for _ in range(depth)]
         self.host = [torch.zeros(self.world * nbytes, dtype=torch.uint8).pin_memory() for _ in range(depth)]
         self.copy_stream = torch.cuda.Stream()
-        self.compute_streams = [torch.cuda.Stream() for _ in range(depth)]   # one per work set: the MSMs overlap on the GPU
+        self.compute_streams = [torch.cuda.Stream() for _ in range(depth)]   # one per work set: the sequences overlap on the GPU
         self.ev = [torch.cuda.Event() for _ in range(depth)]
+        self.count = [0] * depth
         self.next_ticket = self.next_collect = 0
 
     def submit(self, d_points, d_scalars) -> int:
+        return self.submit_batch([(d_points, d_scalars)])
+
+    def submit_batch(self, inputs) -> int:
+        """inputs: 1..batch pairs (d_points, d_scalars) of CUDA uint8 tensors, all of n points."""
         torch = self.torch
-        assert self.next_ticket - self.next_collect < self.depth, "every slot has an MSM in flight"
+        assert 1 <= len(inputs) <= self.batch, "between 1 and `batch` MSMs per launch sequence"
+        assert self.next_ticket - self.next_collect < self.depth, "every slot has a launch sequence in flight"
         slot = self.next_ticket % self.depth
+        self.count[slot] = len(inputs)
         cur = self.compute_streams[slot]
         cur.wait_stream(torch.cuda.current_stream())    # the caller's inputs are ready on its stream
-        self.ctx.set_option("workset", slot)            # the slot's previous MSM was collected: its buffers are free
+        self.ctx.set_option("workset", slot)            # the slot's previous sequence was collected: its buffers are free
         with torch.cuda.stream(cur):                    # (rows of windows this rank does not own stay zero from allocation)
-            self.ctx.partial_device(d_points.data_ptr(), d_scalars.data_ptr(), self.n, self.part[slot].data_ptr(), cur.cuda_stream)
+            if len(inputs) == 1:
+                self.ctx.partial_device(inputs[0][0].data_ptr(), inputs[0][1].data_ptr(), self.n, self.part[slot].data_ptr(), cur.cuda_stream)
+            else:
+                self.ctx.partial_device_batch([p.data_ptr() for p, _ in inputs], [s.data_ptr() for _, s in inputs], self.n,
+                                              self.part[slot].data_ptr(), cur.cuda_stream)
             if self.gloo:                               # rehearsal path (no CUDA all_gather in gloo): blocking
                 src = self.part[slot].cpu()
                 self.dist.all_gather_into_tensor(self.gathered[slot], src, group=self.group)
@@ -126,10 +141,22 @@ class ShardedPipeline:
         return t
 
     def collect(self, ticket: int) -> bytes:
+        out = self.collect_batch(ticket)
+        assert len(out) == 1, "a batch was submitted under this ticket: use collect_batch"
+        return out[0]
+
+    def collect_batch(self, ticket: int):
         from .binding import finalize_gathered
         assert ticket == self.next_collect, "collect in submission order"
         slot = ticket % self.depth
         self.ev[slot].synchronize()
         self.next_collect += 1
         self.ctx.partial_wait(slot)                     # done already (the copy is ordered behind it): reports scalar-range errors
-        return finalize_gathered(self.host[slot].data_ptr(), self.world, self.c, self.W, self.bucket_bits, self.curve)
+        if self.batch == 1:
+            return [finalize_gathered(self.host[slot].data_ptr(), self.world, self.c, self.W, self.bucket_bits, self.curve)]
+        rows = self.host[slot].view(self.world, self.batch, self.row_block)       # [rank][MSM][W rows]
+        out = []
+        for m in range(self.count[slot]):
+            mine = rows[:, m, :].contiguous()
+            out.append(finalize_gathered(mine.data_ptr(), self.world, self.c, self.W, self.bucket_bits, self.curve))
+        return out
