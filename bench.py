@@ -322,8 +322,8 @@ def main():
                    "points_note": ("chain = n distinct subgroup points (a + i*b)*G, an arithmetic progression generated by te_msm_synth_inputs "
                                    "(SURVEY 8d asks for seeded-random a_i*G: performance-equivalent -- every point is a distinct, "
                                    "uniformly spread field element; tests/ use the oracle's seeded-random points)") if args.points == "chain" else "harness mode: one fixed point replicated",
-                   "parallelism": "windows sharded over %d rank(s), one %s all-gather of %d B partial sums per MSM"
-                                  % (world, "RCCL" if (world > 1 and dist.get_backend() == "nccl") else "gloo (rehearsal: ranks share one GPU)", W * 720) if world > 1 else "single GPU"},
+                   "parallelism": "windows sharded over %d rank(s), one %s all-gather of %d B partial sums per launch sequence of %d MSM(s)"
+                                  % (world, "RCCL" if (world > 1 and dist.get_backend() == "nccl") else "gloo (rehearsal: ranks share one GPU)", batch * W * 720, batch) if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_info": traffic_info,
                      "algorithmic_bytes_per_launch": acc_bytes_rank * last, "kernel_ms": acc_ms * last, "msms_per_launch": last,

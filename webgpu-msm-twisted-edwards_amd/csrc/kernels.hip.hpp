@@ -95,19 +95,30 @@ __global__ void __launch_bounds__(TE_DIG_THREADS) k_digits(const uint4* __restri
   const uint32_t half_stride = prm.nst >> 1;
   const uint32_t ZERO_DIGIT = prm.zero_digit;
   bool bad = false;
-  for (uint32_t step = 0; step < TE_DIG_BLOCK / (2u * TE_DIG_THREADS); step++) {
-    const uint32_t pair = (blockIdx.x * (TE_DIG_BLOCK / (2u * TE_DIG_THREADS)) + step) * TE_DIG_THREADS + threadIdx.x, i0 = 2u * pair;
+  // every load of the block's two steps is issued before the first digit is extracted (one memory latency, not two)
+  constexpr uint32_t STEPS = TE_DIG_BLOCK / (2u * TE_DIG_THREADS);
+  const size_t st = prm.sc_stride;
+  uint4 ld[STEPS][6];
+#pragma unroll
+  for (uint32_t step = 0; step < STEPS; step++) {
+    const uint32_t i0 = 2u * ((blockIdx.x * STEPS + step) * TE_DIG_THREADS + threadIdx.x);
+    const size_t ia = min(i0, prm.n - 1u), ib = min(i0 + 1u, prm.n - 1u);        // clamped: unconditional loads
+    ld[step][0] = scalars[st * ia]; ld[step][1] = scalars[st * ia + 1]; ld[step][2] = scalars[st * ib]; ld[step][3] = scalars[st * ib + 1];
+    ld[step][4] = ld[step][5] = make_uint4(0u, 0u, 0u, 0u);
+    if (st == 3) { ld[step][4] = scalars[st * ia + 2]; ld[step][5] = scalars[st * ib + 2]; }
+  }
+#pragma unroll
+  for (uint32_t step = 0; step < STEPS; step++) {
+    const uint32_t pair = (blockIdx.x * STEPS + step) * TE_DIG_THREADS + threadIdx.x, i0 = 2u * pair;
     if (i0 >= prm.nst) break;
     if (i0 >= prm.n) {                                   // padding entries: digit 0
       for (int k = 0; k < prm.nw_local; k++) out[(size_t)k * half_stride + pair] = ZERO_DIGIT | (ZERO_DIGIT << 16);
       continue;
     }
     const bool second = i0 + 1u < prm.n;
-    const size_t j1 = second ? (size_t)i0 + 1 : (size_t)i0;       // clamped: unconditional loads
-    const size_t st = prm.sc_stride;
-    const uint4 a0 = scalars[st * i0], a1 = scalars[st * i0 + 1], b0 = scalars[st * j1], b1 = scalars[st * j1 + 1];
-    if (st == 3) {                                        // 48-byte records hold values below 2^256
-      const uint4 a2 = scalars[st * i0 + 2], b2 = scalars[st * j1 + 2];
+    const uint4 a0 = ld[step][0], a1 = ld[step][1], b0 = ld[step][2], b1 = ld[step][3];
+    {                                                     // 48-byte records hold values below 2^256
+      const uint4 a2 = ld[step][4], b2 = ld[step][5];
       bad |= (a2.x | a2.y | a2.z | a2.w | b2.x | b2.y | b2.z | b2.w) != 0u;
     }
     uint32_t s[2][10] = {{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, 0u, 0u}, {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, 0u, 0u}};
@@ -125,6 +136,7 @@ __global__ void __launch_bounds__(TE_DIG_THREADS) k_digits(const uint4* __restri
       const int bit = w * C;
       if (bit >= 288) break;
       const int word = bit >> 5, off = bit & 31;
+      if (w < prm.num_windows && w != next) continue;    // a window of another shard (uniform): nothing to extract
       uint32_t v[2];
 #pragma unroll
       for (int t = 0; t < 2; t++) {
