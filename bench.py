@@ -291,14 +291,14 @@ def main():
 
     # VALU-issue roofline of the dominant kernel: wave instructions per launch from the ISA listing
     # (profiles/r02_isa_hist_k_accumulate.txt) x measured issue cost against 1024 SIMDs
-    per_point_cycles = None if bls else 6553.0            # estimated VALU issue cycles per 64 accumulated points (tools/isa_hist.py)
+    per_point_cycles = 15536.0 if bls else 6127.0           # estimated VALU issue cycles per 64 accumulated points (tools/isa_hist.py)
     valu = None
     if per_point_cycles and acc_ms > 0:
         waves = (W / div) * n / 64.0
         floor_ms = waves * per_point_cycles / 1024.0 / 2.4e6          # at the 2.4 GHz peak clock
         valu = {"bound": "valu-issue", "floor_ms_at_2.4GHz": floor_ms, "kernel_ms": acc_ms, "frac": floor_ms / acc_ms,
                 "alone_frac": floor_ms / stage_ms["accumulate"] if stage_ms.get("accumulate") else None,
-                "note": "1134 v_mad_u64_u32 (4.49 clk each, half rate) + ~450 full-rate VALU instructions per accumulated point and wave"}
+                "note": ("2912 v_mad_u64_u32 + 750 other VALU instructions" if bls else "1071 v_mad_u64_u32 (4.49 clk each) + 406 other VALU instructions") + " per accumulated point and wave (profiles/r02_isa_hist_k_accumulate.txt)"}
 
     out = {
         "metric": "MSMs/sec at n=2^%d %s (pipelined throughput = 1000/ms_per_step; single-MSM latency in latency_ms)" % (args.log2n, "BLS12-377 G1" if bls else "Twisted-Edwards BLS12"),

@@ -5,7 +5,7 @@ usage: tools/isa_hist.py <listing.s> <kernel-substring> [--loop]
   --loop   restrict to the hottest loop: the basic blocks between the LAST backward branch target and that branch
            (k_accumulate's per-point loop)
 Prints the count per mnemonic and per class, with the issue cost measured by tools/ubench.hip
-(profiles/r01_ubench_instruction_rates.txt: cycles per wave instruction at 4 waves/SIMD).
+(profiles/r01_ubench_instruction_rates.txt, r02_ubench_instruction_rates.txt: cycles per wave instruction at 4 waves/SIMD).
 """
 import re
 import sys
@@ -16,7 +16,9 @@ COST = {"v_mad_u64_u32": 4.49, "v_add_u32": 2.62, "v_sub_u32": 2.62, "v_subrev_u
         "v_mov_b32": 2.41, "v_lshrrev_b64": 4.17, "v_lshlrev_b64": 4.17, "v_lshl_add_u64": 4.17, "v_cndmask_b32": 4.29, "v_add3_u32": 4.29,
         "v_lshrrev_b32": 2.62, "v_lshlrev_b32": 2.62, "v_alignbit_b32": 4.28, "v_and_or_b32": 4.29, "v_lshl_or_b32": 4.29, "v_lshl_add_u32": 4.29,
         "v_bfe_u32": 4.29, "v_add_co_u32": 4.19, "v_addc_co_u32": 4.19, "v_sub_co_u32": 4.19, "v_subb_co_u32": 4.19, "v_mul_lo_u32": 4.30,
-        "v_mul_hi_u32": 4.27}
+        "v_mul_hi_u32": 4.27,
+        # profiles/r02_ubench_instruction_rates.txt
+        "v_bitop3_b32": 2.71, "v_not_b32": 2.46, "v_sad_u32": 4.31}
 
 
 def kernel_body(lines, name):

@@ -70,6 +70,12 @@ KERNEL32(k_sub_co_chain, "v_sub_co_u32 %0, vcc, %0, %1\n\tv_subb_co_u32 %0, vcc,
 KERNEL32(k_addc_pair, "v_add_co_u32 %0, vcc, %0, %1\n\tv_addc_co_u32 %0, vcc, %0, %2, vcc")
 KERNEL32(k_alignbit, "v_alignbit_b32 %0, %0, %1, 13")
 KERNEL32(k_and_or, "v_and_or_b32 %0, %0, %1, %2")
+KERNEL32(k_bitop3, "v_bitop3_b32 %0, %0, %1, %0 bitop3:0xc")
+KERNEL32(k_sad_u32, "v_sad_u32 %0, %0, %1, %2")
+KERNEL32(k_not_b32, "v_not_b32 %0, %0")
+KERNEL32(k_lshrrev_b32, "v_lshrrev_b32 %0, 3, %0")
+KERNEL32(k_and_b32, "v_and_b32 %0, %0, %1")
+KERNEL32(k_sub_u32, "v_sub_u32 %0, %1, %0")
 KERNEL64(k_mad_u64_u32, "v_mad_u64_u32 %0, vcc, %1, %2, %0")
 KERNEL64(k_mad_u64_u32_addc, "v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc")
 KERNEL64(k_lshl_add_u64, "v_lshl_add_u64 %0, %0, 0, %0")
@@ -84,7 +90,7 @@ struct entry { const char* name; kern_t k; int instrs_per_slot; };
 int main() {
   std::vector<entry> es = {
     {"v_add_u32", k_add_u32, 1}, {"v_mov_b32", k_mov_b32, 1}, {"v_add3_u32", k_add3_u32, 1}, {"v_fma_f32", k_fma_f32, 1},
-    {"v_cndmask_b32", k_cndmask, 1}, {"v_cndmask_b32_e64 (sgpr)", k_cndmask_e64, 1}, {"v_cmp+v_cndmask (pair)", k_cmp_cndmask, 2}, {"v_sub_co+v_subb_co (pair)", k_sub_co_chain, 2}, {"v_alignbit_b32", k_alignbit, 1}, {"v_and_or_b32", k_and_or, 1},
+    {"v_cndmask_b32", k_cndmask, 1}, {"v_cndmask_b32_e64 (sgpr)", k_cndmask_e64, 1}, {"v_cmp+v_cndmask (pair)", k_cmp_cndmask, 2}, {"v_sub_co+v_subb_co (pair)", k_sub_co_chain, 2}, {"v_alignbit_b32", k_alignbit, 1}, {"v_and_or_b32", k_and_or, 1}, {"v_bitop3_b32", k_bitop3, 1}, {"v_sad_u32", k_sad_u32, 1}, {"v_not_b32", k_not_b32, 1}, {"v_lshrrev_b32", k_lshrrev_b32, 1}, {"v_and_b32", k_and_b32, 1}, {"v_sub_u32", k_sub_u32, 1},
     {"v_add_co+v_addc_co (pair)", k_addc_pair, 2},
     {"v_mul_lo_u32", k_mul_lo_u32, 1}, {"v_mul_hi_u32", k_mul_hi_u32, 1}, {"v_mad_u64_u32", k_mad_u64_u32, 1},
     {"v_mad_u64_u32+v_addc_co (pair)", k_mad_u64_u32_addc, 2},
