@@ -28,16 +28,16 @@ while time.time() < t_end:
                  ("graph", rnd.choice([0, 0, 1])), ("profile", rnd.choice([0, 0, 1, 2]))):
         ctx.set_option(k, v)
         opts[k] = v
-    batch = []
+    mode = rnd.choice(["run", "run", "tickets", "tickets", "shards", "batch"])
+    batch, n_common = [], int(2 ** rnd.uniform(0, 17.5))
     for _ in range(rnd.randint(1, pkg.WORKSETS)):
-        n = int(2 ** rnd.uniform(0, 20.2 if rnd.random() < 0.05 else 17.5))
+        n = n_common if mode == "batch" else int(2 ** rnd.uniform(0, 20.2 if rnd.random() < 0.05 else 17.5))      # one launch sequence takes MSMs of one size
         seed = rnd.randrange(1 << 30)
         pts, sc = orc.gen_points(seed, n), orc.gen_scalars(seed, n)
         if rnd.random() < 0.2:
             sc = sc[:sb] * n
         batch.append((pts, sc, n))
     exp = [orc.msm(p, s, threads=8) for p, s, _ in batch]
-    mode = rnd.choice(["run", "run", "tickets", "tickets", "shards"])
     if mode == "run":
         got = [ctx.run(p, s) for p, s, _ in batch]
     elif mode == "shards":
@@ -58,6 +58,25 @@ while time.time() < t_end:
             ctx.set_window_shard(0, 1)
             ctx.set_option("workset", 0)
             got.append(pkg.finalize_host(pkg.merge_partials(rows, W, world, ctx.row_bytes), cb, W, None if opts["signed_digits"] else cb, curve=ctx.curve))
+    elif mode == "batch":
+        world = rnd.choice([1, 2, 4, 8])
+        n = batch[0][2]
+        dev = [(torch.frombuffer(bytearray(p), dtype=torch.uint8).cuda(), torch.frombuffer(bytearray(s), dtype=torch.uint8).cuda()) for p, s, _ in batch]
+        cb, W = ctx.plan(n)
+        blk = W * ctx.row_bytes
+        per_rank = []
+        for r in range(world):
+            ctx.set_window_shard(r, world)
+            ctx.set_option("workset", r % pkg.WORKSETS)
+            part = torch.zeros(len(dev) * blk, dtype=torch.uint8, device="cuda")
+            ctx.partial_device_batch([a.data_ptr() for a, _ in dev], [b.data_ptr() for _, b in dev], n, part.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            ctx.partial_wait(r % pkg.WORKSETS)
+            per_rank.append(part.cpu().numpy().tobytes())
+        ctx.set_window_shard(0, 1)
+        ctx.set_option("workset", 0)
+        got = [pkg.finalize_host(pkg.merge_partials([rows[m * blk:(m + 1) * blk] for rows in per_rank], W, world, ctx.row_bytes), cb, W,
+                                 None if opts["signed_digits"] else cb, curve=ctx.curve) for m in range(len(dev))]
     else:
         dev = [(torch.frombuffer(bytearray(p), dtype=torch.uint8).cuda(), torch.frombuffer(bytearray(s), dtype=torch.uint8).cuda(), n) for p, s, n in batch]
         torch.cuda.synchronize()
