@@ -654,6 +654,8 @@ template <int N> __device__ __forceinline__ ete_t<N> load_ete(const ete_t<N>* sr
   return a;
 }
 
+struct __attribute__((aligned(4))) idx4 { uint32_t v[4]; };      // 16 bytes at 4-byte alignment: one global_load_dwordx4
+#define TE_IDX_STRIP 16u       // sorted indices a lane fetches at a time (k_accumulate); d_sorted is padded by as many words
 // registers: N = 9 fits four waves per SIMD (128 VGPRs); N = 14 holds 56 + 2 x 56 words of points alone: two waves
 template <int N>
 __global__ void __launch_bounds__(256, N == 9 ? 4 : 2) k_accumulate(const rec_slot<N>* __restrict__ recs, const uint32_t* __restrict__ sorted,
@@ -663,6 +665,7 @@ __global__ void __launch_bounds__(256, N == 9 ? 4 : 2) k_accumulate(const rec_sl
                                                     const uint32_t* __restrict__ num_segments, ete_t<N>* __restrict__ buckets,
                                                     ete_t<N>* __restrict__ seg_out, uint32_t n, uint32_t logB, uint32_t seg_len, uint32_t ids, uint32_t onto,
                                                     uint32_t win_per_msm) {
+  __shared__ uint32_t idx_strip[256 * TE_IDX_STRIP];
   const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
   if (gid >= (order ? *num_segments : ids)) return;
   const uint32_t sgm = order ? order[gid] : gid;
@@ -693,10 +696,27 @@ __global__ void __launch_bounds__(256, N == 9 ? 4 : 2) k_accumulate(const rec_sl
       acc = ete_from_pnt(first);
       j0 = 1;
     }
+    // Indices come through a private LDS strip, TE_IDX_STRIP at a time: a lane's list is 4 B per addition, and between two of its
+    // accesses the wave front has pulled megabytes of records through the L2 -- read one by one, every index access
+    // re-fetched its 128-byte line (profiles/r02_pmc_l2_k_accumulate.txt: 6 M extra lines per launch).  Entries beyond the
+    // lane's segment are other lists' (or the 16 words of padding behind `sorted`) and are never used.
+    uint32_t* const strip = idx_strip + threadIdx.x * TE_IDX_STRIP;
+    auto refill = [&](uint32_t pos) {                      // two rounds of eight: the second one finds the line in the L2
+      const idx4* src = reinterpret_cast<const idx4*>(lst + pos);
+      idx4* dst = reinterpret_cast<idx4*>(strip);
+#pragma unroll
+      for (uint32_t h = 0; h < TE_IDX_STRIP / 4u; h += 2u) {
+        const idx4 v0 = src[h], v1 = src[h + 1u];
+        dst[h] = v0; dst[h + 1u] = v1;
+      }
+    };
+    if (((j0 + 2u) & (TE_IDX_STRIP - 1u)) != 0u) refill((j0 + 2u) & ~(TE_IDX_STRIP - 1u));
     for (uint32_t j = j0; j < cnt; j++) {
       const uint32_t e_cur = e;
       pnt_t<N> nxt = cur;
-      const uint32_t e_nn = lst[min(j + 2u, last)];            // unconditional, clamped
+      const uint32_t pn = j + 2u;
+      if ((pn & (TE_IDX_STRIP - 1u)) == 0u) refill(pn);
+      const uint32_t e_nn = strip[pn & (TE_IDX_STRIP - 1u)];
       if (j + 1 < cnt) { e = e_n; nxt = load_pnt<N>(recs, e); }
       acc = ete_madd(acc, pnt_cneg(cur, (e_cur >> 31) != 0u));
       cur = nxt; e_n = e_nn;

@@ -191,7 +191,8 @@ template <typename T> int ensure(te_ctx* ctx, workset_t& ws, T*& ptr, size_t& ca
 
 int ensure_buffers(te_ctx* ctx, gpu_t& d, workset_t& ws, uint64_t n, const plan_t& p) {
   HIP_TRY(ctx, hipSetDevice(d.device));
-  const size_t nd = (size_t)p.nw * p.nst + 16, wb = (size_t)p.nw * p.B, ab = sizes_of(p.curve).acc;
+  // + 64: k_accumulate fetches its sorted indices TE_IDX_STRIP at a time and may read that far past the end of a list
+  const size_t nd = (size_t)p.nw * p.nst + 64, wb = (size_t)p.nw * p.B, ab = sizes_of(p.curve).acc;
   int rc = 0;
   if ((rc = ensure(ctx, ws, ws.d_recs, ws.cap[0], (size_t)n * sizes_of(p.curve).rec * (size_t)p.batch))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_digits, ws.cap[1], nd))) return rc;
