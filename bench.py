@@ -291,7 +291,7 @@ def main():
 
     # VALU-issue roofline of the dominant kernel: wave instructions per launch from the ISA listing
     # (profiles/r02_isa_hist_k_accumulate.txt) x measured issue cost against 1024 SIMDs
-    per_point_cycles = 15536.0 if bls else 6127.0           # estimated VALU issue cycles per 64 accumulated points (tools/isa_hist.py)
+    per_point_cycles = 15545.0 if bls else 6136.0           # estimated VALU issue cycles per 64 accumulated points (tools/isa_hist.py)
     valu = None
     if per_point_cycles and acc_ms > 0:
         waves = (W / div) * n / 64.0

@@ -5,7 +5,7 @@ REPO="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$REPO/gpurun_out/prof_shard"; rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp TE_BENCH_FORCE_DIST=1 TE_BENCH_REHEARSE_WORLD=${1:-8}
 cd /tmp
-rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -- python3 $REPO/bench.py --steps 60 --warmup 3 --no-cpu-baseline > "$OUT/trace.log" 2>&1 || { tail -5 "$OUT/trace.log"; exit 1; }
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -- python3 $REPO/bench.py --steps 1024 --warmup 3 --no-cpu-baseline --no-sizes --no-host-buffers > "$OUT/trace.log" 2>&1 || { tail -5 "$OUT/trace.log"; exit 1; }
 python3 - "$OUT" <<'PY'
 import csv, glob, os, sys
 from collections import defaultdict
@@ -31,8 +31,9 @@ for s, e, _ in sel:
         cur_e = max(cur_e, e)
 busy += cur_e - cur_s
 span = hi - lo
-n_acc = i1 - i0
-print("window %.2f ms, %d MSMs (k_accumulate launches) -> %.3f ms per MSM; GPU has at least one kernel running %.0f %% of the time" % (span / 1e6, n_acc, span / 1e6 / max(n_acc, 1), 100.0 * busy / span))
+n_seq = i1 - i0
+n_acc = sum(1 for r in sel if r[2] == "k_digits")          # one k_digits launch per MSM; a launch sequence may carry several (--batch)
+print("window %.2f ms, %d launch sequences (k_accumulate launches) carrying %d MSMs -> %.3f ms per MSM; GPU has at least one kernel running %.0f %% of the time" % (span / 1e6, n_seq, n_acc, span / 1e6 / max(n_acc, 1), 100.0 * busy / span))
 print("sum of kernel durations per MSM: %.0f us (overlapped kernels counted separately)" % (sum(sum(v) for v in dur.values()) / max(n_acc, 1)))
 for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
     print("%-28s n=%4d mean %7.1f us  per MSM %7.1f us" % (k[:28], len(v), sum(v) / len(v), sum(v) / max(n_acc, 1)))
