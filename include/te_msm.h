@@ -124,7 +124,8 @@ int te_msm_partial_device(te_ctx* ctx, const void* d_points_xy_le, const void* d
  * d_scalars_le[m] (arrays of device pointers, in host memory, read before the call returns) and its W rows go to
  * d_partials + m * W * row bytes.  The windows of the batch are sorted, accumulated and reduced together, as if they were
  * count x (windows of this shard) windows of one MSM: what a rank of a D-GPU window-sharded job needs, because its W/D windows per
- * MSM are too little work for a launch sequence of their own (measured at D = 8: 0.26 ms per MSM one by one).  There is no reference
+ * MSM are too little work for a launch sequence of their own (rehearsed per-rank step at D = 8: 0.27 ms per MSM one by one,
+ * 0.20 ms in batches of eight).  There is no reference
  * counterpart: the reference awaits one compute_msm at a time (full_benchmarks.ts:97-110).  A scalar out of range anywhere
  * in the batch fails the whole batch (te_msm_partial_wait).  Same work set and stream rules as te_msm_partial_device. */
 #define TE_MSM_MAX_BATCH 8
