@@ -287,6 +287,19 @@ t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
 merged = pkg.exchange_partials(t, W, dist)
 res = pkg.finalize_host(merged, c, W)
 assert res == o.msm(pts, sc), "rank %d mismatch" % rank
+# a launch sequence carrying three MSMs (te_msm_partial_device_batch): rows [MSM][W] per rank, ONE all-gather, the gathered
+# finalize per MSM -- what ShardedPipeline.collect_batch does with the GPU's rows
+batch, blk = 3, W * 720
+ins = [(o.gen_points(80 + m, n), o.gen_scalars(90 + m, n)) for m in range(batch)]
+mine = bytearray()
+for p_, s_ in ins:
+    assert L.fpc_partial_rows(p_, s_, n, c, first, step, buf) == 0
+    mine += buf.raw
+gathered = torch.empty(world * batch * blk, dtype=torch.uint8)
+dist.all_gather_into_tensor(gathered, torch.frombuffer(mine, dtype=torch.uint8))
+for m, (p_, s_) in enumerate(ins):
+    rows = pkg.rows_of_batched_msm(gathered, world, batch, m)
+    assert pkg.finalize_gathered(rows.data_ptr(), world, c, W) == o.msm(p_, s_), "rank %d, MSM %d of the batch" % (rank, m)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """

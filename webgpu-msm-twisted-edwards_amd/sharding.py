@@ -68,6 +68,12 @@ def compute_msm_sharded(ctx, d_points, d_scalars, n: int, partials, dist=None, g
     return ctx.finalize(merged, c, W)
 
 
+def rows_of_batched_msm(gathered, world: int, batch: int, m: int):
+    """gathered: the all-gathered rows of a launch sequence that carried `batch` MSMs, a 1-D uint8 CPU tensor laid out
+    [rank][MSM][W rows].  Returns MSM m's rows as a contiguous [rank][W rows] tensor -- the layout finalize_gathered takes."""
+    return gathered.view(world, batch, -1)[:, m, :].contiguous()
+
+
 class ShardedPipeline:
     """Window-sharded MSMs with `depth` launch sequences in flight per rank, each on its own stream and device work set: the
     all-gather, the read-back and the host tail of one overlap the device work of the following ones (the multi-GPU
@@ -154,9 +160,8 @@ class ShardedPipeline:
         self.ctx.partial_wait(slot)                     # done already (the copy is ordered behind it): reports scalar-range errors
         if self.batch == 1:
             return [finalize_gathered(self.host[slot].data_ptr(), self.world, self.c, self.W, self.bucket_bits, self.curve)]
-        rows = self.host[slot].view(self.world, self.batch, self.row_block)       # [rank][MSM][W rows]
         out = []
         for m in range(self.count[slot]):
-            mine = rows[:, m, :].contiguous()
+            mine = rows_of_batched_msm(self.host[slot], self.world, self.batch, m)
             out.append(finalize_gathered(mine.data_ptr(), self.world, self.c, self.W, self.bucket_bits, self.curve))
         return out
