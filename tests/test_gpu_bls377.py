@@ -140,6 +140,31 @@ def test_window_shards_on_one_gpu(pkg, world):
     assert pkg.finalize_host(pkg.merge_partials(rows, cW[1], world, 1120), *cW, curve=pkg.CURVE_BLS12_377_G1) == exp
 
 
+@pytest.mark.parametrize("world,count,n", [(1, 2, 3000), (4, 4, 9000)])
+def test_batches_of_window_sharded_msms(pkg, world, count, n):
+    """te_msm_partial_device_batch for this curve (224-byte record slabs, 1120-byte rows): every MSM of a launch sequence,
+    merged over the ranks, against the oracle"""
+    import torch
+    ins = [(o.gen_points(500 + m, n), o.gen_scalars(520 + m, n)) for m in range(count)]
+    dev = [(_dev(p), _dev(s)) for p, s in ins]
+    per_rank = []
+    for r in range(world):
+        with pkg.MsmContext((0,)) as c:
+            c.set_option("curve", pkg.CURVE_BLS12_377_G1)
+            c.set_window_shard(*pkg.window_shard_for_rank(r, world))
+            cbits, W = c.plan(n)
+            blk = W * c.row_bytes
+            part = torch.zeros(count * blk, dtype=torch.uint8, device="cuda")
+            c.partial_device_batch([p.data_ptr() for p, _ in dev], [s.data_ptr() for _, s in dev], n, part.data_ptr(),
+                                   torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            c.partial_wait(0)
+            per_rank.append(part.cpu().numpy().tobytes())
+    for m, (p_, s_) in enumerate(ins):
+        merged = pkg.merge_partials([rows[m * blk:(m + 1) * blk] for rows in per_rank], W, world, 1120)
+        assert pkg.finalize_host(merged, cbits, W, curve=pkg.CURVE_BLS12_377_G1) == o.msm(p_, s_, threads=8), f"MSM {m} of the batch"
+
+
 def test_giant_buckets_and_host_pieces(bls):
     """skew: all scalars equal (one bucket per window holds every point: thousands of parts summed by the block-level
     combine) and window sizes whose top window has a single occupied bucket; te_msm_run in pieces"""
