@@ -270,7 +270,11 @@ def main():
         elapsed = float(t.item())
 
     ms_per_step = elapsed * 1e3 / args.steps
-    acc_ms_live = stage_acc.get("accumulate", 0.0) / args.steps
+    # the dominant kernel's duration per launch: its own device clock, first wave in .. last wave out (what a kernel trace
+    # reports); the HIP-event interval around the launch is kept beside it -- with several MSMs in flight it also contains the
+    # time the launch waited for CUs held by the other streams' kernels
+    acc_ms_events = stage_acc.get("accumulate", 0.0) / args.steps
+    acc_ms_live = stage_acc.get("accumulate_on_device", 0.0) / args.steps or acc_ms_events
     # full per-stage breakdown from a few extra, untimed steps (an event at every stage boundary costs idle time)
     ctx.set_option("profile", 2)
     stage_acc, extra = {}, 3
@@ -291,13 +295,14 @@ def main():
 
     # VALU-issue roofline of the dominant kernel: wave instructions per launch from the ISA listing
     # (profiles/r02_isa_hist_k_accumulate.txt) x measured issue cost against 1024 SIMDs
+    alone_ms = stage_ms.get("accumulate_on_device") or stage_ms.get("accumulate")
     per_point_cycles = 15545.0 if bls else 6136.0           # estimated VALU issue cycles per 64 accumulated points (tools/isa_hist.py)
     valu = None
     if per_point_cycles and acc_ms > 0:
         waves = (W / div) * n / 64.0
         floor_ms = waves * per_point_cycles / 1024.0 / 2.4e6          # at the 2.4 GHz peak clock
         valu = {"bound": "valu-issue", "floor_ms_at_2.4GHz": floor_ms, "kernel_ms": acc_ms, "frac": floor_ms / acc_ms,
-                "alone_frac": floor_ms / stage_ms["accumulate"] if stage_ms.get("accumulate") else None,
+                "alone_frac": floor_ms / alone_ms if alone_ms else None,
                 "note": ("2912 v_mad_u64_u32 + 750 other VALU instructions" if bls else "1071 v_mad_u64_u32 (4.49 clk each) + 406 other VALU instructions") + " per accumulated point and wave (profiles/r02_isa_hist_k_accumulate.txt)"}
 
     out = {
@@ -329,9 +334,10 @@ def main():
                      "algorithmic_bytes_per_launch": acc_bytes_rank * last, "kernel_ms": acc_ms * last, "msms_per_launch": last,
                      # the timed region keeps `depth` MSMs in flight: the kernel shares the GPU with the other MSMs' kernels,
                      # so its duration there is longer than when it has the GPU to itself (untimed single-MSM pass)
-                     "alone": {"kernel_ms": stage_ms.get("accumulate"),
-                               "achieved": acc_bytes_rank / (stage_ms["accumulate"] * 1e-3) / 1e9 if stage_ms.get("accumulate") else None,
-                               "frac": acc_bytes_rank / (stage_ms["accumulate"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if stage_ms.get("accumulate") else None},
+                     "kernel_ms_event_interval": acc_ms_events * last,
+                     "alone": {"kernel_ms": alone_ms, "kernel_ms_event_interval": stage_ms.get("accumulate"),
+                               "achieved": acc_bytes_rank / (alone_ms * 1e-3) / 1e9 if alone_ms else None,
+                               "frac": acc_bytes_rank / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if alone_ms else None},
                      "binding_roofline": valu,
                      "note": ("VALU-bound: 8 products of 14-limb operands per gathered point" if bls else
                               "the north star names the HBM roofline; the kernel is VALU-issue bound (7 field products per gathered "

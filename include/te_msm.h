@@ -171,8 +171,10 @@ int te_msm_synth_inputs(uint64_t seed, uint64_t n, int fixed_point, uint8_t* poi
 int te_msm_synth_inputs_bls12_377(uint64_t seed, uint64_t n, uint8_t* points_xy_le, uint8_t* scalars_le);
 
 /* ---- measurement / stage verification (the reference's `debug` flags, submission.ts:892-1363) --- */
-/* Per-stage device time of the last run in ms (needs option "profile" >= 1; level 1 reports "accumulate" only).  Returns the number of
- * stages written; names[i] points to static strings. */
+/* Per-stage device time of the last run in ms (needs option "profile" >= 1; level 1 reports "accumulate" only), from HIP events
+ * on the engine's stream, plus "accumulate_on_device": the dominant kernel's own device clock from its first wave in to its last
+ * wave out -- what a kernel trace reports; with several MSMs in flight the event interval also contains the time the launch
+ * waited behind other streams' kernels.  Returns the number of stages written; names[i] points to static strings. */
 int te_msm_stage_ms(te_ctx* ctx, float* ms, const char** names, int max_stages);
 /* Copies an intermediate buffer of the last run to host memory.  stage is one of
  * "records" (n x 128 B), "digits" / "part_keys" (nw rows of u16, row stride n rounded up to 8), "part_idx" (same rows, u32),

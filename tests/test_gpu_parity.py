@@ -560,6 +560,14 @@ def test_host_buffers_in_pieces(pkg, model, ora):
         assert c.collect(t) == exp
         c.set_option("profile", 2)                                     # stage timing refers to one whole MSM
         assert c.run(pts, sc) == exp and "accumulate" in c.stage_ms()
+        # the dominant kernel also reports its own device clock (first wave in .. last wave out): inside the event interval
+        for level in (1, 2):
+            c.set_option("profile", level)
+            assert c.run_device(dp.data_ptr(), ds.data_ptr(), n) == exp
+            st = c.stage_ms()
+            assert 0.0 < st["accumulate_on_device"] <= st["accumulate"] * 1.02 + 0.01, st
+        c.set_option("profile", 0)
+        assert c.run_device(dp.data_ptr(), ds.data_ptr(), n) == exp
 
 
 def test_two_work_sets_overlap_on_two_streams(pkg, model, ora):

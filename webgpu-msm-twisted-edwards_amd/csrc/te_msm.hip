@@ -32,8 +32,9 @@ thread_local std::string g_init_error;
 // in execution order: everything that needs only the scalars first, so that a host-buffer call can upload the points
 // (2/3 of the bytes) while those stages already run
 enum { ST_DIGITS = 0, ST_SCATTER, ST_BSORT, ST_ORDER, ST_PREP, ST_ACCUM, ST_TREE, ST_WEIGHTED, ST_COUNT };
-const char* const kStageNames[ST_COUNT] = {"digits", "part_scatter", "bucket_sort", "order", "prep_points",
-                                           "accumulate", "marginal_sums", "weighted_sum"};
+// the last entry is not an event interval: k_accumulate's own first-wave-in .. last-wave-out device clock
+const char* const kStageNames[ST_COUNT + 1] = {"digits", "part_scatter", "bucket_sort", "order", "prep_points",
+                                               "accumulate", "marginal_sums", "weighted_sum", "accumulate_on_device"};
 
 // per-curve sizes: wire format, device accumulator, record slot, partial row (5 points), result
 struct curve_sizes { size_t point_in, scalar_in, acc, rec, row, result; };
@@ -91,13 +92,16 @@ struct workset_t {
   hipGraphExec_t g_front = nullptr, g_back = nullptr; graph_key g_key = {};
 };
 constexpr int TE_MAX_WINDOWS = 64;    // window_bits >= 4
-constexpr size_t Z_ROWS = 8, Z_HIST = Z_ROWS + (size_t)TE_MAX_WINDOWS * TE_MAX_ROW_BYTES / 4, Z_CURSOR = Z_HIST + 1024 * TE_HIST_COPIES, Z_END = Z_CURSOR + 1024;
+// words 8..11 of the block: two 64-bit device clock readings of k_accumulate (first wave in, last wave out), see Z_CLOCK
+constexpr size_t Z_CLOCK = 8;
+constexpr size_t Z_ROWS = 12, Z_HIST = Z_ROWS + (size_t)TE_MAX_WINDOWS * TE_MAX_ROW_BYTES / 4, Z_CURSOR = Z_HIST + 1024 * TE_HIST_COPIES, Z_END = Z_CURSOR + 1024;
 
 struct gpu_t {
   int device = 0;
   int w_first = 0, w_step = 1;
   workset_t ws[TE_MSM_WORKSETS];
   int last_ws = 0;
+  int wall_clock_khz = 0;                // rate of wall_clock64() on this device
   void *d_in_points = nullptr, *d_in_scalars = nullptr; uint64_t cap_in = 0;   // te_msm_run staging
   uint64_t next_ticket = 1, next_collect = 1;
   int ticket_ws[TE_MSM_WORKSETS] = {};   // work set of ticket t at index t % TE_MSM_WORKSETS
@@ -118,7 +122,7 @@ struct te_ctx {
   int opt_host_chunks = 0;     // te_msm_run: pieces a large host buffer is uploaded and processed in (0 = choose from n)
   int opt_graph = 0;           // replay the launch sequence around k_accumulate as HIP graphs
   int opt_workset = 0;         // work set used by te_msm_run* / te_msm_partial_device
-  float stage_ms[ST_COUNT] = {};
+  float stage_ms[ST_COUNT + 1] = {};
   bool have_stage_ms = false;
 };
 
@@ -343,7 +347,8 @@ struct msm_launch {
       hipLaunchKernelGGL(te::k_accumulate<N>, dim3((smax + 255) / 256), dim3(256), 0, stream, reinterpret_cast<const te::rec_slot<N>*>(ws.d_recs), ws.d_sorted,
                          ws.d_bucket_start, ws.d_bucket_count, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv, order, ws.d_num_seg,
                          reinterpret_cast<te::ete_t<N>*>(ws.d_buckets), reinterpret_cast<te::ete_t<N>*>(ws.d_seg_out), n32, p.logB, p.seg_len, smax, onto ? 1u : 0u,
-                         (uint32_t)p.nw1);
+                         (uint32_t)p.nw1,
+                         prof ? reinterpret_cast<unsigned long long*>(ws.d_zero + Z_CLOCK) : nullptr);
     }
     return 0;
   }
@@ -414,7 +419,7 @@ struct msm_launch {
       mark(ST_WEIGHTED);
     }
     mark(ST_COUNT);
-    if (!own_rows) HIP_TRY(ctx, hipMemcpyAsync(ws.h_err, ws.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    if (!own_rows) HIP_TRY(ctx, hipMemcpyAsync(ws.h_err, ws.d_zero, Z_ROWS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));   // flag + clock words
     return 0;
   }
   int reduce() { return bls() ? reduce_t<14>() : reduce_t<9>(); }
@@ -525,6 +530,13 @@ int collect_stage_ms(te_ctx* ctx, workset_t& ws) {
     float ms = -1.0f;
     if (ws.prof_level >= 2 || i == ST_ACCUM) ok = ok && hipEventElapsedTime(&ms, ws.ev[i], ws.ev[i + 1]) == hipSuccess;
     ctx->stage_ms[i] = ms;
+  }
+  {
+    // k_accumulate stamped ~clock of its first wave and the clock of its last one (atomic max on zeroed words); they came
+    // back with the flag.  Unlike the event interval this excludes the time the launch waited behind other streams' kernels.
+    uint64_t c[2]; memcpy(c, ws.h_err + Z_CLOCK, sizeof c);
+    const int khz = ctx->devs[0].wall_clock_khz;      // stage times are a single-device feature
+    ctx->stage_ms[ST_COUNT] = (c[0] && c[1] && khz > 0 && c[1] >= ~c[0]) ? (float)((double)(c[1] - ~c[0]) / khz) : -1.0f;
   }
   if (!ok) (void)hipGetLastError();
   ctx->have_stage_ms = ok;
@@ -735,6 +747,7 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
     d.w_first = i; d.w_step = n_dev;
     if (d.device < 0 || d.device >= count) { g_init_error = "te_msm_init: device id out of range"; delete ctx; return TE_MSM_EINVAL; }
     hipError_t er = hipSetDevice(d.device);
+    if (er == hipSuccess) { int khz = 0; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, d.device) == hipSuccess) d.wall_clock_khz = khz; }
     if (er == hipSuccess)                // k_reduce_tail keeps up to 256 + 16 points in LDS (39 KB / 61 KB)
       er = hipFuncSetAttribute(reinterpret_cast<const void*>(te::k_reduce_tail<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     if (er == hipSuccess)
@@ -969,7 +982,7 @@ int te_msm_stage_ms(te_ctx* ctx, float* ms, const char** names, int max_stages) 
   if (!ctx || !ms) return TE_MSM_EINVAL;
   if (!ctx->have_stage_ms) return set_err(ctx, TE_MSM_ESTATE, "no profiled run yet (set option profile=1)");
   int k = 0;
-  for (int i = 0; i < ST_COUNT && k < max_stages; i++) {
+  for (int i = 0; i < ST_COUNT + 1 && k < max_stages; i++) {
     if (ctx->stage_ms[i] < 0) continue;            // not measured at this profile level
     ms[k] = ctx->stage_ms[i]; if (names) names[k] = kStageNames[i]; k++;
   }
