@@ -17,6 +17,7 @@ n = 2^16..2^20 (full_benchmarks.ts:13-15 runs 16..20).
 """
 import argparse
 import hashlib
+import re
 import importlib
 import json
 import os
@@ -32,10 +33,15 @@ KERNEL_SOURCES = ("kernels.hip.hpp", "curve.hpp", "fp.hpp")     # what decides k
 
 
 def kernel_sources_sha():
+    """hash of the CODE of the kernel sources: comments and white space do not take part, so that re-wording a comment does
+    not declare a profile stale (tools/summarize_prof.py computes the same)"""
     h = hashlib.sha256()
     for f in KERNEL_SOURCES:
-        with open(os.path.join(ROOT, PKG, "csrc", f), "rb") as fh:
-            h.update(fh.read())
+        with open(os.path.join(ROOT, PKG, "csrc", f), "r", errors="replace") as fh:
+            text = fh.read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        h.update(re.sub(r"\s+", "", text).encode())
     return h.hexdigest()[:16]
 
 

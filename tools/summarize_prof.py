@@ -61,8 +61,12 @@ def main(root):
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "webgpu-msm-twisted-edwards_amd", "csrc")
-    for f in ("kernels.hip.hpp", "curve.hpp", "fp.hpp"):          # the same list as bench.py KERNEL_SOURCES
-        h.update(open(os.path.join(csrc, f), "rb").read())
+    import re
+    for f in ("kernels.hip.hpp", "curve.hpp", "fp.hpp"):          # the same list and the same rule as bench.py kernel_sources_sha
+        text = open(os.path.join(csrc, f), "r", errors="replace").read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        h.update(re.sub(r"\s+", "", text).encode())
     json.dump({"workload": "bench.py default (n = 2^20, c = 16, one GPU)", "commit": os.environ.get("TE_COMMIT", "unknown"),
                "kernel_sources_sha": h.hexdigest()[:16],
                "correction": "hbm_bytes_per_launch = %.2f x FETCH_SIZE + WRITE_SIZE (factor: see profiles/r02_fetch_calibration.txt)" % factor,

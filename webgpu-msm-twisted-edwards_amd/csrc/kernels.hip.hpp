@@ -599,7 +599,8 @@ static_assert(sizeof(rec_slot<9>) == sizeof(pnt_slot) && sizeof(rec_slot<14>) ==
 
 // ------------------------------------------------------------------------------------------------
 // K3: bucket accumulation, one thread per segment, scheduled through order[] (or natural order when
-// order == nullptr).  The next record is fetched while the current addition runs.  A bucket that is a single
+// order == nullptr).  The next record is fetched while the current addition runs; the first entry of a segment is not
+// added to the neutral element but converted (ete_from_pnt, 3 products instead of 7).  A bucket that is a single
 // segment is written straight to buckets[]; parts of a split bucket go to seg_out[] for k_seg_combine*.
 // (A variant that fused level 2 of the sort into this kernel -- one block per 256 buckets, lists consumed
 // straight from LDS -- was measured at 2.8 ms against 1.4 ms: block-granular scheduling leaves < 1 wave per
@@ -684,10 +685,11 @@ __global__ void __launch_bounds__(256, N == 9 ? 4 : 2) k_accumulate(const rec_sl
   // buffers in pieces): the first part of every bucket continues from that value instead of the neutral element
   ete_t<N> acc = (onto && part == 0u) ? load_ete<N>(buckets + g) : ete_identity_t<N>();
   if (cnt) {
-    // Software pipeline: while the addition of entry j runs, the record of entry j+1 AND the index of entry j+2 are in
-    // flight -- nothing that is loaded in an iteration is waited for in the same iteration.  (The first version fetched
-    // index j+1 and then its record inside one iteration: an s_waitcnt on the index in front of the record loads, one
-    // memory latency exposed per addition.)
+    // Software pipeline: while the addition of entry j runs, the record of entry j+1 is in flight and the index of entry
+    // j+2 is read from the LDS strip below -- nothing that is loaded in an iteration is waited for in the same iteration
+    // except the strip's refill, once in TE_IDX_STRIP additions.  (The first version fetched index j+1 and then its
+    // record inside one iteration: an s_waitcnt on the index in front of the record loads, one memory latency exposed
+    // per addition.)
     const uint32_t last = cnt - 1u;
     uint32_t j0 = 0;
     uint32_t e = lst[0], e_n = lst[min(1u, last)];
@@ -700,10 +702,11 @@ __global__ void __launch_bounds__(256, N == 9 ? 4 : 2) k_accumulate(const rec_sl
       acc = ete_from_pnt(first);
       j0 = 1;
     }
-    // Indices come through a private LDS strip, TE_IDX_STRIP at a time: a lane's list is 4 B per addition, and between two of its
-    // accesses the wave front has pulled megabytes of records through the L2 -- read one by one, every index access
-    // re-fetched its 128-byte line (profiles/r02_pmc_l2_k_accumulate.txt: 6 M extra lines per launch).  Entries beyond the
-    // lane's segment are other lists' (or the 16 words of padding behind `sorted`) and are never used.
+    // Indices come through a private LDS strip, TE_IDX_STRIP at a time: a lane's list is 4 B per addition, and between two
+    // of its accesses the wave front has pulled megabytes of records through the L2 -- read one by one, every index access
+    // re-fetched its 128-byte line (profiles/r02_pmc_l2_k_accumulate.txt: 6 M extra lines per launch; FETCH_SIZE 1.60 ->
+    // 1.36 GB raw per launch with the strip).  Entries beyond the lane's segment belong to other lists (or to the 64 words
+    // of padding behind `sorted`, ensure_buffers) and are never used.
     uint32_t* const strip = idx_strip + threadIdx.x * TE_IDX_STRIP;
     auto refill = [&](uint32_t pos) {                      // two rounds of eight: the second one finds the line in the L2
       const idx4* src = reinterpret_cast<const idx4*>(lst + pos);
