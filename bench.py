@@ -307,8 +307,11 @@ def main():
     if per_point_cycles and acc_ms > 0:
         waves = (W / div) * n / 64.0
         floor_ms = waves * per_point_cycles / 1024.0 / 2.4e6          # at the 2.4 GHz peak clock
+        ghz = stage_ms.get("accumulate_core_clock_ghz")      # mean shader clock of the kernel's waves in the untimed single-MSM pass
         valu = {"bound": "valu-issue", "floor_ms_at_2.4GHz": floor_ms, "kernel_ms": acc_ms, "frac": floor_ms / acc_ms,
                 "alone_frac": floor_ms / alone_ms if alone_ms else None,
+                "core_clock_ghz_alone": ghz,
+                "alone_frac_at_measured_clock": (floor_ms * 2.4 / ghz) / alone_ms if (ghz and alone_ms) else None,
                 "note": ("2912 v_mad_u64_u32 + 750 other VALU instructions" if bls else "1071 v_mad_u64_u32 (4.49 clk each) + 406 other VALU instructions") + " per accumulated point and wave (profiles/r02_isa_hist_k_accumulate.txt)"}
 
     out = {
@@ -350,7 +353,7 @@ def main():
                               "point, see binding_roofline and DESIGN.md section 4)")},
         "msm_algorithmic_bytes": whole_bytes,
         "msm_algorithmic_gbps": whole_bytes / (ms_per_step * 1e-3) / 1e9,
-        "stage_ms_untimed_pass": stage_ms,
+        "stage_ms_untimed_pass": {k: v for k, v in stage_ms.items() if not k.endswith("_ghz")},
         "result_x": str(int.from_bytes(result[:32], "little")),
     }
     if sharded:

@@ -174,7 +174,9 @@ int te_msm_synth_inputs_bls12_377(uint64_t seed, uint64_t n, uint8_t* points_xy_
 /* Per-stage device time of the last run in ms (needs option "profile" >= 1; level 1 reports "accumulate" only), from HIP events
  * on the engine's stream, plus "accumulate_on_device": the dominant kernel's own device clock from its first wave in to its last
  * wave out -- what a kernel trace reports; with several MSMs in flight the event interval also contains the time the launch
- * waited behind other streams' kernels.  Returns the number of stages written; names[i] points to static strings. */
+ * waited behind other streams' kernels -- and "accumulate_core_clock_ghz" (a frequency, not a time): the mean shader clock the
+ * kernel's waves ran at, from per-wave shader-clock and wall-clock ticks.  Returns the number of entries written; names[i]
+ * points to static strings. */
 int te_msm_stage_ms(te_ctx* ctx, float* ms, const char** names, int max_stages);
 /* Copies an intermediate buffer of the last run to host memory.  stage is one of
  * "records" (n x 128 B), "digits" / "part_keys" (nw rows of u16, row stride n rounded up to 8), "part_idx" (same rows, u32),

@@ -566,6 +566,7 @@ def test_host_buffers_in_pieces(pkg, model, ora):
             assert c.run_device(dp.data_ptr(), ds.data_ptr(), n) == exp
             st = c.stage_ms()
             assert 0.0 < st["accumulate_on_device"] <= st["accumulate"] * 1.02 + 0.01, st
+            assert 0.5 < st["accumulate_core_clock_ghz"] < 3.0, st                    # MI355X: up to 2.4 GHz
         c.set_option("profile", 0)
         assert c.run_device(dp.data_ptr(), ds.data_ptr(), n) == exp
 

@@ -667,10 +667,11 @@ __global__ void __launch_bounds__(256, N == 9 ? 4 : 2) k_accumulate(const rec_sl
                                                     ete_t<N>* __restrict__ seg_out, uint32_t n, uint32_t logB, uint32_t seg_len, uint32_t ids, uint32_t onto,
                                                     uint32_t win_per_msm, unsigned long long* __restrict__ clk) {
   __shared__ uint32_t idx_strip[256 * TE_IDX_STRIP];
-  // profiling: ~clock of the first wave in and clock of the last wave out, by atomic max on two zeroed words -- the
-  // kernel's own duration on the device, which an event pair around the launch overstates when other streams' kernels
-  // hold the CUs (te_msm_stage_ms "accumulate_on_device")
-  if (clk && threadIdx.x == 0) atomicMax(clk, ~(unsigned long long)wall_clock64());
+  // profiling: ~clock of the first wave in and clock of the last wave out, by atomic max on zeroed words -- the kernel's
+  // own duration on the device, which an event pair around the launch overstates when other streams' kernels hold the
+  // CUs (te_msm_stage_ms "accumulate_on_device"); per-wave shader-clock and wall-clock ticks give the core clock it ran at
+  const unsigned long long t0_wall = clk ? (unsigned long long)wall_clock64() : 0ull, t0_core = clk ? (unsigned long long)clock64() : 0ull;   // scalar registers
+  if (clk && threadIdx.x == 0) atomicMax(clk, ~t0_wall);
   const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
   if (gid >= (order ? *num_segments : ids)) return;
   const uint32_t sgm = order ? order[gid] : gid;
@@ -731,7 +732,13 @@ __global__ void __launch_bounds__(256, N == 9 ? 4 : 2) k_accumulate(const rec_sl
   }
   const bool whole = bucket_count[g] <= seg_len;
   store_ete<N>(whole ? buckets + g : seg_out + sgm, acc);
-  if (clk && (uint32_t)__lane_id() == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) atomicMax(clk + 1, (unsigned long long)wall_clock64());
+  if (clk && (uint32_t)__lane_id() == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) {
+    const unsigned long long t1_wall = (unsigned long long)wall_clock64(), t1_core = (unsigned long long)clock64();
+    atomicMax(clk + 1, t1_wall);
+    // the shader clock counts per XCD and is not synchronised across them: every wave adds its OWN core ticks and wall ticks;
+    // the ratio of the two sums is the mean core clock the kernel's waves ran at
+    atomicAdd(clk + 2, t1_core - t0_core); atomicAdd(clk + 3, t1_wall - t0_wall);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

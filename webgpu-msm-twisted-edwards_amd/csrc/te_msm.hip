@@ -32,9 +32,10 @@ thread_local std::string g_init_error;
 // in execution order: everything that needs only the scalars first, so that a host-buffer call can upload the points
 // (2/3 of the bytes) while those stages already run
 enum { ST_DIGITS = 0, ST_SCATTER, ST_BSORT, ST_ORDER, ST_PREP, ST_ACCUM, ST_TREE, ST_WEIGHTED, ST_COUNT };
-// the last entry is not an event interval: k_accumulate's own first-wave-in .. last-wave-out device clock
-const char* const kStageNames[ST_COUNT + 1] = {"digits", "part_scatter", "bucket_sort", "order", "prep_points",
-                                               "accumulate", "marginal_sums", "weighted_sum", "accumulate_on_device"};
+// the last two entries are not event intervals: k_accumulate's own first-wave-in .. last-wave-out device clock in ms, and the
+// mean shader clock over that span in GHz (not a time: te_msm_stage_ms reports it under its own name)
+const char* const kStageNames[ST_COUNT + 2] = {"digits", "part_scatter", "bucket_sort", "order", "prep_points",
+                                               "accumulate", "marginal_sums", "weighted_sum", "accumulate_on_device", "accumulate_core_clock_ghz"};
 
 // per-curve sizes: wire format, device accumulator, record slot, partial row (5 points), result
 struct curve_sizes { size_t point_in, scalar_in, acc, rec, row, result; };
@@ -92,9 +93,10 @@ struct workset_t {
   hipGraphExec_t g_front = nullptr, g_back = nullptr; graph_key g_key = {};
 };
 constexpr int TE_MAX_WINDOWS = 64;    // window_bits >= 4
-// words 8..11 of the block: two 64-bit device clock readings of k_accumulate (first wave in, last wave out), see Z_CLOCK
+// words 8..15 of the block: four 64-bit device clock readings of k_accumulate (first wave in / last wave out, wall clock and
+// shader clock), see Z_CLOCK
 constexpr size_t Z_CLOCK = 8;
-constexpr size_t Z_ROWS = 12, Z_HIST = Z_ROWS + (size_t)TE_MAX_WINDOWS * TE_MAX_ROW_BYTES / 4, Z_CURSOR = Z_HIST + 1024 * TE_HIST_COPIES, Z_END = Z_CURSOR + 1024;
+constexpr size_t Z_ROWS = 16, Z_HIST = Z_ROWS + (size_t)TE_MAX_WINDOWS * TE_MAX_ROW_BYTES / 4, Z_CURSOR = Z_HIST + 1024 * TE_HIST_COPIES, Z_END = Z_CURSOR + 1024;
 
 struct gpu_t {
   int device = 0;
@@ -122,7 +124,7 @@ struct te_ctx {
   int opt_host_chunks = 0;     // te_msm_run: pieces a large host buffer is uploaded and processed in (0 = choose from n)
   int opt_graph = 0;           // replay the launch sequence around k_accumulate as HIP graphs
   int opt_workset = 0;         // work set used by te_msm_run* / te_msm_partial_device
-  float stage_ms[ST_COUNT + 1] = {};
+  float stage_ms[ST_COUNT + 2] = {};
   bool have_stage_ms = false;
 };
 
@@ -534,9 +536,13 @@ int collect_stage_ms(te_ctx* ctx, workset_t& ws) {
   {
     // k_accumulate stamped ~clock of its first wave and the clock of its last one (atomic max on zeroed words); they came
     // back with the flag.  Unlike the event interval this excludes the time the launch waited behind other streams' kernels.
-    uint64_t c[2]; memcpy(c, ws.h_err + Z_CLOCK, sizeof c);
+    uint64_t c[4]; memcpy(c, ws.h_err + Z_CLOCK, sizeof c);
     const int khz = ctx->devs[0].wall_clock_khz;      // stage times are a single-device feature
-    ctx->stage_ms[ST_COUNT] = (c[0] && c[1] && khz > 0 && c[1] >= ~c[0]) ? (float)((double)(c[1] - ~c[0]) / khz) : -1.0f;
+    const bool have = c[0] && c[1] && khz > 0 && c[1] > ~c[0];
+    const double ms = have ? (double)(c[1] - ~c[0]) / khz : -1.0;
+    ctx->stage_ms[ST_COUNT] = (float)ms;
+    // c[2] / c[3]: core ticks / wall ticks summed over the kernel's waves; wall ticks run at khz
+    ctx->stage_ms[ST_COUNT + 1] = (have && c[2] && c[3]) ? (float)((double)c[2] / (double)c[3] * khz * 1e-6) : -1.0f;
   }
   if (!ok) (void)hipGetLastError();
   ctx->have_stage_ms = ok;
@@ -982,7 +988,7 @@ int te_msm_stage_ms(te_ctx* ctx, float* ms, const char** names, int max_stages) 
   if (!ctx || !ms) return TE_MSM_EINVAL;
   if (!ctx->have_stage_ms) return set_err(ctx, TE_MSM_ESTATE, "no profiled run yet (set option profile=1)");
   int k = 0;
-  for (int i = 0; i < ST_COUNT + 1 && k < max_stages; i++) {
+  for (int i = 0; i < ST_COUNT + 2 && k < max_stages; i++) {
     if (ctx->stage_ms[i] < 0) continue;            // not measured at this profile level
     ms[k] = ctx->stage_ms[i]; if (names) names[k] = kStageNames[i]; k++;
   }
