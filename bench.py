@@ -279,6 +279,7 @@ def main():
     # the dominant kernel's duration per launch: its own device clock, first wave in .. last wave out (what a kernel trace
     # reports); the HIP-event interval around the launch is kept beside it -- with several MSMs in flight it also contains the
     # time the launch waited for CUs held by the other streams' kernels
+    ghz_timed = (stage_acc.get("accumulate_core_clock_ghz", 0.0) / args.steps) or None
     acc_ms_events = stage_acc.get("accumulate", 0.0) / args.steps
     acc_ms_live = stage_acc.get("accumulate_on_device", 0.0) / args.steps or acc_ms_events
     # full per-stage breakdown from a few extra, untimed steps (an event at every stage boundary costs idle time)
@@ -310,7 +311,7 @@ def main():
         ghz = stage_ms.get("accumulate_core_clock_ghz")      # mean shader clock of the kernel's waves in the untimed single-MSM pass
         valu = {"bound": "valu-issue", "floor_ms_at_2.4GHz": floor_ms, "kernel_ms": acc_ms, "frac": floor_ms / acc_ms,
                 "alone_frac": floor_ms / alone_ms if alone_ms else None,
-                "core_clock_ghz_alone": ghz,
+                "core_clock_ghz_alone": ghz, "core_clock_ghz_timed_region": ghz_timed,
                 "alone_frac_at_measured_clock": (floor_ms * 2.4 / ghz) / alone_ms if (ghz and alone_ms) else None,
                 "note": ("2912 v_mad_u64_u32 + 750 other VALU instructions" if bls else "1071 v_mad_u64_u32 (4.49 clk each) + 406 other VALU instructions") + " per accumulated point and wave (profiles/r02_isa_hist_k_accumulate.txt)"}
 
