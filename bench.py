@@ -3,8 +3,9 @@
 A "step" is one full MSM (n = 2^20 Twisted-Edwards BLS12 points, 16-bit signed windows) over
 synthetic inputs already resident in HBM.  N = 1: te_msm_submit_device / te_msm_collect (device stages + host
 tail), several MSMs in flight.  N > 1: the MSM's 16 windows are sharded over the ranks (one process per GPU), the
-11 KB of partial sums are exchanged with one RCCL all-gather per MSM, and every rank runs the host tail
-("scaling": "strong").
+11 KB of partial sums per MSM are exchanged with one RCCL all-gather per launch sequence -- a sequence carries one MSM,
+or, from four ranks on, as many MSMs as there are ranks (te_msm_partial_device_batch, --batch) -- and every rank runs the
+host tail ("scaling": "strong").
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
