@@ -656,6 +656,7 @@ template <int N> __device__ __forceinline__ ete_t<N> load_ete(const ete_t<N>* sr
 }
 
 struct __attribute__((aligned(4))) idx4 { uint32_t v[4]; };      // 16 bytes at 4-byte alignment: one global_load_dwordx4
+#define TE_CLK_SLOTS 64u       // copies of k_accumulate's four profiling words (64-bit each), see the kernel
 #define TE_IDX_STRIP 16u       // sorted indices a lane fetches at a time (k_accumulate); d_sorted is padded by as many words
 // registers: N = 9 fits four waves per SIMD (128 VGPRs); N = 14 holds 56 + 2 x 56 words of points alone: two waves
 template <int N>
@@ -669,9 +670,12 @@ __global__ void __launch_bounds__(256, N == 9 ? 4 : 2) k_accumulate(const rec_sl
   __shared__ uint32_t idx_strip[256 * TE_IDX_STRIP];
   // profiling: ~clock of the first wave in and clock of the last wave out, by atomic max on zeroed words -- the kernel's
   // own duration on the device, which an event pair around the launch overstates when other streams' kernels hold the
-  // CUs (te_msm_stage_ms "accumulate_on_device"); per-wave shader-clock and wall-clock ticks give the core clock it ran at
+  // CUs (te_msm_stage_ms "accumulate_on_device"); per-wave shader-clock and wall-clock ticks give the core clock it ran at.
+  // TE_CLK_SLOTS copies of every word, chosen by block: thousands of waves ending together on ONE address serialise
+  // (0.1 ms at n = 2^16, where all segments are short); the host folds the copies.
+  unsigned long long* const slot = clk ? clk + (blockIdx.x & (TE_CLK_SLOTS - 1u)) : nullptr;
   const unsigned long long t0_wall = clk ? (unsigned long long)wall_clock64() : 0ull, t0_core = clk ? (unsigned long long)clock64() : 0ull;   // scalar registers
-  if (clk && threadIdx.x == 0) atomicMax(clk, ~t0_wall);
+  if (clk && threadIdx.x == 0) atomicMax(slot, ~t0_wall);
   const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
   if (gid >= (order ? *num_segments : ids)) return;
   const uint32_t sgm = order ? order[gid] : gid;
@@ -734,10 +738,10 @@ __global__ void __launch_bounds__(256, N == 9 ? 4 : 2) k_accumulate(const rec_sl
   store_ete<N>(whole ? buckets + g : seg_out + sgm, acc);
   if (clk && (uint32_t)__lane_id() == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) {
     const unsigned long long t1_wall = (unsigned long long)wall_clock64(), t1_core = (unsigned long long)clock64();
-    atomicMax(clk + 1, t1_wall);
+    atomicMax(slot + TE_CLK_SLOTS, t1_wall);
     // the shader clock counts per XCD and is not synchronised across them: every wave adds its OWN core ticks and wall ticks;
     // the ratio of the two sums is the mean core clock the kernel's waves ran at
-    atomicAdd(clk + 2, t1_core - t0_core); atomicAdd(clk + 3, t1_wall - t0_wall);
+    atomicAdd(slot + 2u * TE_CLK_SLOTS, t1_core - t0_core); atomicAdd(slot + 3u * TE_CLK_SLOTS, t1_wall - t0_wall);
   }
 }
 

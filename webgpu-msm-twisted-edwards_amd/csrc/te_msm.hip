@@ -93,10 +93,10 @@ struct workset_t {
   hipGraphExec_t g_front = nullptr, g_back = nullptr; graph_key g_key = {};
 };
 constexpr int TE_MAX_WINDOWS = 64;    // window_bits >= 4
-// words 8..15 of the block: four 64-bit device clock readings of k_accumulate (first wave in / last wave out, wall clock and
-// shader clock), see Z_CLOCK
+// words [Z_CLOCK, Z_ROWS): k_accumulate's profiling words, 4 x TE_CLK_SLOTS 64-bit values (first wave in / last wave out on the
+// wall clock, core and wall ticks summed over the waves), see the kernel
 constexpr size_t Z_CLOCK = 8;
-constexpr size_t Z_ROWS = 16, Z_HIST = Z_ROWS + (size_t)TE_MAX_WINDOWS * TE_MAX_ROW_BYTES / 4, Z_CURSOR = Z_HIST + 1024 * TE_HIST_COPIES, Z_END = Z_CURSOR + 1024;
+constexpr size_t Z_ROWS = Z_CLOCK + 4 * 2 * TE_CLK_SLOTS, Z_HIST = Z_ROWS + (size_t)TE_MAX_WINDOWS * TE_MAX_ROW_BYTES / 4, Z_CURSOR = Z_HIST + 1024 * TE_HIST_COPIES, Z_END = Z_CURSOR + 1024;
 
 struct gpu_t {
   int device = 0;
@@ -536,7 +536,12 @@ int collect_stage_ms(te_ctx* ctx, workset_t& ws) {
   {
     // k_accumulate stamped ~clock of its first wave and the clock of its last one (atomic max on zeroed words); they came
     // back with the flag.  Unlike the event interval this excludes the time the launch waited behind other streams' kernels.
-    uint64_t c[4]; memcpy(c, ws.h_err + Z_CLOCK, sizeof c);
+    uint64_t raw[4 * TE_CLK_SLOTS]; memcpy(raw, ws.h_err + Z_CLOCK, sizeof raw);
+    uint64_t c[4] = {0, 0, 0, 0};                      // max ~start, max end, sum of core ticks, sum of wall ticks over the copies
+    for (uint32_t i = 0; i < TE_CLK_SLOTS; i++) {
+      c[0] = std::max(c[0], raw[i]); c[1] = std::max(c[1], raw[TE_CLK_SLOTS + i]);
+      c[2] += raw[2 * TE_CLK_SLOTS + i]; c[3] += raw[3 * TE_CLK_SLOTS + i];
+    }
     const int khz = ctx->devs[0].wall_clock_khz;      // stage times are a single-device feature
     const bool have = c[0] && c[1] && khz > 0 && c[1] > ~c[0];
     const double ms = have ? (double)(c[1] - ~c[0]) / khz : -1.0;
