@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--digits", choices=("signed", "unsigned"), default="signed",
                     help="signed window digits, 2^(c-1) buckets (BASELINE config 3, the reference's shipped behaviour) or unsigned, 2^c buckets (config 2)")
     ap.add_argument("--inflight", type=int, default=0,
-                    help="MSMs in flight in pipelined mode (1..8, each on its own stream / work set); 0 = 4 on one GPU, 8 when the windows are sharded (small per-rank kernels)")
+                    help="MSMs in flight in pipelined mode (1..8, each on its own stream / work set); 0 = 6 on one GPU (4 below n = 2^20), 8 when the windows are sharded (small per-rank kernels)")
     ap.add_argument("--batch", type=int, default=0,
                     help="window-sharded runs: MSMs per launch sequence (te_msm_partial_device_batch); 0 = as many as make a rank's sequence "
                          "carry a whole MSM's worth of windows (D ranks -> D, at most 8; 1 below D = 4); 1 = one MSM per sequence")
@@ -149,7 +149,8 @@ def main():
     assert not (bls and (world > 1 or force_dist)), "BLS12-377 is single-GPU (window sharding is Twisted-Edwards only)"
     sharded = world > 1 or force_dist
     pipelined = not args.no_pipeline
-    depth = max(1, min(args.inflight or (8 if sharded else 4), pkg.WORKSETS))
+    # N = 1: six 2^20-point MSMs in flight, four of the smaller sizes (measured optima, see te_msm_init on hardware queues)
+    depth = max(1, min(args.inflight or (8 if sharded else (6 if args.log2n >= 20 else 4)), pkg.WORKSETS))
     sb = 48 if bls else 32
 
     def make_inputs(log2n):
@@ -400,7 +401,8 @@ def main():
                     dp2 = torch.frombuffer(bytearray(p2), dtype=torch.uint8).cuda()
                     ds2 = torch.frombuffer(bytearray(s2), dtype=torch.uint8).cuda()
                     torch.cuda.synchronize()
-                    for t in [sx.submit_device(dp2.data_ptr(), ds2.data_ptr(), m) for _ in range(depth)]:
+                    depth2 = min(depth, 4)
+                    for t in [sx.submit_device(dp2.data_ptr(), ds2.data_ptr(), m) for _ in range(depth2)]:
                         ref = sx.collect(t)
                     l2 = []
                     for _ in range(3):
@@ -413,7 +415,7 @@ def main():
                     tk = []
                     for _ in range(reps):
                         tk.append(sx.submit_device(dp2.data_ptr(), ds2.data_ptr(), m))
-                        if len(tk) >= depth:
+                        if len(tk) >= depth2:
                             sx.collect(tk.pop(0))
                     while tk:
                         sx.collect(tk.pop(0))
