@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--digits", choices=("signed", "unsigned"), default="signed",
                     help="signed window digits, 2^(c-1) buckets (BASELINE config 3, the reference's shipped behaviour) or unsigned, 2^c buckets (config 2)")
     ap.add_argument("--inflight", type=int, default=0,
-                    help="MSMs in flight in pipelined mode (1..8, each on its own stream / work set); 0 = 6 on one GPU (4 below n = 2^20), 8 when the windows are sharded (small per-rank kernels)")
+                    help="MSMs in flight in pipelined mode (1..8, each on its own stream / work set); 0 = 4 on one GPU, 8 when the windows are sharded (small per-rank kernels)")
     ap.add_argument("--batch", type=int, default=0,
                     help="window-sharded runs: MSMs per launch sequence (te_msm_partial_device_batch); 0 = as many as make a rank's sequence "
                          "carry a whole MSM's worth of windows (D ranks -> D, at most 8; 1 below D = 4); 1 = one MSM per sequence")
@@ -149,8 +149,7 @@ def main():
     assert not (bls and (world > 1 or force_dist)), "BLS12-377 is single-GPU (window sharding is Twisted-Edwards only)"
     sharded = world > 1 or force_dist
     pipelined = not args.no_pipeline
-    # N = 1: six 2^20-point MSMs in flight, four of the smaller sizes (measured optima, see te_msm_init on hardware queues)
-    depth = max(1, min(args.inflight or (8 if sharded else (6 if args.log2n >= 20 else 4)), pkg.WORKSETS))
+    depth = max(1, min(args.inflight or (8 if sharded else 4), pkg.WORKSETS))
     sb = 48 if bls else 32
 
     def make_inputs(log2n):
@@ -393,16 +392,20 @@ def main():
         out["sizes"] = {str(args.log2n): {"ms_per_step": ms_per_step, "latency_ms": min(lat), "host_buffers_ms": hb, "window_bits": c}}
         if not args.no_sizes and not bls and args.log2n == 20:
             # the other harness sizes (full_benchmarks.ts:13-15), short runs, window size chosen by the engine
-            with pkg.MsmContext((dev,)) as sx:
-                sx.set_option("signed_digits", 1 if args.digits == "signed" else 0)
+            # on the SAME context: which hardware queues a context's streams share depends on how many streams the process
+            # created before it (the runtime multiplexes all streams onto four queues), and a second context was measured 15-25 %
+            # slower at these sizes than the first
+            sx = ctx
+            sx.set_option("window_bits", 0)
+            sx.set_option("profile", 0)
+            if True:
                 for lg in (16, 17, 18, 19):
                     m = 1 << lg
                     p2, s2 = make_inputs(lg)
                     dp2 = torch.frombuffer(bytearray(p2), dtype=torch.uint8).cuda()
                     ds2 = torch.frombuffer(bytearray(s2), dtype=torch.uint8).cuda()
                     torch.cuda.synchronize()
-                    depth2 = min(depth, 4)
-                    for t in [sx.submit_device(dp2.data_ptr(), ds2.data_ptr(), m) for _ in range(depth2)]:
+                    for t in [sx.submit_device(dp2.data_ptr(), ds2.data_ptr(), m) for _ in range(depth)]:
                         ref = sx.collect(t)
                     l2 = []
                     for _ in range(3):
@@ -415,7 +418,7 @@ def main():
                     tk = []
                     for _ in range(reps):
                         tk.append(sx.submit_device(dp2.data_ptr(), ds2.data_ptr(), m))
-                        if len(tk) >= depth2:
+                        if len(tk) >= depth:
                             sx.collect(tk.pop(0))
                     while tk:
                         sx.collect(tk.pop(0))
@@ -423,6 +426,8 @@ def main():
                     hb2, r2 = host_buffer_ms(sx, p2, s2)
                     assert r2 == ref
                     out["sizes"][str(lg)] = {"ms_per_step": per, "latency_ms": min(l2), "host_buffers_ms": hb2, "window_bits": sx.plan(m)[0]}
+            sx.set_option("window_bits", args.window_bits)
+            sx.set_option("profile", 1)
     if rank == 0 and world == 1 and not sharded and not args.no_cpu_baseline:
         threads = args.cpu_threads or min(16, os.cpu_count() or 1)
         t0 = time.perf_counter()

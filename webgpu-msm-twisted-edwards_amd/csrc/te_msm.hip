@@ -763,15 +763,9 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
       er = hipFuncSetAttribute(reinterpret_cast<const void*>(te::k_reduce_tail<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     if (er == hipSuccess)
       er = hipFuncSetAttribute(reinterpret_cast<const void*>(te::k_reduce_tail<14>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    // All compute streams first, then the copy streams.  The runtime multiplexes streams onto four hardware queues and the
-    // creation order decides which MSMs in flight share one (kernels of one queue run in order).  Created alternately with
-    // their copy streams, the compute streams of work sets 0..3 did: small MSMs lost 15-25 % of their pipelined throughput
-    // (n = 2^16: 0.23 -> 0.19 ms per MSM, 2^17: 0.32 -> 0.26, 2^18: 0.42 -> 0.39).  For n = 2^20 the same change needs six
-    // MSMs in flight instead of four to reach the same rate (bench.py); with four, four accumulations run at once and their
-    // four record tables no longer fit the Infinity Cache (955-985 against 1 000-1 010 MSM/s).
-    for (workset_t& ws : d.ws) if (er == hipSuccess) er = hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking);
-    for (workset_t& ws : d.ws) if (er == hipSuccess) er = hipStreamCreateWithFlags(&ws.copy_stream, hipStreamNonBlocking);
-    for (workset_t& ws : d.ws) {       // the small fixed allocations of every work set; the big buffers come with the first MSM
+    for (workset_t& ws : d.ws) {       // the small fixed allocations of both work sets; the big buffers come with the first MSM
+      if (er == hipSuccess) er = hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking);
+      if (er == hipSuccess) er = hipStreamCreateWithFlags(&ws.copy_stream, hipStreamNonBlocking);
       if (er == hipSuccess) er = hipEventCreateWithFlags(&ws.ev_copy, hipEventDisableTiming);
       if (er == hipSuccess) er = hipEventCreateWithFlags(&ws.ev_start, hipEventDisableTiming);
       if (er == hipSuccess) er = hipHostMalloc((void**)&ws.h_err, Z_ROWS * 4 + (size_t)TE_MAX_WINDOWS * TE_MAX_ROW_BYTES, hipHostMallocDefault);
