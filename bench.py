@@ -392,9 +392,8 @@ def main():
         out["sizes"] = {str(args.log2n): {"ms_per_step": ms_per_step, "latency_ms": min(lat), "host_buffers_ms": hb, "window_bits": c}}
         if not args.no_sizes and not bls and args.log2n == 20:
             # the other harness sizes (full_benchmarks.ts:13-15), short runs, window size chosen by the engine
-            # on the SAME context: which hardware queues a context's streams share depends on how many streams the process
-            # created before it (the runtime multiplexes all streams onto four queues), and a second context was measured 15-25 %
-            # slower at these sizes than the first
+            # on the same context (its work sets own the buffers already; te_msm_init spreads every context's streams over the
+            # hardware queues)
             sx = ctx
             sx.set_option("window_bits", 0)
             sx.set_option("profile", 0)

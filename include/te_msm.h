@@ -136,6 +136,13 @@ int te_msm_partial_device_batch(te_ctx* ctx, const void* const* d_points_xy_le, 
  * last te_msm_partial_device call on that work set has finished and returns its status (TE_MSM_ESCALAR if a scalar was
  * out of range). */
 int te_msm_partial_wait(te_ctx* ctx, int workset);
+/* The private stream of a work set (what TE_MSM_OWN_STREAM selects) as a hipStream_t, for callers that order their own work
+ * -- a collective, a copy -- behind te_msm_partial_device without a host round trip (PyTorch: torch.cuda.ExternalStream).
+ * te_msm_init measures which of its streams the runtime put on the same hardware queue (kernels of one queue run in order;
+ * see csrc/te_msm.hip, assign_streams_by_queue) and distributes them so that work sets 0..3, and 4..7, sit on different queues:
+ * MSMs in flight on the context's own streams overlap whatever other streams the process has created.  *hw_queue_class
+ * (optional) receives the measured class of the work set's stream, -1 when the probe did not run (TE_MSM_QUEUE_PROBE=0). */
+int te_msm_workset_stream(te_ctx* ctx, int workset, void** stream, int* hw_queue_class);
 /* Host tail (replaces submission.ts:362-412: de-Montgomery, sum, Horner, toAffine): folds the W rows
  * (host memory; rows of absent windows all-zero are skipped as identity) into the affine result.
  * Waits for, and reports a pending TE_MSM_ESCALAR of, the last te_msm_partial_device call of this context.  The digit

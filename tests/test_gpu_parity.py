@@ -571,6 +571,24 @@ def test_host_buffers_in_pieces(pkg, model, ora):
         assert c.run_device(dp.data_ptr(), ds.data_ptr(), n) == exp
 
 
+def test_work_set_streams_are_spread_over_the_hardware_queues(pkg):
+    """te_msm_init measures which of its streams share a hardware queue and hands them out so that work sets 0..3 (and 4..7)
+    are on as many different queues as the runtime has -- in every context, whatever streams the process created before"""
+    import torch
+    extra = [torch.cuda.Stream() for _ in range(3)]                       # shift the runtime's stream counter
+    for _ in range(3):
+        with pkg.MsmContext((0,)) as c:
+            got = [c.workset_stream(i) for i in range(pkg.WORKSETS)]
+            assert all(h != 0 for h, _ in got) and len({h for h, _ in got}) == pkg.WORKSETS
+            cls = [k for _, k in got]
+            if -1 in cls:
+                pytest.skip("the queue probe did not run")
+            nq = len(set(cls))
+            assert 1 <= nq <= pkg.WORKSETS
+            assert len(set(cls[:4])) == min(4, nq), cls                  # the first four work sets never share while they need not
+    del extra
+
+
 def test_two_work_sets_overlap_on_two_streams(pkg, model, ora):
     """te_msm_partial_device on alternating work sets and streams: many MSMs in flight pairwise, each equal to the oracle;
     a scalar-range error is reported by te_msm_partial_wait for the work set that saw it"""

@@ -96,6 +96,8 @@ def _lib() -> ctypes.CDLL:
         L.te_msm_partial_device.restype = ci
         L.te_msm_partial_device_batch.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), u64, ci, vp, vp]
         L.te_msm_partial_device_batch.restype = ci
+        L.te_msm_workset_stream.argtypes = [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(ci)]
+        L.te_msm_workset_stream.restype = ci
         L.te_msm_partial_wait.argtypes = [vp, ci]
         L.te_msm_partial_wait.restype = ci
         L.te_msm_finalize.argtypes = [vp, cp, ci, ci, cp]
@@ -222,6 +224,13 @@ class MsmContext:
             raise MsmError(-1, "batch of %d point buffers and %d scalar buffers (1..%d of each)" % (count, len(d_scalars), MAX_BATCH))
         pv, sv = (ctypes.c_void_p * count)(*d_points), (ctypes.c_void_p * count)(*d_scalars)
         self._check(self._L.te_msm_partial_device_batch(self._h, pv, sv, n, count, d_partials, ctypes.c_void_p(stream)))
+
+    def workset_stream(self, workset: int):
+        """(hipStream_t handle as int, measured hardware-queue class or -1) of a work set's private stream
+        (te_msm_workset_stream); wrap the handle with torch.cuda.ExternalStream to order torch work behind it."""
+        st, cls = ctypes.c_void_p(), ctypes.c_int(-1)
+        self._check(self._L.te_msm_workset_stream(self._h, workset, ctypes.byref(st), ctypes.byref(cls)))
+        return int(st.value or 0), int(cls.value)
 
     def partial_wait(self, workset: int = 0):
         """Blocks until the last partial_device call on that work set is done; raises on a scalar-range error."""

@@ -64,7 +64,8 @@ struct graph_key { const void *pts, *sc, *out; uint64_t n, generation; int c, w_
 // several MSMs overlap ON THE DEVICE: the launch gaps and the latency-bound reduction tail of one are filled by the wide kernels of the
 // other (te_msm_submit_device alternates them; "workset" option for te_msm_partial_device callers).
 struct workset_t {
-  hipStream_t stream = nullptr, copy_stream = nullptr;   // copy_stream: host-buffer uploads beside the compute stream
+  hipStream_t stream = nullptr, copy_stream = nullptr;   // copy_stream: host-buffer uploads beside the compute stream (created on first use)
+  int hw_queue_class = -1;            // which of the measured hardware-queue classes `stream` is on (-1: not probed)
   hipEvent_t ev_copy = nullptr, ev_start = nullptr;
   size_t cap[40] = {};                                  // per-buffer capacity in bytes (ensure())
   uint8_t* d_recs = nullptr;          // record slots of the plan's curve (te::rec_slot<N>)
@@ -457,6 +458,70 @@ template <typename F> int capture_graph(te_ctx* ctx, workset_t& ws, hipGraphExec
 // measured and is not used: for one MSM the conversion and the sort stages are both bandwidth-bound and merely slow each
 // other down (latency 1.36 -> 1.38 ms), and with several MSMs in flight every extra stream competes for the runtime's few
 // hardware queues (four by default; GPU_MAX_HW_QUEUES=8 did not help) and serialises the others: 941 -> 862 MSM/s.
+// the copy stream of a work set exists from its first host-buffer MSM on (te_msm_run): a context that only ever sees
+// device-resident inputs owns one stream per work set
+int need_copy_stream(te_ctx* ctx, workset_t& ws) {
+  if (!ws.copy_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ws.copy_stream, hipStreamNonBlocking));
+  return 0;
+}
+
+// The runtime multiplexes all streams of a process onto a few hardware queues (four unless GPU_MAX_HW_QUEUES says otherwise)
+// and kernels of one queue run in order: MSMs in flight on two streams of the same queue do not overlap.  Which stream
+// gets which queue follows from how many streams the process created before (tools/queue_probe.hip: 0 1 2 3 3 2 1 0 3 2
+// 1 0 ...), so a context created after other streams -- PyTorch's, RCCL's, another context's -- found its first four work
+// sets on two queues: n = 2^16 / 2^17 / 2^18 ran at 0.23 / 0.32 / 0.42 instead of 0.19 / 0.24 / 0.35 ms per MSM.  Instead
+// of trusting the creation order, te_msm_init creates the eight compute streams, MEASURES which of them share a queue
+// (pairs of k_spin kernels: one duration when they overlap, two when they are serialised; ~10 ms once) and hands them
+// to the work sets so that sets 0..3 and sets 4..7 each sit on as many different queues as there are.
+int assign_streams_by_queue(gpu_t& d) {
+  hipStream_t cand[TE_MSM_WORKSETS];
+  for (auto& s : cand) { hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking); if (e != hipSuccess) return -1; }
+  int cls[TE_MSM_WORKSETS], ncls = 0;
+  for (int& c : cls) c = -1;
+  const char* env = getenv("TE_MSM_QUEUE_PROBE");
+  bool probed = false;
+  if (!(env && env[0] == '0') && d.wall_clock_khz > 0) {
+    uint32_t* flag = nullptr;
+    if (hipMalloc((void**)&flag, 4) == hipSuccess) {
+      const unsigned long long ticks = (unsigned long long)d.wall_clock_khz * 3 / 10;      // 0.3 ms
+      auto pair_ms = [&](int a, int b) {
+        (void)hipStreamSynchronize(cand[a]); (void)hipStreamSynchronize(cand[b]);
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(te::k_spin, dim3(1), dim3(64), 0, cand[a], ticks, flag);
+        hipLaunchKernelGGL(te::k_spin, dim3(1), dim3(64), 0, cand[b], ticks, flag);
+        (void)hipStreamSynchronize(cand[a]); (void)hipStreamSynchronize(cand[b]);
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      };
+      (void)pair_ms(0, 1);                                                                    // first launch: code upload
+      // one kernel alone (the same stream twice runs them back to back: half of that), best of two
+      const double alone = std::min(pair_ms(0, 0), pair_ms(0, 0)) * 0.5;
+      auto shared = [&](int a, int b) { return std::min(pair_ms(a, b), pair_ms(a, b)) > 1.6 * alone; };
+      for (int i = 0; i < TE_MSM_WORKSETS; i++) {
+        if (cls[i] >= 0) continue;
+        cls[i] = ncls;
+        for (int j = i + 1; j < TE_MSM_WORKSETS; j++) if (cls[j] < 0 && shared(i, j)) cls[j] = ncls;
+        ncls++;
+      }
+      (void)hipFree(flag);
+      probed = hipGetLastError() == hipSuccess;
+    }
+  }
+  if (getenv("TE_MSM_QUEUE_DUMP")) { fprintf(stderr, "[te_msm_init] queue classes of the 8 streams in creation order:"); for (int c : cls) fprintf(stderr, " %d", c); fprintf(stderr, "\n"); }
+  // round-robin over the queue classes: first one stream of every class, then the next of every class, ...
+  int order[TE_MSM_WORKSETS], k = 0;
+  if (probed && ncls > 1 && ncls < TE_MSM_WORKSETS) {
+    bool used[TE_MSM_WORKSETS] = {};
+    while (k < TE_MSM_WORKSETS) {
+      for (int c = 0; c < ncls && k < TE_MSM_WORKSETS; c++)
+        for (int i = 0; i < TE_MSM_WORKSETS; i++) if (!used[i] && cls[i] == c) { used[i] = true; order[k++] = i; break; }
+    }
+  } else {
+    for (int i = 0; i < TE_MSM_WORKSETS; i++) order[i] = i;
+  }
+  for (int i = 0; i < TE_MSM_WORKSETS; i++) { d.ws[i].stream = cand[order[i]]; d.ws[i].hw_queue_class = probed ? cls[order[i]] : -1; }
+  return 0;
+}
+
 int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, const void* d_scalars, uint64_t n,
                     void* d_partials_out, hipStream_t stream, const std::function<int(hipStream_t)>* upload_points = nullptr, int force_c = 0,
                     bool side_stream = false, int batch = 1) {
@@ -501,6 +566,7 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, 
   } else {
     // side stream: [upload of the points] -> records; it starts behind everything already enqueued on `stream`
     HIP_TRY(ctx, hipEventRecord(ws.ev_start, stream));
+    if (int rc = need_copy_stream(ctx, ws)) return rc;
     HIP_TRY(ctx, hipStreamWaitEvent(ws.copy_stream, ws.ev_start, 0));
     if (upload_points) { if (int rc = (*upload_points)(ws.copy_stream)) return rc; }
     msm_launch S = L; S.stream = ws.copy_stream;
@@ -614,6 +680,7 @@ int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_
   }
   if (ws.used && ws.last_stream != ws.stream) HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ws.ev_done, 0));
   HIP_TRY(ctx, hipEventRecord(ws.ev_start, ws.stream));
+  if (int rc = need_copy_stream(ctx, ws)) return rc;
   HIP_TRY(ctx, hipStreamWaitEvent(ws.copy_stream, ws.ev_start, 0));
   const bool tr = getenv("TE_MSM_TRACE_HOST") != nullptr;
   const auto t00 = std::chrono::steady_clock::now();
@@ -763,9 +830,8 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
       er = hipFuncSetAttribute(reinterpret_cast<const void*>(te::k_reduce_tail<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     if (er == hipSuccess)
       er = hipFuncSetAttribute(reinterpret_cast<const void*>(te::k_reduce_tail<14>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    for (workset_t& ws : d.ws) {       // the small fixed allocations of both work sets; the big buffers come with the first MSM
-      if (er == hipSuccess) er = hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking);
-      if (er == hipSuccess) er = hipStreamCreateWithFlags(&ws.copy_stream, hipStreamNonBlocking);
+    if (er == hipSuccess && assign_streams_by_queue(d) != 0) er = hipErrorOutOfMemory;
+    for (workset_t& ws : d.ws) {       // the small fixed allocations of every work set; the big buffers come with the first MSM
       if (er == hipSuccess) er = hipEventCreateWithFlags(&ws.ev_copy, hipEventDisableTiming);
       if (er == hipSuccess) er = hipEventCreateWithFlags(&ws.ev_start, hipEventDisableTiming);
       if (er == hipSuccess) er = hipHostMalloc((void**)&ws.h_err, Z_ROWS * 4 + (size_t)TE_MAX_WINDOWS * TE_MAX_ROW_BYTES, hipHostMallocDefault);
@@ -912,6 +978,15 @@ int te_msm_partial_device_batch(te_ctx* ctx, const void* const* d_points_xy_le, 
   if (count == 1) return enqueue_partial(ctx, d, ws, d_points_xy_le[0], d_scalars_le[0], n, d_partials, st);
   // the pointer arrays are only read while the launches are enqueued
   return enqueue_partial(ctx, d, ws, d_points_xy_le, d_scalars_le, n, d_partials, st, nullptr, 0, false, count);
+}
+
+int te_msm_workset_stream(te_ctx* ctx, int workset, void** stream, int* hw_queue_class) {
+  if (!ctx || workset < 0 || workset >= TE_MSM_WORKSETS || !stream) return TE_MSM_EINVAL;
+  if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_workset_stream needs a single-device context");
+  const workset_t& ws = ctx->devs[0].ws[workset];
+  *stream = (void*)ws.stream;
+  if (hw_queue_class) *hw_queue_class = ws.hw_queue_class;
+  return 0;
 }
 
 int te_msm_partial_wait(te_ctx* ctx, int workset) {
