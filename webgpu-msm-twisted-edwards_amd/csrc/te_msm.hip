@@ -473,52 +473,61 @@ int need_copy_stream(te_ctx* ctx, workset_t& ws) {
 // of trusting the creation order, te_msm_init creates the eight compute streams, MEASURES which of them share a queue
 // (pairs of k_spin kernels: one duration when they overlap, two when they are serialised; ~10 ms once) and hands them
 // to the work sets so that sets 0..3 and sets 4..7 each sit on as many different queues as there are.
+// classes[i] = index of the hardware queue class of streams[i] (classes numbered by first appearance); returns the number of
+// classes, or -1 when the measurement could not run (then classes[] is all -1)
+int classify_streams_by_queue(gpu_t& d, const hipStream_t* streams, int n, int* cls) {
+  for (int i = 0; i < n; i++) cls[i] = -1;
+  const char* env = getenv("TE_MSM_QUEUE_PROBE");
+  if ((env && env[0] == '0') || d.wall_clock_khz <= 0 || n < 2) return -1;
+  uint32_t* flag = nullptr;
+  if (hipMalloc((void**)&flag, 4) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  const unsigned long long ticks = (unsigned long long)d.wall_clock_khz * 3 / 10;      // 0.3 ms
+  auto pair_ms = [&](int a, int b) {
+    (void)hipStreamSynchronize(streams[a]); (void)hipStreamSynchronize(streams[b]);
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(te::k_spin, dim3(1), dim3(64), 0, streams[a], ticks, flag);
+    hipLaunchKernelGGL(te::k_spin, dim3(1), dim3(64), 0, streams[b], ticks, flag);
+    (void)hipStreamSynchronize(streams[a]); (void)hipStreamSynchronize(streams[b]);
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  };
+  (void)pair_ms(0, 1);                                                                    // first launch: code upload
+  // one kernel alone (the same stream twice runs them back to back: half of that), best of two
+  const double alone = std::min(pair_ms(0, 0), pair_ms(0, 0)) * 0.5;
+  auto shared = [&](int a, int b) { return std::min(pair_ms(a, b), pair_ms(a, b)) > 1.6 * alone; };
+  int ncls = 0;
+  for (int i = 0; i < n; i++) {
+    if (cls[i] >= 0) continue;
+    cls[i] = ncls;
+    for (int j = i + 1; j < n; j++) if (cls[j] < 0 && shared(i, j)) cls[j] = ncls;
+    ncls++;
+  }
+  (void)hipFree(flag);
+  if (hipGetLastError() != hipSuccess) { for (int i = 0; i < n; i++) cls[i] = -1; return -1; }
+  if (getenv("TE_MSM_QUEUE_DUMP")) { fprintf(stderr, "[te_msm] hardware-queue classes of %d streams:", n); for (int i = 0; i < n; i++) fprintf(stderr, " %d", cls[i]); fprintf(stderr, "\n"); }
+  return ncls;
+}
+
+// order[k] = which stream comes k-th when the streams are dealt round-robin over their classes: first one stream of every
+// class, then the next of every class, ... (identity when nothing was measured)
+void deal_over_classes(const int* cls, int n, int ncls, int* order) {
+  int k = 0;
+  if (ncls > 1 && ncls < n) {
+    std::vector<char> used(n, 0);
+    while (k < n)
+      for (int c = 0; c < ncls && k < n; c++)
+        for (int i = 0; i < n; i++) if (!used[i] && cls[i] == c) { used[i] = 1; order[k++] = i; break; }
+  } else {
+    for (int i = 0; i < n; i++) order[i] = i;
+  }
+}
+
 int assign_streams_by_queue(gpu_t& d) {
   hipStream_t cand[TE_MSM_WORKSETS];
   for (auto& s : cand) { hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking); if (e != hipSuccess) return -1; }
-  int cls[TE_MSM_WORKSETS], ncls = 0;
-  for (int& c : cls) c = -1;
-  const char* env = getenv("TE_MSM_QUEUE_PROBE");
-  bool probed = false;
-  if (!(env && env[0] == '0') && d.wall_clock_khz > 0) {
-    uint32_t* flag = nullptr;
-    if (hipMalloc((void**)&flag, 4) == hipSuccess) {
-      const unsigned long long ticks = (unsigned long long)d.wall_clock_khz * 3 / 10;      // 0.3 ms
-      auto pair_ms = [&](int a, int b) {
-        (void)hipStreamSynchronize(cand[a]); (void)hipStreamSynchronize(cand[b]);
-        const auto t0 = std::chrono::steady_clock::now();
-        hipLaunchKernelGGL(te::k_spin, dim3(1), dim3(64), 0, cand[a], ticks, flag);
-        hipLaunchKernelGGL(te::k_spin, dim3(1), dim3(64), 0, cand[b], ticks, flag);
-        (void)hipStreamSynchronize(cand[a]); (void)hipStreamSynchronize(cand[b]);
-        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-      };
-      (void)pair_ms(0, 1);                                                                    // first launch: code upload
-      // one kernel alone (the same stream twice runs them back to back: half of that), best of two
-      const double alone = std::min(pair_ms(0, 0), pair_ms(0, 0)) * 0.5;
-      auto shared = [&](int a, int b) { return std::min(pair_ms(a, b), pair_ms(a, b)) > 1.6 * alone; };
-      for (int i = 0; i < TE_MSM_WORKSETS; i++) {
-        if (cls[i] >= 0) continue;
-        cls[i] = ncls;
-        for (int j = i + 1; j < TE_MSM_WORKSETS; j++) if (cls[j] < 0 && shared(i, j)) cls[j] = ncls;
-        ncls++;
-      }
-      (void)hipFree(flag);
-      probed = hipGetLastError() == hipSuccess;
-    }
-  }
-  if (getenv("TE_MSM_QUEUE_DUMP")) { fprintf(stderr, "[te_msm_init] queue classes of the 8 streams in creation order:"); for (int c : cls) fprintf(stderr, " %d", c); fprintf(stderr, "\n"); }
-  // round-robin over the queue classes: first one stream of every class, then the next of every class, ...
-  int order[TE_MSM_WORKSETS], k = 0;
-  if (probed && ncls > 1 && ncls < TE_MSM_WORKSETS) {
-    bool used[TE_MSM_WORKSETS] = {};
-    while (k < TE_MSM_WORKSETS) {
-      for (int c = 0; c < ncls && k < TE_MSM_WORKSETS; c++)
-        for (int i = 0; i < TE_MSM_WORKSETS; i++) if (!used[i] && cls[i] == c) { used[i] = true; order[k++] = i; break; }
-    }
-  } else {
-    for (int i = 0; i < TE_MSM_WORKSETS; i++) order[i] = i;
-  }
-  for (int i = 0; i < TE_MSM_WORKSETS; i++) { d.ws[i].stream = cand[order[i]]; d.ws[i].hw_queue_class = probed ? cls[order[i]] : -1; }
+  int cls[TE_MSM_WORKSETS], order[TE_MSM_WORKSETS];
+  const int ncls = classify_streams_by_queue(d, cand, TE_MSM_WORKSETS, cls);
+  deal_over_classes(cls, TE_MSM_WORKSETS, ncls, order);
+  for (int i = 0; i < TE_MSM_WORKSETS; i++) { d.ws[i].stream = cand[order[i]]; d.ws[i].hw_queue_class = cls[order[i]]; }
   return 0;
 }
 

@@ -106,9 +106,10 @@ class ShardedPipeline:
         self.gathered = [torch.zeros(self.world * nbytes, dtype=torch.uint8, device=gdev) for _ in range(depth)]
         self.host = [torch.zeros(self.world * nbytes, dtype=torch.uint8).pin_memory() for _ in range(depth)]
         self.copy_stream = torch.cuda.Stream()
-        # one stream per work set: the sequences overlap on the GPU.  (The context's own streams, whose hardware queues
-        # te_msm_init measures and spreads -- MsmContext.workset_stream + torch.cuda.ExternalStream -- were tried here and
-        # measured 8-15 % slower than torch's pool streams with the collective in between.)
+        # one stream per work set: the sequences overlap on the GPU.  torch's pool streams, left alone: both the context's own
+        # streams (whose hardware queues te_msm_init measures) through torch.cuda.ExternalStream and pool streams that had
+        # been run through the same measurement were 8-15 % (four sequences in flight) to 70 % (eight) slower -- the runtime
+        # binds a stream to a hardware queue when it is first used, and apparently binds better under load than an idle probe does.
         self.compute_streams = [torch.cuda.Stream() for _ in range(depth)]
         self.ev = [torch.cuda.Event() for _ in range(depth)]
         self.count = [0] * depth
