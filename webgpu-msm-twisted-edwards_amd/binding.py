@@ -26,7 +26,8 @@ class MsmError(RuntimeError):
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "libtemsm.so")
+    """libtemsm.so next to this file; TE_MSM_LIB names another build of the SAME library (A/B measurements of build variants)."""
+    return os.environ.get("TE_MSM_LIB") or os.path.join(_HERE, "libtemsm.so")
 
 
 def build_library(force: bool = False) -> str:

@@ -1050,14 +1050,4 @@ __global__ void __launch_bounds__(256) k_prep_points377(const uint4* __restrict_
   store_pnt<14>(recs + i, pnt_from_sw377(te377::fq_from_words32(xw), te377::fq_from_words32(yw)));
 }
 
-// ------------------------------------------------------------------------------------------------
-// te_msm_init's hardware-queue probe: one wave that waits `ticks` of the constant-rate wall clock (bounded: it always ends).
-// Two of these on two streams take as long as one when the streams sit on different hardware queues, twice as long when
-// the runtime put them on the same one.
-__global__ void __launch_bounds__(64) k_spin(unsigned long long ticks, uint32_t* out) {
-  const unsigned long long t0 = (unsigned long long)wall_clock64();
-  while ((unsigned long long)wall_clock64() - t0 < ticks) { }
-  if (out && threadIdx.x == 0) out[0] = 1u;
-}
-
 }  // namespace te

@@ -23,6 +23,7 @@
 #include "host_tail.hpp"
 #include "synth.hpp"
 #include "kernels.hip.hpp"
+#include "probe.hip.hpp"
 #include "host_tail377.hpp"
 
 namespace {
