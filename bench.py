@@ -14,7 +14,8 @@ host tail ("scaling": "strong").
 One JSON line on rank 0.  `value` / `ms_per_step` = pipelined throughput with inputs resident in HBM; `latency_ms` =
 one synchronous MSM from resident inputs; `host_buffers_ms` = one te_msm_run from pageable host buffers (what the
 reference's compute_msm(Buffer, Buffer) delivers, PCIe included; never `value`); `sizes` = the same three figures for
-n = 2^16..2^20 (full_benchmarks.ts:13-15 runs 16..20).
+n = 2^16..2^20 (full_benchmarks.ts:13-15 runs 16..20); `configs` = short passes of BASELINE configs 2 (unsigned windows) and
+5 (BLS12-377 G1) at n = 2^20, each with its own parity check, roofline and cpu_baseline.
 """
 import argparse
 import hashlib
@@ -30,12 +31,13 @@ sys.path.insert(0, ROOT)
 PKG = "webgpu-msm-twisted-edwards_amd"
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-KERNEL_SOURCES = ("kernels.hip.hpp", "curve.hpp", "fp.hpp")     # what decides k_accumulate's memory traffic
+ISA_JSON = os.path.join(ROOT, "profiles", "isa_cycles.json")
+KERNEL_SOURCES = ("kernels.hip.hpp", "curve.hpp", "fp.hpp")     # what decides k_accumulate's memory traffic and instruction count
 
 
 def kernel_sources_sha():
     """hash of the CODE of the kernel sources: comments and white space do not take part, so that re-wording a comment does
-    not declare a profile stale (tools/summarize_prof.py computes the same)"""
+    not declare a profile stale (tools/summarize_prof.py and tools/isa_hist.py compute the same)"""
     h = hashlib.sha256()
     for f in KERNEL_SOURCES:
         with open(os.path.join(ROOT, PKG, "csrc", f), "r", errors="replace") as fh:
@@ -69,6 +71,18 @@ def measured_traffic(log2n, c, world, default_workload=True):
     return k.get("hbm_bytes_per_launch"), info
 
 
+def isa_cycles(bls):
+    """estimated VALU issue cycles per 64 accumulated points, from the ISA listing of the build (tools/isa_hist.py --json ->
+    profiles/isa_cycles.json, which records the hash of the sources it was taken from)"""
+    fallback = {"cycles": 15545.0 if bls else 6136.0, "note": "round-2 listing (profiles/r02_isa_hist_k_accumulate.txt)", "stale": True}
+    try:
+        j = json.load(open(ISA_JSON))
+        k = j["k_accumulate<14>" if bls else "k_accumulate<9>"]
+    except (OSError, KeyError, ValueError):
+        return fallback
+    return {"cycles": float(k["valu_issue_cycles"]), "note": k.get("note", ""), "stale": j.get("kernel_sources_sha") != kernel_sources_sha()}
+
+
 def algorithmic_bytes(n, W, B, bls=False):
     """whole MSM, and the share of the dominant kernel (bucket accumulation)."""
     if bls:                                               # 48-B coordinates and scalar records, 144-B projective buckets
@@ -76,6 +90,120 @@ def algorithmic_bytes(n, W, B, bls=False):
     whole = 96 * n + W * n * (64 + 4) + 2 * W * B * 128 + 64
     accumulate = W * n * (64 + 4) + W * B * 128          # gather each point + its 4-B index once, write each bucket once
     return whole, accumulate
+
+
+def pipelined_pass(ctx, dp, ds, n, steps, depth, note=None):
+    """`steps` MSMs back to back, `depth` in flight (te_msm_submit_device / te_msm_collect); returns (seconds, last result)"""
+    import torch
+    result, tickets = None, []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tickets.append(ctx.submit_device(dp, ds, n))
+        if len(tickets) >= depth:
+            result = ctx.collect(tickets.pop(0))
+            if note:
+                note()
+    while tickets:
+        result = ctx.collect(tickets.pop(0))
+        if note:
+            note()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, result
+
+
+def alone_pass(ctx, step, reps):
+    """`reps` synchronous MSMs at profile level 2 (an event at every stage boundary): mean stage times with ONE MSM on the GPU"""
+    ctx.set_option("profile", 2)
+    acc = {}
+    for _ in range(reps):
+        step()
+        for k, v in ctx.stage_ms().items():
+            acc[k] = acc.get(k, 0.0) + v
+    ctx.set_option("profile", 1)
+    return {k: v / reps for k, v in acc.items()}
+
+
+def roofline_block(acc_bytes, alone, timed, bls, waves, traffic=None, traffic_info=None, msms_per_launch=1):
+    """roofline of the dominant kernel.  `achieved` = algorithmic bytes per launch / the kernel's mean duration with the GPU
+    to itself (HIP events around the launch on the engine's stream, measured live in this run; agrees with the kernel trace
+    of `bench.py --no-pipeline`): a per-launch cost that cannot exceed ms_per_step.  The duration seen in the timed region,
+    where `depth` MSMs share the GPU and two accumulations usually overlap, is a concurrency-stretched span: side field."""
+    alone_ms = alone.get("accumulate") or alone.get("accumulate_on_device")
+    achieved = acc_bytes / (alone_ms * 1e-3) / 1e9 if alone_ms else 0.0
+    isa = isa_cycles(bls)
+    ghz = alone.get("accumulate_core_clock_ghz")
+    floor_ms = waves * isa["cycles"] / 1024.0 / 2.4e6          # 1024 SIMDs at the 2.4 GHz peak clock
+    valu = {"bound": "valu-issue", "floor_ms_at_2.4GHz": floor_ms, "kernel_ms": alone_ms, "frac": floor_ms / alone_ms if alone_ms else None,
+            "core_clock_ghz": ghz, "frac_at_measured_clock": (floor_ms * 2.4 / ghz) / alone_ms if (ghz and alone_ms) else None,
+            "valu_issue_cycles_per_64_points": isa["cycles"], "isa_listing_stale": isa["stale"], "note": isa["note"]}
+    out = {"bound": "hbm", "kernel": "k_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_info": traffic_info,
+           "algorithmic_bytes_per_launch": acc_bytes, "kernel_ms": alone_ms, "kernel_ms_device_clock": alone.get("accumulate_on_device"),
+           "msms_per_launch": msms_per_launch,
+           "duration": "mean of the launches of an untimed pass inside this run with one MSM on the GPU (HIP events on the engine's stream)",
+           "timed_region": timed, "binding_roofline": valu,
+           "note": ("VALU-bound: 8 products of 14-limb operands per gathered point" if bls else
+                    "the north star names the HBM roofline; the kernel is VALU-issue bound (7 field products per gathered "
+                    "point, see binding_roofline and DESIGN.md section 4)")}
+    return out
+
+
+def side_config(pkg, dev, name, curve, digits, log2n, depth, threads, steps, expect=None, inputs=None):
+    """a short pass of another BASELINE config on a fresh context: pipelined throughput, latency, the dominant kernel alone,
+    parity against the config's oracle (timed: its cpu_baseline)"""
+    import torch
+    bls = curve == "bls12-377"
+    n = 1 << log2n
+    if inputs is None:
+        inputs = pkg.synth_inputs(0x5EED0000 + log2n, n, curve=pkg.CURVE_BLS12_377_G1 if bls else pkg.CURVE_TE_BLS12)
+    pts, sc = inputs
+    dpt = torch.frombuffer(bytearray(pts), dtype=torch.uint8).cuda()
+    dst = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    dp, ds = dpt.data_ptr(), dst.data_ptr()
+    with pkg.MsmContext((dev,)) as cx:
+        cx.set_option("window_bits", 16)
+        cx.set_option("signed_digits", 1 if digits == "signed" else 0)
+        if bls:
+            cx.set_option("curve", pkg.CURVE_BLS12_377_G1)
+        cx.set_option("profile", 1)
+        c, W = cx.plan(n)
+        B = 1 << (c - 1 if digits == "signed" else c)
+        for t in [cx.submit_device(dp, ds, n) for _ in range(depth)]:      # every work set allocates its buffers outside the timed pass
+            result = cx.collect(t)
+        lat = []
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            cx.run_device(dp, ds, n)
+            lat.append((time.perf_counter() - t1) * 1e3)
+        elapsed, result = pipelined_pass(cx, dp, ds, n, steps, depth)
+        alone = alone_pass(cx, lambda: cx.run_device(dp, ds, n), 4)
+    whole, acc_bytes = algorithmic_bytes(n, W, B, bls)
+    out = {"workload": "n=2^%d %s MSM, %d-bit %s windows (%d windows x %d buckets), inputs resident in HBM" % (
+               log2n, "BLS12-377 G1" if bls else "TE-BLS12", c, digits, W, B),
+           "value": steps / elapsed, "unit": "MSM/s", "steps": steps, "ms_per_step": elapsed * 1e3 / steps, "latency_ms": min(lat),
+           "roofline": roofline_block(acc_bytes, alone, None, bls, W * n / 64.0),
+           "msm_algorithmic_bytes": whole}
+    if expect is None:
+        t0 = time.perf_counter()
+        if bls:
+            from oracle import oracle377       # cpu_baseline leg (and result checker) only
+            expect = oracle377.msm(pts, sc, c=16, threads=threads)
+        else:
+            from oracle import oracle          # cpu_baseline leg (and result checker) only
+            expect = oracle.msm(pts, sc, c=16, bpr_mode=1, threads=threads)
+        cpu_s = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "MSM/s", "cores": threads, "kind": "port",
+                               "sample": "1 full MSM at n=2^%d (oracle/%s), %.1f s" % (
+                                   log2n, "bls377_oracle.c; parity unpinned by the reference" if bls else "te_oracle.c", cpu_s)}
+    else:
+        out["cpu_baseline"] = "same inputs as the headline run: see its cpu_baseline (the oracle's result does not depend on the digit form)"
+    out["parity"] = "bit-exact vs oracle" if expect == result else "MISMATCH vs oracle"
+    if bls:
+        out["parity"] += " (oracle unpinned by the reference: it holds no code or vector for this curve)"
+    return out, expect == result
 
 
 def main():
@@ -90,6 +218,7 @@ def main():
                     help="uniform: the harness's distribution; equal: one scalar repeated (worst-case skew); small: 64-bit scalars")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sizes", action="store_true", help="skip the n = 2^16..2^19 side table")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short passes of BASELINE configs 2 and 5 (unsigned windows, BLS12-377 G1)")
     ap.add_argument("--no-host-buffers", action="store_true", help="skip the te_msm_run (host buffer) timing: kernel traces of one configuration only")
     ap.add_argument("--segment-len", type=int, default=0)
     ap.add_argument("--curve", choices=("te", "bls12-377"), default="te",
@@ -101,6 +230,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0,
                     help="window-sharded runs: MSMs per launch sequence (te_msm_partial_device_batch); 0 = as many as make a rank's sequence "
                          "carry a whole MSM's worth of windows (D ranks -> D, at most 8; 1 below D = 4); 1 = one MSM per sequence")
+    ap.add_argument("--bases", choices=("shared", "distinct"), default="shared",
+                    help="window-sharded batches: every MSM of a batch names the SAME point buffer (a prover's batch over one SRS: the "
+                         "engine converts it once per launch sequence) or each its own copy")
     ap.add_argument("--no-pipeline", action="store_true", help="N=1: await every MSM before submitting the next (latency mode)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -151,6 +283,7 @@ def main():
     pipelined = not args.no_pipeline
     depth = max(1, min(args.inflight or (8 if sharded else 4), pkg.WORKSETS))
     sb = 48 if bls else 32
+    threads = args.cpu_threads or min(16, os.cpu_count() or 1)
 
     def make_inputs(log2n):
         n = 1 << log2n
@@ -203,6 +336,11 @@ def main():
         if batch > 1 and not args.inflight:
             depth = 4
     pipe = pkg.ShardedPipeline(ctx, n, dist, depth=depth, batch=batch) if (sharded and pipelined) else None
+    # the point buffers the MSMs of one batch name: one shared buffer, or a copy per MSM (same bytes, distinct addresses)
+    base_copies = [d_pts] + ([d_pts.clone() for _ in range(batch - 1)] if (args.bases == "distinct" and batch > 1) else [])
+
+    def batch_inputs(k):
+        return [(base_copies[m % len(base_copies)], d_sc) for m in range(k)]
 
     result = None
     for _ in range(args.warmup):
@@ -210,12 +348,12 @@ def main():
     # warm-up of the pipelined form as well: every work set allocates its device buffers on first use, which must not
     # fall into the timed region (one untimed round over all of them)
     if pipelined and sharded:
-        for t in [pipe.submit_batch([(d_pts, d_sc)] * batch) for _ in range(depth)]:
+        for t in [pipe.submit_batch(batch_inputs(batch)) for _ in range(depth)]:
             result = pipe.collect_batch(t)[-1]
     elif pipelined:
         for t in [ctx.submit_device(d_pts.data_ptr(), d_sc.data_ptr(), n) for _ in range(depth)]:
             result = ctx.collect(t)
-    stage_acc = {}
+    stage_acc, stage_cnt = {}, [0]
 
     def sync():
         if sharded:
@@ -225,6 +363,7 @@ def main():
     def note_stage():
         for k, v in ctx.stage_ms().items():          # HIP events recorded on the engine's own stream
             stage_acc[k] = stage_acc.get(k, 0.0) + v
+        stage_cnt[0] += 1
 
     # latency of ONE synchronous MSM (device stages + read-back + host tail), before the timed throughput region
     lat = []
@@ -233,88 +372,83 @@ def main():
         t1 = time.perf_counter()
         step()
         lat.append((time.perf_counter() - t1) * 1e3)
-    stage_acc.clear()
 
     last = 1                                           # MSMs in the last launch sequence (window-sharded batches)
-    sync()
-    t0 = time.perf_counter()
-    if pipelined and sharded:
-        # the same with window shards: all-gather, read-back and host tail of MSM i overlap the device work of MSM i+1
+
+    def sharded_pass(inputs_of):
+        """args.steps window-sharded MSMs, `depth` launch sequences of up to `batch` MSMs in flight: all-gather, read-back and
+        host tail of one sequence overlap the device work of the next; returns (seconds, MSMs in the last sequence, result)"""
+        res, k = None, 1
+        sync()
+        t0 = time.perf_counter()
         tickets, sent = [], 0
         while sent < args.steps:
-            last = min(batch, args.steps - sent)
-            tickets.append(pipe.submit_batch([(d_pts, d_sc)] * last))
-            sent += last
+            k = min(batch, args.steps - sent)
+            tickets.append(pipe.submit_batch(inputs_of(k)))
+            sent += k
             if len(tickets) >= depth:
-                result = pipe.collect_batch(tickets.pop(0))[-1]
+                res = pipe.collect_batch(tickets.pop(0))[-1]
         while tickets:
-            result = pipe.collect_batch(tickets.pop(0))[-1]
-        torch.cuda.synchronize()
+            res = pipe.collect_batch(tickets.pop(0))[-1]
+        sync()
+        el = time.perf_counter() - t0
+        if sharded:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda" if dist.get_backend() != "gloo" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, k, res
+
+    distinct_line = None
+    if pipelined and sharded:
+        elapsed, last, result = sharded_pass(batch_inputs)
         note_stage()                                   # events of the last launch sequence (`last` MSMs): a sample, not the mean
-        for k in list(stage_acc):
-            stage_acc[k] *= args.steps / last          # -> per MSM after the division by steps below
-    elif pipelined:
-        # K independent MSMs back to back, `depth` in flight on as many streams: host tail and device work of consecutive
-        # MSMs overlap, and on the GPU the gaps and latency-bound tail of one are filled by the wide kernels of another
-        tickets = []
-        for i in range(args.steps):
-            tickets.append(ctx.submit_device(d_pts.data_ptr(), d_sc.data_ptr(), n))
-            if len(tickets) >= depth:
-                result = ctx.collect(tickets.pop(0))
-                note_stage()
-        while tickets:
-            result = ctx.collect(tickets.pop(0))
-            note_stage()
+        if batch > 1 and len(base_copies) == 1:
+            # the same again with a point buffer of its own per MSM of a batch (same bytes at distinct addresses): a shared
+            # buffer is converted once per launch sequence, distinct ones once each -- both figures belong in the line
+            copies = [d_pts] + [d_pts.clone() for _ in range(batch - 1)]
+            torch.cuda.synchronize()
+            el2, _, res2 = sharded_pass(lambda k: [(copies[m], d_sc) for m in range(k)])
+            assert res2 == result
+            distinct_line = {"ms_per_step": el2 * 1e3 / args.steps, "value": args.steps / el2,
+                             "note": "every MSM of a batch names its own copy of the point buffer: %d conversions per launch sequence instead of one" % batch}
+            del copies
     else:
-        for _ in range(args.steps):
-            result = step()
-            note_stage()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if sharded:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() != "gloo" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        sync()
+        t0 = time.perf_counter()
+        if pipelined:
+            # K independent MSMs back to back, `depth` in flight on as many streams: host tail and device work of consecutive
+            # MSMs overlap, and on the GPU the gaps and latency-bound tail of one are filled by the wide kernels of another
+            _, result = pipelined_pass(ctx, d_pts.data_ptr(), d_sc.data_ptr(), n, args.steps, depth, note_stage)
+        else:
+            for _ in range(args.steps):
+                result = step()
+                note_stage()
+        sync()
+        elapsed = time.perf_counter() - t0
+        if sharded:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() != "gloo" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
 
     ms_per_step = elapsed * 1e3 / args.steps
-    # the dominant kernel's duration per launch: its own device clock, first wave in .. last wave out (what a kernel trace
-    # reports); the HIP-event interval around the launch is kept beside it -- with several MSMs in flight it also contains the
-    # time the launch waited for CUs held by the other streams' kernels
-    ghz_timed = (stage_acc.get("accumulate_core_clock_ghz", 0.0) / args.steps) or None
-    acc_ms_events = stage_acc.get("accumulate", 0.0) / args.steps
-    acc_ms_live = stage_acc.get("accumulate_on_device", 0.0) / args.steps or acc_ms_events
-    # full per-stage breakdown from a few extra, untimed steps (an event at every stage boundary costs idle time)
-    ctx.set_option("profile", 2)
-    stage_acc, extra = {}, 3
-    for _ in range(extra):
-        step()
-        for k, v in ctx.stage_ms().items():
-            stage_acc[k] = stage_acc.get(k, 0.0) + v
-    stage_ms = {k: v / extra for k, v in stage_acc.items()}
-    ctx.set_option("profile", 1)
+    # the dominant kernel in the timed region, per LAUNCH (a launch carries `last` MSMs in a window-sharded batch): means over
+    # the sampled launches -- a span on the device clock (first wave in .. last wave out) and the HIP-event interval around
+    # the launch.  With `depth` MSMs in flight two accumulations usually share the GPU: these spans are stretched by the
+    # concurrency and can exceed ms_per_step; the roofline uses the alone figure below.
+    cnt = max(stage_cnt[0], 1)
+    timed = {"kernel_ms_span_device_clock": stage_acc.get("accumulate_on_device", 0.0) / cnt or None,
+             "kernel_ms_event_interval": stage_acc.get("accumulate", 0.0) / cnt or None,
+             "core_clock_ghz": stage_acc.get("accumulate_core_clock_ghz", 0.0) / cnt or None,
+             "launches_sampled": stage_cnt[0], "msms_per_launch": last, "in_flight": depth if pipelined else 1,
+             "note": "concurrency-stretched: %d launch sequences share the GPU" % (depth if pipelined else 1)}
+    # full per-stage breakdown from a few extra, untimed steps with the GPU to itself (an event at every stage boundary)
+    stage_ms = alone_pass(ctx, step, 6)
     whole_bytes, acc_bytes = algorithmic_bytes(n, W, B, bls)
     div = rehearse or world
     acc_bytes_rank = acc_bytes / div                      # windows are sharded
-    acc_ms = acc_ms_live
-    achieved = acc_bytes_rank / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
     traffic, traffic_info = (None, None) if bls else measured_traffic(
         args.log2n, c, world if not rehearse else rehearse,
         args.digits == "signed" and args.scalars == "uniform" and args.points == "chain" and not args.segment_len)
-
-    # VALU-issue roofline of the dominant kernel: wave instructions per launch from the ISA listing
-    # (profiles/r02_isa_hist_k_accumulate.txt) x measured issue cost against 1024 SIMDs
-    alone_ms = stage_ms.get("accumulate_on_device") or stage_ms.get("accumulate")
-    per_point_cycles = 15545.0 if bls else 6136.0           # estimated VALU issue cycles per 64 accumulated points (tools/isa_hist.py)
-    valu = None
-    if per_point_cycles and acc_ms > 0:
-        waves = (W / div) * n / 64.0
-        floor_ms = waves * per_point_cycles / 1024.0 / 2.4e6          # at the 2.4 GHz peak clock
-        ghz = stage_ms.get("accumulate_core_clock_ghz")      # mean shader clock of the kernel's waves in the untimed single-MSM pass
-        valu = {"bound": "valu-issue", "floor_ms_at_2.4GHz": floor_ms, "kernel_ms": acc_ms, "frac": floor_ms / acc_ms,
-                "alone_frac": floor_ms / alone_ms if alone_ms else None,
-                "core_clock_ghz_alone": ghz, "core_clock_ghz_timed_region": ghz_timed,
-                "alone_frac_at_measured_clock": (floor_ms * 2.4 / ghz) / alone_ms if (ghz and alone_ms) else None,
-                "note": ("2912 v_mad_u64_u32 + 750 other VALU instructions" if bls else "1071 v_mad_u64_u32 (4.49 clk each) + 406 other VALU instructions") + " per accumulated point and wave (profiles/r02_isa_hist_k_accumulate.txt)"}
 
     out = {
         "metric": "MSMs/sec at n=2^%d %s (pipelined throughput = 1000/ms_per_step; single-MSM latency in latency_ms)" % (args.log2n, "BLS12-377 G1" if bls else "Twisted-Edwards BLS12"),
@@ -338,21 +472,10 @@ def main():
                    "points_note": ("chain = n distinct subgroup points (a + i*b)*G, an arithmetic progression generated by te_msm_synth_inputs "
                                    "(SURVEY 8d asks for seeded-random a_i*G: performance-equivalent -- every point is a distinct, "
                                    "uniformly spread field element; tests/ use the oracle's seeded-random points)") if args.points == "chain" else "harness mode: one fixed point replicated",
-                   "parallelism": "windows sharded over %d rank(s), one %s all-gather of %d B partial sums per launch sequence of %d MSM(s)"
-                                  % (world, "RCCL" if (world > 1 and dist.get_backend() == "nccl") else "gloo (rehearsal: ranks share one GPU)", batch * W * 720, batch) if world > 1 else "single GPU"},
-        "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_info": traffic_info,
-                     "algorithmic_bytes_per_launch": acc_bytes_rank * last, "kernel_ms": acc_ms * last, "msms_per_launch": last,
-                     # the timed region keeps `depth` MSMs in flight: the kernel shares the GPU with the other MSMs' kernels,
-                     # so its duration there is longer than when it has the GPU to itself (untimed single-MSM pass)
-                     "kernel_ms_event_interval": acc_ms_events * last,
-                     "alone": {"kernel_ms": alone_ms, "kernel_ms_event_interval": stage_ms.get("accumulate"),
-                               "achieved": acc_bytes_rank / (alone_ms * 1e-3) / 1e9 if alone_ms else None,
-                               "frac": acc_bytes_rank / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if alone_ms else None},
-                     "binding_roofline": valu,
-                     "note": ("VALU-bound: 8 products of 14-limb operands per gathered point" if bls else
-                              "the north star names the HBM roofline; the kernel is VALU-issue bound (7 field products per gathered "
-                              "point, see binding_roofline and DESIGN.md section 4)")},
+                   "parallelism": "windows sharded over %d rank(s), one %s all-gather of %d B partial sums per launch sequence of %d MSM(s), %s point buffers"
+                                  % (world, "RCCL" if (world > 1 and dist.get_backend() == "nccl") else "gloo (rehearsal: ranks share one GPU)", batch * W * 720, batch,
+                                     "one shared" if len(base_copies) == 1 else "distinct") if world > 1 else "single GPU"},
+        "roofline": roofline_block(acc_bytes_rank, stage_ms, timed, bls, (W / div) * n / 64.0, traffic, traffic_info),
         "msm_algorithmic_bytes": whole_bytes,
         "msm_algorithmic_gbps": whole_bytes / (ms_per_step * 1e-3) / 1e9,
         "stage_ms_untimed_pass": {k: v for k, v in stage_ms.items() if not k.endswith("_ghz")},
@@ -361,8 +484,11 @@ def main():
     if sharded:
         out["rccl_ranks"] = dist.get_world_size()
         out["backend"] = dist.get_backend()
-        # per-rank dominant-kernel time (live, last MSM of the timed region), gathered so that rank 0 reports all of them
-        km = torch.tensor([acc_ms], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+        out["batch_bases"] = "shared" if len(base_copies) == 1 else "distinct"
+        if distinct_line:
+            out["batch_distinct_bases"] = distinct_line
+        # per-rank dominant-kernel time (alone pass), gathered so that rank 0 reports all of them
+        km = torch.tensor([stage_ms.get("accumulate", 0.0)], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         kms = [torch.zeros_like(km) for _ in range(world)]
         dist.all_gather(kms, km)
         out["per_rank_kernel_ms"] = [float(x.item()) for x in kms]
@@ -386,49 +512,43 @@ def main():
         hb, r_host = host_buffer_ms(ctx, pts, sc)
         out["host_buffers_ms"] = hb
         out["pcie_inclusive_ms_host_buffers"] = hb
-        out["host_buffers_path"] = "te_msm_run, profile 0, host_chunks=%d (0 = automatic: 4 pieces from 2^20 points, 2 from 2^18)" % ctx.get_option("host_chunks")
+        out["host_buffers_path"] = ("te_msm_run, profile 0, host_chunks=%d (0 = automatic: the buffers are uploaded and processed in 3 pieces "
+                                    "from 2^19 points, 2 from 2^17, whole below)" % ctx.get_option("host_chunks"))
         out["host_buffers_gbps"] = (len(pts) + len(sc)) / (hb * 1e-3) / 1e9
         assert r_host == result
-        out["sizes"] = {str(args.log2n): {"ms_per_step": ms_per_step, "latency_ms": min(lat), "host_buffers_ms": hb, "window_bits": c}}
+        out["sizes"] = {str(args.log2n): {"ms_per_step": ms_per_step, "latency_ms": min(lat), "host_buffers_ms": hb, "window_bits": c,
+                                          "core_clock_ghz": stage_ms.get("accumulate_core_clock_ghz")}}
         if not args.no_sizes and not bls and args.log2n == 20:
-            # the other harness sizes (full_benchmarks.ts:13-15), short runs, window size chosen by the engine
-            # on the same context (its work sets own the buffers already; te_msm_init spreads every context's streams over the
-            # hardware queues)
+            # the other harness sizes (full_benchmarks.ts:13-15), short runs, window size chosen by the engine, on the same
+            # context (its work sets own the buffers already)
             sx = ctx
             sx.set_option("window_bits", 0)
-            sx.set_option("profile", 0)
-            if True:
-                for lg in (16, 17, 18, 19):
-                    m = 1 << lg
-                    p2, s2 = make_inputs(lg)
-                    dp2 = torch.frombuffer(bytearray(p2), dtype=torch.uint8).cuda()
-                    ds2 = torch.frombuffer(bytearray(s2), dtype=torch.uint8).cuda()
-                    torch.cuda.synchronize()
-                    for t in [sx.submit_device(dp2.data_ptr(), ds2.data_ptr(), m) for _ in range(depth)]:
-                        ref = sx.collect(t)
-                    l2 = []
-                    for _ in range(3):
-                        t1 = time.perf_counter()
-                        assert sx.run_device(dp2.data_ptr(), ds2.data_ptr(), m) == ref
-                        l2.append((time.perf_counter() - t1) * 1e3)
-                    reps = 40
+            for lg in (16, 17, 18, 19):
+                m = 1 << lg
+                p2, s2 = make_inputs(lg)
+                dp2 = torch.frombuffer(bytearray(p2), dtype=torch.uint8).cuda()
+                ds2 = torch.frombuffer(bytearray(s2), dtype=torch.uint8).cuda()
+                torch.cuda.synchronize()
+                sx.set_option("profile", 0)
+                for t in [sx.submit_device(dp2.data_ptr(), ds2.data_ptr(), m) for _ in range(depth)]:
+                    ref = sx.collect(t)
+                l2 = []
+                for _ in range(4):
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
-                    tk = []
-                    for _ in range(reps):
-                        tk.append(sx.submit_device(dp2.data_ptr(), ds2.data_ptr(), m))
-                        if len(tk) >= depth:
-                            sx.collect(tk.pop(0))
-                    while tk:
-                        sx.collect(tk.pop(0))
-                    per = (time.perf_counter() - t1) * 1e3 / reps
-                    hb2, r2 = host_buffer_ms(sx, p2, s2)
-                    assert r2 == ref
-                    out["sizes"][str(lg)] = {"ms_per_step": per, "latency_ms": min(l2), "host_buffers_ms": hb2, "window_bits": sx.plan(m)[0]}
+                    assert sx.run_device(dp2.data_ptr(), ds2.data_ptr(), m) == ref
+                    l2.append((time.perf_counter() - t1) * 1e3)
+                el, _ = pipelined_pass(sx, dp2.data_ptr(), ds2.data_ptr(), m, 40, depth)
+                hb2, r2 = host_buffer_ms(sx, p2, s2)
+                assert r2 == ref
+                sx.set_option("profile", 1)            # the kernel stamps its own clock: one more MSM for the core clock at this size
+                assert sx.run_device(dp2.data_ptr(), ds2.data_ptr(), m) == ref
+                out["sizes"][str(lg)] = {"ms_per_step": el * 1e3 / 40, "latency_ms": min(l2), "host_buffers_ms": hb2, "window_bits": sx.plan(m)[0],
+                                         "core_clock_ghz": sx.stage_ms().get("accumulate_core_clock_ghz")}
             sx.set_option("window_bits", args.window_bits)
             sx.set_option("profile", 1)
+    exp = None
     if rank == 0 and world == 1 and not sharded and not args.no_cpu_baseline:
-        threads = args.cpu_threads or min(16, os.cpu_count() or 1)
         t0 = time.perf_counter()
         if bls:
             from oracle import oracle377       # cpu_baseline leg (and result checker) only
@@ -446,9 +566,29 @@ def main():
             raise SystemExit("GPU result differs from the oracle")
     if "parity" not in out and not sharded:
         out["parity"] = "not checked (--no-cpu-baseline)"
+    default_run = (rank == 0 and world == 1 and not sharded and not bls and args.log2n == 20 and args.digits == "signed"
+                   and args.scalars == "uniform" and args.points == "chain" and pipelined)
+    if default_run and not args.no_configs and not args.no_cpu_baseline:
+        # BASELINE configs 2 and 5 in the driver's one line: short passes, each checked against its oracle
+        ctx.close()
+        ctx = None
+        out["configs"] = {}
+        bad = []
+        cu, ok = side_config(pkg, dev, "unsigned", "te", "unsigned", 20, depth, threads, 40, expect=exp, inputs=(pts, sc))
+        out["configs"]["unsigned"] = cu
+        if not ok:
+            bad.append("unsigned")
+        cb, ok = side_config(pkg, dev, "bls12_377", "bls12-377", "signed", 20, depth, threads, 24)
+        out["configs"]["bls12_377"] = cb
+        if not ok:
+            bad.append("bls12_377")
+        if bad:
+            print(json.dumps(out))
+            raise SystemExit("GPU result differs from the oracle in configs: %s" % bad)
     if sharded and rehearse:
         out["parity"] = "not checked: rehearsal of rank 0 of %d (partial sum)" % rehearse
-        out["config"]["parallelism"] = "REHEARSAL: the per-rank step of a %d-GPU run on one GPU" % rehearse
+        out["config"]["parallelism"] = "REHEARSAL: the per-rank step of a %d-GPU run on one GPU (%s point buffers per batch)" % (
+            rehearse, "one shared" if len(base_copies) == 1 else "distinct")
     elif sharded:
         # untimed cross-check of the sharded path: the same MSM on this rank's GPU alone must give the same point
         with pkg.MsmContext((dev,)) as solo:
@@ -466,7 +606,8 @@ def main():
             raise SystemExit("window-sharded result differs from the single-GPU result")
     if rank == 0:
         print(json.dumps(out))
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
     if sharded:
         dist.barrier()
         dist.destroy_process_group()

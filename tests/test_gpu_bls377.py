@@ -165,6 +165,36 @@ def test_batches_of_window_sharded_msms(pkg, world, count, n):
         assert pkg.finalize_host(merged, cbits, W, curve=pkg.CURVE_BLS12_377_G1) == o.msm(p_, s_, threads=8), f"MSM {m} of the batch"
 
 
+def test_full_size_window_shards_d2(pkg):
+    """n = 2^20 with the windows sharded over two ranks (run one after the other on the one GPU), two MSMs per launch
+    sequence, merged with te_msm_finalize_gathered_curve -- against this curve's oracle (unpinned by the reference)"""
+    import torch
+    n, world, count = 1 << 20, 2, 2
+    pts, _ = pkg.synth_inputs(0x5EED0060, n, scalars=False, curve=pkg.CURVE_BLS12_377_G1)
+    ssets = [o.gen_scalars(0x5EED0061 + m, n) for m in range(count)]
+    exp = [o.msm(pts, sc, c=16, threads=16) for sc in ssets]
+    dp, dscs = _dev(pts), [_dev(sc) for sc in ssets]
+    torch.cuda.synchronize()
+    gathered = None
+    for r in range(world):
+        with pkg.MsmContext((0,)) as c:
+            c.set_option("curve", pkg.CURVE_BLS12_377_G1)
+            c.set_option("window_bits", 16)
+            c.set_window_shard(*pkg.window_shard_for_rank(r, world))
+            cbits, W = c.plan(n)
+            blk = W * c.row_bytes
+            if gathered is None:
+                gathered = torch.zeros(world, count, blk, dtype=torch.uint8)
+            part = torch.zeros(count * blk, dtype=torch.uint8, device="cuda")
+            c.partial_device_batch([dp.data_ptr()] * count, [d.data_ptr() for d in dscs], n, part.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            c.partial_wait(0)
+            gathered[r] = part.cpu().view(count, blk)
+    for m in range(count):
+        mine = gathered[:, m, :].contiguous()
+        assert pkg.finalize_gathered(mine.data_ptr(), world, cbits, W, curve=pkg.CURVE_BLS12_377_G1) == exp[m], f"MSM {m}"
+
+
 def test_giant_buckets_and_host_pieces(bls):
     """skew: all scalars equal (one bucket per window holds every point: thousands of parts summed by the block-level
     combine) and window sizes whose top window has a single occupied bucket; te_msm_run in pieces"""

@@ -31,6 +31,7 @@ def test_stages_against_oracle(ctx, fpcheck, model, ora, n, c):
     pts, sc = ora.gen_points(500 + n, n), ora.gen_scalars(500 + n, n)
     ctx.set_option("window_bits", c)
     ctx.set_option("sort_buckets", 1)
+    ctx.set_option("prezero", 0)           # keep counters and rows in the zeroed block for the checks below
     res = ctx.run(pts, sc)
     W, B = (256 + c - 1) // c, 1 << (c - 1)
     # K1a: records == the same limb code compiled for the host
@@ -128,6 +129,11 @@ def test_stages_against_oracle(ctx, fpcheck, model, ora, n, c):
     # K4: partial rows -> product host tail == oracle; and the emulated rows agree after the tail
     assert res == ora.msm(pts, sc, threads=8)
     ctx.set_option("window_bits", 0)
+    ctx.set_option("prezero", 1)
+    # with the default (the zeroed block is cleared behind the read-back) the same stages are refused, not read as zeros
+    assert ctx.run(pts, sc) == res
+    with pytest.raises(Exception):
+        ctx.debug_read("bucket_count", 4)
 
 
 # ------------------------------------------------------------------ end to end, golden fixtures
@@ -164,6 +170,7 @@ def test_unsigned_digits(pkg, model, ora, c, n):
         u.set_option("window_bits", c)
         u.set_option("signed_digits", 0)
         assert u.get_option("signed_digits") == 0
+        u.set_option("prezero", 0)         # bucket_count is read back below
         assert u.run(pts, sc) == exp
         W, B = (256 + c - 1) // c, 1 << c
         nst = (n + 7) & ~7
@@ -337,6 +344,41 @@ def test_batches_of_window_sharded_msms(pkg, ora, world, count, n, opts):
     for m in range(count):
         merged = pkg.merge_partials([rows[m * blk:(m + 1) * blk] for rows in per_rank], W, world)
         assert pkg.finalize_host(merged, cbits, W, bb) == exp[m], f"MSM {m} of the batch"
+
+
+@pytest.mark.parametrize("world,count", [(8, 8), (4, 4)])
+def test_full_size_window_sharded_batches(pkg, ora, world, count):
+    """BASELINE config 4 at its full size, against the oracle: n = 2^20, the D ranks' window shards run one after another on
+    the one GPU through te_msm_partial_device_batch (a batch of D MSMs per launch sequence, as bench.py --gpus D does), the
+    rows of every MSM merged with te_msm_finalize_gathered.  The batch mixes shared and distinct point buffers: two point
+    sets, `count` different scalar sets (a point buffer named by several MSMs of a call is converted once)."""
+    import torch
+    n = 1 << 20
+    psets = [pkg.synth_inputs(0x5EED0040 + k, n, scalars=False)[0] for k in range(2)]
+    ssets = [ora.gen_scalars(0x5EED0050 + m, n) for m in range(count)]
+    dpts = [_dev(p) for p in psets]
+    dscs = [_dev(sc) for sc in ssets]
+    which = [0 if m % 3 != 1 else 1 for m in range(count)]                 # point set of MSM m: 0 1 0 0 1 0 0 1
+    exp = [ora.msm(psets[which[m]], ssets[m], c=16, threads=16) for m in range(count)]
+    torch.cuda.synchronize()
+    gathered = None
+    for r in range(world):
+        with pkg.MsmContext((0,)) as c:
+            c.set_option("window_bits", 16)
+            c.set_window_shard(*pkg.window_shard_for_rank(r, world))
+            cbits, W = c.plan(n)
+            blk = W * 720
+            if gathered is None:
+                gathered = torch.zeros(world, count, blk, dtype=torch.uint8)
+            part = torch.zeros(count * blk, dtype=torch.uint8, device="cuda")
+            c.partial_device_batch([dpts[which[m]].data_ptr() for m in range(count)], [d.data_ptr() for d in dscs], n, part.data_ptr(),
+                                   torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            c.partial_wait(0)
+            gathered[r] = part.cpu().view(count, blk)
+    for m in range(count):
+        mine = gathered[:, m, :].contiguous()                              # [rank][W rows]: the layout an all-gather delivers
+        assert pkg.finalize_gathered(mine.data_ptr(), world, cbits, W) == exp[m], f"MSM {m} of the batch"
 
 
 def test_batch_argument_checks(pkg, ora):
@@ -571,21 +613,35 @@ def test_host_buffers_in_pieces(pkg, model, ora):
         assert c.run_device(dp.data_ptr(), ds.data_ptr(), n) == exp
 
 
-def test_work_set_streams_are_spread_over_the_hardware_queues(pkg):
-    """te_msm_init measures which of its streams share a hardware queue and hands them out so that work sets 0..3 (and 4..7)
-    are on as many different queues as the runtime has -- in every context, whatever streams the process created before"""
+def test_work_set_streams_are_spread_over_the_hardware_queues(pkg, ora):
+    """The first te_msm_submit_device of a context (not te_msm_init: one-shot callers never pay the ~16 ms) measures which of
+    its streams share a hardware queue, twice, and -- when both measurements agree -- re-deals them so that work sets 0..3
+    (and 4..7) sit on as many different queues as the runtime has, whatever streams the process created before.  Results
+    before and after the re-deal are the oracle's."""
     import torch
     extra = [torch.cuda.Stream() for _ in range(3)]                       # shift the runtime's stream counter
+    n = 5000
+    pts, sc = ora.gen_points(77, n), ora.gen_scalars(77, n)
+    exp = ora.msm(pts, sc, threads=4)
+    dp, ds = _dev(pts), _dev(sc)
+    torch.cuda.synchronize()
     for _ in range(3):
         with pkg.MsmContext((0,)) as c:
+            before = [c.workset_stream(i) for i in range(pkg.WORKSETS)]
+            assert all(h != 0 for h, _ in before) and len({h for h, _ in before}) == pkg.WORKSETS
+            assert all(k == -1 for _, k in before), "te_msm_init must not measure anything"
+            assert c.run_device(dp.data_ptr(), ds.data_ptr(), n) == exp          # on a stream in creation order
+            tickets = [c.submit_device(dp.data_ptr(), ds.data_ptr(), n) for _ in range(4)]
+            assert all(c.collect(t) == exp for t in tickets)
             got = [c.workset_stream(i) for i in range(pkg.WORKSETS)]
-            assert all(h != 0 for h, _ in got) and len({h for h, _ in got}) == pkg.WORKSETS
+            assert {h for h, _ in got} == {h for h, _ in before}, "the same eight streams, re-dealt"
             cls = [k for _, k in got]
             if -1 in cls:
-                pytest.skip("the queue probe did not run")
+                continue                                                  # probe off, or its two measurements disagreed: creation order kept
             nq = len(set(cls))
             assert 1 <= nq <= pkg.WORKSETS
             assert len(set(cls[:4])) == min(4, nq), cls                  # the first four work sets never share while they need not
+            assert c.run_device(dp.data_ptr(), ds.data_ptr(), n) == exp
     del extra
 
 

@@ -31,7 +31,10 @@ import json, sys
 for l in open(sys.argv[3]):
     if l.startswith("{"):
         j = json.loads(l)
-        print("D=%s --batch %s  %.4f ms per MSM and rank  %7.1f MSM/s upper bound  latency of one step %.3f ms  [%s]" % (sys.argv[1], sys.argv[2], j["ms_per_step"], j["value"], j["latency_ms"], j["mode"]))
+        dl = j.get("batch_distinct_bases")
+        print("D=%s --batch %s  %.4f ms per MSM and rank (%s)  %7.1f MSM/s upper bound  latency of one step %.3f ms  [%s]" % (
+            sys.argv[1], sys.argv[2], j["ms_per_step"], ("shared bases; distinct bases %.4f" % dl["ms_per_step"]) if dl else "one MSM per sequence",
+            j["value"], j["latency_ms"], j["mode"]))
 PY
   done
 done

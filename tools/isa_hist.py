@@ -37,9 +37,21 @@ def kernel_body(lines, name):
     return body
 
 
-def main():
-    path, name = sys.argv[1], sys.argv[2]
-    loop_only = "--loop" in sys.argv
+def sources_sha():
+    """the rule of bench.py kernel_sources_sha()"""
+    import hashlib
+    import os
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "webgpu-msm-twisted-edwards_amd", "csrc")
+    h = hashlib.sha256()
+    for f in ("kernels.hip.hpp", "curve.hpp", "fp.hpp"):
+        text = open(os.path.join(csrc, f), "r", errors="replace").read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        h.update(re.sub(r"\s+", "", text).encode())
+    return h.hexdigest()[:16]
+
+
+def analyse(path, name, loop_only, quiet=False):
     lines = open(path).read().split("\n")
     body = kernel_body(lines, name)
     # instructions with their label context
@@ -72,6 +84,11 @@ def main():
     total = sum(ops.values())
     valu = {k: v for k, v in ops.items() if k.startswith("v_")}
     cyc = sum(COST.get(k, 4.3) * v for k, v in valu.items())
+    if quiet:
+        return {"valu_issue_cycles": round(cyc, 1), "valu_instructions": sum(valu.values()), "mads": ops.get("v_mad_u64_u32", 0),
+                "instructions": total, "s_nop": ops.get("s_nop", 0),
+                "note": "%d v_mad_u64_u32 (%.2f clk each) + %d other VALU instructions per 64 accumulated points (tools/isa_hist.py on the built listing)"
+                        % (ops.get("v_mad_u64_u32", 0), COST["v_mad_u64_u32"], sum(valu.values()) - ops.get("v_mad_u64_u32", 0))}
     print("kernel %s: %s, %d instructions (%d VALU, %d SALU, %d memory, %d other)" % (
         name, "hottest loop" if loop_only else "whole kernel", total, sum(valu.values()),
         sum(v for k, v in ops.items() if k.startswith("s_") and not k.startswith(("s_waitcnt", "s_nop", "s_cbranch", "s_branch"))),
@@ -80,6 +97,20 @@ def main():
     print("estimated VALU issue: %.0f cycles per wave pass (mads %.0f)" % (cyc, COST["v_mad_u64_u32"] * ops.get("v_mad_u64_u32", 0)))
     for k, v in sorted(ops.items(), key=lambda kv: -kv[1]):
         print("  %-24s %6d  %5.1f %%%s" % (k, v, 100.0 * v / total, ("   ~%.2f cyc" % COST[k]) if k in COST else ""))
+
+
+def main():
+    if "--json" in sys.argv:
+        # usage: isa_hist.py <listing.s> --json out.json : the per-point loop of both accumulation kernels, with the sources' hash
+        import json
+        path, outp = sys.argv[1], sys.argv[sys.argv.index("--json") + 1]
+        j = {"listing": path, "kernel_sources_sha": sources_sha(),
+             "k_accumulate<9>": analyse(path, "k_accumulateILi9", True, quiet=True),
+             "k_accumulate<14>": analyse(path, "k_accumulateILi14", True, quiet=True)}
+        json.dump(j, open(outp, "w"), indent=1)
+        print(json.dumps(j, indent=1))
+        return
+    analyse(sys.argv[1], sys.argv[2], "--loop" in sys.argv)
 
 
 if __name__ == "__main__":

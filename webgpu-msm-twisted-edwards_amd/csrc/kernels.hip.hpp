@@ -16,6 +16,13 @@
 
 namespace te {
 
+// A launch sequence can carry up to TE_BATCH_MAX MSMs of the same n (te_msm_partial_device_batch): one launch of k_digits
+// and of the record conversion covers all of them (blockIdx.y = MSM / record slab), with the input pointers in a table.
+#define TE_BATCH_MAX 8
+struct batch_ptrs { const uint4* p[TE_BATCH_MAX]; };
+// record slab of MSM m: MSMs of a call that name the SAME point buffer share one conversion (slab = first MSM naming it)
+struct batch_slabs { uint32_t s[TE_BATCH_MAX]; };
+
 struct digits_params {
   uint32_t half[10];   // signed digits: sum_w 2^(c*w + c-1) over ALL windows of the decomposition, 9 limbs (+1 zero); unsigned: 0
   uint32_t zero_digit; // stored code of digit 0: 2^(c-1) signed, 0 unsigned
@@ -36,8 +43,10 @@ struct pnt_slot { uint4 q[8]; };
 // with one point per lane straight to memory (16-B pieces at 64-B / 128-B stride) the kernel spent most of its 70 us
 // issuing 12 million 16-byte requests.  Records are swizzled in LDS (16-B piece q of record r at piece q ^ (r & 7)) so
 // that both the per-record writes and the per-piece reads are conflict-free.
-__global__ void __launch_bounds__(256) k_prep_points(const uint4* __restrict__ pts, pnt_slot* __restrict__ recs, uint32_t n) {
+__global__ void __launch_bounds__(256) k_prep_points(batch_ptrs in, batch_slabs row_slab, pnt_slot* __restrict__ recs, uint32_t n) {
   __shared__ uint4 lds[256 * 8];                        // 32 KB: first the block's 256 points (16 KB), then its 256 records
+  const uint4* __restrict__ pts = in.p[blockIdx.y];     // grid row y converts point buffer y into record slab s = row_slab[y]: slots [s * n, (s + 1) * n)
+  recs += (size_t)row_slab.s[blockIdx.y] * n;
   const uint32_t t = threadIdx.x, base = blockIdx.x * 256u;
   const uint32_t pieces_in = (n - base < 256u ? n - base : 256u) * 4u;     // valid 16-B input pieces of this block
   const uint4* __restrict__ src = pts + (size_t)base * 4u;
@@ -85,9 +94,13 @@ __global__ void __launch_bounds__(256) k_prep_points(const uint4* __restrict__ p
 #define TE_DIG_THREADS 512u
 __device__ __forceinline__ bool digit_bucket(uint32_t stored, uint32_t half, uint32_t& bucket, uint32_t& neg);
 template <int C>
-__global__ void __launch_bounds__(TE_DIG_THREADS) k_digits(const uint4* __restrict__ scalars, uint16_t* __restrict__ digits,
+__global__ void __launch_bounds__(TE_DIG_THREADS) k_digits(batch_ptrs in, uint16_t* __restrict__ digits,
                                                 digits_params prm, uint32_t* __restrict__ err, uint32_t* __restrict__ counts1) {
   __shared__ uint32_t hist[4096];                        // [local window][partition]: nw_local * P <= 4096 for every plan
+  // MSM blockIdx.y of the launch sequence: its scalars, its digit rows and level-1 counts [y * nw_local, (y + 1) * nw_local)
+  const uint4* __restrict__ scalars = in.p[blockIdx.y];
+  digits += (size_t)blockIdx.y * prm.nw_local * prm.nst;
+  counts1 += (size_t)blockIdx.y * prm.nw_local * prm.CH * prm.P;
   const uint32_t hn = (uint32_t)prm.nw_local * prm.P;
   for (uint32_t j = threadIdx.x; j < hn; j += TE_DIG_THREADS) hist[j] = 0u;
   __syncthreads();
@@ -666,7 +679,7 @@ __global__ void __launch_bounds__(256, N == 9 ? 4 : 2) k_accumulate(const rec_sl
                                                     const uint32_t* __restrict__ seg_lenv, const uint32_t* __restrict__ order,
                                                     const uint32_t* __restrict__ num_segments, ete_t<N>* __restrict__ buckets,
                                                     ete_t<N>* __restrict__ seg_out, uint32_t n, uint32_t logB, uint32_t seg_len, uint32_t ids, uint32_t onto,
-                                                    uint32_t win_per_msm, unsigned long long* __restrict__ clk) {
+                                                    uint32_t win_per_msm, batch_slabs slabs, unsigned long long* __restrict__ clk) {
   __shared__ uint32_t idx_strip[256 * TE_IDX_STRIP];
   // profiling: ~clock of the first wave in and clock of the last wave out, by atomic max on zeroed words -- the kernel's
   // own duration on the device, which an event pair around the launch overstates when other streams' kernels hold the
@@ -682,7 +695,7 @@ __global__ void __launch_bounds__(256, N == 9 ? 4 : 2) k_accumulate(const rec_sl
   const uint32_t g = seg_bucket[sgm];                // g = k * B + b
   if (g == TE_SEG_INVALID) return;
   const uint32_t k = g >> logB;
-  recs += (size_t)(k / win_per_msm) * n;             // a batch of MSMs (te_msm_partial_device_batch): window k belongs to MSM k / win_per_msm
+  recs += (size_t)slabs.s[k / win_per_msm] * n;      // a batch of MSMs (te_msm_partial_device_batch): window k belongs to MSM k / win_per_msm
   const uint32_t part = sgm - seg_base[g];
   const uint32_t cnt = seg_lenv[sgm];
   const uint32_t* lst = sorted + (size_t)k * n + bucket_start[g] + part * seg_len;
@@ -962,6 +975,11 @@ template <int N> struct tail_params_t {
   uint32_t win_per_msm, msm_stride;      // batch: window k of the launch is window k % win_per_msm of MSM k / win_per_msm, whose rows start msm_stride points further
 };
 template <int N> __device__ __forceinline__ uint32_t* lds_point(uint32_t* base, uint32_t idx) { return base + (size_t)idx * geo<N>::PW; }
+// exchange through LDS among the lanes of ONE wave: the wave's earlier LDS writes are complete and visible before its later reads
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
 
 template <int N>
 __global__ void __launch_bounds__(1024) k_reduce_tail(tail_params_t<N> prm) {
@@ -1006,7 +1024,8 @@ __global__ void __launch_bounds__(1024) k_reduce_tail(tail_params_t<N> prm) {
     }
     __syncthreads();
   }
-  // ---- C: the first wave alone (16 quads, quad v holds M[v]); the other waves are done
+  // ---- C: the first wave alone (16 quads, quad v holds M[v]); the other waves are done.  One wave: its LDS operations
+  // complete in order, so a wave-level fence orders the exchanges below (no block barrier after other waves have left)
   if (threadIdx.x >= 64u) return;
   {
     const uint32_t v = i, Nv = nout;                                           // Nv <= 16
@@ -1014,23 +1033,23 @@ __global__ void __launch_bounds__(1024) k_reduce_tail(tail_params_t<N> prm) {
     uint32_t* slot = lds_point<N>(sc, v);
     for (uint32_t d = 1; d < 16u; d <<= 1) {           // inclusive suffix scan
       store_coord<N>(slot + wq, mine);
-      __syncthreads();
+      wave_lds_sync();
       const bool act = v + d < Nv;
       const fel<N> other = act ? load_coord<N>(lds_point<N>(sc, v + d) + wq) : identity_coord<N>(q);
       const fel<N> sum = ete_add_team<N>(mine, other, q);
       mine = fp_select<N>(act, sum, mine);
-      __syncthreads();
+      wave_lds_sync();
     }
     ete_t<N>* row = prm.rows + (size_t)(k / prm.win_per_msm) * prm.msm_stride + (size_t)(k % prm.win_per_msm) * prm.row_stride;
     if (v == 0) { if (dgt == 0) store_coord<N>(words<N>(row) + wq, mine); mine = identity_coord<N>(q); }
     for (uint32_t s = 8; s > 0; s >>= 1) {             // tree sum of S_1..S_{N-1} (slot 0 = identity)
       if (v >= s && v < 2 * s) store_coord<N>(slot + wq, mine);
-      __syncthreads();
+      wave_lds_sync();
       const bool act = v < s && v + s < Nv;
       const fel<N> other = act ? load_coord<N>(lds_point<N>(sc, v + s) + wq) : identity_coord<N>(q);
       const fel<N> sum = ete_add_team<N>(mine, other, q);
       mine = fp_select<N>(act, sum, mine);
-      __syncthreads();
+      wave_lds_sync();
     }
     if (v == 0) store_coord<N>(words<N>(row + 1 + dgt) + wq, mine);
   }
@@ -1039,9 +1058,11 @@ __global__ void __launch_bounds__(1024) k_reduce_tail(tail_params_t<N> prm) {
 // ------------------------------------------------------------------------------------------------
 // K1a for BLS12-377 G1: short-Weierstrass affine (x, y), 48-byte little-endian each -> projective twisted-Edwards record
 // (curve.hpp, pnt_from_sw377), one lane per point; loads and stores are 16 bytes per lane.
-__global__ void __launch_bounds__(256) k_prep_points377(const uint4* __restrict__ pts, rec_slot<14>* __restrict__ recs, uint32_t n) {
+__global__ void __launch_bounds__(256) k_prep_points377(batch_ptrs in, batch_slabs row_slab, rec_slot<14>* __restrict__ recs, uint32_t n) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
+  const uint4* __restrict__ pts = in.p[blockIdx.y];
+  recs += (size_t)row_slab.s[blockIdx.y] * n;
   uint4 u[6];
 #pragma unroll
   for (int j = 0; j < 6; j++) u[j] = pts[6 * (size_t)i + j];

@@ -81,11 +81,14 @@ struct workset_t {
   // [Z_HIST..) segment-length histogram (TE_HIST_COPIES copies), [Z_CURSOR..) reservation cursors of the schedule, [Z_END..) the level-1 histogram
   // counts1[window][chunk][partition], then bucket_count[window][bucket].  d_err .. d_bucket_count point into d_zero.
   uint32_t *d_zero = nullptr; size_t zero_words = 0;
+  size_t zero_clean_words = 0;        // words of d_zero known to be zero on the set's stream: the block is cleared AFTER an MSM's read-back
+                                      // (clear_zero_block), so that the next MSM on the set starts with its first kernel, not a fill
   uint32_t *d_err = nullptr, *d_num_seg = nullptr, *d_size_hist = nullptr, *d_size_cursor = nullptr;
   uint8_t* d_partials = nullptr;      // = d_zero + Z_ROWS: TE_MAX_WINDOWS rows
   uint32_t* h_err = nullptr;          // pinned: mirror of d_zero[0 .. Z_ROWS + rows)
   uint8_t* h_partials = nullptr;      // = h_err + Z_ROWS
-  hipEvent_t ev_done = nullptr;
+  hipEvent_t ev_done = nullptr;       // the set is free again (everything of its last MSM, the clearing of the zeroed block included)
+  hipEvent_t ev_result = nullptr;     // flag + rows of its last MSM are in host memory (recorded before the clearing: what a caller waits for)
   hipEvent_t ev[ST_COUNT + 1] = {};
   plan_t plan; uint64_t n = 0; bool used = false;
   uint64_t pending_ticket = 0;        // ticket of an MSM submitted on this set and not collected yet (0 = none)
@@ -110,6 +113,7 @@ struct gpu_t {
   uint64_t next_ticket = 1, next_collect = 1;
   int ticket_ws[TE_MSM_WORKSETS] = {};   // work set of ticket t at index t % TE_MSM_WORKSETS
   std::vector<hipEvent_t> piece_events;  // te_msm_run in pieces: "piece i has arrived"
+  bool queues_probed = false;            // the lazy hardware-queue measurement has run (spread_streams_over_queues)
 };
 
 }  // namespace
@@ -126,6 +130,7 @@ struct te_ctx {
   int opt_host_chunks = 0;     // te_msm_run: pieces a large host buffer is uploaded and processed in (0 = choose from n)
   int opt_graph = 0;           // replay the launch sequence around k_accumulate as HIP graphs
   int opt_workset = 0;         // work set used by te_msm_run* / te_msm_partial_device
+  int opt_prezero = 1;         // clear a work set's zeroed block behind an MSM's read-back instead of in front of the next MSM's first kernel
   float stage_ms[ST_COUNT + 2] = {};
   bool have_stage_ms = false;
 };
@@ -208,7 +213,7 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, workset_t& ws, uint64_t n, const plan_
   {
     const size_t c1 = (size_t)p.nw * p.CH * p.P;
     ws.zero_words = Z_END + c1 + wb;
-    if ((rc = ensure(ctx, ws, ws.d_zero, ws.cap[3], ws.zero_words))) return rc;
+    { const uint32_t* before = ws.d_zero; if ((rc = ensure(ctx, ws, ws.d_zero, ws.cap[3], ws.zero_words))) return rc; if (ws.d_zero != before) ws.zero_clean_words = 0; }
     ws.d_err = ws.d_zero; ws.d_num_seg = ws.d_zero + 1; ws.d_size_hist = ws.d_zero + Z_HIST; ws.d_size_cursor = ws.d_zero + Z_CURSOR;
     ws.d_partials = reinterpret_cast<uint8_t*>(ws.d_zero + Z_ROWS);
     ws.d_counts1 = ws.d_zero + Z_END; ws.d_bucket_count = ws.d_counts1 + c1;
@@ -239,9 +244,10 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, workset_t& ws, uint64_t n, const plan_
   return 0;
 }
 
-template <int C> void launch_digits(const uint4* sc, uint16_t* dg, const te::digits_params& prm, uint32_t* err, uint32_t* counts1, hipStream_t s) {
-  hipLaunchKernelGGL(te::k_digits<C>, dim3((prm.nst + TE_DIG_BLOCK - 1u) / TE_DIG_BLOCK), dim3(TE_DIG_THREADS), 0, s, sc, dg, prm, err, counts1);
+template <int C> void launch_digits(const te::batch_ptrs& sc, int batch, uint16_t* dg, const te::digits_params& prm, uint32_t* err, uint32_t* counts1, hipStream_t s) {
+  hipLaunchKernelGGL(te::k_digits<C>, dim3((prm.nst + TE_DIG_BLOCK - 1u) / TE_DIG_BLOCK, batch), dim3(TE_DIG_THREADS), 0, s, sc, dg, prm, err, counts1);
 }
+static_assert(TE_BATCH_MAX == TE_MSM_MAX_BATCH, "batch tables");
 
 // One MSM's device work in three parts, so that the parts before and after the dominant kernel can be replayed as HIP
 // graphs (one launch each instead of ~30: the host-side enqueue cost, ~0.35 ms, is what bounds small MSMs and the
@@ -266,17 +272,31 @@ struct msm_launch {
     return front_points();
   }
 
-  // points -> records (needs only the points; runs last of the front part)
+  // record slab of MSM m: MSMs of one call that name the same point buffer share one conversion (same pointer in one call =
+  // same data; nothing is remembered across calls).  slab = index of the first MSM with that pointer.
+  te::batch_slabs slabs() const {
+    te::batch_slabs r; memset(&r, 0, sizeof r);
+    for (int m = 0; m < p.batch; m++) {
+      int first = m;
+      for (int j = 0; j < m; j++) if (points_of(j) == points_of(m)) { first = j; break; }
+      r.s[m] = (uint32_t)first;
+    }
+    return r;
+  }
+
+  // points -> records (needs only the points; runs last of the front part): one launch, one grid row per DISTINCT point buffer
   int front_points() {
     const uint32_t n32 = this->n32();
     mark(ST_PREP);
-    for (int m = 0; m < p.batch; m++) {                 // records of MSM m: slots [m * n, (m + 1) * n)
-      uint8_t* recs = ws.d_recs + (size_t)m * n * sizes_of(p.curve).rec;
-      if (p.curve == TE_MSM_CURVE_BLS12_377_G1)
-        hipLaunchKernelGGL(te::k_prep_points377, dim3((n32 + 255) / 256), dim3(256), 0, stream, (const uint4*)points_of(m), reinterpret_cast<te::rec_slot<14>*>(recs), n32);
-      else
-        hipLaunchKernelGGL(te::k_prep_points, dim3((n32 + 255) / 256), dim3(256), 0, stream, (const uint4*)points_of(m), reinterpret_cast<te::pnt_slot*>(recs), n32);
-    }
+    const te::batch_slabs sl = slabs();
+    te::batch_ptrs tab; memset(&tab, 0, sizeof tab);
+    te::batch_slabs row_slab; memset(&row_slab, 0, sizeof row_slab);
+    int rows = 0;
+    for (int m = 0; m < p.batch; m++) if ((int)sl.s[m] == m) { tab.p[rows] = (const uint4*)points_of(m); row_slab.s[rows] = (uint32_t)m; rows++; }
+    if (p.curve == TE_MSM_CURVE_BLS12_377_G1)
+      hipLaunchKernelGGL(te::k_prep_points377, dim3((n32 + 255) / 256, rows), dim3(256), 0, stream, tab, row_slab, reinterpret_cast<te::rec_slot<14>*>(ws.d_recs), n32);
+    else
+      hipLaunchKernelGGL(te::k_prep_points, dim3((n32 + 255) / 256, rows), dim3(256), 0, stream, tab, row_slab, reinterpret_cast<te::pnt_slot*>(ws.d_recs), n32);
     return 0;
   }
 
@@ -284,7 +304,10 @@ struct msm_launch {
   int front_scalars() {
     const uint32_t n32 = this->n32();
     // flags, counters, histograms, bucket counts (a later piece of the same MSM keeps word 0, the final-carry flag)
-    HIP_TRY(ctx, hipMemsetAsync(ws.d_zero + (onto ? 1 : 0), 0, (ws.zero_words - (onto ? 1 : 0)) * sizeof(uint32_t), stream));
+    // -- unless the block is still clean from the clearing that followed the set's previous MSM (clear_zero_block)
+    if (onto || ws.zero_clean_words < ws.zero_words)
+      HIP_TRY(ctx, hipMemsetAsync(ws.d_zero + (onto ? 1 : 0), 0, (ws.zero_words - (onto ? 1 : 0)) * sizeof(uint32_t), stream));
+    ws.zero_clean_words = 0;
     mark(ST_DIGITS);
     te::sort_geom sg;
     sg.n = n32; sg.nst = p.nst; sg.B = p.B; sg.logS = p.logS; sg.S = p.S; sg.P = p.P; sg.CH = p.CH; sg.chunk_len = p.chunk_len; sg.half = p.signed_digits ? p.B : 0u;
@@ -295,25 +318,25 @@ struct msm_launch {
       prm.sc_stride = (uint32_t)(sizes_of(p.curve).scalar_in / 16);
       prm.n = n32; prm.nst = p.nst; prm.num_windows = p.W; prm.w_first = d.w_first; prm.w_step = d.w_step; prm.nw_local = p.nw1;
       prm.half_code = sg.half; prm.logS = p.logS; prm.P = p.P; prm.CH = p.CH; prm.chunk_len = p.chunk_len;
-      for (int m = 0; m < p.batch; m++) {                // MSM m fills digit rows and level-1 counts [m * nw1, (m + 1) * nw1)
-        const uint4* sc = (const uint4*)scalars_of(m);
-        uint16_t* dg = ws.d_digits + (size_t)m * p.nw1 * p.nst;
-        uint32_t* c1 = ws.d_counts1 + (size_t)m * p.nw1 * p.CH * p.P;
-        switch (p.c) {
-          case 4: launch_digits<4>(sc, dg, prm, ws.d_err, c1, stream); break;
-          case 5: launch_digits<5>(sc, dg, prm, ws.d_err, c1, stream); break;
-          case 6: launch_digits<6>(sc, dg, prm, ws.d_err, c1, stream); break;
-          case 7: launch_digits<7>(sc, dg, prm, ws.d_err, c1, stream); break;
-          case 8: launch_digits<8>(sc, dg, prm, ws.d_err, c1, stream); break;
-          case 9: launch_digits<9>(sc, dg, prm, ws.d_err, c1, stream); break;
-          case 10: launch_digits<10>(sc, dg, prm, ws.d_err, c1, stream); break;
-          case 11: launch_digits<11>(sc, dg, prm, ws.d_err, c1, stream); break;
-          case 12: launch_digits<12>(sc, dg, prm, ws.d_err, c1, stream); break;
-          case 13: launch_digits<13>(sc, dg, prm, ws.d_err, c1, stream); break;
-          case 14: launch_digits<14>(sc, dg, prm, ws.d_err, c1, stream); break;
-          case 15: launch_digits<15>(sc, dg, prm, ws.d_err, c1, stream); break;
-          default: launch_digits<16>(sc, dg, prm, ws.d_err, c1, stream); break;
-        }
+      // one launch over the MSMs of the sequence: MSM m (blockIdx.y) fills digit rows and level-1 counts [m * nw1, (m + 1) * nw1)
+      te::batch_ptrs sc; memset(&sc, 0, sizeof sc);
+      for (int m = 0; m < p.batch; m++) sc.p[m] = (const uint4*)scalars_of(m);
+      uint16_t* dg = ws.d_digits;
+      uint32_t* c1 = ws.d_counts1;
+      switch (p.c) {
+        case 4: launch_digits<4>(sc, p.batch, dg, prm, ws.d_err, c1, stream); break;
+        case 5: launch_digits<5>(sc, p.batch, dg, prm, ws.d_err, c1, stream); break;
+        case 6: launch_digits<6>(sc, p.batch, dg, prm, ws.d_err, c1, stream); break;
+        case 7: launch_digits<7>(sc, p.batch, dg, prm, ws.d_err, c1, stream); break;
+        case 8: launch_digits<8>(sc, p.batch, dg, prm, ws.d_err, c1, stream); break;
+        case 9: launch_digits<9>(sc, p.batch, dg, prm, ws.d_err, c1, stream); break;
+        case 10: launch_digits<10>(sc, p.batch, dg, prm, ws.d_err, c1, stream); break;
+        case 11: launch_digits<11>(sc, p.batch, dg, prm, ws.d_err, c1, stream); break;
+        case 12: launch_digits<12>(sc, p.batch, dg, prm, ws.d_err, c1, stream); break;
+        case 13: launch_digits<13>(sc, p.batch, dg, prm, ws.d_err, c1, stream); break;
+        case 14: launch_digits<14>(sc, p.batch, dg, prm, ws.d_err, c1, stream); break;
+        case 15: launch_digits<15>(sc, p.batch, dg, prm, ws.d_err, c1, stream); break;
+        default: launch_digits<16>(sc, p.batch, dg, prm, ws.d_err, c1, stream); break;
       }
     }
     const uint32_t cap_w = p.B + (uint32_t)(n / p.seg_len);        // segment ids of one window (see k_part_scatter)
@@ -351,7 +374,7 @@ struct msm_launch {
       hipLaunchKernelGGL(te::k_accumulate<N>, dim3((smax + 255) / 256), dim3(256), 0, stream, reinterpret_cast<const te::rec_slot<N>*>(ws.d_recs), ws.d_sorted,
                          ws.d_bucket_start, ws.d_bucket_count, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv, order, ws.d_num_seg,
                          reinterpret_cast<te::ete_t<N>*>(ws.d_buckets), reinterpret_cast<te::ete_t<N>*>(ws.d_seg_out), n32, p.logB, p.seg_len, smax, onto ? 1u : 0u,
-                         (uint32_t)p.nw1,
+                         (uint32_t)p.nw1, slabs(),
                          prof ? reinterpret_cast<unsigned long long*>(ws.d_zero + Z_CLOCK) : nullptr);
     }
     return 0;
@@ -470,16 +493,19 @@ int need_copy_stream(te_ctx* ctx, workset_t& ws) {
 // and kernels of one queue run in order: MSMs in flight on two streams of the same queue do not overlap.  Which stream
 // gets which queue follows from how many streams the process created before (tools/queue_probe.hip: 0 1 2 3 3 2 1 0 3 2
 // 1 0 ...), so a context created after other streams -- PyTorch's, RCCL's, another context's -- found its first four work
-// sets on two queues: n = 2^16 / 2^17 / 2^18 ran at 0.23 / 0.32 / 0.42 instead of 0.19 / 0.24 / 0.35 ms per MSM.  Instead
-// of trusting the creation order, te_msm_init creates the eight compute streams, MEASURES which of them share a queue
-// (pairs of k_spin kernels: one duration when they overlap, two when they are serialised; ~10 ms once) and hands them
-// to the work sets so that sets 0..3 and sets 4..7 each sit on as many different queues as there are.
+// sets on two queues: n = 2^16 / 2^17 / 2^18 ran at 0.23 / 0.32 / 0.42 instead of 0.19 / 0.24 / 0.35 ms per MSM.
+// Only callers that keep several MSMs in flight care, so the measurement is LAZY: te_msm_init hands the streams out in
+// creation order, and the first te_msm_submit_device (every work set idle, device synchronised) measures which of them
+// share a queue (pairs of k_spin kernels: one duration when they overlap, two when they are serialised; ~16 ms once)
+// and re-deals them so that sets 0..3 and sets 4..7 each sit on as many different queues as there are.  One-shot callers
+// (te_msm_run, compute_msm with force_recompile) never pay it.  The host-timed pairs can be disturbed by other work on
+// the GPU, so a classification is accepted only when a second, independent measurement gives the same classes;
+// otherwise the creation order stays.  TE_MSM_QUEUE_PROBE=0 turns the measurement off.
 // classes[i] = index of the hardware queue class of streams[i] (classes numbered by first appearance); returns the number of
 // classes, or -1 when the measurement could not run (then classes[] is all -1)
 int classify_streams_by_queue(gpu_t& d, const hipStream_t* streams, int n, int* cls) {
   for (int i = 0; i < n; i++) cls[i] = -1;
-  const char* env = getenv("TE_MSM_QUEUE_PROBE");
-  if ((env && env[0] == '0') || d.wall_clock_khz <= 0 || n < 2) return -1;
+  if (d.wall_clock_khz <= 0 || n < 2) return -1;
   uint32_t* flag = nullptr;
   if (hipMalloc((void**)&flag, 4) != hipSuccess) { (void)hipGetLastError(); return -1; }
   const unsigned long long ticks = (unsigned long long)d.wall_clock_khz * 3 / 10;      // 0.3 ms
@@ -504,7 +530,6 @@ int classify_streams_by_queue(gpu_t& d, const hipStream_t* streams, int n, int* 
   }
   (void)hipFree(flag);
   if (hipGetLastError() != hipSuccess) { for (int i = 0; i < n; i++) cls[i] = -1; return -1; }
-  if (getenv("TE_MSM_QUEUE_DUMP")) { fprintf(stderr, "[te_msm] hardware-queue classes of %d streams:", n); for (int i = 0; i < n; i++) fprintf(stderr, " %d", cls[i]); fprintf(stderr, "\n"); }
   return ncls;
 }
 
@@ -522,15 +547,49 @@ void deal_over_classes(const int* cls, int n, int ncls, int* order) {
   }
 }
 
-int assign_streams_by_queue(gpu_t& d) {
-  hipStream_t cand[TE_MSM_WORKSETS];
-  for (auto& s : cand) { hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking); if (e != hipSuccess) return -1; }
-  int cls[TE_MSM_WORKSETS], order[TE_MSM_WORKSETS];
-  const int ncls = classify_streams_by_queue(d, cand, TE_MSM_WORKSETS, cls);
-  deal_over_classes(cls, TE_MSM_WORKSETS, ncls, order);
-  for (int i = 0; i < TE_MSM_WORKSETS; i++) { d.ws[i].stream = cand[order[i]]; d.ws[i].hw_queue_class = cls[order[i]]; }
+// te_msm_init: one compute stream per work set, in creation order (no measurement)
+int create_workset_streams(gpu_t& d) {
+  for (int i = 0; i < TE_MSM_WORKSETS; i++) {
+    if (hipStreamCreateWithFlags(&d.ws[i].stream, hipStreamNonBlocking) != hipSuccess) {
+      for (int j = 0; j < i; j++) { (void)hipStreamDestroy(d.ws[j].stream); d.ws[j].stream = nullptr; }
+      d.ws[i].stream = nullptr;
+      return -1;
+    }
+    d.ws[i].hw_queue_class = -1;
+  }
   return 0;
 }
+
+// first te_msm_submit_device of a context (see above).  Never fatal: any failure leaves the creation order in place.
+void spread_streams_over_queues(gpu_t& d) {
+  d.queues_probed = true;
+  const char* env = getenv("TE_MSM_QUEUE_PROBE");
+  if (env && env[0] == '0') return;
+  for (const workset_t& ws : d.ws) if (ws.pending_ticket) return;            // cannot happen on the first submit; be safe
+  if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return; }
+  hipStream_t cand[TE_MSM_WORKSETS];
+  for (int i = 0; i < TE_MSM_WORKSETS; i++) cand[i] = d.ws[i].stream;
+  int cls[TE_MSM_WORKSETS], again[TE_MSM_WORKSETS], order[TE_MSM_WORKSETS];
+  const int ncls = classify_streams_by_queue(d, cand, TE_MSM_WORKSETS, cls);
+  const int ncls2 = ncls > 0 ? classify_streams_by_queue(d, cand, TE_MSM_WORKSETS, again) : -1;
+  const bool agree = ncls > 0 && ncls2 == ncls && memcmp(cls, again, sizeof cls) == 0;
+  if (getenv("TE_MSM_QUEUE_DUMP")) {
+    fprintf(stderr, "[te_msm] hardware-queue classes of %d streams (%s):", TE_MSM_WORKSETS, agree ? "two measurements agree" : "measurements disagree: creation order kept");
+    for (int i = 0; i < TE_MSM_WORKSETS; i++) fprintf(stderr, " %d/%d", cls[i], ncls2 > 0 ? again[i] : -1);
+    fprintf(stderr, "\n");
+  }
+  if (!agree) return;
+  deal_over_classes(cls, TE_MSM_WORKSETS, ncls, order);
+  for (int i = 0; i < TE_MSM_WORKSETS; i++) {
+    workset_t& ws = d.ws[i];
+    // the set's buffers were last used on its old stream: everything is idle (device synchronised above), so the new stream
+    // needs no wait; last_stream follows so that enqueue_partial does not add one
+    if (ws.last_stream == ws.stream) ws.last_stream = cand[order[i]];
+    ws.stream = cand[order[i]]; ws.hw_queue_class = cls[order[i]];
+  }
+}
+
+int finish_sequence(te_ctx* ctx, workset_t& ws, hipStream_t stream);
 
 int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, const void* d_scalars, uint64_t n,
                     void* d_partials_out, hipStream_t stream, const std::function<int(hipStream_t)>* upload_points = nullptr, int force_c = 0,
@@ -550,7 +609,9 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, 
   // (an event between two kernels costs ~4 us of idle stream time, 11 of them ~2 % of a 2^20 MSM)
   msm_launch L{ctx, d, ws, p, d_points, d_scalars, n, d_partials_out, ctx->opt_profile, stream, own_rows};
   if (ctx->opt_graph && ctx->opt_profile < 2 && !upload_points && batch == 1) {
-    // the graphs hold pointers and geometry: re-captured when any of them changes (including a buffer reallocation)
+    // the graphs hold pointers and geometry: re-captured when any of them changes (including a buffer reallocation);
+    // the captured front always clears the zeroed block itself
+    ws.zero_clean_words = 0;
     graph_key key; memset(&key, 0, sizeof key);          // padding bytes take part in the memcmp below
     key.pts = d_points; key.sc = d_scalars; key.out = d_partials_out; key.n = n; key.generation = ws.generation;
     key.c = p.c; key.w_first = d.w_first; key.w_step = d.w_step; key.seg_len = (int)p.seg_len;
@@ -588,14 +649,31 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, 
     L.mark(ST_TREE);
     if (int rc = L.back()) return rc;
   }
-  HIP_TRY(ctx, hipEventRecord(ws.ev_done, stream));
+  // rows in the caller's buffer: the sequence ends here (the flag's read-back is part of reduce()); rows in the set's own
+  // block: the caller's fetch_rows() ends it
+  if (!own_rows) { if (int rc = finish_sequence(ctx, ws, stream)) return rc; }
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }
 
-// one device-to-host copy: final-carry flag + the W rows of the work set's own row buffer (enqueue_partial with nullptr)
+// one device-to-host copy: final-carry flag + the W rows of the work set's own row buffer (enqueue_partial with nullptr);
+// ends the launch sequence
 int fetch_rows(te_ctx* ctx, workset_t& ws, hipStream_t stream) {
   HIP_TRY(ctx, hipMemcpyAsync(ws.h_err, ws.d_zero, Z_ROWS * 4 + (size_t)ws.plan.W * sizes_of(ws.plan.curve).row, hipMemcpyDeviceToHost, stream));
+  return finish_sequence(ctx, ws, stream);
+}
+
+// End of an MSM's launch sequence on `stream`: flag and rows are on their way to the host (ev_result); behind them the
+// zeroed block is cleared for the set's NEXT MSM -- 4 us of fill and a launch gap that would otherwise sit in front of that
+// MSM's first kernel, on its critical path -- and ev_done marks the set free.  Not with captured graphs (the fill is part of
+// the captured front) and not with "prezero" = 0 (stage verifiers read counters and rows from the block afterwards).
+int finish_sequence(te_ctx* ctx, workset_t& ws, hipStream_t stream) {
+  HIP_TRY(ctx, hipEventRecord(ws.ev_result, stream));
+  if (ctx->opt_prezero && !ctx->opt_graph) {
+    HIP_TRY(ctx, hipMemsetAsync(ws.d_zero, 0, ws.zero_words * sizeof(uint32_t), stream));
+    ws.zero_clean_words = ws.zero_words;
+  }
+  HIP_TRY(ctx, hipEventRecord(ws.ev_done, stream));
   return 0;
 }
 
@@ -640,6 +718,7 @@ void free_dev(gpu_t& d) {
     for (uint8_t* q : ws.d_red) if (q) (void)hipFree(q);
     if (ws.h_err) (void)hipHostFree(ws.h_err);
     if (ws.ev_done) (void)hipEventDestroy(ws.ev_done);
+    if (ws.ev_result) (void)hipEventDestroy(ws.ev_result);
     if (ws.g_front) (void)hipGraphExecDestroy(ws.g_front);
     if (ws.g_back) (void)hipGraphExecDestroy(ws.g_back);
     for (auto& ev : ws.ev) if (ev) (void)hipEventDestroy(ev);
@@ -725,9 +804,8 @@ int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_
   }
   ws.plan = p; ws.n = piece_lo(last_piece + 1) - piece_lo(last_piece); ws.used = true; ws.last_stream = ws.stream; ws.prof_level = 0; d.last_ws = 0;
   if (int rc = fetch_rows(ctx, ws, ws.stream)) return rc;
-  HIP_TRY(ctx, hipEventRecord(ws.ev_done, ws.stream));
   HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, hipStreamSynchronize(ws.stream));
+  HIP_TRY(ctx, hipEventSynchronize(ws.ev_result));
   stamp("device done", 0);
   if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
   if (pf.curve == TE_MSM_CURVE_BLS12_377_G1) te377_host::horner_to_affine(ws.h_partials, pf.c, (int)pf.logB, pf.W, out);
@@ -801,7 +879,7 @@ int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, boo
     gpu_t& d = ctx->devs[i];
     workset_t& ws = d.ws[wsel];
     HIP_TRY(ctx, hipSetDevice(d.device));
-    HIP_TRY(ctx, hipStreamSynchronize(ws.stream));
+    HIP_TRY(ctx, hipEventSynchronize(ws.ev_result));
     if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
     for (int w = d.w_first; w < p0.W; w += d.w_step)
       memcpy(&merged[(size_t)w * sz.row], ws.h_partials + (size_t)w * sz.row, sz.row);
@@ -840,13 +918,14 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
       er = hipFuncSetAttribute(reinterpret_cast<const void*>(te::k_reduce_tail<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     if (er == hipSuccess)
       er = hipFuncSetAttribute(reinterpret_cast<const void*>(te::k_reduce_tail<14>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    if (er == hipSuccess && assign_streams_by_queue(d) != 0) er = hipErrorOutOfMemory;
+    if (er == hipSuccess && create_workset_streams(d) != 0) er = hipErrorOutOfMemory;
     for (workset_t& ws : d.ws) {       // the small fixed allocations of every work set; the big buffers come with the first MSM
       if (er == hipSuccess) er = hipEventCreateWithFlags(&ws.ev_copy, hipEventDisableTiming);
       if (er == hipSuccess) er = hipEventCreateWithFlags(&ws.ev_start, hipEventDisableTiming);
       if (er == hipSuccess) er = hipHostMalloc((void**)&ws.h_err, Z_ROWS * 4 + (size_t)TE_MAX_WINDOWS * TE_MAX_ROW_BYTES, hipHostMallocDefault);
       if (er == hipSuccess) ws.h_partials = reinterpret_cast<uint8_t*>(ws.h_err + Z_ROWS);
       if (er == hipSuccess) er = hipEventCreateWithFlags(&ws.ev_done, hipEventDisableTiming);
+      if (er == hipSuccess) er = hipEventCreateWithFlags(&ws.ev_result, hipEventDisableTiming);
       for (auto& evn : ws.ev) if (er == hipSuccess) er = hipEventCreate(&evn);
       if (er == hipSuccess) *ws.h_err = 0;
     }
@@ -885,6 +964,8 @@ int te_msm_submit_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_
   // the lowest-numbered free work set (each has its own stream: the MSMs overlap on the device).  Not ticket % sets: with
   // fewer MSMs in flight than sets only as many sets as needed are ever touched -- no buffer allocation in the middle
   // of a run, and a smaller footprint in the Infinity Cache.
+  HIP_TRY(ctx, hipSetDevice(d.device));
+  if (!d.queues_probed) spread_streams_over_queues(d);      // once per context, with nothing in flight
   int wi = 0;
   while (wi < TE_MSM_WORKSETS && d.ws[wi].pending_ticket) wi++;
   if (wi == TE_MSM_WORKSETS) return set_err(ctx, TE_MSM_ESTATE, "every work set has an MSM in flight: collect one first");
@@ -892,7 +973,6 @@ int te_msm_submit_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_
   HIP_TRY(ctx, hipSetDevice(d.device));
   if (int rc = enqueue_partial(ctx, d, ws, d_points_xy_le, d_scalars_le, n, nullptr, ws.stream)) return rc;
   if (int rc = fetch_rows(ctx, ws, ws.stream)) return rc;
-  HIP_TRY(ctx, hipEventRecord(ws.ev_done, ws.stream));
   *ticket = d.next_ticket++;
   ws.pending_ticket = *ticket;
   d.ticket_ws[*ticket % TE_MSM_WORKSETS] = wi;
@@ -905,7 +985,7 @@ int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]) {
   gpu_t& d = ctx->devs[0];
   if (ticket != d.next_collect || ticket >= d.next_ticket) return set_err(ctx, TE_MSM_ESTATE, "tickets must be collected in submission order");
   workset_t& ws = d.ws[d.ticket_ws[ticket % TE_MSM_WORKSETS]];
-  HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));     // on failure the ticket stays collectable
+  HIP_TRY(ctx, hipEventSynchronize(ws.ev_result));   // on failure the ticket stays collectable
   (void)collect_stage_ms(ctx, ws);
   d.next_collect++; ws.pending_ticket = 0;           // the MSM is over, with a result or with a scalar-range error
   if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
@@ -925,6 +1005,7 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   }
   if (!strcmp(key, "profile")) { ctx->opt_profile = value < 0 ? 0 : (value > 2 ? 2 : (int)value); ctx->have_stage_ms = false; return 0; }
   if (!strcmp(key, "graph")) { ctx->opt_graph = value ? 1 : 0; return 0; }
+  if (!strcmp(key, "prezero")) { ctx->opt_prezero = value ? 1 : 0; return 0; }
   if (!strcmp(key, "host_chunks")) { if (value < 0 || value > 64) return set_err(ctx, TE_MSM_EINVAL, "host_chunks out of range"); ctx->opt_host_chunks = (int)value; return 0; }
   if (!strcmp(key, "workset")) { if (value < 0 || value >= TE_MSM_WORKSETS) return set_err(ctx, TE_MSM_EINVAL, "workset out of range"); ctx->opt_workset = (int)value; return 0; }
   if (!strcmp(key, "segment_len")) { if (value < 1 || value > 1000000) return set_err(ctx, TE_MSM_EINVAL, "segment_len must be in [1, 1e6]"); ctx->opt_seg_len = (int)value; return 0; }
@@ -942,6 +1023,7 @@ int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value) {
   if (!strcmp(key, "segment_len")) { *value = ctx->opt_seg_len; return 0; }
   if (!strcmp(key, "workset")) { *value = ctx->opt_workset; return 0; }
   if (!strcmp(key, "graph")) { *value = ctx->opt_graph; return 0; }
+  if (!strcmp(key, "prezero")) { *value = ctx->opt_prezero; return 0; }
   if (!strcmp(key, "host_chunks")) { *value = ctx->opt_host_chunks; return 0; }
   return set_err(ctx, TE_MSM_EINVAL, "unknown option");
 }
@@ -1004,7 +1086,7 @@ int te_msm_partial_wait(te_ctx* ctx, int workset) {
   if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_partial_wait needs a single-device context");
   workset_t& ws = ctx->devs[0].ws[workset];
   if (!ws.used) return 0;
-  HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));
+  HIP_TRY(ctx, hipEventSynchronize(ws.ev_result));
   if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
   return 0;
 }
@@ -1015,7 +1097,7 @@ int te_msm_finalize(te_ctx* ctx, const uint8_t* partials, int window_bits, int n
   workset_t& ws = d.ws[d.last_ws];
   int bucket_bits = ctx->opt_signed ? window_bits - 1 : window_bits;
   if (ws.used) {
-    HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));
+    HIP_TRY(ctx, hipEventSynchronize(ws.ev_result));
     if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
     (void)collect_stage_ms(ctx, ws);
     // the rows were produced under ws.plan: its digit form decides, not an option changed since
@@ -1106,6 +1188,8 @@ int64_t te_msm_debug_read(te_ctx* ctx, const char* stage, void* dst, uint64_t ca
   if (!ws.used) return set_err(ctx, TE_MSM_ESTATE, "no run yet");
   const plan_t& p = ws.plan; const uint64_t n = ws.n;
   const void* src = nullptr; uint64_t bytes = 0;
+  if (ws.zero_clean_words && (!strcmp(stage, "bucket_count") || !strcmp(stage, "num_segments") || !strcmp(stage, "partials")))
+    return set_err(ctx, TE_MSM_ESTATE, "this stage lives in the block that is cleared behind an MSM's read-back: set option prezero = 0 before the run to keep it");
   if (!strcmp(stage, "records")) { src = ws.d_recs; bytes = n * sizes_of(p.curve).rec; }
   else if (!strcmp(stage, "digits")) { src = ws.d_digits; bytes = (uint64_t)p.nw * p.nst * 2; }   // row stride nst = n rounded up to 8
   else if (!strcmp(stage, "bucket_count")) { src = ws.d_bucket_count; bytes = (uint64_t)p.nw * p.B * 4; }
