@@ -195,6 +195,23 @@ def test_full_size_window_shards_d2(pkg):
         assert pkg.finalize_gathered(mine.data_ptr(), world, cbits, W, curve=pkg.CURVE_BLS12_377_G1) == exp[m], f"MSM {m}"
 
 
+def test_pipelined_full_size(pkg):
+    """n = 2^20 with four MSMs in flight, three rounds: at this size the launch sequences really overlap on the device (the
+    small pipelined cases finish before the next one starts).  Round 3 shipped a build step for an hour that broke exactly
+    this and nothing else in the suite (profiles/r03_peephole_experiment.txt)."""
+    import torch
+    n = 1 << 20
+    pts, sc = pkg.synth_inputs(0x5EED0070, n, curve=pkg.CURVE_BLS12_377_G1)
+    exp = o.msm(pts, sc, c=16, threads=16)
+    dp, ds = _dev(pts), _dev(sc)
+    torch.cuda.synchronize()
+    with pkg.MsmContext((0,)) as c:
+        c.set_option("curve", pkg.CURVE_BLS12_377_G1)
+        for _ in range(3):
+            tickets = [c.submit_device(dp.data_ptr(), ds.data_ptr(), n) for _ in range(4)]
+            assert [c.collect(t) == exp for t in tickets] == [True] * 4
+
+
 def test_giant_buckets_and_host_pieces(bls):
     """skew: all scalars equal (one bucket per window holds every point: thousands of parts summed by the block-level
     combine) and window sizes whose top window has a single occupied bucket; te_msm_run in pieces"""

@@ -381,6 +381,21 @@ def test_full_size_window_sharded_batches(pkg, ora, world, count):
         assert pkg.finalize_gathered(mine.data_ptr(), world, cbits, W) == exp[m], f"MSM {m} of the batch"
 
 
+def test_pipelined_full_size(pkg, ora):
+    """n = 2^20, eight MSMs in flight on eight work sets (two alternating input sets), three rounds: the launch sequences
+    overlap on the device for real at this size; every result against the oracle"""
+    import torch
+    n = 1 << 20
+    ins = [pkg.synth_inputs(0x5EED0080 + k, n) for k in range(2)]
+    exp = [ora.msm(p, s, c=16, threads=16) for p, s in ins]
+    dev = [(_dev(p), _dev(s)) for p, s in ins]
+    torch.cuda.synchronize()
+    with pkg.MsmContext((0,)) as c:
+        for _ in range(3):
+            tickets = [c.submit_device(dev[i & 1][0].data_ptr(), dev[i & 1][1].data_ptr(), n) for i in range(pkg.WORKSETS)]
+            assert [c.collect(t) == exp[i & 1] for i, t in enumerate(tickets)] == [True] * pkg.WORKSETS
+
+
 def test_batch_argument_checks(pkg, ora):
     import torch
     n = 100
