@@ -4,8 +4,8 @@
 //   K1 convert_point_coords_and_decompose_scalars (wgsl/cuzk/convert_point_coords_and_decompose_scalars
 //      .template.wgsl:37-123)                    -> k_prep_points + k_digits<C>
 //   K2 transpose (wgsl/cuzk/transpose.wgsl:32-76; 16 threads in total)
-//                                                -> (histogram in k_digits) k_part_scatter / k_l2_count / k_seg_plan / k_l2_place
-//                                                   (two-level counting sort, all stores coalesced) + k_order_scatter
+//                                                -> (histogram in k_digits) k_part_scatter / k_l2_count / k_seg_plan / k_l2_place_order
+//                                                   (two-level counting sort, all stores coalesced; the segment schedule rides along)
 //   K3 smvp (wgsl/cuzk/smvp.template.wgsl:58-152) -> k_accumulate (7-product mixed additions)
 //   K4/K5 bpr stage_1/2 (wgsl/cuzk/bpr.template.wgsl:73-171) + the CPU sum of 4096 points
 //      (submission.ts:362-393)                   -> k_sum_groups[_team] (fold levels) + k_reduce_tail (digit marginals, weighted sums)
@@ -231,6 +231,7 @@ struct sort_geom {
   uint32_t n, nst;       // entries per window; row stride of digits / part_keys / part_idx (multiple of 8, >= n)
   uint32_t B, logS, S, P, CH, chunk_len;   // chunk_len is a multiple of TE_TILE
   uint32_t half;         // stored code of digit 0 (see digit_bucket)
+  uint32_t slice;        // level 2: entries per block, <= TE_SLICE (multiple of 8)
 };
 #define TE_TILE 4096u
 
@@ -346,6 +347,10 @@ __global__ void __launch_bounds__(512) k_part_scatter(const uint16_t* __restrict
 //                segment schedule, see below)
 //   k_l2_place : LDS count again, reserve [base, base+c) in every touched bucket with one atomicAdd on
 //                bucket_cursor, sort the piece by bucket in LDS and copy each run to its reserved range.
+// The slice length follows n: a slice is cut into pieces at partition boundaries and a block works its pieces off one after
+// the other (loads, LDS rounds, a returning global atomic: 4-5 us each), so a slice should hold about ONE partition's worth of
+// entries -- n / P -- not more: with 8192 at n = 2^16 (1024 entries per partition) every block ran eight pieces in a row
+// and k_l2_place took 37 us for 7 MB.
 #define TE_SLICE 8192u
 
 // loads the 16-byte groups covering entries [a, b) of a row (<= TE_SLICE + 8 entries), 5 groups per thread
@@ -380,8 +385,8 @@ __global__ void __launch_bounds__(256) k_l2_count(const uint16_t* __restrict__ p
   const uint32_t k = blockIdx.y, t = threadIdx.x;
   const uint32_t* ps = part_start + k * g.P; const uint32_t* pc = part_count + k * g.P;
   const uint32_t row_total = ps[g.P - 1] + pc[g.P - 1];
-  uint32_t s0 = blockIdx.x * TE_SLICE;
-  const uint32_t s1 = min(row_total, s0 + TE_SLICE);
+  uint32_t s0 = blockIdx.x * g.slice;
+  const uint32_t s1 = min(row_total, s0 + g.slice);
   if (s0 >= s1) return;
   const uint16_t* keys_row = part_keys + (size_t)k * g.nst; const uint32_t* idx_row = part_idx + (size_t)k * g.nst;
   uint32_t p = find_partition(ps, pc, g.P, s0);
@@ -407,19 +412,22 @@ __global__ void __launch_bounds__(256) k_l2_count(const uint16_t* __restrict__ p
   }
 }
 
-// grid (nslices, nw), block 256
-__global__ void __launch_bounds__(256, 3) k_l2_place(const uint16_t* __restrict__ part_keys, const uint32_t* __restrict__ part_idx,
-                                                  const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ part_count,
-                                                  uint32_t* __restrict__ bucket_cursor, uint32_t* __restrict__ sorted, sort_geom g) {
-  __shared__ uint32_t cnt_s[256], lex_s[256], off_s[256], gbase_s[256];
-  __shared__ uint32_t list[TE_SLICE + 8];
-  __shared__ uint8_t list_b[TE_SLICE + 8];
-  __shared__ uint32_t sm[17];
-  const uint32_t k = blockIdx.y, t = threadIdx.x;
+// LDS of one level-2 placement block, in words: four 256-entry tables, the piece's entries and their buckets, scan scratch
+#define TE_PLACE_LDS_WORDS (4u * 256u + (TE_SLICE + 8u) + (TE_SLICE + 8u) / 4u + 2u + 17u)
+// slice `slice_id` of local window k (block of 256 threads; lds: TE_PLACE_LDS_WORDS words)
+__device__ __forceinline__ void l2_place_block(uint32_t slice_id, uint32_t k, uint32_t* __restrict__ lds,
+                                               const uint16_t* __restrict__ part_keys, const uint32_t* __restrict__ part_idx,
+                                               const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ part_count,
+                                               uint32_t* __restrict__ bucket_cursor, uint32_t* __restrict__ sorted, const sort_geom& g) {
+  uint32_t* const cnt_s = lds; uint32_t* const lex_s = lds + 256; uint32_t* const off_s = lds + 512; uint32_t* const gbase_s = lds + 768;
+  uint32_t* const list = lds + 1024;
+  uint8_t* const list_b = reinterpret_cast<uint8_t*>(list + (TE_SLICE + 8u));
+  uint32_t* const sm = list + (TE_SLICE + 8u) + (TE_SLICE + 8u) / 4u + 2u;
+  const uint32_t t = threadIdx.x;
   const uint32_t* ps = part_start + k * g.P; const uint32_t* pc = part_count + k * g.P;
   const uint32_t row_total = ps[g.P - 1] + pc[g.P - 1];
-  uint32_t s0 = blockIdx.x * TE_SLICE;
-  const uint32_t s1 = min(row_total, s0 + TE_SLICE);
+  uint32_t s0 = slice_id * g.slice;
+  const uint32_t s1 = min(row_total, s0 + g.slice);
   if (s0 >= s1) return;
   const uint16_t* keys_row = part_keys + (size_t)k * g.nst; const uint32_t* idx_row = part_idx + (size_t)k * g.nst;
   uint32_t* out = sorted + (size_t)k * g.n;
@@ -554,13 +562,13 @@ __global__ void __launch_bounds__(256) k_seg_plan(const uint32_t* __restrict__ b
   for (uint32_t j = t; j < 1024u; j += blockDim.x) if (h[j]) atomicAdd(&my_hist[j], h[j]);
 }
 
-// grid 256 blocks of 256; `ids` = size of the segment id space (host-known); rel_cursor zeroed per MSM.
+// Counting sort of the valid segment ids by descending length: block `ob` of `nob` (256 threads; lds: 2 * 1024 + 17 words);
+// `ids` = size of the segment id space (host-known); rel_cursor zeroed per MSM.
 // order[] receives the valid segment ids by descending length; block 0 writes their number to *num_segments.
-__global__ void __launch_bounds__(256) k_order_scatter(const uint32_t* __restrict__ lenv, uint32_t ids, const uint32_t* __restrict__ size_hist,
-                                                       uint32_t* __restrict__ rel_cursor, uint32_t* __restrict__ order, uint32_t* __restrict__ num_segments) {
-  __shared__ uint32_t h[1024];
-  __shared__ uint32_t base[1024];
-  __shared__ uint32_t sm[17];
+__device__ __forceinline__ void order_scatter_block(uint32_t ob, uint32_t nob, uint32_t* __restrict__ lds, const uint32_t* __restrict__ lenv, uint32_t ids,
+                                                    const uint32_t* __restrict__ size_hist, uint32_t* __restrict__ rel_cursor,
+                                                    uint32_t* __restrict__ order, uint32_t* __restrict__ num_segments) {
+  uint32_t* const h = lds; uint32_t* const base = lds + 1024; uint32_t* const sm = lds + 2048;
   // descending start of every length: number of segments longer than s (each block scans the histogram itself)
   {
     uint32_t run = 0;
@@ -574,13 +582,13 @@ __global__ void __launch_bounds__(256) k_order_scatter(const uint32_t* __restric
       base[s] = run + ex;
       run += bt;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) *num_segments = run;
+    if (ob == 0 && threadIdx.x == 0) *num_segments = run;
   }
   for (uint32_t j = threadIdx.x; j < 1024u; j += 256u) h[j] = 0;
   __syncthreads();
   // the block owns a contiguous slice so that each thread sees the same elements in both passes
-  const uint32_t per = (ids + gridDim.x - 1) / gridDim.x;
-  const uint32_t lo = blockIdx.x * per, hi = min(ids, lo + per);
+  const uint32_t per = (ids + nob - 1) / nob;
+  const uint32_t lo = min(ids, ob * per), hi = min(ids, lo + per);
   for (uint32_t g = lo + threadIdx.x; g < hi; g += 256u) { const uint32_t l = lenv[g]; if (l != TE_SEG_INVALID) atomicAdd(&h[min(l, 1023u)], 1u); }
   __syncthreads();
   for (uint32_t j = threadIdx.x; j < 1024u; j += 256u) { base[j] += h[j] ? atomicAdd(&rel_cursor[j], h[j]) : 0u; h[j] = 0; }
@@ -592,6 +600,21 @@ __global__ void __launch_bounds__(256) k_order_scatter(const uint32_t* __restric
     const uint32_t pos = base[s] + atomicAdd(&h[s], 1u);
     order[pos] = g;
   }
+}
+
+// Level-2 placement and the segment schedule in ONE launch: both need only k_seg_plan's output and neither needs the other,
+// and the schedule is latency-bound (a few dependent rounds over 3 MB: 20 us as a launch of its own, between k_l2_place
+// and the record conversion on one MSM's critical path).  grid (order_cols + nslices, nw), block 256: blocks with
+// blockIdx.x < order_cols sort segments (order_cols * nw of them, dispatched first), the others place a slice each.
+struct order_args { const uint32_t* lenv; uint32_t ids; const uint32_t* size_hist; uint32_t* rel_cursor; uint32_t* order; uint32_t* num_segments; uint32_t order_cols; };
+__global__ void __launch_bounds__(256, 3) k_l2_place_order(const uint16_t* __restrict__ part_keys, const uint32_t* __restrict__ part_idx,
+                                                           const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ part_count,
+                                                           uint32_t* __restrict__ bucket_cursor, uint32_t* __restrict__ sorted, sort_geom g, order_args oa) {
+  __shared__ uint32_t lds[TE_PLACE_LDS_WORDS];
+  if (blockIdx.x < oa.order_cols)
+    order_scatter_block(blockIdx.y * oa.order_cols + blockIdx.x, gridDim.y * oa.order_cols, lds, oa.lenv, oa.ids, oa.size_hist, oa.rel_cursor, oa.order, oa.num_segments);
+  else
+    l2_place_block(blockIdx.x - oa.order_cols, blockIdx.y, lds, part_keys, part_idx, part_start, part_count, bucket_cursor, sorted, g);
 }
 
 // ================================================================================================

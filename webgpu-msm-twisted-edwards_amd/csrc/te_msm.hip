@@ -57,6 +57,7 @@ struct plan_t {
   uint32_t CH = 0, chunk_len = 0, nst = 0;   // level-1 chunks per window (chunk_len multiple of 4096); padded row stride
   uint32_t seg_len = 64;
   uint32_t S = 0, logS = 0, P = 0;   // level-1 partition: S buckets each, P = B/S partitions per window
+  uint32_t slice = 0;                // level 2: entries per block (about one partition's worth, 1024..TE_SLICE)
 };
 
 struct graph_key { const void *pts, *sc, *out; uint64_t n, generation; int c, w_first, w_step, seg_len, sort; };
@@ -189,6 +190,11 @@ void make_plan(const te_ctx* ctx, const gpu_t& d, uint64_t n, plan_t& p, int for
   p.S = p.B < 256u ? p.B : 256u;
   p.seg_len = (uint32_t)ctx->opt_seg_len;
   p.P = p.B / p.S; p.logS = ilog2(p.S);
+  {
+    uint64_t per = (n + p.P - 1) / p.P;                         // entries of one partition for well-spread digits
+    per = (per + 1023u) & ~(uint64_t)1023u;
+    p.slice = (uint32_t)std::min<uint64_t>(TE_SLICE, std::max<uint64_t>(1024u, per));
+  }
 }
 
 template <typename T> int ensure(te_ctx* ctx, workset_t& ws, T*& ptr, size_t& cap_bytes, size_t need_elems) {
@@ -310,7 +316,7 @@ struct msm_launch {
     ws.zero_clean_words = 0;
     mark(ST_DIGITS);
     te::sort_geom sg;
-    sg.n = n32; sg.nst = p.nst; sg.B = p.B; sg.logS = p.logS; sg.S = p.S; sg.P = p.P; sg.CH = p.CH; sg.chunk_len = p.chunk_len; sg.half = p.signed_digits ? p.B : 0u;
+    sg.n = n32; sg.nst = p.nst; sg.B = p.B; sg.logS = p.logS; sg.S = p.S; sg.P = p.P; sg.CH = p.CH; sg.chunk_len = p.chunk_len; sg.half = p.signed_digits ? p.B : 0u; sg.slice = p.slice;
     if (p.nw > 0) {
       te::digits_params prm; memset(&prm, 0, sizeof prm);
       if (p.signed_digits) for (int w = 0; w < p.W; w++) { const int bit = w * p.c + p.c - 1; if (bit < 320) prm.half[bit >> 5] |= 1u << (bit & 31); }
@@ -347,19 +353,22 @@ struct msm_launch {
     mark(ST_BSORT);
     const uint32_t total = this->total();
     if (p.nw > 0) {
-      const uint32_t nslices = (p.nst + TE_SLICE - 1u) / TE_SLICE;
+      const uint32_t nslices = (p.nst + p.slice - 1u) / p.slice;
       hipLaunchKernelGGL(te::k_l2_count, dim3(nslices, p.nw), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx, ws.d_part_start,
                          ws.d_part_count, ws.d_bucket_count, sg);
       // d_num_seg[1..3] = split / giant bucket counters, zeroed with the rest
       hipLaunchKernelGGL(te::k_seg_plan, dim3(p.P, p.nw), dim3(p.S), 0, stream, ws.d_bucket_count, ws.d_part_start, ws.d_part_count, ws.d_seg_part_base,
                          ws.d_bucket_start, ws.d_bucket_cursor, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv, ws.d_size_hist, ws.d_split_list,
                          ws.d_num_seg + 1, ws.d_large_list, ws.d_chunk_list, p.B, p.S, p.seg_len, cap_w, total, chunk_cap());
-      hipLaunchKernelGGL(te::k_l2_place, dim3(nslices, p.nw), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx, ws.d_part_start,
-                         ws.d_part_count, ws.d_bucket_cursor, ws.d_sorted, sg);
+      // level-2 placement + the segment schedule (counts the valid segments, d_num_seg[0]; with "sort_buckets" = 0 the
+      // schedule is simply not used) in one launch
+      te::order_args oa;
+      oa.lenv = ws.d_seg_lenv; oa.ids = smax(); oa.size_hist = ws.d_size_hist; oa.rel_cursor = ws.d_size_cursor; oa.order = ws.d_order; oa.num_segments = ws.d_num_seg;
+      oa.order_cols = (uint32_t)std::min(64, std::max(1, 128 / p.nw));
+      hipLaunchKernelGGL(te::k_l2_place_order, dim3(oa.order_cols + nslices, p.nw), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx, ws.d_part_start,
+                         ws.d_part_count, ws.d_bucket_cursor, ws.d_sorted, sg, oa);
     }
     mark(ST_ORDER);
-    if (p.nw > 0)      // also counts the valid segments (d_num_seg[0]); with "sort_buckets" = 0 the schedule is simply not used
-      hipLaunchKernelGGL(te::k_order_scatter, dim3(256), dim3(256), 0, stream, ws.d_seg_lenv, smax(), ws.d_size_hist, ws.d_size_cursor, ws.d_order, ws.d_num_seg);
     return 0;
   }
 
@@ -416,7 +425,12 @@ struct msm_launch {
         for (int i = 0; i < 2; i++) {
           chain_t& c = ch[i];
           if (c.r <= 4u) continue;
-          const uint32_t K = (c.r % 8u == 0) ? 8u : (c.r % 4u == 0) ? 4u : 2u;
+          uint32_t K = (c.r % 8u == 0) ? 8u : (c.r % 4u == 0) ? 4u : 2u;
+          // a level with at least 65536 outputs runs one thread per output (VALU-efficient: 9 products per addition); below that
+          // it needs four lanes per output and 16 lane-products per addition.  Where folding by 8 falls below the line and by
+          // 4 stays above it, fold by 4 (n = 2^16, 2^17: 18 windows x 16384 buckets -- the first level by 8 took 62 us as a
+          // team kernel)
+          if (K == 8u && (uint64_t)(c.n / 8u) * (uint64_t)p.nw < 65536u && (uint64_t)(c.n / 4u) * (uint64_t)p.nw >= 65536u) K = 4u;
           te::sum_job_t<N>& j = js.j[nj++];
           j.in = c.cur; j.out = c.buf[c.pp]; j.K = K; j.n_out = c.n / K;
           j.inner = i == 0 ? c.r / K : (c.r / K) * L;          // rows: sub-blocks inside one hi; cols: whole slabs of L
