@@ -43,39 +43,51 @@ struct pnt_slot { uint4 q[8]; };
 // with one point per lane straight to memory (16-B pieces at 64-B / 128-B stride) the kernel spent most of its 70 us
 // issuing 12 million 16-byte requests.  Records are swizzled in LDS (16-B piece q of record r at piece q ^ (r & 7)) so
 // that both the per-record writes and the per-piece reads are conflict-free.
-__global__ void __launch_bounds__(256) k_prep_points(batch_ptrs in, batch_slabs row_slab, pnt_slot* __restrict__ recs, uint32_t n) {
-  __shared__ uint4 lds[256 * 8];                        // 32 KB: first the block's 256 points (16 KB), then its 256 records
-  const uint4* __restrict__ pts = in.p[blockIdx.y];     // grid row y converts point buffer y into record slab s = row_slab[y]: slots [s * n, (s + 1) * n)
-  recs += (size_t)row_slab.s[blockIdx.y] * n;
-  const uint32_t t = threadIdx.x, base = blockIdx.x * 256u;
+// The first 256 threads of the block convert points [256 blk, 256 blk + 256) of one buffer; lds: 256 * 8 uint4 (32 KB).
+// Threads beyond 256 (the fused launch below has 512-thread blocks) only take part in the barriers.
+__device__ __forceinline__ void prep_points_block(uint32_t blk, uint4* __restrict__ lds, const uint4* __restrict__ pts, pnt_slot* __restrict__ recs, uint32_t n) {
+  const uint32_t t = threadIdx.x, base = blk * 256u;
+  const bool active = t < 256u;                          // whole waves: no divergence
   const uint32_t pieces_in = (n - base < 256u ? n - base : 256u) * 4u;     // valid 16-B input pieces of this block
   const uint4* __restrict__ src = pts + (size_t)base * 4u;
+  if (active) {
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const uint32_t g = (uint32_t)j * 256u + t;
-    lds[g] = src[g < pieces_in ? g : 0u];               // clamped: unconditional loads
+    for (int j = 0; j < 4; j++) {
+      const uint32_t g = (uint32_t)j * 256u + t;
+      lds[g] = src[g < pieces_in ? g : 0u];             // clamped: unconditional loads
+    }
   }
   __syncthreads();
-  const uint4 a0 = lds[4 * t + 0], a1 = lds[4 * t + 1], b0 = lds[4 * t + 2], b1 = lds[4 * t + 3];
+  uint4 a0 = make_uint4(0u, 0u, 0u, 0u), a1 = a0, b0 = a0, b1 = a0;
+  if (active) { a0 = lds[4 * t + 0]; a1 = lds[4 * t + 1]; b0 = lds[4 * t + 2]; b1 = lds[4 * t + 3]; }
   __syncthreads();
-  const uint32_t xw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-  const uint32_t yw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-  const pnt r = pnt_from_affine_raw(fp_from_words32(xw), fp_from_words32(yw));
-  uint32_t w[32];
+  if (active) {
+    const uint32_t xw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const uint32_t yw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    const pnt r = pnt_from_affine_raw(fp_from_words32(xw), fp_from_words32(yw));
+    uint32_t w[32];
 #pragma unroll
-  for (int j = 0; j < NL; j++) { w[j] = r.hm.v[j]; w[NL + j] = r.hp.v[j]; w[2 * NL + j] = r.dt.v[j]; }
+    for (int j = 0; j < NL; j++) { w[j] = r.hm.v[j]; w[NL + j] = r.hp.v[j]; w[2 * NL + j] = r.dt.v[j]; }
 #pragma unroll
-  for (int j = 3 * NL; j < 32; j++) w[j] = 0u;
+    for (int j = 3 * NL; j < 32; j++) w[j] = 0u;
 #pragma unroll
-  for (int q = 0; q < 8; q++) lds[8 * t + ((uint32_t)q ^ (t & 7u))] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
-  __syncthreads();
-  const uint32_t pieces_out = pieces_in * 2u;
-  uint4* __restrict__ dst = reinterpret_cast<uint4*>(recs + base);
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const uint32_t g = (uint32_t)j * 256u + t, rr = g >> 3, q = g & 7u;
-    if (g < pieces_out) dst[g] = lds[8 * rr + (q ^ (rr & 7u))];
+    for (int q = 0; q < 8; q++) lds[8 * t + ((uint32_t)q ^ (t & 7u))] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
   }
+  __syncthreads();
+  if (active) {
+    const uint32_t pieces_out = pieces_in * 2u;
+    uint4* __restrict__ dst = reinterpret_cast<uint4*>(recs + base);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t g = (uint32_t)j * 256u + t, rr = g >> 3, q = g & 7u;
+      if (g < pieces_out) dst[g] = lds[8 * rr + (q ^ (rr & 7u))];
+    }
+  }
+}
+__global__ void __launch_bounds__(256) k_prep_points(batch_ptrs in, batch_slabs row_slab, pnt_slot* __restrict__ recs, uint32_t n) {
+  __shared__ uint4 lds[256 * 8];                        // 32 KB: first the block's 256 points (16 KB), then its 256 records
+  // grid row y converts point buffer y into record slab s = row_slab[y]: slots [s * n, (s + 1) * n)
+  prep_points_block(blockIdx.x, lds, in.p[blockIdx.y], recs + (size_t)row_slab.s[blockIdx.y] * n, n);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -251,16 +263,24 @@ __device__ __forceinline__ void unpack8(const uint4& v, uint32_t (&d)[8]) {
 // ids [k * capW, (k+1) * capW), capW = B + n / seg_len; inside, partition p starts at p * S + sum_{p' < p} floor(count_p' / seg_len)
 // -- an upper bound on the segments of the earlier partitions that needs no bucket counts (ids left over are marked invalid
 // by k_seg_plan).
-__global__ void __launch_bounds__(512) k_part_scatter(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ counts1,
-                                                      uint16_t* __restrict__ part_keys, uint32_t* __restrict__ part_idx,
-                                                      uint32_t* __restrict__ part_start, uint32_t* __restrict__ part_count,
-                                                      uint32_t* __restrict__ seg_part_base, uint32_t seg_len, uint32_t cap_w, sort_geom g) {
-  __shared__ uint32_t st_idx[TE_TILE];
-  __shared__ uint16_t st_key[TE_TILE];
-  __shared__ uint16_t st_part[TE_TILE];
-  __shared__ uint32_t tile_cnt[512], tile_off[512], run_base[512];
-  __shared__ uint32_t sm[17];
-  const uint32_t ch = blockIdx.x, k = blockIdx.y, t = threadIdx.x;
+struct scatter_args {
+  const uint16_t* digits; const uint32_t* counts1; uint16_t* part_keys; uint32_t* part_idx;
+  uint32_t *part_start, *part_count, *seg_part_base; uint32_t seg_len, cap_w; sort_geom g;
+};
+// LDS of one level-1 block in words: the tile's indices, keys and partitions, three 512-entry tables, scan scratch
+#define TE_SCATTER_LDS_WORDS (TE_TILE + TE_TILE / 2u + TE_TILE / 2u + 3u * 512u + 17u)
+// chunk `ch` of local window `k` (block of 512 threads; lds: TE_SCATTER_LDS_WORDS words)
+__device__ __forceinline__ void part_scatter_block(uint32_t ch, uint32_t k, uint32_t* __restrict__ lds, const scatter_args& a) {
+  uint32_t* const st_idx = lds;
+  uint16_t* const st_key = reinterpret_cast<uint16_t*>(lds + TE_TILE);
+  uint16_t* const st_part = reinterpret_cast<uint16_t*>(lds + TE_TILE + TE_TILE / 2u);
+  uint32_t* const tile_cnt = lds + 2u * TE_TILE; uint32_t* const tile_off = tile_cnt + 512; uint32_t* const run_base = tile_cnt + 1024;
+  uint32_t* const sm = tile_cnt + 1536;
+  const uint16_t* __restrict__ digits = a.digits; const uint32_t* __restrict__ counts1 = a.counts1;
+  uint16_t* __restrict__ part_keys = a.part_keys; uint32_t* __restrict__ part_idx = a.part_idx;
+  uint32_t* __restrict__ part_start = a.part_start; uint32_t* __restrict__ part_count = a.part_count; uint32_t* __restrict__ seg_part_base = a.seg_part_base;
+  const uint32_t seg_len = a.seg_len, cap_w = a.cap_w; const sort_geom& g = a.g;
+  const uint32_t t = threadIdx.x;
   {
     // P is a power of two <= 256: 512 / P threads share a partition's column of counts (independent loads, eight in flight)
     tile_cnt[t] = 0u; tile_off[t] = 0u;
@@ -334,6 +354,30 @@ __global__ void __launch_bounds__(512) k_part_scatter(const uint16_t* __restrict
     __syncthreads();
     for (uint32_t p = t; p < g.P; p += 512u) run_base[p] += tile_cnt[p];
     __syncthreads();
+  }
+}
+
+// grid (CH, nw), block 512
+__global__ void __launch_bounds__(512) k_part_scatter(scatter_args a) {
+  __shared__ uint32_t lds[TE_SCATTER_LDS_WORDS];
+  part_scatter_block(blockIdx.x, blockIdx.y, lds, a);
+}
+
+// Level 1 of the sort and the record conversion in ONE launch (device-resident inputs): neither needs the other, the
+// scatter is bound by its LDS rounds and barriers (2.3 TB/s of its 128 MB) and the conversion by memory and four products per
+// point -- side by side they fill each other's gaps, back to back they cost 56 + 39 us on one MSM's critical path.
+// 1-D grid of scatter_blocks + prep_blocks blocks of 512 threads, the two kinds interleaved evenly (Bresenham); a
+// conversion block works with its first 256 threads (the other four waves only meet the barriers).
+__global__ void __launch_bounds__(512) k_part_scatter_prep(scatter_args a, uint32_t scatter_blocks, batch_ptrs in, batch_slabs row_slab,
+                                                           pnt_slot* __restrict__ recs, uint32_t n, uint32_t prep_blocks_per_row, uint32_t prep_blocks) {
+  __shared__ uint4 lds4[(TE_SCATTER_LDS_WORDS + 3u) / 4u > 256u * 8u ? (TE_SCATTER_LDS_WORDS + 3u) / 4u : 256u * 8u];
+  const uint64_t tot = (uint64_t)scatter_blocks + prep_blocks, b = blockIdx.x;
+  const uint32_t s_before = (uint32_t)(b * scatter_blocks / tot), s_after = (uint32_t)((b + 1u) * scatter_blocks / tot);
+  if (s_after > s_before) {                               // this block is scatter block number s_before
+    part_scatter_block(s_before % a.g.CH, s_before / a.g.CH, reinterpret_cast<uint32_t*>(lds4), a);
+  } else {
+    const uint32_t pb = (uint32_t)b - s_before, row = pb / prep_blocks_per_row, blk = pb - row * prep_blocks_per_row;
+    prep_points_block(blk, lds4, in.p[row], recs + (size_t)row_slab.s[row] * n, n);
   }
 }
 

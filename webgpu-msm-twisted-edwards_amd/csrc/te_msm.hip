@@ -131,6 +131,7 @@ struct te_ctx {
   int opt_host_chunks = 0;     // te_msm_run: pieces a large host buffer is uploaded and processed in (0 = choose from n)
   int opt_graph = 0;           // replay the launch sequence around k_accumulate as HIP graphs
   int opt_workset = 0;         // work set used by te_msm_run* / te_msm_partial_device
+  int opt_fuse_prep = 1;       // device-resident inputs: convert the points in the launch of the sort's first level (k_part_scatter_prep)
   int opt_prezero = 1;         // clear a work set's zeroed block behind an MSM's read-back instead of in front of the next MSM's first kernel
   float stage_ms[ST_COUNT + 2] = {};
   bool have_stage_ms = false;
@@ -273,9 +274,21 @@ struct msm_launch {
   const void* scalars_of(int m) const { return p.batch > 1 ? static_cast<const void* const*>(d_scalars)[m] : d_scalars; }
   void mark(int i) const { if (prof >= 2 || (prof == 1 && (i == ST_ACCUM || i == ST_ACCUM + 1))) (void)hipEventRecord(ws.ev[i], stream); }
 
+  // device-resident inputs, no per-stage timing: the record conversion rides in the launch of the sort's first level
+  bool can_fuse_prep() const { return ctx->opt_fuse_prep && p.curve == TE_MSM_CURVE_TE_BLS12 && prof < 2 && p.nw > 0; }
   int front() {
+    if (can_fuse_prep()) return front_scalars(true);
     if (int rc = front_scalars()) return rc;
     return front_points();
+  }
+
+  // the distinct point buffers of the sequence (grid rows of the conversion) and the record slab of each
+  int prep_rows(te::batch_ptrs& tab, te::batch_slabs& row_slab) const {
+    const te::batch_slabs sl = slabs();
+    memset(&tab, 0, sizeof tab); memset(&row_slab, 0, sizeof row_slab);
+    int rows = 0;
+    for (int m = 0; m < p.batch; m++) if ((int)sl.s[m] == m) { tab.p[rows] = (const uint4*)points_of(m); row_slab.s[rows] = (uint32_t)m; rows++; }
+    return rows;
   }
 
   // record slab of MSM m: MSMs of one call that name the same point buffer share one conversion (same pointer in one call =
@@ -294,11 +307,8 @@ struct msm_launch {
   int front_points() {
     const uint32_t n32 = this->n32();
     mark(ST_PREP);
-    const te::batch_slabs sl = slabs();
-    te::batch_ptrs tab; memset(&tab, 0, sizeof tab);
-    te::batch_slabs row_slab; memset(&row_slab, 0, sizeof row_slab);
-    int rows = 0;
-    for (int m = 0; m < p.batch; m++) if ((int)sl.s[m] == m) { tab.p[rows] = (const uint4*)points_of(m); row_slab.s[rows] = (uint32_t)m; rows++; }
+    te::batch_ptrs tab; te::batch_slabs row_slab;
+    const int rows = prep_rows(tab, row_slab);
     if (p.curve == TE_MSM_CURVE_BLS12_377_G1)
       hipLaunchKernelGGL(te::k_prep_points377, dim3((n32 + 255) / 256, rows), dim3(256), 0, stream, tab, row_slab, reinterpret_cast<te::rec_slot<14>*>(ws.d_recs), n32);
     else
@@ -306,8 +316,9 @@ struct msm_launch {
     return 0;
   }
 
-  // scalars -> digits, two-level counting sort, segment schedule (needs only the scalars)
-  int front_scalars() {
+  // scalars -> digits, two-level counting sort, segment schedule (needs only the scalars); with_prep: the points -> records
+  // conversion shares the launch of the sort's first level (k_part_scatter_prep)
+  int front_scalars(bool with_prep = false) {
     const uint32_t n32 = this->n32();
     // flags, counters, histograms, bucket counts (a later piece of the same MSM keeps word 0, the final-carry flag)
     // -- unless the block is still clean from the clearing that followed the set's previous MSM (clear_zero_block)
@@ -347,9 +358,19 @@ struct msm_launch {
     }
     const uint32_t cap_w = p.B + (uint32_t)(n / p.seg_len);        // segment ids of one window (see k_part_scatter)
     mark(ST_SCATTER);
-    if (p.nw > 0)
-      hipLaunchKernelGGL(te::k_part_scatter, dim3(p.CH, p.nw), dim3(512), 0, stream, ws.d_digits, ws.d_counts1, ws.d_part_keys, ws.d_part_idx,
-                         ws.d_part_start, ws.d_part_count, ws.d_seg_part_base, p.seg_len, cap_w, sg);
+    if (p.nw > 0) {
+      te::scatter_args sa;
+      sa.digits = ws.d_digits; sa.counts1 = ws.d_counts1; sa.part_keys = ws.d_part_keys; sa.part_idx = ws.d_part_idx; sa.part_start = ws.d_part_start;
+      sa.part_count = ws.d_part_count; sa.seg_part_base = ws.d_seg_part_base; sa.seg_len = p.seg_len; sa.cap_w = cap_w; sa.g = sg;
+      if (with_prep) {
+        te::batch_ptrs tab; te::batch_slabs row_slab;
+        const uint32_t rows = (uint32_t)prep_rows(tab, row_slab), per_row = (n32 + 255u) / 256u, sblocks = p.CH * (uint32_t)p.nw;
+        hipLaunchKernelGGL(te::k_part_scatter_prep, dim3(sblocks + rows * per_row), dim3(512), 0, stream, sa, sblocks, tab, row_slab,
+                           reinterpret_cast<te::pnt_slot*>(ws.d_recs), n32, per_row, rows * per_row);
+      } else {
+        hipLaunchKernelGGL(te::k_part_scatter, dim3(p.CH, p.nw), dim3(512), 0, stream, sa);
+      }
+    }
     mark(ST_BSORT);
     const uint32_t total = this->total();
     if (p.nw > 0) {
@@ -425,12 +446,9 @@ struct msm_launch {
         for (int i = 0; i < 2; i++) {
           chain_t& c = ch[i];
           if (c.r <= 4u) continue;
-          uint32_t K = (c.r % 8u == 0) ? 8u : (c.r % 4u == 0) ? 4u : 2u;
-          // a level with at least 65536 outputs runs one thread per output (VALU-efficient: 9 products per addition); below that
-          // it needs four lanes per output and 16 lane-products per addition.  Where folding by 8 falls below the line and by
-          // 4 stays above it, fold by 4 (n = 2^16, 2^17: 18 windows x 16384 buckets -- the first level by 8 took 62 us as a
-          // team kernel)
-          if (K == 8u && (uint64_t)(c.n / 8u) * (uint64_t)p.nw < 65536u && (uint64_t)(c.n / 4u) * (uint64_t)p.nw >= 65536u) K = 4u;
+          const uint32_t K = (c.r % 8u == 0) ? 8u : (c.r % 4u == 0) ? 4u : 2u;
+          // (folding by 4 where that keeps a level above the 65536 outputs a thread-per-output launch needs -- n = 2^16, 2^17 --
+          // was measured: 42 + 26 + 16 us against 62 + 16 us: one more dependent level costs more than the cheaper first one saves)
           te::sum_job_t<N>& j = js.j[nj++];
           j.in = c.cur; j.out = c.buf[c.pp]; j.K = K; j.n_out = c.n / K;
           j.inner = i == 0 ? c.r / K : (c.r / K) * L;          // rows: sub-blocks inside one hi; cols: whole slabs of L
@@ -642,9 +660,13 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, 
     L.mark(ST_TREE);
     HIP_TRY(ctx, hipGraphLaunch(ws.g_back, stream));
   } else if (ctx->opt_profile >= 2 || !(side_stream || upload_points)) {
-    if (int rc = L.front_scalars()) return rc;
-    if (upload_points) { if (int rc = (*upload_points)(stream)) return rc; }
-    if (int rc = L.front_points()) return rc;
+    if (!upload_points && L.can_fuse_prep()) {
+      if (int rc = L.front()) return rc;
+    } else {
+      if (int rc = L.front_scalars()) return rc;
+      if (upload_points) { if (int rc = (*upload_points)(stream)) return rc; }
+      if (int rc = L.front_points()) return rc;
+    }
     if (int rc = L.accumulate()) return rc;
     L.mark(ST_TREE);
     if (int rc = L.back()) return rc;
@@ -1020,6 +1042,7 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   if (!strcmp(key, "profile")) { ctx->opt_profile = value < 0 ? 0 : (value > 2 ? 2 : (int)value); ctx->have_stage_ms = false; return 0; }
   if (!strcmp(key, "graph")) { ctx->opt_graph = value ? 1 : 0; return 0; }
   if (!strcmp(key, "prezero")) { ctx->opt_prezero = value ? 1 : 0; return 0; }
+  if (!strcmp(key, "fuse_prep")) { ctx->opt_fuse_prep = value ? 1 : 0; return 0; }
   if (!strcmp(key, "host_chunks")) { if (value < 0 || value > 64) return set_err(ctx, TE_MSM_EINVAL, "host_chunks out of range"); ctx->opt_host_chunks = (int)value; return 0; }
   if (!strcmp(key, "workset")) { if (value < 0 || value >= TE_MSM_WORKSETS) return set_err(ctx, TE_MSM_EINVAL, "workset out of range"); ctx->opt_workset = (int)value; return 0; }
   if (!strcmp(key, "segment_len")) { if (value < 1 || value > 1000000) return set_err(ctx, TE_MSM_EINVAL, "segment_len must be in [1, 1e6]"); ctx->opt_seg_len = (int)value; return 0; }
@@ -1038,6 +1061,7 @@ int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value) {
   if (!strcmp(key, "workset")) { *value = ctx->opt_workset; return 0; }
   if (!strcmp(key, "graph")) { *value = ctx->opt_graph; return 0; }
   if (!strcmp(key, "prezero")) { *value = ctx->opt_prezero; return 0; }
+  if (!strcmp(key, "fuse_prep")) { *value = ctx->opt_fuse_prep; return 0; }
   if (!strcmp(key, "host_chunks")) { *value = ctx->opt_host_chunks; return 0; }
   return set_err(ctx, TE_MSM_EINVAL, "unknown option");
 }
