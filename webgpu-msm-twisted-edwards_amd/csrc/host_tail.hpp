@@ -8,6 +8,7 @@
 #pragma once
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 
 namespace te_host {
 
@@ -29,19 +30,32 @@ static inline void sub_mod_raw(Fe& a) {
 }
 static inline Fe canon(Fe a) { while (ge_mod(a)) sub_mod_raw(a); return a; }   // any 256-bit value -> [0, p)
 
+// r < 2p  ->  r mod p, without a branch: the comparison with p is data-dependent and unpredictable, and a mispredicted
+// branch per field operation costs more than the operation's arithmetic (it also empties the window the independent products
+// of a doubling overlap in) -- measured: 240 -> 130 ns per doubling
+static inline Fe reduce_once(const Fe& r) {
+  Fe d; uint64_t br = 0;
+  for (int i = 0; i < 4; i++) { const u128 x = (u128)r.l[i] - MOD[i] - br; d.l[i] = (uint64_t)x; br = (uint64_t)(x >> 64) & 1; }
+  const uint64_t keep = (uint64_t)0 - br;            // all ones when r < p
+  Fe o;
+  for (int i = 0; i < 4; i++) o.l[i] = (r.l[i] & keep) | (d.l[i] & ~keep);
+  return o;
+}
 static inline Fe add(const Fe& a, const Fe& b) {
   Fe r; u128 c = 0;
   for (int i = 0; i < 4; i++) { c += (u128)a.l[i] + b.l[i]; r.l[i] = (uint64_t)c; c >>= 64; }
-  if (ge_mod(r)) sub_mod_raw(r);     // a, b < p < 2^253: no carry out
-  return r;
+  return reduce_once(r);             // a, b < p < 2^253: no carry out
 }
 static inline Fe sub(const Fe& a, const Fe& b) {
   Fe r; uint64_t br = 0;
   for (int i = 0; i < 4; i++) { u128 d = (u128)a.l[i] - b.l[i] - br; r.l[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
-  if (br) { u128 c = 0; for (int i = 0; i < 4; i++) { c += (u128)r.l[i] + MOD[i]; r.l[i] = (uint64_t)c; c >>= 64; } }
+  const uint64_t m = (uint64_t)0 - br;               // borrow: add p back
+  u128 c = 0;
+  for (int i = 0; i < 4; i++) { c += (u128)r.l[i] + (MOD[i] & m); r.l[i] = (uint64_t)c; c >>= 64; }
   return r;
 }
-static inline Fe mul(const Fe& a, const Fe& b) {
+// a * b / R mod p, portable form (CIOS; also the reference the assembly form below is checked against at start-up)
+static inline Fe mul_c(const Fe& a, const Fe& b) {
   uint64_t t[5] = {0, 0, 0, 0, 0};
   for (int i = 0; i < 4; i++) {
     u128 c = 0;
@@ -56,8 +70,49 @@ static inline Fe mul(const Fe& a, const Fe& b) {
   if (t[4] || ge_mod(r)) sub_mod_raw(r);
   return r;
 }
+#if defined(__x86_64__)
+// The same product with mulx and the two independent carry chains of adcx / adox (BMI2 + ADX), four rounds of
+// "t += a * b_i; t = (t + m p) / 2^64".  p < 2^253 leaves three spare bits, so the running value never needs a fifth word
+// beyond the round's own carry (the "no-carry" interleaving of the gnark / blst field code).  About 2.5 times the speed of the
+// compiler's code for mul_c, on the 256 dependent doublings of Horner's rule -- the one serial stretch of an MSM that runs on
+// a host core.  Used when the CPU has both extensions (have_adx(), checked once; tail_selftest compares the two forms).
+__attribute__((target("bmi2,adx"))) static inline Fe mul_adx(const Fe& a, const Fe& b) {
+  uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, A = 0, B = 0;
+#define TE_HOST_MUL_ROUND(i)                                                                                          \
+    "movq " #i "*8(%[b]), %%rdx\n\t"                                                                                 \
+    "xorq %%rax, %%rax\n\t"                                                                                          \
+    "mulxq 0(%[a]), %%rax, %[A]\n\t"  "adoxq %%rax, %[t0]\n\t" "adcxq %[A], %[t1]\n\t"                              \
+    "mulxq 8(%[a]), %%rax, %[A]\n\t"  "adoxq %%rax, %[t1]\n\t" "adcxq %[A], %[t2]\n\t"                              \
+    "mulxq 16(%[a]), %%rax, %[A]\n\t" "adoxq %%rax, %[t2]\n\t" "adcxq %[A], %[t3]\n\t"                              \
+    "mulxq 24(%[a]), %%rax, %[A]\n\t" "adoxq %%rax, %[t3]\n\t"                                                      \
+    "movl $0, %%eax\n\t" "adcxq %%rax, %[A]\n\t" "adoxq %%rax, %[A]\n\t"                                            \
+    "movq %[t0], %%rdx\n\t" "imulq %[ninv], %%rdx\n\t"                                                              \
+    "xorq %%rax, %%rax\n\t"                                                                                          \
+    "mulxq %[q0], %%rax, %[B]\n\t" "adcxq %[t0], %%rax\n\t" "movq %[B], %[t0]\n\t"                                  \
+    "adcxq %[t1], %[t0]\n\t" "mulxq %[q1], %%rax, %[t1]\n\t" "adoxq %%rax, %[t0]\n\t"                               \
+    "adcxq %[t2], %[t1]\n\t" "mulxq %[q2], %%rax, %[t2]\n\t" "adoxq %%rax, %[t1]\n\t"                               \
+    "adcxq %[t3], %[t2]\n\t" "mulxq %[q3], %%rax, %[t3]\n\t" "adoxq %%rax, %[t2]\n\t"                               \
+    "movl $0, %%eax\n\t" "adcxq %%rax, %[t3]\n\t" "adoxq %[A], %[t3]\n\t"
+  __asm__(TE_HOST_MUL_ROUND(0) TE_HOST_MUL_ROUND(1) TE_HOST_MUL_ROUND(2) TE_HOST_MUL_ROUND(3)
+          : [t0] "+&r"(t0), [t1] "+&r"(t1), [t2] "+&r"(t2), [t3] "+&r"(t3), [A] "+&r"(A), [B] "+&r"(B)
+          : [a] "r"(a.l), [b] "r"(b.l), [ninv] "m"(MOD_NEG_INV), [q0] "m"(MOD[0]), [q1] "m"(MOD[1]), [q2] "m"(MOD[2]), [q3] "m"(MOD[3]),
+            "m"(*(const uint64_t(*)[4])a.l), "m"(*(const uint64_t(*)[4])b.l)
+          : "rax", "rdx", "cc");
+#undef TE_HOST_MUL_ROUND
+  const Fe r = {{t0, t1, t2, t3}};
+  return reduce_once(r);
+}
+static inline bool have_adx() {           // TE_MSM_HOST_MUL=c forces the portable form (A/B measurements)
+  static const bool v = __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("adx") && !(getenv("TE_MSM_HOST_MUL") && getenv("TE_MSM_HOST_MUL")[0] == 'c');
+  return v;
+}
+static inline Fe mul(const Fe& a, const Fe& b) { return have_adx() ? mul_adx(a, b) : mul_c(a, b); }
+#else
+static inline bool have_adx() { return false; }
+static inline Fe mul(const Fe& a, const Fe& b) { return mul_c(a, b); }
+#endif
 // a * a / R mod p: the 6 cross products once, doubled, then the same interleaved reduction (about 3/4 of mul's multiplications)
-static inline Fe sqr(const Fe& a) {
+static inline Fe sqr_c(const Fe& a) {
   uint64_t w[8];
   {
     u128 c = (u128)a.l[0] * a.l[1]; w[1] = (uint64_t)c; c >>= 64;
@@ -88,6 +143,7 @@ static inline Fe sqr(const Fe& a) {
   if (top || ge_mod(r)) sub_mod_raw(r);
   return r;
 }
+static inline Fe sqr(const Fe& a) { return have_adx() ? mul(a, a) : sqr_c(a); }
 static inline Fe inv(const Fe& a) {            // a^(p-2)
   uint64_t e[4] = {MOD[0] - 2, MOD[1], MOD[2], MOD[3]};
   Fe acc = ONE_M, base = a;
@@ -210,11 +266,14 @@ static inline bool tail_selftest() {
   const Fe t = mul(ONE_M, one_raw);                                // R * 1 / R = 1
   if (!(t.l[0] == 1 && !t.l[1] && !t.l[2] && !t.l[3])) return false;
   Fe v = {{0x243f6a8885a308d3ULL, 0x13198a2e03707344ULL, 0xa4093822299f31d0ULL, 0x082efa98ec4e6c89ULL}};     // below p
-  for (int i = 0; i < 8; i++) {                                    // the dedicated squaring against the general product
-    const Fe a = sqr(v), b = mul(v, v);
-    if (memcmp(a.l, b.l, 32) != 0) return false;
-    v = add(a, ONE_M);
+  Fe u = ONE_M;
+  for (int i = 0; i < 64; i++) {                                   // every form of the product against the portable one
+    const Fe a = sqr_c(v), b = mul_c(v, v), c = mul(v, u), d = mul_c(v, u), e = sqr(v);
+    if (memcmp(a.l, b.l, 32) != 0 || memcmp(c.l, d.l, 32) != 0 || memcmp(e.l, b.l, 32) != 0) return false;
+    u = add(c, v); v = add(a, ONE_M);
   }
+  const Fe top = {{MOD[0] - 1, MOD[1], MOD[2], MOD[3]}};           // p - 1: the widest operands
+  { const Fe c = mul(top, top), d = mul_c(top, top); if (memcmp(c.l, d.l, 32) != 0) return false; }
   return true;
 }
 

@@ -942,6 +942,7 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
     return TE_MSM_EDEVICE;
   }
   te_ctx* ctx = new te_ctx();
+  if (const char* e = getenv("TE_MSM_FUSE_PREP")) ctx->opt_fuse_prep = e[0] != '0';      // A/B measurements; option "fuse_prep"
   ctx->devs.resize(n_dev);
   for (int i = 0; i < n_dev; i++) {
     gpu_t& d = ctx->devs[i];
