@@ -79,7 +79,9 @@ __device__ __forceinline__ void mont_mul_fma(const double (&a)[5], const double 
 // (spills at the 128 registers that four waves per SIMD allow), or 2 (no spills)
 template <int NC>
 __global__ void __launch_bounds__(256, 4) k_fma(double* io, fma_consts k, int sample) {
-  __builtin_amdgcn_s_setreg((1 << 11) | (2 << 6) | 1, 3);                    // MODE.FP_ROUND[3:2] (f64) = toward zero
+  // MODE.FP_ROUND[3:2] (f64) = toward zero.  As inline asm: after the s_setreg builtin the compiler's mode-register pass puts
+  // the default (nearest-even) back in front of the first FMA.
+  asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 3");
   double x[NC][5], y[5];
   const size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * 5 * (CHAINS + 1);
   for (int c = 0; c < NC; c++) for (int i = 0; i < 5; i++) x[c][i] = io[base + 5 * c + i];
