@@ -25,7 +25,8 @@ while time.time() < t_end:
     opts = {}
     for k, v in (("window_bits", rnd.choice([0, 0, 4, 7, 10, 13, 15, 16])), ("signed_digits", rnd.choice([1, 1, 0])),
                  ("segment_len", rnd.choice([64, 64, 1, 7, 500])), ("sort_buckets", rnd.choice([1, 1, 0])), ("host_chunks", rnd.choice([0, 1, 3, 5])),
-                 ("graph", rnd.choice([0, 0, 1])), ("profile", rnd.choice([0, 0, 1, 2]))):
+                 ("graph", rnd.choice([0, 0, 1])), ("profile", rnd.choice([0, 0, 1, 2])), ("prezero", rnd.choice([1, 1, 0])),
+                 ("fuse_prep", rnd.choice([1, 1, 0]))):
         ctx.set_option(k, v)
         opts[k] = v
     mode = rnd.choice(["run", "run", "tickets", "tickets", "shards", "batch"])
@@ -33,7 +34,11 @@ while time.time() < t_end:
     for _ in range(rnd.randint(1, pkg.WORKSETS)):
         n = n_common if mode == "batch" else int(2 ** rnd.uniform(0, 20.2 if rnd.random() < 0.05 else 17.5))      # one launch sequence takes MSMs of one size
         seed = rnd.randrange(1 << 30)
-        pts, sc = orc.gen_points(seed, n), orc.gen_scalars(seed, n)
+        if mode == "batch" and batch and rnd.random() < 0.4:
+            pts = batch[rnd.randrange(len(batch))][0]                  # a point buffer several MSMs of the sequence share (same object -> same device pointer below)
+        else:
+            pts = orc.gen_points(seed, n)
+        sc = orc.gen_scalars(seed, n)
         if rnd.random() < 0.2:
             sc = sc[:sb] * n
         batch.append((pts, sc, n))
@@ -61,7 +66,11 @@ while time.time() < t_end:
     elif mode == "batch":
         world = rnd.choice([1, 2, 4, 8])
         n = batch[0][2]
-        dev = [(torch.frombuffer(bytearray(p), dtype=torch.uint8).cuda(), torch.frombuffer(bytearray(s), dtype=torch.uint8).cuda()) for p, s, _ in batch]
+        pdev = {}
+        for p, _, _ in batch:
+            if id(p) not in pdev:
+                pdev[id(p)] = torch.frombuffer(bytearray(p), dtype=torch.uint8).cuda()
+        dev = [(pdev[id(p)], torch.frombuffer(bytearray(s), dtype=torch.uint8).cuda()) for p, s, _ in batch]
         cb, W = ctx.plan(n)
         blk = W * ctx.row_bytes
         per_rank = []
