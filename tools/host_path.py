@@ -31,13 +31,19 @@ if int(r2) == 0: rt.cudaHostUnregister(hs.data_ptr())
 with pkg.MsmContext((0,)) as ctx:
     ctx.set_option("window_bits", 16)
     ref = ctx.run(pts, sc)
-    for k in (1, 2, 3, 4, 5, 6, 8):
+    import os
+    for k, split in ((1, None), (2, None), (3, None), (4, None), (5, None), (6, None), (8, None), (3, "40,35,25"), (3, "45,33,22"), (4, "32,27,23,18"), (4, "35,28,22,15"), (5, "28,24,20,16,12")):
         ctx.set_option("host_chunks", k)
+        if split:
+            os.environ["TE_MSM_HOST_SPLIT"] = split
+        else:
+            os.environ.pop("TE_MSM_HOST_SPLIT", None)
         ts = []
-        for _ in range(6):
+        for _ in range(8):
             t0 = time.perf_counter(); r = ctx.run(pts, sc); ts.append((time.perf_counter() - t0) * 1e3)
         assert r == ref
-        print("te_msm_run, %d piece(s): best %.3f ms, median %.3f ms  (%.1f GB/s of input)" % (k, min(ts), sorted(ts)[len(ts) // 2], nbytes / min(ts) / 1e6))
+        print("te_msm_run, %d piece(s)%s: best %.3f ms, median %.3f ms  (%.1f GB/s of input)" % (k, (" split " + split) if split else "", min(ts), sorted(ts)[len(ts) // 2], nbytes / min(ts) / 1e6))
+    os.environ.pop("TE_MSM_HOST_SPLIT", None)
     dpts = torch.frombuffer(bytearray(pts), dtype=torch.uint8).cuda(); dsc = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
     torch.cuda.synchronize()
     ts = []

@@ -797,8 +797,22 @@ int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_
   // 2.64 ms); the staging itself runs at ~55 GB/s whatever the piece size.  What limits the call is the device: every
   // piece pays ~13 launches on a fraction of the points, so K pieces keep it busy ~(1.25 + 0.15 K) ms -- about as long as
   // the 1.8 ms the bytes need to cross PCIe; three or four pieces are the optimum, more pieces lose.
-  auto piece_lo = [&](int i) -> uint64_t { return i >= K ? n : n * (uint64_t)i / (uint64_t)K; };     // first point of piece i
-  const uint64_t m_max = (n + (uint64_t)K - 1) / (uint64_t)K;
+  // piece boundaries: equal pieces, or TE_MSM_HOST_SPLIT="w0,w1,..." (relative weights, experiments)
+  std::vector<uint64_t> bounds((size_t)K + 1, n);
+  {
+    std::vector<double> wgt((size_t)K, 1.0);
+    if (const char* e = getenv("TE_MSM_HOST_SPLIT")) {
+      int i = 0; const char* q = e;
+      while (*q && i < K) { char* end = nullptr; const double v = strtod(q, &end); if (end == q) break; if (v > 0) wgt[(size_t)i] = v; i++; q = *end == ',' ? end + 1 : end; }
+    }
+    double tot = 0, run = 0; for (double v : wgt) tot += v;
+    for (int i = 0; i < K; i++) { bounds[(size_t)i] = (uint64_t)((double)n * (run / tot)); run += wgt[(size_t)i]; }
+    bounds[0] = 0; bounds[(size_t)K] = n;
+    for (int i = 1; i <= K; i++) if (bounds[(size_t)i] < bounds[(size_t)i - 1]) bounds[(size_t)i] = bounds[(size_t)i - 1];
+  }
+  auto piece_lo = [&](int i) -> uint64_t { return i >= K ? n : bounds[(size_t)i]; };     // first point of piece i
+  uint64_t m_max = 0;
+  for (int i = 0; i < K; i++) m_max = std::max(m_max, piece_lo(i + 1) - piece_lo(i));
   {
     plan_t pm; make_plan(ctx, d, m_max, pm, pf.c);
     if (int rc = ensure_buffers(ctx, d, ws, m_max, pm)) return rc;        // every buffer at its final size before the first piece
@@ -815,7 +829,14 @@ int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_
   plan_t p;
   bool first = true;
   int last_piece = K - 1;
-  while (last_piece > 0 && piece_lo(last_piece) == n) last_piece--;       // empty tail pieces (n < K (K+1) / 2)
+  while (last_piece > 0 && piece_lo(last_piece) == piece_lo(last_piece + 1)) last_piece--;       // empty tail pieces
+  // ALL scalars first, in one copy (a third of the bytes): every extra pageable copy call costs ~43 us of pipeline drain
+  // (six calls for three pieces ended at 2.02 ms where one pair of calls takes 1.85), and with the scalars there the sort
+  // of piece i + 1 is enqueued behind piece i's accumulation and runs while piece i + 1's points are still crossing PCIe.
+  HIP_TRY(ctx, hipMemcpyAsync(dscs, src_scalars, n * sz.scalar_in, hipMemcpyHostToDevice, ws.copy_stream));
+  HIP_TRY(ctx, hipEventRecord(evs[K], ws.copy_stream));
+  HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, evs[K], 0));
+  stamp("scalars staged", -1);
   for (int i = 0; i < K; i++) {
     const uint64_t lo = piece_lo(i), hi = piece_lo(i + 1), m = hi - lo;
     if (m == 0) continue;
@@ -823,11 +844,7 @@ int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_
     if (int rc = ensure_buffers(ctx, d, ws, m, p)) return rc;              // no reallocation: only the pointers into the zeroed block move
     msm_launch L{ctx, d, ws, p, dpts + lo * sz.point_in, dscs + lo * sz.scalar_in, m, ws.d_partials, 0, ws.stream, true, !first};
     first = false;
-    HIP_TRY(ctx, hipMemcpyAsync(dscs + lo * sz.scalar_in, src_scalars + lo * sz.scalar_in, m * sz.scalar_in, hipMemcpyHostToDevice, ws.copy_stream));
-    HIP_TRY(ctx, hipEventRecord(evs[K], ws.copy_stream));
-    HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, evs[K], 0));
     if (int rc = L.front_scalars()) return rc;                             // digits, sort and schedule run while the piece's points cross PCIe
-    stamp("scalars staged, scalar stages enqueued", i);
     HIP_TRY(ctx, hipMemcpyAsync(dpts + lo * sz.point_in, src_points + lo * sz.point_in, m * sz.point_in, hipMemcpyHostToDevice, ws.copy_stream));
     stamp("points staged", i);
     HIP_TRY(ctx, hipEventRecord(evs[i], ws.copy_stream));
