@@ -90,17 +90,24 @@ int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]);
  *                   result, accepts any 256-bit scalar (no final-carry error)
  *   "curve"         TE_MSM_CURVE_TE_BLS12 (default) or TE_MSM_CURVE_BLS12_377_G1, see above
  *   "sort_buckets"  1 = schedule buckets by descending size (default), 0 = natural order
- *   "segment_len"   a bucket longer than this is accumulated by several threads (default 64)
+ *   "segment_len"   a bucket longer than this is accumulated by several threads and the parts summed afterwards; 0 = from n
+ *                   (default: twice the mean bucket size as a power of two in [16, 64]; read-only "segment_len_used" reports
+ *                   what the last MSM ran with)
  *   "profile"       1 = HIP events around the dominant kernel (accumulate) only, 2 = around every stage
  *                   (te_msm_stage_ms); 0 = none (default)
  *   "graph"         1 = replay the ~30 launches before and after the accumulate kernel as two HIP graphs, captured on
  *                   first use and re-captured when pointers, n or options change; 0 = launch every kernel (default: on
  *                   ROCm 7.2 / MI355X the replay measured ~5 % slower than plain launches).
  *                   Ignored at profile level 2.
- *   "host_chunks"   te_msm_run (Twisted-Edwards, one device): pieces the host buffers are uploaded and processed in, so
- *                   that PCIe transfer and device work overlap; 0 = from n (4 from 2^20 points, 2 from 2^18, else 1),
- *                   1 = whole.  The result does not depend on it.
- *   "workset"       which of the TE_MSM_WORKSETS device work sets te_msm_run* / te_msm_partial_device use (default 0) */
+ *   "host_chunks"   te_msm_run (one device): pieces the point buffer is uploaded and processed in, so that PCIe transfer
+ *                   and device work overlap (all scalars go first, in one copy); 0 = from n (3 from 2^19 points, 2 from
+ *                   2^17, else 1), 1 = whole.  The result does not depend on it.
+ *   "workset"       which of the TE_MSM_WORKSETS device work sets te_msm_run* / te_msm_partial_device use (default 0)
+ *   "prezero"       1 (default) = a work set's block of counters is cleared BEHIND an MSM's read-back, for its next MSM
+ *                   (the next MSM starts with its first kernel instead of a fill); 0 = cleared in front of every MSM --
+ *                   te_msm_debug_read of "bucket_count" / "num_segments" / "partials" needs 0 (it refuses otherwise)
+ *   "fuse_prep"     1 (default) = device-resident Twisted-Edwards inputs: the points -> records conversion shares the launch
+ *                   of the sort's first level; 0 = a launch of its own (A/B measurements; env TE_MSM_FUSE_PREP) */
 int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value);
 int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value);
 
@@ -125,7 +132,9 @@ int te_msm_partial_device(te_ctx* ctx, const void* d_points_xy_le, const void* d
  * d_partials + m * W * row bytes.  The windows of the batch are sorted, accumulated and reduced together, as if they were
  * count x (windows of this shard) windows of one MSM: what a rank of a D-GPU window-sharded job needs, because its W/D windows per
  * MSM are too little work for a launch sequence of their own (rehearsed per-rank step at D = 8: 0.27 ms per MSM one by one,
- * 0.20 ms in batches of eight).  There is no reference
+ * 0.17 ms in batches of eight).  MSMs of one call that name the SAME point buffer share one conversion
+ * of it (same pointer in one call = same data; nothing is remembered across calls) -- a prover's batch over one SRS converts
+ * it once per call; the scalars of all MSMs are decomposed by one launch.  There is no reference
  * counterpart: the reference awaits one compute_msm at a time (full_benchmarks.ts:97-110).  A scalar out of range anywhere
  * in the batch fails the whole batch (te_msm_partial_wait).  Same work set and stream rules as te_msm_partial_device. */
 #define TE_MSM_MAX_BATCH 8
@@ -138,10 +147,13 @@ int te_msm_partial_device_batch(te_ctx* ctx, const void* const* d_points_xy_le, 
 int te_msm_partial_wait(te_ctx* ctx, int workset);
 /* The private stream of a work set (what TE_MSM_OWN_STREAM selects) as a hipStream_t, for callers that order their own work
  * -- a collective, a copy -- behind te_msm_partial_device without a host round trip (PyTorch: torch.cuda.ExternalStream).
- * te_msm_init measures which of its streams the runtime put on the same hardware queue (kernels of one queue run in order;
- * see csrc/te_msm.hip, assign_streams_by_queue) and distributes them so that work sets 0..3, and 4..7, sit on different queues:
- * MSMs in flight on the context's own streams overlap whatever other streams the process has created.  *hw_queue_class
- * (optional) receives the measured class of the work set's stream, -1 when the probe did not run (TE_MSM_QUEUE_PROBE=0). */
+ * The FIRST te_msm_submit_device of a context (not te_msm_init: one-shot callers never pay the ~16 ms) measures which of
+ * its streams the runtime put on the same hardware queue (kernels of one queue run in order; see csrc/te_msm.hip,
+ * spread_streams_over_queues), twice, and -- when both measurements agree -- re-deals them so that work sets 0..3, and 4..7,
+ * sit on different queues: MSMs in flight on the context's own streams overlap whatever other streams the process has
+ * created.  The handles may therefore change at that call: query them after it.  *hw_queue_class (optional) receives the
+ * measured class of the work set's stream, -1 before the measurement, when it is off (TE_MSM_QUEUE_PROBE=0) or when its
+ * two passes disagreed (creation order kept). */
 int te_msm_workset_stream(te_ctx* ctx, int workset, void** stream, int* hw_queue_class);
 /* Host tail (replaces submission.ts:362-412: de-Montgomery, sum, Horner, toAffine): folds the W rows
  * (host memory; rows of absent windows all-zero are skipped as identity) into the affine result.

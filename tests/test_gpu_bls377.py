@@ -100,7 +100,7 @@ def test_skew_and_split_buckets(bls):
     for seg in (1, 3, 64):
         bls.set_option("segment_len", seg)
         assert bls.run(pts, sc) == exp
-    bls.set_option("segment_len", 64)
+    bls.set_option("segment_len", 0)
 
 
 def test_device_resident_and_pipelined(bls, pkg):

@@ -86,7 +86,7 @@ def test_stages_against_oracle(ctx, fpcheck, model, ora, n, c):
         assert np.array_equal(neg.astype(bool), d[idx] < 0), "sign bit"
     # work segments: every bucket is cut into pieces of at most segment_len entries; the schedule is a permutation of
     # the segments in descending length
-    seg_len = ctx.get_option("segment_len")
+    seg_len = ctx.get_option("segment_len_used")
     nseg = int(np.frombuffer(ctx.debug_read("num_segments", 4), dtype=np.uint32)[0])
     per_bucket = np.maximum(1, -(-cnt.reshape(-1).astype(np.int64) // seg_len))
     assert nseg == int(per_bucket.sum())
@@ -223,7 +223,7 @@ def test_segment_lengths(ctx, ora, seg_len):
         ctx.set_option("window_bits", c)
         assert ctx.run(pts, sc) == exp
     ctx.set_option("window_bits", 0)
-    ctx.set_option("segment_len", 64)
+    ctx.set_option("segment_len", 0)
 
 
 def test_empty_input(ctx):
@@ -565,7 +565,7 @@ def test_many_parts_per_bucket(ctx, ora):
         assert ctx.run(pts, sc) == ora.msm(pts, sc, threads=8)
     finally:
         ctx.set_option("window_bits", 0)
-        ctx.set_option("segment_len", 64)
+        ctx.set_option("segment_len", 0)
 
 
 def test_random_configurations(pkg, ora):

@@ -127,7 +127,7 @@ struct te_ctx {
   int opt_curve = TE_MSM_CURVE_TE_BLS12;   // which group the point buffers are in (option "curve")
   int opt_signed = 1;          // signed window digits (the reference's shipped behaviour); 0 = plain unsigned windows, 2^c buckets
   int opt_profile = 0;
-  int opt_seg_len = 64;        // work segment: at most this many entries of one bucket per thread
+  int opt_seg_len = 0;         // work segment: at most this many entries of one bucket per thread; 0 = from n (make_plan)
   int opt_host_chunks = 0;     // te_msm_run: pieces a large host buffer is uploaded and processed in (0 = choose from n)
   int opt_graph = 0;           // replay the launch sequence around k_accumulate as HIP graphs
   int opt_workset = 0;         // work set used by te_msm_run* / te_msm_partial_device
@@ -167,7 +167,7 @@ int auto_window_bits(uint64_t n) {
   return c;
 }
 
-void make_plan(const te_ctx* ctx, const gpu_t& d, uint64_t n, plan_t& p, int force_c = 0, int batch = 1) {
+void make_plan(const te_ctx* ctx, const gpu_t& d, uint64_t n, plan_t& p, int force_c = 0, int batch = 1, uint32_t force_seg = 0) {
   p.curve = ctx->opt_curve;
   p.c = force_c ? force_c : ctx->opt_window_bits ? ctx->opt_window_bits : auto_window_bits(n);
   p.W = (256 + p.c - 1) / p.c;
@@ -189,7 +189,20 @@ void make_plan(const te_ctx* ctx, const gpu_t& d, uint64_t n, plan_t& p, int for
   p.CH = ch;
   // level-1 partition = S consecutive buckets of one window
   p.S = p.B < 256u ? p.B : 256u;
-  p.seg_len = (uint32_t)ctx->opt_seg_len;
+  if (force_seg) {
+    p.seg_len = force_seg;               // the pieces of one host-buffer MSM share the geometry (and the buffers) of the largest
+  } else if (ctx->opt_seg_len) {
+    p.seg_len = (uint32_t)ctx->opt_seg_len;
+  } else {
+    // Twice the mean bucket size, as a power of two in [16, 64].  A thread works one segment off serially (~8-11 us per
+    // addition with four waves per SIMD): at n = 2^20 (32 entries per bucket) 64 balances the longest chains against the
+    // VALU-bound whole, at smaller n the whole shrinks and long segments set the kernel's duration -- measured latency of
+    // one MSM (profiles/r03_segment_len_sweep.txt): 2^16 0.366 -> 0.346 ms, 2^17 0.466 -> 0.410, 2^18 0.582 -> 0.53-0.54
+    // with 16 / 16 / 16-32 instead of 64; 2^19 equal at 32; 2^20 1.23 (64) against 1.32 (32).
+    uint64_t a = (2 * n + p.B - 1) / p.B, s2 = 16;
+    while (s2 < a && s2 < 64) s2 <<= 1;
+    p.seg_len = (uint32_t)s2;
+  }
   p.P = p.B / p.S; p.logS = ilog2(p.S);
   {
     uint64_t per = (n + p.P - 1) / p.P;                         // entries of one partition for well-spread digits
@@ -813,8 +826,10 @@ int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_
   auto piece_lo = [&](int i) -> uint64_t { return i >= K ? n : bounds[(size_t)i]; };     // first point of piece i
   uint64_t m_max = 0;
   for (int i = 0; i < K; i++) m_max = std::max(m_max, piece_lo(i + 1) - piece_lo(i));
+  uint32_t seg_all = 0;
   {
     plan_t pm; make_plan(ctx, d, m_max, pm, pf.c);
+    seg_all = pm.seg_len;
     if (int rc = ensure_buffers(ctx, d, ws, m_max, pm)) return rc;        // every buffer at its final size before the first piece
   }
   if (ws.used && ws.last_stream != ws.stream) HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ws.ev_done, 0));
@@ -840,7 +855,7 @@ int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_
   for (int i = 0; i < K; i++) {
     const uint64_t lo = piece_lo(i), hi = piece_lo(i + 1), m = hi - lo;
     if (m == 0) continue;
-    make_plan(ctx, d, m, p, pf.c);
+    make_plan(ctx, d, m, p, pf.c, 1, seg_all);
     if (int rc = ensure_buffers(ctx, d, ws, m, p)) return rc;              // no reallocation: only the pointers into the zeroed block move
     msm_launch L{ctx, d, ws, p, dpts + lo * sz.point_in, dscs + lo * sz.scalar_in, m, ws.d_partials, 0, ws.stream, true, !first};
     first = false;
@@ -1063,7 +1078,7 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   if (!strcmp(key, "fuse_prep")) { ctx->opt_fuse_prep = value ? 1 : 0; return 0; }
   if (!strcmp(key, "host_chunks")) { if (value < 0 || value > 64) return set_err(ctx, TE_MSM_EINVAL, "host_chunks out of range"); ctx->opt_host_chunks = (int)value; return 0; }
   if (!strcmp(key, "workset")) { if (value < 0 || value >= TE_MSM_WORKSETS) return set_err(ctx, TE_MSM_EINVAL, "workset out of range"); ctx->opt_workset = (int)value; return 0; }
-  if (!strcmp(key, "segment_len")) { if (value < 1 || value > 1000000) return set_err(ctx, TE_MSM_EINVAL, "segment_len must be in [1, 1e6]"); ctx->opt_seg_len = (int)value; return 0; }
+  if (!strcmp(key, "segment_len")) { if (value < 0 || value > 1000000) return set_err(ctx, TE_MSM_EINVAL, "segment_len must be 0 (from n) or in [1, 1e6]"); ctx->opt_seg_len = (int)value; return 0; }
   return set_err(ctx, TE_MSM_EINVAL, "unknown option");
 }
 
@@ -1076,6 +1091,7 @@ int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value) {
   if (!strcmp(key, "profile")) { *value = ctx->opt_profile; return 0; }
   if (!strcmp(key, "num_devices")) { *value = (int64_t)ctx->devs.size(); return 0; }
   if (!strcmp(key, "segment_len")) { *value = ctx->opt_seg_len; return 0; }
+  if (!strcmp(key, "segment_len_used")) { const gpu_t& d0 = ctx->devs[0]; *value = d0.ws[d0.last_ws].used ? (int64_t)d0.ws[d0.last_ws].plan.seg_len : 0; return 0; }
   if (!strcmp(key, "workset")) { *value = ctx->opt_workset; return 0; }
   if (!strcmp(key, "graph")) { *value = ctx->opt_graph; return 0; }
   if (!strcmp(key, "prezero")) { *value = ctx->opt_prezero; return 0; }
