@@ -1017,39 +1017,6 @@ __global__ void __launch_bounds__(256) k_sum_groups_team(sum_jobs_t<N> js, uint3
   }
 }
 
-// The same fold for K = 8 with SIXTEEN lanes (one DPP row) per output, as a tree: quad i of the row adds inputs 2i and 2i + 1,
-// then quads 0 and 2 add their right neighbours' sums (row_shl:4), then quad 0 adds quad 2's (row_shl:8) -- three
-// dependent team additions instead of seven.  For the levels whose grid is far too small to fill the chip anyway (the second
-// fold level: 512 outputs per window and chain at c = 16): 18.5 -> ~10 us on one MSM's critical path.
-template <int N> __device__ __forceinline__ fel<N> row_from_right(const fel<N>& v, const int lanes) {   // value of lane + 4 (or + 8) of my row
-  fel<N> r;
-#pragma unroll
-  for (int i = 0; i < N; i++)
-    r.v[i] = (uint32_t)(lanes == 4 ? __builtin_amdgcn_mov_dpp((int)v.v[i], 0x104, 0xf, 0xf, true) : __builtin_amdgcn_mov_dpp((int)v.v[i], 0x108, 0xf, 0xf, true));
-  return r;
-}
-template <int N>
-__global__ void __launch_bounds__(256) k_sum_groups_tree(sum_jobs_t<N> js, uint32_t nw) {
-  const sum_job_t<N>& j = js.j[blockIdx.y];                               // j.K == 8 (host)
-  const uint32_t total = j.n_out * nw, q = threadIdx.x & 3u, qd = (threadIdx.x >> 2) & 3u, wq = team_word<N>(q);
-  const uint32_t rows_per_grid = (gridDim.x * 256u) >> 4;
-  const uint32_t rounds = (total + rows_per_grid - 1u) / rows_per_grid;    // uniform trip count: every lane of a row takes part in the DPP moves
-  for (uint32_t it = 0; it < rounds; it++) {
-    const uint32_t g0 = it * rows_per_grid + ((blockIdx.x * 256u + threadIdx.x) >> 4);
-    const bool live = g0 < total;
-    const uint32_t g = live ? g0 : 0u;
-    const uint32_t k = g / j.n_out, o = g - k * j.n_out;
-    const uint32_t outer = o / j.inner, qq = o - outer * j.inner;
-    const ete_t<N>* src = j.in + (size_t)k * j.in_per_window + (size_t)outer * 8u * j.inner + qq;
-    const fel<N> a = load_coord<N>(words<N>(src + (size_t)(2u * qd) * j.inner) + wq);
-    const fel<N> b = load_coord<N>(words<N>(src + (size_t)(2u * qd + 1u) * j.inner) + wq);
-    fel<N> acc = ete_add_team<N>(a, b, q);                                 // quads 0..3: inputs (0,1) (2,3) (4,5) (6,7)
-    acc = ete_add_team<N>(acc, row_from_right<N>(acc, 4), q);              // quads 0, 2: + right neighbour (quads 1, 3: unused)
-    acc = ete_add_team<N>(acc, row_from_right<N>(acc, 8), q);              // quad 0: + quad 2
-    if (live && qd == 0u) store_coord<N>(words<N>(j.out + (size_t)k * j.out_per_window + o) + wq, acc);
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // K4 tail: everything after the wide fold levels in ONE launch, one block per (window, digit) -- team additions, points in
 // LDS.  Replaces the last fold levels, the four second-phase chains and the weighted-sum kernel: six dependent,

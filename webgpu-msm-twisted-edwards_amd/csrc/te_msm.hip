@@ -473,16 +473,9 @@ struct msm_launch {
         if (most >= 65536u) {               // at least one wave per SIMD with a thread per output: throughput-bound level
           uint32_t blocks = (most + 255) / 256; if (blocks > 4096) blocks = 4096;
           hipLaunchKernelGGL(te::k_sum_groups<N>, dim3(blocks, nj), dim3(256), 0, stream, js, (uint32_t)p.nw);
-        } else {                            // latency-bound level: four lanes per output, or -- by 8 with few outputs -- a row of sixteen as a tree
-          bool all8 = true;
-          for (int q = 0; q < nj; q++) all8 = all8 && js.j[q].K == 8u;
-          if (all8 && most <= 16384u) {
-            uint32_t blocks = (most * 16 + 255) / 256; if (blocks < 1) blocks = 1;
-            hipLaunchKernelGGL(te::k_sum_groups_tree<N>, dim3(blocks, nj), dim3(256), 0, stream, js, (uint32_t)p.nw);
-          } else {
-            uint32_t blocks = (most * 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
-            hipLaunchKernelGGL(te::k_sum_groups_team<N>, dim3(blocks, nj), dim3(256), 0, stream, js, (uint32_t)p.nw);
-          }
+        } else {                            // latency-bound level: four lanes per output
+          uint32_t blocks = (most * 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+          hipLaunchKernelGGL(te::k_sum_groups_team<N>, dim3(blocks, nj), dim3(256), 0, stream, js, (uint32_t)p.nw);
         }
       }
       mark(ST_WEIGHTED);
