@@ -363,7 +363,11 @@ def main():
         torch.cuda.synchronize()
 
     def note_stage():
-        for k, v in ctx.stage_ms().items():          # HIP events recorded on the engine's own stream
+        try:
+            st = ctx.stage_ms()                       # HIP events recorded on the engine's own stream
+        except pkg.MsmError:
+            return                                    # no profiled launch sequence collected yet
+        for k, v in st.items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
         stage_cnt[0] += 1
 

@@ -850,10 +850,15 @@ int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_
   // ALL scalars first, in one copy (a third of the bytes): every extra pageable copy call costs ~43 us of pipeline drain
   // (six calls for three pieces ended at 2.02 ms where one pair of calls takes 1.85), and with the scalars there the sort
   // of piece i + 1 is enqueued behind piece i's accumulation and runs while piece i + 1's points are still crossing PCIe.
-  HIP_TRY(ctx, hipMemcpyAsync(dscs, src_scalars, n * sz.scalar_in, hipMemcpyHostToDevice, ws.copy_stream));
-  HIP_TRY(ctx, hipEventRecord(evs[K], ws.copy_stream));
-  HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, evs[K], 0));
-  stamp("scalars staged", -1);
+  // (Twisted-Edwards only: there the link is the bottleneck.  BLS12-377 -- 144 MB to upload, but 2.0 ms of accumulation -- is
+  // bound by the device, which must not sit idle while 48 MB of scalar records arrive: piece by piece, 4.1 against 4.7 ms.)
+  const bool scalars_first = pf.curve == TE_MSM_CURVE_TE_BLS12;
+  if (scalars_first) {
+    HIP_TRY(ctx, hipMemcpyAsync(dscs, src_scalars, n * sz.scalar_in, hipMemcpyHostToDevice, ws.copy_stream));
+    HIP_TRY(ctx, hipEventRecord(evs[K], ws.copy_stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, evs[K], 0));
+    stamp("scalars staged", -1);
+  }
   for (int i = 0; i < K; i++) {
     const uint64_t lo = piece_lo(i), hi = piece_lo(i + 1), m = hi - lo;
     if (m == 0) continue;
@@ -861,6 +866,12 @@ int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_
     if (int rc = ensure_buffers(ctx, d, ws, m, p)) return rc;              // no reallocation: only the pointers into the zeroed block move
     msm_launch L{ctx, d, ws, p, dpts + lo * sz.point_in, dscs + lo * sz.scalar_in, m, ws.d_partials, 0, ws.stream, true, !first};
     first = false;
+    if (!scalars_first) {
+      HIP_TRY(ctx, hipMemcpyAsync(dscs + lo * sz.scalar_in, src_scalars + lo * sz.scalar_in, m * sz.scalar_in, hipMemcpyHostToDevice, ws.copy_stream));
+      HIP_TRY(ctx, hipEventRecord(evs[K], ws.copy_stream));
+      HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, evs[K], 0));
+      stamp("scalars staged", i);
+    }
     if (int rc = L.front_scalars()) return rc;                             // digits, sort and schedule run while the piece's points cross PCIe
     HIP_TRY(ctx, hipMemcpyAsync(dpts + lo * sz.point_in, src_points + lo * sz.point_in, m * sz.point_in, hipMemcpyHostToDevice, ws.copy_stream));
     stamp("points staged", i);
@@ -1161,6 +1172,7 @@ int te_msm_partial_wait(te_ctx* ctx, int workset) {
   workset_t& ws = ctx->devs[0].ws[workset];
   if (!ws.used) return 0;
   HIP_TRY(ctx, hipEventSynchronize(ws.ev_result));
+  (void)collect_stage_ms(ctx, ws);                   // stage times of that launch sequence, when it was profiled (te_msm_stage_ms)
   if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
   return 0;
 }
