@@ -802,16 +802,14 @@ int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_
   }
   uint8_t* dpts = static_cast<uint8_t*>(d.d_in_points);
   uint8_t* dscs = static_cast<uint8_t*>(d.d_in_scalars);
-  // Pieces of n / K points: piece i crosses PCIe on the side stream while piece i-1 is digit-decomposed, sorted, converted
-  // and ACCUMULATED ONTO THE SAME BUCKETS on the main stream; one bucket reduction at the end.  (The first version ran
-  // every piece as a complete MSM with its own reduction of all W x 2^(c-1) buckets: K reductions, which made more than
-  // four pieces a loss.)  Pageable copies return once the data has left the caller's buffer, so the host alternates
-  // between staging a piece and enqueueing the previous piece's kernels.
-  // Equal pieces.  Measured alternatives (n = 2^20, tools/host_path.py, TE_MSM_TRACE_HOST=1): linearly falling sizes and
-  // "all scalars first, then the points in pieces" both delay the first accumulation and end later (2.69 / 2.82 ms against
-  // 2.64 ms); the staging itself runs at ~55 GB/s whatever the piece size.  What limits the call is the device: every
-  // piece pays ~13 launches on a fraction of the points, so K pieces keep it busy ~(1.25 + 0.15 K) ms -- about as long as
-  // the 1.8 ms the bytes need to cross PCIe; three or four pieces are the optimum, more pieces lose.
+  // Pieces of n / K points: piece i crosses PCIe on the side stream while piece i-1 is converted and ACCUMULATED ONTO THE SAME
+  // BUCKETS on the main stream; one bucket reduction at the end.  (The first version ran every piece as a complete MSM with
+  // its own reduction of all W x 2^(c-1) buckets: K reductions, which made more than four pieces a loss.)  Pageable copies
+  // return once the data has left the caller's buffer, so the host alternates between staging a piece and enqueueing the
+  // previous piece's kernels.
+  // Measured (n = 2^20, tools/host_path.py, TE_MSM_TRACE_HOST=1, profiles/r03_host_buffer_path.txt): three equal pieces 2.48 ms,
+  // two 2.56, four 2.59 (the device falls behind the uploads: every piece pays a sort and ~10 launches on a fraction of the
+  // points), falling piece sizes 2.51-2.56; the link alone needs 1.85 ms.
   // piece boundaries: equal pieces, or TE_MSM_HOST_SPLIT="w0,w1,..." (relative weights, experiments)
   std::vector<uint64_t> bounds((size_t)K + 1, n);
   {

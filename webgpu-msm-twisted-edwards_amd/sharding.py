@@ -107,7 +107,7 @@ class ShardedPipeline:
         self.host = [torch.zeros(self.world * nbytes, dtype=torch.uint8).pin_memory() for _ in range(depth)]
         self.copy_stream = torch.cuda.Stream()
         # one stream per work set: the sequences overlap on the GPU.  torch's pool streams, left alone: both the context's own
-        # streams (whose hardware queues te_msm_init measures) through torch.cuda.ExternalStream and pool streams that had
+        # streams (whose hardware queues the first te_msm_submit_device measures) through torch.cuda.ExternalStream and pool streams that had
         # been run through the same measurement were 8-15 % (four sequences in flight) to 70 % (eight) slower -- the runtime
         # binds a stream to a hardware queue when it is first used, and apparently binds better under load than an idle probe does.
         self.compute_streams = [torch.cuda.Stream() for _ in range(depth)]
