@@ -155,10 +155,11 @@ int set_err(te_ctx* ctx, int code, const char* msg) { ctx->err = msg; return cod
 uint32_t ilog2(uint32_t v) { uint32_t l = 0; while ((1u << l) < v) l++; return l; }
 
 int auto_window_bits(uint64_t n) {
-  // measured on MI355X (profiles/r01_window_sweep.txt): 16 bits from 2^18 points up, 15 bits for 2^14..2^17 (fewer
-  // buckets to reduce, and at that size the fixed stages weigh more than the additions); below that about
-  // log2(n) + 1 bits so that the W * 2^(c-1) buckets do not dwarf the n points.
-  if (n >= (1ull << 18)) return 16;
+  // measured on MI355X (profiles/r01_window_sweep.txt, r03_n_sweep.txt): 16 bits from 3 * 2^17 points up, 15 bits for
+  // 2^14 .. below that (fewer buckets to reduce, and at that size the fixed stages weigh more than the additions; at n = 2^18
+  // 15 bits: 0.341 ms per MSM pipelined / 0.536 ms latency, 16 bits: 0.357 / 0.547; at 2^19 16 bits win the latency by 4 %);
+  // below 2^14 about log2(n) + 1 bits so that the W * 2^(c-1) buckets do not dwarf the n points.
+  if (n >= (3ull << 17)) return 16;
   if (n >= (1ull << 14)) return 15;
   int lg = 0; while ((1ull << (lg + 1)) <= n) lg++;
   int c = lg + 1;
