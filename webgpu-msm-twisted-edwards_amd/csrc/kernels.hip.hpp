@@ -228,6 +228,23 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds /*
   return res;
 }
 
+// Exclusive scan of in[0..n) (n <= 512, LDS) into out[0..n) by the FIRST WAVE of the block alone, total to *total: no block
+// barrier inside -- the caller puts ONE barrier before (in[] complete) and one after.  (block_excl_scan above costs three.)
+__device__ __forceinline__ void wave0_excl_scan(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total) {
+  if (threadIdx.x >= 64u) return;
+  const uint32_t lane = threadIdx.x, per = (n + 63u) >> 6;           // consecutive values per lane (<= 8)
+  uint32_t v[8], sum = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < 8u; j++) { const uint32_t i = lane * per + j; v[j] = (j < per && i < n) ? in[i] : 0u; sum += v[j]; }
+  uint32_t inc = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += o; }
+  uint32_t run = inc - sum;
+#pragma unroll
+  for (uint32_t j = 0; j < 8u; j++) { const uint32_t i = lane * per + j; if (j < per && i < n) { out[i] = run; run += v[j]; } }
+  if (lane == 63u) *total = inc;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2: counting sort of point indices by bucket, per window, in two levels so that every global store
 // is coalesced.  (The first version scattered 4-byte indices straight to their final position: each
@@ -313,11 +330,13 @@ __device__ __forceinline__ void part_scatter_block(uint32_t ch, uint32_t k, uint
   uint16_t* ok = part_keys + (size_t)k * g.nst;
   uint32_t* oi = part_idx + (size_t)k * g.nst;
   uint4 vnext = d4[min((lo >> 3) + t, last8)];
+  for (uint32_t p = t; p < g.P; p += 512u) tile_cnt[p] = 0u;
+  __syncthreads();
+  // five barriers per tile (the first version had nine: the waves spent 60 % of their time parked): the tile's counters are
+  // cleared in the interval that advances run_base, and the scan over the P partition counts is done by the first wave alone
   for (uint32_t base = lo; base < hi; base += TE_TILE) {
-    for (uint32_t p = t; p < g.P; p += 512u) tile_cnt[p] = 0u;
     const uint4 vcur = vnext;
     vnext = d4[min(((base + TE_TILE) >> 3) + t, last8)];          // prefetch the next tile during the LDS phases
-    __syncthreads();
     uint32_t dd[8], part[8], key[8], rank[8];
     unpack8(vcur, dd);
     const uint32_t i0 = base + t * 8u;
@@ -331,13 +350,9 @@ __device__ __forceinline__ void part_scatter_block(uint32_t ch, uint32_t k, uint
       }
     }
     __syncthreads();
-    uint32_t tile_total;
-    {
-      const uint32_t v = t < g.P ? tile_cnt[t] : 0u;          // P <= 512 = blockDim
-      const uint32_t ex = block_excl_scan(v, sm, tile_total);
-      if (t < g.P) tile_off[t] = ex;
-    }
+    wave0_excl_scan(tile_cnt, tile_off, g.P, &sm[16]);
     __syncthreads();
+    const uint32_t tile_total = sm[16];
 #pragma unroll
     for (int e = 0; e < 8; e++) {
       if (part[e] != 0xffffffffu) {
@@ -352,7 +367,7 @@ __device__ __forceinline__ void part_scatter_block(uint32_t ch, uint32_t k, uint
       ok[gpos] = st_key[s]; oi[gpos] = st_idx[s];
     }
     __syncthreads();
-    for (uint32_t p = t; p < g.P; p += 512u) run_base[p] += tile_cnt[p];
+    for (uint32_t p = t; p < g.P; p += 512u) { run_base[p] += tile_cnt[p]; tile_cnt[p] = 0u; }
     __syncthreads();
   }
 }
@@ -434,11 +449,11 @@ __global__ void __launch_bounds__(256) k_l2_count(const uint16_t* __restrict__ p
   if (s0 >= s1) return;
   const uint16_t* keys_row = part_keys + (size_t)k * g.nst; const uint32_t* idx_row = part_idx + (size_t)k * g.nst;
   uint32_t p = find_partition(ps, pc, g.P, s0);
+  cnt_s[t] = 0u;
+  __syncthreads();
   while (s0 < s1) {
     const uint32_t pe = ps[p] + pc[p], e1 = min(s1, pe);
     if (e1 <= s0) { p++; continue; }                 // empty partition (uniform branch)
-    cnt_s[t] = 0u;
-    __syncthreads();
     piece_regs r; uint32_t head, total;
     load_piece(keys_row, idx_row, s0, e1, t, false, r, head, total);
 #pragma unroll
@@ -450,6 +465,7 @@ __global__ void __launch_bounds__(256) k_l2_count(const uint16_t* __restrict__ p
     }
     __syncthreads();
     const uint32_t c0 = cnt_s[t];
+    cnt_s[t] = 0u;                                      // for the block's next piece (two barriers per piece, not three)
     if (c0) atomicAdd(&bucket_count[(size_t)k * g.B + (size_t)p * g.S + t], c0);
     __syncthreads();
     s0 = e1; p++;
@@ -476,11 +492,11 @@ __device__ __forceinline__ void l2_place_block(uint32_t slice_id, uint32_t k, ui
   const uint16_t* keys_row = part_keys + (size_t)k * g.nst; const uint32_t* idx_row = part_idx + (size_t)k * g.nst;
   uint32_t* out = sorted + (size_t)k * g.n;
   uint32_t p = find_partition(ps, pc, g.P, s0);
+  cnt_s[t] = 0u;
+  __syncthreads();
   while (s0 < s1) {
     const uint32_t pe = ps[p] + pc[p], e1 = min(s1, pe), len = e1 - s0;
     if (e1 <= s0) { p++; continue; }                 // empty partition (uniform branch)
-    cnt_s[t] = 0u;
-    __syncthreads();
     piece_regs r; uint32_t head, total;
     load_piece(keys_row, idx_row, s0, e1, t, true, r, head, total);
 #pragma unroll
@@ -491,13 +507,14 @@ __device__ __forceinline__ void l2_place_block(uint32_t slice_id, uint32_t k, ui
       for (int e = 0; e < 8; e++) { const uint32_t pos = e0 + (uint32_t)e; if (pos >= head && pos < total) atomicAdd(&cnt_s[kv[e] & 0x7fffu], 1u); }
     }
     __syncthreads();
+    wave0_excl_scan(cnt_s, lex_s, 256u, &sm[16]);      // the first wave scans the 256 bucket counts; five barriers per piece, not eight
     {
-      const uint32_t c0 = cnt_s[t];
-      uint32_t bt;
-      const uint32_t ex = block_excl_scan(c0, sm, bt);
-      lex_s[t] = ex; off_s[t] = ex;
+      const uint32_t c0 = cnt_s[t];                    // (reserving the output ranges needs only the counts: it overlaps the scan)
       gbase_s[t] = c0 ? atomicAdd(&bucket_cursor[(size_t)k * g.B + (size_t)p * g.S + t], c0) : 0u;
     }
+    __syncthreads();
+    off_s[t] = lex_s[t];
+    cnt_s[t] = 0u;                                      // for the block's next piece
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < 5; c++) {
