@@ -95,7 +95,7 @@ int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]);
  *                   what the last MSM ran with)
  *   "profile"       1 = HIP events around the dominant kernel (accumulate) only, 2 = around every stage
  *                   (te_msm_stage_ms); 0 = none (default)
- *   "graph"         1 = replay the ~30 launches before and after the accumulate kernel as two HIP graphs, captured on
+ *   "graph"         1 = replay the launches before and after the accumulate kernel (five and five) as two HIP graphs, captured on
  *                   first use and re-captured when pointers, n or options change; 0 = launch every kernel (default: on
  *                   ROCm 7.2 / MI355X the replay measured ~5 % slower than plain launches).
  *                   Ignored at profile level 2.
@@ -131,7 +131,7 @@ int te_msm_partial_device(te_ctx* ctx, const void* d_points_xy_le, const void* d
  * d_scalars_le[m] (arrays of device pointers, in host memory, read before the call returns) and its W rows go to
  * d_partials + m * W * row bytes.  The windows of the batch are sorted, accumulated and reduced together, as if they were
  * count x (windows of this shard) windows of one MSM: what a rank of a D-GPU window-sharded job needs, because its W/D windows per
- * MSM are too little work for a launch sequence of their own (rehearsed per-rank step at D = 8: 0.27 ms per MSM one by one,
+ * MSM are too little work for a launch sequence of their own (rehearsed per-rank step at D = 8: 0.25 ms per MSM one by one,
  * 0.17 ms in batches of eight).  MSMs of one call that name the SAME point buffer share one conversion
  * of it (same pointer in one call = same data; nothing is remembered across calls) -- a prover's batch over one SRS converts
  * it once per call; the scalars of all MSMs are decomposed by one launch.  There is no reference
