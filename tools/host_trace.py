@@ -1,5 +1,5 @@
 import importlib, sys, time, os
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("webgpu-msm-twisted-edwards_amd")
 n = 1 << 20
 pts, sc = pkg.synth_inputs(0x5EED0014, n)
