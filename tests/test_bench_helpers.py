@@ -1,0 +1,60 @@
+"""bench.py's bookkeeping (no GPU): the algorithmic byte counts of SURVEY.md 8d, the staleness rule of the committed counter
+profile and ISA listing, and that the committed evidence files parse."""
+import json
+import os
+import sys
+import warnings
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_algorithmic_bytes_match_the_survey():
+    # A(2^20) = 1 375 731 776 B, A(2^16) = 211 812 416 B (signed 16-bit windows); unsigned: + 134 217 728
+    whole, acc = bench.algorithmic_bytes(1 << 20, 16, 1 << 15)
+    assert whole == 1375731776 and acc == 16 * (1 << 20) * 68 + 16 * (1 << 15) * 128 == 1207959552
+    assert bench.algorithmic_bytes(1 << 16, 16, 1 << 15)[0] == 211812416
+    assert bench.algorithmic_bytes(1 << 20, 16, 1 << 16)[0] == 1375731776 + 134217728
+    assert bench.algorithmic_bytes(1 << 20, 16, 1 << 15, bls=True)[0] == 1979711584
+
+
+def test_sources_hash_ignores_comments_and_white_space(tmp_path, monkeypatch):
+    sha = bench.kernel_sources_sha()
+    assert len(sha) == 16 and sha == bench.kernel_sources_sha()
+    # the same code with another comment hashes the same; another token does not
+    src = os.path.join(ROOT, bench.PKG, "csrc")
+    fake = tmp_path / bench.PKG / "csrc"
+    fake.mkdir(parents=True)
+    for f in bench.KERNEL_SOURCES:
+        text = open(os.path.join(src, f)).read()
+        (fake / f).write_text("// a new comment\n" + text.replace("\n", "\n  ", 3))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.kernel_sources_sha() == sha
+    (fake / bench.KERNEL_SOURCES[0]).write_text((fake / bench.KERNEL_SOURCES[0]).read_text() + "\nint x;\n")
+    assert bench.kernel_sources_sha() != sha
+
+
+def test_traffic_figure_is_withheld_when_the_sources_changed(tmp_path, monkeypatch):
+    j = json.load(open(bench.TRAFFIC_JSON))
+    assert {"kernel_sources_sha", "kernels", "correction"} <= set(j) and "k_accumulate" in j["kernels"]
+    val, info = bench.measured_traffic(20, 16, 1)
+    if info.get("stale"):
+        warnings.warn("profiles/pmc_traffic.json was taken from other kernel sources: re-run tools/final_profiles.sh")
+        assert val is None and info["stale_value"] > 1e9
+    else:
+        assert 1.2e9 < val < 4e9                       # between the algorithmic bytes and 3x of them
+    assert bench.measured_traffic(19, 16, 1)[0] is None     # another workload: no figure
+    stale = dict(j, kernel_sources_sha="0" * 16)
+    p = tmp_path / "t.json"
+    p.write_text(json.dumps(stale))
+    monkeypatch.setattr(bench, "TRAFFIC_JSON", str(p))
+    val, info = bench.measured_traffic(20, 16, 1)
+    assert val is None and info["stale"] is True
+
+
+def test_isa_listing_figures():
+    te, bls = bench.isa_cycles(False), bench.isa_cycles(True)
+    assert 5000 < te["cycles"] < 8000 and 12000 < bls["cycles"] < 20000
+    j = json.load(open(bench.ISA_JSON))
+    assert j["k_accumulate<9>"]["mads"] == 7 * 153     # seven field products of 153 multiply-accumulates per accumulated point
