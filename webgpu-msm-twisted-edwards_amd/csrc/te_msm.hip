@@ -83,7 +83,7 @@ struct workset_t {
   // counts1[window][chunk][partition], then bucket_count[window][bucket].  d_err .. d_bucket_count point into d_zero.
   uint32_t *d_zero = nullptr; size_t zero_words = 0;
   size_t zero_clean_words = 0;        // words of d_zero known to be zero on the set's stream: the block is cleared AFTER an MSM's read-back
-                                      // (clear_zero_block), so that the next MSM on the set starts with its first kernel, not a fill
+                                      // (finish_sequence), so that the next MSM on the set starts with its first kernel, not a fill
   uint32_t *d_err = nullptr, *d_num_seg = nullptr, *d_size_hist = nullptr, *d_size_cursor = nullptr;
   uint8_t* d_partials = nullptr;      // = d_zero + Z_ROWS: TE_MAX_WINDOWS rows
   uint32_t* h_err = nullptr;          // pinned: mirror of d_zero[0 .. Z_ROWS + rows)
@@ -335,7 +335,7 @@ struct msm_launch {
   int front_scalars(bool with_prep = false) {
     const uint32_t n32 = this->n32();
     // flags, counters, histograms, bucket counts (a later piece of the same MSM keeps word 0, the final-carry flag)
-    // -- unless the block is still clean from the clearing that followed the set's previous MSM (clear_zero_block)
+    // -- unless the block is still clean from the clearing that followed the set's previous MSM (finish_sequence)
     if (onto || ws.zero_clean_words < ws.zero_words)
       HIP_TRY(ctx, hipMemsetAsync(ws.d_zero + (onto ? 1 : 0), 0, (ws.zero_words - (onto ? 1 : 0)) * sizeof(uint32_t), stream));
     ws.zero_clean_words = 0;
