@@ -103,6 +103,7 @@ int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]);
  *                   and device work overlap (all scalars go first, in one copy); 0 = from n (3 from 2^19 points, 2 from
  *                   2^17, else 1), 1 = whole.  The result does not depend on it.
  *   "workset"       which of the TE_MSM_WORKSETS device work sets te_msm_run* / te_msm_partial_device use (default 0)
+ *   read-only:      "num_devices", "segment_len_used", "peer_copies" (hipMemcpyPeerAsync calls a multi-device context issued)
  *   "prezero"       1 (default) = a work set's block of counters is cleared BEHIND an MSM's read-back, for its next MSM
  *                   (the next MSM starts with its first kernel instead of a fill); 0 = cleared in front of every MSM --
  *                   te_msm_debug_read of "bucket_count" / "num_segments" / "partials" needs 0 (it refuses otherwise)

@@ -418,9 +418,22 @@ def test_multi_device_context_same_gpu(pkg, ora):
     """n_dev = 2 with the same device id twice: exercises the in-process window sharding."""
     n = 20000
     pts, sc = ora.gen_points(32, n), ora.gen_scalars(32, n)
+    exp = ora.msm(pts, sc, threads=8)
+    dp, ds = _dev(pts), _dev(sc)
+    import torch
+    torch.cuda.synchronize()
     with pkg.MsmContext((0, 0)) as c:
         assert c.get_option("num_devices") == 2
-        assert c.run(pts, sc) == ora.msm(pts, sc, threads=8)
+        assert c.run(pts, sc) == exp                                   # host buffers: every device uploads for itself
+        assert c.get_option("peer_copies") == 0
+        # device-resident inputs live on the first device: the second "device" gets them through hipMemcpyPeerAsync -- the
+        # copies are issued and ordered in front of its kernels also when both ids name one physical GPU (the only form a
+        # one-GPU box can run: whether the path is right across two physical devices stays unmeasured, DESIGN.md section 5)
+        for k in range(3):
+            assert c.run_device(dp.data_ptr(), ds.data_ptr(), n) == exp
+            assert c.get_option("peer_copies") == 2 * (k + 1)
+    with pkg.MsmContext((0, 0, 0)) as c3:                               # 16 windows over three "devices": 6 + 5 + 5
+        assert c3.run_device(dp.data_ptr(), ds.data_ptr(), n) == exp and c3.get_option("peer_copies") == 4
 
 
 # ------------------------------------------------------------------ BASELINE.json's full size

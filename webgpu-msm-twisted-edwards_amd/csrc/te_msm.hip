@@ -135,6 +135,7 @@ struct te_ctx {
   int opt_prezero = 1;         // clear a work set's zeroed block behind an MSM's read-back instead of in front of the next MSM's first kernel
   float stage_ms[ST_COUNT + 2] = {};
   bool have_stage_ms = false;
+  int64_t stat_peer_copies = 0;  // hipMemcpyPeerAsync calls issued so far (multi-device contexts fed from device 0's memory; get_option "peer_copies")
 };
 
 namespace {
@@ -943,6 +944,7 @@ int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, boo
         // inputs live on device 0's memory: wait for nothing (caller's data is ready), copy peer-to-peer
         HIP_TRY(ctx, hipMemcpyPeerAsync(d.d_in_points, d.device, src_points, ctx->devs[0].device, n * sz.point_in, ws.stream));
         HIP_TRY(ctx, hipMemcpyPeerAsync(d.d_in_scalars, d.device, src_scalars, ctx->devs[0].device, n * sz.scalar_in, ws.stream));
+        ctx->stat_peer_copies += 2;
       }
       dp = d.d_in_points; ds = d.d_in_scalars;
     }
@@ -1102,6 +1104,7 @@ int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value) {
   if (!strcmp(key, "curve")) { *value = ctx->opt_curve; return 0; }
   if (!strcmp(key, "profile")) { *value = ctx->opt_profile; return 0; }
   if (!strcmp(key, "num_devices")) { *value = (int64_t)ctx->devs.size(); return 0; }
+  if (!strcmp(key, "peer_copies")) { *value = ctx->stat_peer_copies; return 0; }
   if (!strcmp(key, "segment_len")) { *value = ctx->opt_seg_len; return 0; }
   if (!strcmp(key, "segment_len_used")) { const gpu_t& d0 = ctx->devs[0]; *value = d0.ws[d0.last_ws].used ? (int64_t)d0.ws[d0.last_ws].plan.seg_len : 0; return 0; }
   if (!strcmp(key, "workset")) { *value = ctx->opt_workset; return 0; }
