@@ -472,7 +472,13 @@ struct msm_launch {
           most = std::max(most, j.n_out * (uint32_t)p.nw);
         }
         if (!nj) break;
-        if (most >= 65536u) {               // at least one wave per SIMD with a thread per output: throughput-bound level
+        // From 32768 outputs on a level runs one thread per output (9 products per addition, k_sum_groups); below that four
+        // lanes per output (16 lane-products per addition, but three dependent products instead of nine: k_sum_groups_team).
+        // The line was at 65536 ("one wave per SIMD") until round 3: at n = 2^16..2^18 (18 windows x 16384 buckets, first level
+        // 36864 outputs) the thread form is as fast for one MSM (0.344 against 0.346 ms) and leaves more of the VALU to the
+        // other MSMs in flight: 0.1645 against 0.1785 ms per MSM at 2^16, 0.224 against 0.239 at 2^17.  16384 would also move
+        // the second level of unsigned 16-bit windows (64 blocks of serial additions: slower for one MSM).
+        if (most >= 32768u) {
           uint32_t blocks = (most + 255) / 256; if (blocks > 4096) blocks = 4096;
           hipLaunchKernelGGL(te::k_sum_groups<N>, dim3(blocks, nj), dim3(256), 0, stream, js, (uint32_t)p.nw);
         } else {                            // latency-bound level: four lanes per output.  (Sixteen lanes per output as a tree --
