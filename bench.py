@@ -522,7 +522,7 @@ def main():
         out["host_buffers_ms"] = hb
         out["pcie_inclusive_ms_host_buffers"] = hb
         out["host_buffers_path"] = ("te_msm_run, profile 0, host_chunks=%d (0 = automatic: the buffers are uploaded and processed in 3 pieces "
-                                    "from 2^19 points, 2 from 2^17, whole below)" % ctx.get_option("host_chunks"))
+                                    "from 3 * 2^18 points, 2 from 2^17, whole below)" % ctx.get_option("host_chunks"))
         out["host_buffers_gbps"] = (len(pts) + len(sc)) / (hb * 1e-3) / 1e9
         assert r_host == result
         out["sizes"] = {str(args.log2n): {"ms_per_step": ms_per_step, "latency_ms": min(lat), "host_buffers_ms": hb, "window_bits": c,

@@ -100,7 +100,7 @@ int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]);
  *                   ROCm 7.2 / MI355X the replay measured ~5 % slower than plain launches).
  *                   Ignored at profile level 2.
  *   "host_chunks"   te_msm_run (one device): pieces the point buffer is uploaded and processed in, so that PCIe transfer
- *                   and device work overlap (all scalars go first, in one copy); 0 = from n (3 from 2^19 points, 2 from
+ *                   and device work overlap (all scalars go first, in one copy); 0 = from n (3 from 3 * 2^18 points, 2 from
  *                   2^17, else 1), 1 = whole.  The result does not depend on it.
  *   "workset"       which of the TE_MSM_WORKSETS device work sets te_msm_run* / te_msm_partial_device use (default 0)
  *   read-only:      "num_devices", "segment_len_used", "peer_copies" (hipMemcpyPeerAsync calls a multi-device context issued)

@@ -914,7 +914,9 @@ int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, boo
   if (src_is_host && nd == 1 && !ctx->opt_profile && ctx->opt_workset == 0 &&
       ctx->devs[0].w_step == 1 && ctx->devs[0].next_ticket == ctx->devs[0].next_collect) {
     // no tickets in flight, no stage timing requested: every work set is free for the pieces
-    const int K = ctx->opt_host_chunks ? ctx->opt_host_chunks : (n >= (1ull << 19) ? 3 : n >= (1ull << 17) ? 2 : 1);
+    // measured (tools/sweep_host_chunks.py, ms for 1 / 2 / 3 pieces): 2^17 0.672 / 0.659 / 0.773, 2^18 1.005 / 0.927 / 1.001,
+    // 2^19 1.642 / 1.407 / 1.424, 2^20 2.991 / 2.464 / 2.380
+    const int K = ctx->opt_host_chunks ? ctx->opt_host_chunks : (n >= (3ull << 18) ? 3 : n >= (1ull << 17) ? 2 : 1);
     if (K > 1 && n >= (uint64_t)K) return run_host_chunked(ctx, static_cast<const uint8_t*>(src_points), static_cast<const uint8_t*>(src_scalars), n, K, out);
   }
   // the work set this call runs on: the selected one, unless a submitted MSM still owns it (tickets exist on
