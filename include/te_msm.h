@@ -53,10 +53,17 @@ typedef struct te_ctx te_ctx;
 
 /* Replaces get_device() + per-call buffer/pipeline creation (implementation/cuzk/gpu.ts:14-25,
  * submission.ts:96-97).  The context is persistent: buffers and streams live across calls.
- * n_dev == 1: one GPU.  n_dev > 1: the windows of every MSM are sharded over the listed devices
- * inside this process (device ids may repeat).  For one-process-per-GPU deployments use n_dev == 1
- * plus te_msm_set_window_shard / te_msm_partial_device / te_msm_finalize and exchange the partial
- * sums yourself (bench.py does it with an RCCL all-gather). */
+ * n_dev == 1: one GPU.  n_dev > 1: every MSM is sharded over the listed devices inside this process
+ * (device ids may repeat) -- this is how a single-process host (the reference's JavaScript, README.md:551
+ * "multi-device" future work) uses a node's GPUs:
+ *   te_msm_run (host buffers): POINT shards.  Points and scalars are cut into n_dev contiguous slices; one
+ *     host thread per device uploads its slice over that device's own PCIe link (the upload is most of a
+ *     host-buffer call: 1.85 of 2.47 ms at n = 2^20 on one device) and runs all windows on it; the host tail
+ *     folds the sum of the devices' rows.  Window bits follow the slice size.  Option "host_shard_min": fewer
+ *     devices are used when a slice would hold fewer points than that (default 4096).
+ *   te_msm_run_device (inputs resident on the first device): WINDOW shards, inputs copied peer-to-peer.
+ * For one-process-per-GPU deployments use n_dev == 1 plus te_msm_set_window_shard / te_msm_partial_device /
+ * te_msm_finalize and exchange the partial sums yourself (bench.py does it with an RCCL all-gather). */
 int te_msm_init(const int* device_ids, int n_dev, te_ctx** out);
 void te_msm_destroy(te_ctx* ctx);
 const char* te_msm_last_error(const te_ctx* ctx);   /* ctx may be NULL: last init error */
@@ -76,12 +83,25 @@ int te_msm_run_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_sca
  * tail of MSM k overlaps the device work of MSM k+1, and on the GPU the launch gaps and the latency-bound reduction tail
  * of one MSM are filled by the wide kernels of the others (the reference's full_benchmarks.ts loop awaits each call; a
  * prover calling MSMs back to back does not have to).
- * Inputs must stay valid until the ticket is collected.  Tickets must be collected in submission order.
+ * Inputs must stay valid until the ticket is collected.  Tickets may be collected in any order (until round 4: in
+ * submission order only).
  * A work set owned by an uncollected ticket is never reused underneath it: te_msm_run / te_msm_run_device move to a
  * free work set (TE_MSM_ESTATE when all TE_MSM_WORKSETS are owned), te_msm_partial_device on such a set returns
  * TE_MSM_ESTATE.  A ticket is consumed by te_msm_collect whether it ends in a result or in TE_MSM_ESCALAR. */
 int te_msm_submit_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_scalars_le, uint64_t n, uint64_t* ticket);
 int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]);
+/* The same pipeline for HOST buffers -- what N concurrent compute_msm() promises of a JavaScript prover map onto
+ * (ui/Benchmark.tsx:32 awaits an async call; nothing stops a caller from having several in flight): uploads the buffers
+ * (in pieces, like te_msm_run) into the staging area of a free work set, enqueues every device stage and returns a ticket
+ * for te_msm_collect.  The call returns when the data has LEFT the caller's buffers (pageable copies are staged by the
+ * calling thread), so points_xy_le / scalars_le may be released as soon as it returns; the upload of MSM k+1 overlaps the
+ * device work of MSM k.  Single-device contexts. */
+int te_msm_submit(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars_le, uint64_t n, uint64_t* ticket);
+/* Blocks until the MSM of `ticket` has left the device (its rows are in host memory); te_msm_collect then returns without
+ * waiting.  This is the ONE entry point that may be called from another thread while the context is in use elsewhere -- it
+ * only waits on the ticket's event -- so a multi-threaded host (libuv's pool under the N-API addon) serialises submit and
+ * collect with a lock of its own and waits outside it. */
+int te_msm_ticket_wait(te_ctx* ctx, uint64_t ticket);
 
 /* Options (the reference hard-codes these: chunk_size submission.ts:80, dispatch table :109-142).
  *   "window_bits"   c in [4,16]; 0 = choose from n (default)
@@ -99,11 +119,17 @@ int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]);
  *                   first use and re-captured when pointers, n or options change; 0 = launch every kernel (default: on
  *                   ROCm 7.2 / MI355X the replay measured ~5 % slower than plain launches).
  *                   Ignored at profile level 2.
- *   "host_chunks"   te_msm_run (one device): pieces the point buffer is uploaded and processed in, so that PCIe transfer
- *                   and device work overlap (all scalars go first, in one copy); 0 = from n (3 from 3 * 2^18 points, 2 from
- *                   2^17, else 1), 1 = whole.  The result does not depend on it.
+ *   "host_chunks"   te_msm_run / te_msm_submit: pieces the point buffer (of one device's slice) is uploaded and processed
+ *                   in, so that PCIe transfer and device work overlap; 0 = from n (3 from 3 * 2^18 points, 2 from 2^17,
+ *                   else 1), 1 = whole.  Twisted-Edwards: all scalars go first, in one copy (the link is the bottleneck);
+ *                   BLS12-377: scalars piece by piece with their points (the device is).  The result does not depend on it.
+ *   "host_shard_min" multi-device te_msm_run: smallest slice worth a device of its own (default 4096 points)
+ *   "queue_probe"   1 (default) = the first te_msm_submit* measures the hardware queues of the work sets' streams (see
+ *                   te_msm_workset_stream); 0 = never (env TE_MSM_QUEUE_PROBE=0).  te_msm_probe_queues does it on request.
  *   "workset"       which of the TE_MSM_WORKSETS device work sets te_msm_run* / te_msm_partial_device use (default 0)
- *   read-only:      "num_devices", "segment_len_used", "peer_copies" (hipMemcpyPeerAsync calls a multi-device context issued)
+ *   read-only:      "num_devices", "segment_len_used", "peer_copies" (hipMemcpyPeerAsync calls a multi-device context issued),
+ *                   "in_flight" (tickets not collected), "streams_final" (te_msm_workset_stream's handles will not change any
+ *                   more), "device_bytes" (device memory held in work-set buffers, see te_msm_trim)
  *   "prezero"       1 (default) = a work set's block of counters is cleared BEHIND an MSM's read-back, for its next MSM
  *                   (the next MSM starts with its first kernel instead of a fill); 0 = cleared in front of every MSM --
  *                   te_msm_debug_read of "bucket_count" / "num_segments" / "partials" needs 0 (it refuses otherwise)
@@ -148,14 +174,24 @@ int te_msm_partial_device_batch(te_ctx* ctx, const void* const* d_points_xy_le, 
 int te_msm_partial_wait(te_ctx* ctx, int workset);
 /* The private stream of a work set (what TE_MSM_OWN_STREAM selects) as a hipStream_t, for callers that order their own work
  * -- a collective, a copy -- behind te_msm_partial_device without a host round trip (PyTorch: torch.cuda.ExternalStream).
- * The FIRST te_msm_submit_device of a context (not te_msm_init: one-shot callers never pay the ~16 ms) measures which of
+ * The FIRST te_msm_submit* of a context (not te_msm_init: one-shot callers never pay the ~16 ms) measures which of
  * its streams the runtime put on the same hardware queue (kernels of one queue run in order; see csrc/te_msm.hip,
  * spread_streams_over_queues), twice, and -- when both measurements agree -- re-deals them so that work sets 0..3, and 4..7,
  * sit on different queues: MSMs in flight on the context's own streams overlap whatever other streams the process has
- * created.  The handles may therefore change at that call: query them after it.  *hw_queue_class (optional) receives the
- * measured class of the work set's stream, -1 before the measurement, when it is off (TE_MSM_QUEUE_PROBE=0) or when its
- * two passes disagreed (creation order kept). */
+ * created.  The measurement waits for the context's own streams only (no device-wide synchronisation: other streams of the
+ * process keep running).  The handles may change at that call: query them after it, or call te_msm_probe_queues first
+ * (option "streams_final" tells).  *hw_queue_class (optional) receives the measured class of the work set's stream, -1
+ * before the measurement, when it is off (option "queue_probe" = 0) or when its two passes disagreed (creation order kept). */
 int te_msm_workset_stream(te_ctx* ctx, int workset, void** stream, int* hw_queue_class);
+/* Runs that measurement NOW (about 16 ms; nothing of this context may be in flight), at a quiet moment the caller chooses,
+ * and fixes the work sets' streams for the life of the context.  Returns the number of hardware-queue classes found
+ * (0: the two passes disagreed, creation order kept) or a negative error. */
+int te_msm_probe_queues(te_ctx* ctx);
+/* Gives device memory back: frees the buffers (about 0.7 GB each at n = 2^20) of the idle work sets numbered >=
+ * keep_worksets, staging areas included (they are allocated on first use and otherwise held until te_msm_destroy -- fine on
+ * 288 GB, unfriendly next to a prover).  Work sets owned by an uncollected ticket are skipped.  Returns the number of
+ * work sets freed.  A later call simply allocates again. */
+int te_msm_trim(te_ctx* ctx, int keep_worksets);
 /* Host tail (replaces submission.ts:362-412: de-Montgomery, sum, Horner, toAffine): folds the W rows
  * (host memory; rows of absent windows all-zero are skipped as identity) into the affine result.
  * Waits for, and reports a pending TE_MSM_ESCALAR of, the last te_msm_partial_device call of this context.  The digit
@@ -181,6 +217,13 @@ int te_msm_finalize_gathered(const uint8_t* gathered, int world, int window_bits
 int te_msm_finalize_host_curve(int curve, const uint8_t* partials, int window_bits, int bucket_bits, int num_windows, uint8_t* out_xy_le);
 int te_msm_finalize_gathered_curve(int curve, const uint8_t* gathered, int world, int window_bits, int bucket_bits, int num_windows,
                                    uint8_t* out_xy_le);
+
+/* The tail over the SUM of several row buffers (each W rows): the rows are linear in the bucket contents, so an MSM whose
+ * POINTS were cut into slices -- every slice run through all windows with the same window_bits, e.g. one slice per GPU
+ * (te_msm_run on a multi-device context does exactly this internally) or per process -- is the fold of the slices' rows
+ * added up.  All-zero rows are skipped.  Pure host code. */
+int te_msm_finalize_sum_curve(int curve, const uint8_t* const* row_sets, int sets, int window_bits, int bucket_bits, int num_windows,
+                              uint8_t* out_xy_le);
 
 /* ---- harness inputs (host code, no device needed).  The reference's harness generates its own random inputs when the
  * ZPrize files are not used (ui/AllBenchmarks.tsx:99-131, reference/webgpu/utils.ts:81-88,118-124): seeded scalars =

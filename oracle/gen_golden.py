@@ -6,7 +6,7 @@ Inputs are regenerated in tests from (seed, n, mode) by oracle.gen_points / gen_
 edge_scalars, so no input data is stored.  y is recovered from the WASM's x exactly as the reference
 does (FieldMath.getPointFromX, reference/utils/FieldMath.ts:31-55).
 
-usage: python -m oracle.gen_golden [--max-n 65536]
+usage: python -m oracle.gen_golden [--max-n 65536] [--only chain_n1048576,fixed_n262144]
 """
 from __future__ import annotations
 
@@ -34,6 +34,10 @@ CASES = [  # (name, seed, n, mode)
     ("edge_n64", 0x5EED0040, 64, "edge"),          # scalars 0, 1, p-1, l, l-1, 2^k boundaries ...
     ("chain_n65536", 0x5EED0010000, 65536, "chain"),
     ("fixed_n65536", 0x5EED0010001, 65536, "fixed"),
+    # round 4: the headline size itself and the harness mode at 2^18 (about 35 + 5 minutes of WASM; run with
+    # --only <names>, which keeps every record already in the fixture)
+    ("chain_n1048576", 0x5EED0100000, 1 << 20, "chain"),
+    ("fixed_n262144", 0x5EED0040001, 1 << 18, "fixed"),
 ]
 
 
@@ -58,10 +62,13 @@ def edge_scalars(seed: int, n: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--max-n", type=int, default=65536)
+    ap.add_argument("--only", default="", help="comma-separated case names: run these (any size) and merge them "
+                                               "into the existing fixture instead of rewriting it")
     args = ap.parse_args()
+    only = [s for s in args.only.split(",") if s]
     cases, meta = [], []
     for name, seed, n, mode in CASES:
-        if n > args.max_n:
+        if (name not in only) if only else (n > args.max_n):
             continue
         pts, sc = make_inputs(seed, n, mode)
         xs = [str(int.from_bytes(pts[64 * i:64 * i + 32], "little")) for i in range(n)]
@@ -85,6 +92,11 @@ def main():
                                  subprocess.check_output(["node", "--version"]).decode().strip(),
                        "wasm_ms": res[name]["ms"]})
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    if only and os.path.exists(OUT):
+        new = {g["name"]: g for g in golden}
+        golden = [g for g in json.load(open(OUT)) if g["name"] not in new] + golden
+        rank = {c[0]: i for i, c in enumerate(CASES)}
+        golden.sort(key=lambda g: rank.get(g["name"], len(rank)))
     json.dump(golden, open(OUT, "w"), indent=1)
     print("wrote", OUT, len(golden), "cases")
 

@@ -174,6 +174,35 @@ def test_window_shards_merge(fpcheck, pkg, ora):
         assert pkg.finalize_gathered(ctypes.addressof(flat), world, c, W) == exp
 
 
+def test_point_shards_merge(fpcheck, pkg, ora):
+    """Point sharding (te_msm_run on a multi-device context; SURVEY 8e "point sharding"): every slice of the points runs
+    ALL windows, the host tail folds the SUM of the slices' rows -- te_msm_finalize_sum_curve, the code the multi-device
+    te_msm_run ends in.  Slices of unequal size, an empty slice (all-zero rows), one slice."""
+    n, c = 230, 9
+    pts, sc = ora.gen_points(19, n), ora.gen_scalars(19, n)
+    W = (256 + c - 1) // c
+    exp = ora.msm(pts, sc)
+    for cuts in ([0, n], [0, 100, n], [0, 1, 2, 50, 50, n], [0] + [29 * k for k in range(1, 8)] + [n]):
+        sets = []
+        for lo, hi in zip(cuts, cuts[1:]):
+            b = ctypes.create_string_buffer(W * 720)                   # an empty slice leaves its rows all zero
+            if hi > lo:
+                assert fpcheck.fpc_partial_rows(pts[64 * lo:64 * hi], sc[32 * lo:32 * hi], hi - lo, c, 0, 1, b) == 0
+            sets.append(b.raw)
+        assert pkg.finalize_sum(sets, c, W) == exp, cuts
+    with pytest.raises(pkg.MsmError):
+        pkg.finalize_sum([], c, W)
+
+
+def test_devices_from_env(pkg, monkeypatch):
+    monkeypatch.delenv("TE_MSM_DEVICES", raising=False)
+    assert pkg.devices_from_env() == (0,)
+    monkeypatch.setenv("TE_MSM_DEVICES", "0,2, 3")
+    assert pkg.devices_from_env() == (0, 2, 3)
+    monkeypatch.setenv("TE_MSM_DEVICES", "1")
+    assert pkg.devices_from_env() == (1,)
+
+
 def test_final_carry_detected_by_emulation(fpcheck, model, ora):
     pts = ora.gen_points(1, 2)
     sc = model.scalars_to_bytes([5, (1 << 256) - 1])
@@ -343,3 +372,8 @@ def test_napi_addon_loads_and_fails_loudly_without_gpu(pkg, tmp_path):
     bad = subprocess.run([_node(), "-e", "require(%r).compute_msm(Buffer.alloc(10), Buffer.alloc(32), false).catch(e => { console.log('rejected:' + e.message); })"
                           % os.path.join(js, "compute_msm.js")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert b"rejected:" in bad.stdout
+    # the device list: TE_MSM_DEVICES and setDevices (no context is created until the first MSM)
+    q = subprocess.run([_node(), "-e", "const m = require(%r); const a = m.getDevices(); m.setDevices([0, 1, 1]); const b = m.getDevices(); m.setDevices([]);"
+                        "console.log(JSON.stringify([a, b, m.getDevices()]));" % os.path.join(js, "compute_msm.js")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, env=dict(os.environ, TE_MSM_DEVICES="2,3"))
+    assert json.loads(q.stdout.decode().strip().splitlines()[-1]) == [[2, 3], [0, 1, 1], [2, 3]], (q.stdout, q.stderr)

@@ -16,6 +16,8 @@ from .binding import (  # noqa: F401
     compute_msm,
     finalize_host,
     finalize_gathered,
+    finalize_sum,
+    devices_from_env,
     synth_inputs,
     build_library,
     library_path,

@@ -31,8 +31,13 @@ def library_path() -> str:
 
 
 def build_library(force: bool = False) -> str:
-    """Compiles csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
+    """Compiles csrc/ for gfx950 with hipcc (cross-compiles without a GPU).  With TE_MSM_LIB set the named file is used as
+    it is -- `make` only ever rebuilds the in-tree library -- and must exist."""
     so = library_path()
+    if os.environ.get("TE_MSM_LIB"):
+        if not os.path.exists(so):
+            raise MsmError(-2, f"TE_MSM_LIB={so} does not exist (the override is never built: it names a finished build)")
+        return so
     csrc = os.path.join(_HERE, "csrc")
     srcs = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(_HERE, "..", "include", "te_msm.h")]
     stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.isfile(s))
@@ -85,6 +90,14 @@ def _lib() -> ctypes.CDLL:
         L.te_msm_submit_device.restype = ci
         L.te_msm_collect.argtypes = [vp, u64, cp]
         L.te_msm_collect.restype = ci
+        L.te_msm_submit.argtypes = [vp, cp, cp, u64, ctypes.POINTER(u64)]
+        L.te_msm_submit.restype = ci
+        L.te_msm_ticket_wait.argtypes = [vp, u64]
+        L.te_msm_ticket_wait.restype = ci
+        L.te_msm_probe_queues.argtypes = [vp]
+        L.te_msm_probe_queues.restype = ci
+        L.te_msm_trim.argtypes = [vp, ci]
+        L.te_msm_trim.restype = ci
         L.te_msm_set_option.argtypes = [vp, cp, ctypes.c_int64]
         L.te_msm_set_option.restype = ci
         L.te_msm_get_option.argtypes = [vp, cp, ctypes.POINTER(ctypes.c_int64)]
@@ -113,6 +126,8 @@ def _lib() -> ctypes.CDLL:
         L.te_msm_finalize_host_curve.restype = ci
         L.te_msm_finalize_gathered_curve.argtypes = [ci, vp, ci, ci, ci, ci, cp]
         L.te_msm_finalize_gathered_curve.restype = ci
+        L.te_msm_finalize_sum_curve.argtypes = [ci, ctypes.POINTER(cp), ci, ci, ci, ci, cp]
+        L.te_msm_finalize_sum_curve.restype = ci
         L.te_msm_synth_inputs.argtypes = [u64, u64, ci, vp, vp]
         L.te_msm_synth_inputs.restype = ci
         L.te_msm_synth_inputs_bls12_377.argtypes = [u64, u64, vp, vp]
@@ -211,6 +226,28 @@ class MsmContext:
         self._check(self._L.te_msm_collect(self._h, ticket, out))
         return out.raw[:self._sizes[2]]
 
+    def submit(self, points: bytes, scalars: bytes) -> int:
+        """Pipelined form for HOST buffers (te_msm_submit): returns a ticket for collect() once the data has left the
+        caller's buffers; the upload of the next MSM overlaps the device work of this one."""
+        pb, sb, _ = self._sizes
+        n = len(scalars) // sb
+        if len(scalars) != sb * n or len(points) != pb * n:
+            raise MsmError(-1, f"points must be {pb}*n bytes and scalars {sb}*n bytes")
+        t = ctypes.c_uint64()
+        self._check(self._L.te_msm_submit(self._h, bytes(points), bytes(scalars), n, ctypes.byref(t)))
+        return t.value
+
+    def ticket_wait(self, ticket: int):
+        self._check(self._L.te_msm_ticket_wait(self._h, ticket))
+
+    def probe_queues(self) -> int:
+        """Measures the hardware queues of the work sets' streams now (te_msm_probe_queues); number of classes found."""
+        return self._check(self._L.te_msm_probe_queues(self._h))
+
+    def trim(self, keep_worksets: int = 0) -> int:
+        """Frees the device buffers of idle work sets >= keep_worksets (te_msm_trim); number of sets freed."""
+        return self._check(self._L.te_msm_trim(self._h, keep_worksets))
+
     # ---- window-sharded building blocks
     def partial_device(self, d_points: int, d_scalars: int, n: int, d_partials: int, stream: int = -1):
         """stream: a hipStream_t handle (0 = HIP's default stream, as torch.cuda.current_stream().cuda_stream
@@ -281,6 +318,17 @@ def finalize_gathered(gathered_ptr: int, world: int, window_bits: int, num_windo
     return out.raw[:96 if curve == CURVE_BLS12_377_G1 else 64]
 
 
+def finalize_sum(row_sets, window_bits: int, num_windows: int, bucket_bits: int | None = None, curve: int = CURVE_TE_BLS12) -> bytes:
+    """Host tail over the SUM of several row buffers (te_msm_finalize_sum_curve): the slices of a point-sharded MSM."""
+    out = ctypes.create_string_buffer(96)
+    bb = window_bits - 1 if bucket_bits is None else bucket_bits
+    arr = (ctypes.c_char_p * len(row_sets))(*[bytes(r) for r in row_sets])
+    rc = _lib().te_msm_finalize_sum_curve(curve, arr, len(row_sets), window_bits, bb, num_windows, out)
+    if rc:
+        raise MsmError(rc, "te_msm_finalize_sum_curve failed")
+    return out.raw[:96 if curve == CURVE_BLS12_377_G1 else 64]
+
+
 def synth_inputs(seed: int, n: int, fixed_point: bool = False, points: bool = True, scalars: bool = True, curve: int = CURVE_TE_BLS12):
     """Seeded harness inputs in compute_msm's wire format (te_msm_synth_inputs): (points 64n bytes, scalars 32n bytes)
     -- 96n / 48n bytes for curve = CURVE_BLS12_377_G1; a part not asked for is None.  Host code only."""
@@ -298,6 +346,18 @@ def synth_inputs(seed: int, n: int, fixed_point: bool = False, points: bool = Tr
 _DEFAULT_CTX = None
 
 
+def devices_from_env(default=(0,)):
+    """TE_MSM_DEVICES="0,1,2,3" (or "all"): the GPUs one compute_msm call is sharded over (the N-API addon reads the same
+    variable).  Unset: device 0."""
+    env = os.environ.get("TE_MSM_DEVICES", "").strip()
+    if not env:
+        return tuple(default)
+    if env == "all":
+        import torch
+        return tuple(range(max(1, torch.cuda.device_count())))
+    return tuple(int(t) for t in env.split(",") if t.strip() != "")
+
+
 def compute_msm(bufferPoints, bufferScalars, log_result: bool = True, force_recompile: bool = False):
     """Python mirror of `compute_msm` (submission/submission.ts:73-78).
 
@@ -310,7 +370,7 @@ def compute_msm(bufferPoints, bufferScalars, log_result: bool = True, force_reco
         _DEFAULT_CTX.close()
         _DEFAULT_CTX = None
     if _DEFAULT_CTX is None:
-        _DEFAULT_CTX = MsmContext((0,))
+        _DEFAULT_CTX = MsmContext(devices_from_env())
     out = _DEFAULT_CTX.run(bytes(bufferPoints), bytes(bufferScalars))
     res = {"x": int.from_bytes(out[:32], "little"), "y": int.from_bytes(out[32:], "little")}
     if log_result:

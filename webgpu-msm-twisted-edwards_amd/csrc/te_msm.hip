@@ -18,6 +18,10 @@
 #include <algorithm>
 #include <functional>
 #include <chrono>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <memory>
 
 #include "../../include/te_msm.h"
 #include "host_tail.hpp"
@@ -97,6 +101,11 @@ struct workset_t {
   hipStream_t last_stream = nullptr;  // stream of the previous MSM on this set: a different one must wait for it (scratch reuse)
   uint64_t generation = 0;            // bumped whenever ensure() reallocates a buffer of this set
   hipGraphExec_t g_front = nullptr, g_back = nullptr; graph_key g_key = {};
+  // host-buffer MSMs (te_msm_run, te_msm_submit): device copies of the caller's buffers, sized in bytes for the curve of the
+  // call, and the "piece i has arrived" events of an upload in pieces
+  void *d_in_points = nullptr, *d_in_scalars = nullptr; size_t cap_in_points = 0, cap_in_scalars = 0;
+  std::vector<hipEvent_t> piece_events;
+  uint64_t idle_calls = 0;            // te_msm_trim: context-level calls since the set was last used
 };
 constexpr int TE_MAX_WINDOWS = 64;    // window_bits >= 4
 // words [Z_CLOCK, Z_ROWS): k_accumulate's profiling words, 4 x TE_CLK_SLOTS 64-bit values (first wave in / last wave out on the
@@ -110,11 +119,31 @@ struct gpu_t {
   workset_t ws[TE_MSM_WORKSETS];
   int last_ws = 0;
   int wall_clock_khz = 0;                // rate of wall_clock64() on this device
-  void *d_in_points = nullptr, *d_in_scalars = nullptr; uint64_t cap_in = 0;   // te_msm_run staging
-  uint64_t next_ticket = 1, next_collect = 1;
-  int ticket_ws[TE_MSM_WORKSETS] = {};   // work set of ticket t at index t % TE_MSM_WORKSETS
-  std::vector<hipEvent_t> piece_events;  // te_msm_run in pieces: "piece i has arrived"
-  bool queues_probed = false;            // the lazy hardware-queue measurement has run (spread_streams_over_queues)
+  uint64_t next_ticket = 1;              // tickets are handed out in order; a ticket lives on the work set whose pending_ticket it is
+  int in_flight = 0;                     // submitted and not collected
+  bool queues_probed = false;            // the hardware-queue measurement has run (spread_streams_over_queues)
+  bool streams_final = false;            // ... and the work sets' streams will not be re-dealt any more
+};
+
+// One host thread per further device of a multi-device context (te_msm_run on n_dev > 1): pageable host-to-device copies
+// block the calling thread while the data is staged, so D uploads issued from one thread in turn run one after another --
+// D threads drive D PCIe links at once.  The threads are persistent (a wake-up costs microseconds; creating a thread and its
+// HIP thread state per call would cost more than a small MSM).
+struct worker_t {
+  std::thread th; std::mutex mu; std::condition_variable cv;
+  std::function<int()> job; bool has_job = false, done = false, quit = false; int rc = 0;
+  void loop() {
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv.wait(lk, [&] { return has_job || quit; });
+      if (quit) return;
+      lk.unlock(); const int r = job(); lk.lock();
+      rc = r; has_job = false; done = true; cv.notify_all();
+    }
+  }
+  void start(std::function<int()> f) { { std::lock_guard<std::mutex> lk(mu); job = std::move(f); has_job = true; done = false; } cv.notify_all(); }
+  int wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done; }); done = false; return rc; }
+  ~worker_t() { { std::lock_guard<std::mutex> lk(mu); quit = true; } cv.notify_all(); if (th.joinable()) th.join(); }
 };
 
 }  // namespace
@@ -122,6 +151,11 @@ struct gpu_t {
 struct te_ctx {
   std::vector<gpu_t> devs;
   std::string err;
+  std::mutex err_mu;           // the per-device host threads of a multi-device te_msm_run report into the one string
+  std::vector<std::unique_ptr<worker_t>> workers;   // devs[i + 1]'s thread; created by the first multi-device host-buffer call
+  std::vector<double> host_split;   // TE_MSM_HOST_SPLIT (relative piece weights of a host-buffer upload; experiments), read once
+  int opt_host_shard_min = 4096;    // multi-device te_msm_run: points per device below which fewer devices are used
+  int opt_queue_probe = 1;          // 1 = the first te_msm_submit* measures the hardware queues (lazily); 0 = never; te_msm_probe_queues does it now
   int opt_window_bits = 0;
   int opt_sort = 1;
   int opt_curve = TE_MSM_CURVE_TE_BLS12;   // which group the point buffers are in (option "curve")
@@ -146,12 +180,12 @@ namespace {
     if (e_ != hipSuccess) {                                                                      \
       char buf_[512];                                                                            \
       snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-      (ctx)->err = buf_;                                                                         \
+      { std::lock_guard<std::mutex> lk_((ctx)->err_mu); (ctx)->err = buf_; }                     \
       return TE_MSM_EDEVICE;                                                                     \
     }                                                                                            \
   } while (0)
 
-int set_err(te_ctx* ctx, int code, const char* msg) { ctx->err = msg; return code; }
+int set_err(te_ctx* ctx, int code, const char* msg) { std::lock_guard<std::mutex> lk(ctx->err_mu); ctx->err = msg; return code; }
 
 uint32_t ilog2(uint32_t v) { uint32_t l = 0; while ((1u << l) < v) l++; return l; }
 
@@ -555,14 +589,14 @@ int need_copy_stream(te_ctx* ctx, workset_t& ws) {
 // and re-deals them so that sets 0..3 and sets 4..7 each sit on as many different queues as there are.  One-shot callers
 // (te_msm_run, compute_msm with force_recompile) never pay it.  The host-timed pairs can be disturbed by other work on
 // the GPU, so a classification is accepted only when a second, independent measurement gives the same classes;
-// otherwise the creation order stays.  TE_MSM_QUEUE_PROBE=0 turns the measurement off.
+// otherwise the creation order stays.  Option "queue_probe" = 0 (env TE_MSM_QUEUE_PROBE=0) turns the lazy measurement off;
+// te_msm_probe_queues runs it at a moment the caller chooses.
 // classes[i] = index of the hardware queue class of streams[i] (classes numbered by first appearance); returns the number of
 // classes, or -1 when the measurement could not run (then classes[] is all -1)
 int classify_streams_by_queue(gpu_t& d, const hipStream_t* streams, int n, int* cls) {
   for (int i = 0; i < n; i++) cls[i] = -1;
   if (d.wall_clock_khz <= 0 || n < 2) return -1;
-  uint32_t* flag = nullptr;
-  if (hipMalloc((void**)&flag, 4) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  uint32_t* const flag = nullptr;       // k_spin takes an optional output word; none here (hipMalloc / hipFree would synchronise the whole device)
   const unsigned long long ticks = (unsigned long long)d.wall_clock_khz * 3 / 10;      // 0.3 ms
   auto pair_ms = [&](int a, int b) {
     (void)hipStreamSynchronize(streams[a]); (void)hipStreamSynchronize(streams[b]);
@@ -583,7 +617,6 @@ int classify_streams_by_queue(gpu_t& d, const hipStream_t* streams, int n, int* 
     for (int j = i + 1; j < n; j++) if (cls[j] < 0 && shared(i, j)) cls[j] = ncls;
     ncls++;
   }
-  (void)hipFree(flag);
   if (hipGetLastError() != hipSuccess) { for (int i = 0; i < n; i++) cls[i] = -1; return -1; }
   return ncls;
 }
@@ -615,13 +648,17 @@ int create_workset_streams(gpu_t& d) {
   return 0;
 }
 
-// first te_msm_submit_device of a context (see above).  Never fatal: any failure leaves the creation order in place.
+// The measurement itself (first te_msm_submit* of a context unless option "queue_probe" = 0, or te_msm_probe_queues at a moment
+// the caller chooses).  Never fatal: any failure leaves the creation order in place.  It waits for THIS context's streams only
+// -- no device-wide synchronisation: other streams of the process (PyTorch's, RCCL's) keep running; should their kernels
+// disturb the host-timed pairs, the two passes disagree and the creation order stays.
 void spread_streams_over_queues(gpu_t& d) {
   d.queues_probed = true;
-  const char* env = getenv("TE_MSM_QUEUE_PROBE");
-  if (env && env[0] == '0') return;
   for (const workset_t& ws : d.ws) if (ws.pending_ticket) return;            // cannot happen on the first submit; be safe
-  if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return; }
+  for (workset_t& ws : d.ws) {
+    if (ws.used && ws.ev_done && hipEventSynchronize(ws.ev_done) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (hipStreamSynchronize(ws.stream) != hipSuccess) { (void)hipGetLastError(); return; }
+  }
   hipStream_t cand[TE_MSM_WORKSETS];
   for (int i = 0; i < TE_MSM_WORKSETS; i++) cand[i] = d.ws[i].stream;
   int cls[TE_MSM_WORKSETS], again[TE_MSM_WORKSETS], order[TE_MSM_WORKSETS];
@@ -637,7 +674,7 @@ void spread_streams_over_queues(gpu_t& d) {
   deal_over_classes(cls, TE_MSM_WORKSETS, ncls, order);
   for (int i = 0; i < TE_MSM_WORKSETS; i++) {
     workset_t& ws = d.ws[i];
-    // the set's buffers were last used on its old stream: everything is idle (device synchronised above), so the new stream
+    // the set's buffers were last used on its old stream: the context's work is over (synchronised above), so the new stream
     // needs no wait; last_stream follows so that enqueue_partial does not add one
     if (ws.last_stream == ws.stream) ws.last_stream = cand[order[i]];
     ws.stream = cand[order[i]]; ws.hw_queue_class = cls[order[i]];
@@ -767,49 +804,77 @@ int collect_stage_ms(te_ctx* ctx, workset_t& ws) {
   return 0;
 }
 
+void free_workset_buffers(workset_t& ws) {      // the big device buffers of a work set (te_msm_trim, free_dev); streams, events and the pinned block stay
+  void** ptrs[] = {(void**)&ws.d_recs, (void**)&ws.d_digits, (void**)&ws.d_part_keys, (void**)&ws.d_zero, (void**)&ws.d_part_start, (void**)&ws.d_part_count,
+                   (void**)&ws.d_part_idx, (void**)&ws.d_seg_part_base, (void**)&ws.d_bucket_start, (void**)&ws.d_bucket_cursor, (void**)&ws.d_sorted,
+                   (void**)&ws.d_seg_base, (void**)&ws.d_seg_bucket, (void**)&ws.d_seg_lenv, (void**)&ws.d_order, (void**)&ws.d_split_list,
+                   (void**)&ws.d_large_list, (void**)&ws.d_chunk_list, (void**)&ws.d_seg_out, (void**)&ws.d_buckets, (void**)&ws.d_red[0], (void**)&ws.d_red[1],
+                   (void**)&ws.d_red[2], (void**)&ws.d_red[3], &ws.d_in_points, &ws.d_in_scalars};
+  for (void** q : ptrs) if (*q) { (void)hipFree(*q); *q = nullptr; }
+  memset(ws.cap, 0, sizeof ws.cap); ws.cap_in_points = ws.cap_in_scalars = 0;
+  ws.zero_words = ws.zero_clean_words = 0;
+  ws.d_err = ws.d_num_seg = ws.d_size_hist = ws.d_size_cursor = ws.d_counts1 = ws.d_bucket_count = nullptr; ws.d_partials = nullptr;
+  if (ws.g_front) { (void)hipGraphExecDestroy(ws.g_front); ws.g_front = nullptr; }
+  if (ws.g_back) { (void)hipGraphExecDestroy(ws.g_back); ws.g_back = nullptr; }
+  ws.generation++; ws.used = false;
+}
+
 void free_dev(gpu_t& d) {
   (void)hipSetDevice(d.device);
   for (workset_t& ws : d.ws) {
-    void* ptrs[] = {ws.d_recs, ws.d_digits, ws.d_part_keys, ws.d_zero, ws.d_part_start, ws.d_part_count, ws.d_part_idx, ws.d_seg_part_base,
-                    ws.d_bucket_start, ws.d_bucket_cursor, ws.d_sorted, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv,
-                    ws.d_order, ws.d_split_list, ws.d_large_list, ws.d_chunk_list, ws.d_seg_out, ws.d_buckets};
-    for (void* q : ptrs) if (q) (void)hipFree(q);
-    for (uint8_t* q : ws.d_red) if (q) (void)hipFree(q);
+    free_workset_buffers(ws);
     if (ws.h_err) (void)hipHostFree(ws.h_err);
     if (ws.ev_done) (void)hipEventDestroy(ws.ev_done);
     if (ws.ev_result) (void)hipEventDestroy(ws.ev_result);
-    if (ws.g_front) (void)hipGraphExecDestroy(ws.g_front);
-    if (ws.g_back) (void)hipGraphExecDestroy(ws.g_back);
     for (auto& ev : ws.ev) if (ev) (void)hipEventDestroy(ev);
     if (ws.ev_copy) (void)hipEventDestroy(ws.ev_copy);
     if (ws.ev_start) (void)hipEventDestroy(ws.ev_start);
+    for (hipEvent_t e : ws.piece_events) (void)hipEventDestroy(e);
     if (ws.copy_stream) (void)hipStreamDestroy(ws.copy_stream);
     if (ws.stream) (void)hipStreamDestroy(ws.stream);
   }
-  if (d.d_in_points) (void)hipFree(d.d_in_points);
-  if (d.d_in_scalars) (void)hipFree(d.d_in_scalars);
-  for (hipEvent_t e : d.piece_events) (void)hipEventDestroy(e);
 }
 
-// te_msm_run for a large Twisted-Edwards MSM on one device: the host buffers are uploaded and processed in K pieces, each
-// a complete MSM of n/K points on its own work set with the window size of the whole -- while piece i is on the GPU,
-// piece i+1 crosses PCIe -- and the pieces' rows are summed in the host tail.
-int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_scalars, uint64_t n, int K, uint8_t out[64]) {
-  gpu_t& d = ctx->devs[0];
-  workset_t& ws = d.ws[0];
-  HIP_TRY(ctx, hipSetDevice(d.device));
-  plan_t pf; make_plan(ctx, d, n, pf);
-  const curve_sizes sz = sizes_of(pf.curve);
-  if (n > d.cap_in) {
-    if (d.d_in_points) HIP_TRY(ctx, hipFree(d.d_in_points));
-    if (d.d_in_scalars) HIP_TRY(ctx, hipFree(d.d_in_scalars));
-    d.d_in_points = d.d_in_scalars = nullptr;
-    HIP_TRY(ctx, hipMalloc(&d.d_in_points, n * 96));
-    HIP_TRY(ctx, hipMalloc(&d.d_in_scalars, n * 48));
-    d.cap_in = n;
+// device copies of a host-buffer call's inputs, in bytes of the call's curve (64 + 32 per point for the Twisted-Edwards
+// wire format, 96 + 48 for BLS12-377)
+int ensure_staging(te_ctx* ctx, workset_t& ws, size_t bytes_points, size_t bytes_scalars) {
+  if (bytes_points > ws.cap_in_points) {
+    if (ws.d_in_points) HIP_TRY(ctx, hipFree(ws.d_in_points));
+    ws.d_in_points = nullptr; ws.cap_in_points = 0;
+    HIP_TRY(ctx, hipMalloc(&ws.d_in_points, bytes_points));
+    ws.cap_in_points = bytes_points;
   }
-  uint8_t* dpts = static_cast<uint8_t*>(d.d_in_points);
-  uint8_t* dscs = static_cast<uint8_t*>(d.d_in_scalars);
+  if (bytes_scalars > ws.cap_in_scalars) {
+    if (ws.d_in_scalars) HIP_TRY(ctx, hipFree(ws.d_in_scalars));
+    ws.d_in_scalars = nullptr; ws.cap_in_scalars = 0;
+    HIP_TRY(ctx, hipMalloc(&ws.d_in_scalars, bytes_scalars));
+    ws.cap_in_scalars = bytes_scalars;
+  }
+  return 0;
+}
+
+const char* const kFinalCarry = "final carry is 1: a scalar does not fit the signed window decomposition";
+
+// pieces a host buffer of n points is uploaded and processed in on ONE device (option "host_chunks", else from n).
+// measured (tools/sweep_host_chunks.py, ms for 1 / 2 / 3 pieces): 2^17 0.672 / 0.659 / 0.773, 2^18 1.005 / 0.927 / 1.001,
+// 2^19 1.642 / 1.407 / 1.424, 2^20 2.991 / 2.464 / 2.380
+int host_pieces(const te_ctx* ctx, uint64_t n) {
+  int K = ctx->opt_host_chunks ? ctx->opt_host_chunks : (n >= (3ull << 18) ? 3 : n >= (1ull << 17) ? 2 : 1);
+  if ((uint64_t)K > n) K = (int)n;
+  return K < 1 ? 1 : K;
+}
+
+// A host-buffer MSM (or one device's slice of it) on work set `ws` of device `d`: the buffers are uploaded and processed in K
+// pieces -- while piece i is on the GPU, piece i+1 crosses PCIe -- whose additions land on the SAME buckets, one reduction at
+// the end, flag + rows on their way to the set's pinned block when the call returns.  Window bits are forced to c (the slices
+// of a point-sharded MSM must agree on the geometry of their rows).  Does not wait: the caller synchronises ws.ev_result.
+int enqueue_host_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* src_points, const uint8_t* src_scalars, uint64_t n, int c, int K) {
+  HIP_TRY(ctx, hipSetDevice(d.device));
+  plan_t pf; make_plan(ctx, d, n, pf, c);
+  const curve_sizes sz = sizes_of(pf.curve);
+  if (int rc = ensure_staging(ctx, ws, n * sz.point_in, n * sz.scalar_in)) return rc;
+  uint8_t* dpts = static_cast<uint8_t*>(ws.d_in_points);
+  uint8_t* dscs = static_cast<uint8_t*>(ws.d_in_scalars);
   // Pieces of n / K points: piece i crosses PCIe on the side stream while piece i-1 is converted and ACCUMULATED ONTO THE SAME
   // BUCKETS on the main stream; one bucket reduction at the end.  (The first version ran every piece as a complete MSM with
   // its own reduction of all W x 2^(c-1) buckets: K reductions, which made more than four pieces a loss.)  Pageable copies
@@ -818,14 +883,11 @@ int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_
   // Measured (n = 2^20, tools/host_path.py, TE_MSM_TRACE_HOST=1, profiles/r03_host_buffer_path.txt): three equal pieces 2.48 ms,
   // two 2.56, four 2.59 (the device falls behind the uploads: every piece pays a sort and ~10 launches on a fraction of the
   // points), falling piece sizes 2.51-2.56; the link alone needs 1.85 ms.
-  // piece boundaries: equal pieces, or TE_MSM_HOST_SPLIT="w0,w1,..." (relative weights, experiments)
+  // piece boundaries: equal pieces, or TE_MSM_HOST_SPLIT="w0,w1,..." (relative weights, experiments; read once in te_msm_init)
   std::vector<uint64_t> bounds((size_t)K + 1, n);
   {
     std::vector<double> wgt((size_t)K, 1.0);
-    if (const char* e = getenv("TE_MSM_HOST_SPLIT")) {
-      int i = 0; const char* q = e;
-      while (*q && i < K) { char* end = nullptr; const double v = strtod(q, &end); if (end == q) break; if (v > 0) wgt[(size_t)i] = v; i++; q = *end == ',' ? end + 1 : end; }
-    }
+    for (size_t i = 0; i < ctx->host_split.size() && i < (size_t)K; i++) wgt[i] = ctx->host_split[i];
     double tot = 0, run = 0; for (double v : wgt) tot += v;
     for (int i = 0; i < K; i++) { bounds[(size_t)i] = (uint64_t)((double)n * (run / tot)); run += wgt[(size_t)i]; }
     bounds[0] = 0; bounds[(size_t)K] = n;
@@ -846,8 +908,8 @@ int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_
   HIP_TRY(ctx, hipStreamWaitEvent(ws.copy_stream, ws.ev_start, 0));
   const bool tr = getenv("TE_MSM_TRACE_HOST") != nullptr;
   const auto t00 = std::chrono::steady_clock::now();
-  auto stamp = [&](const char* what, int i) { if (tr) fprintf(stderr, "[te_msm_run] %8.1f us  %s %d\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t00).count(), what, i); };
-  std::vector<hipEvent_t>& evs = d.piece_events;
+  auto stamp = [&](const char* what, int i) { if (tr) fprintf(stderr, "[te_msm_run dev %d] %8.1f us  %s %d\n", d.device, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t00).count(), what, i); };
+  std::vector<hipEvent_t>& evs = ws.piece_events;
   while ((int)evs.size() < K + 1) { hipEvent_t e; HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); evs.push_back(e); }
   plan_t p;
   bool first = true;
@@ -889,15 +951,71 @@ int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_
     if (i == last_piece) { if (int rc = L.reduce()) return rc; }
     stamp("piece enqueued", i);
   }
-  ws.plan = p; ws.n = piece_lo(last_piece + 1) - piece_lo(last_piece); ws.used = true; ws.last_stream = ws.stream; ws.prof_level = 0; d.last_ws = 0;
+  ws.plan = p; ws.n = piece_lo(last_piece + 1) - piece_lo(last_piece); ws.used = true; ws.last_stream = ws.stream; ws.prof_level = 0; d.last_ws = (int)(&ws - d.ws);
   if (int rc = fetch_rows(ctx, ws, ws.stream)) return rc;
   HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+// te_msm_run for a large MSM on one device: enqueue_host_slice on work set 0, wait, host tail
+int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_scalars, uint64_t n, int K, uint8_t out[64]) {
+  gpu_t& d = ctx->devs[0];
+  workset_t& ws = d.ws[0];
+  plan_t pf; make_plan(ctx, d, n, pf);
+  if (int rc = enqueue_host_slice(ctx, d, ws, src_points, src_scalars, n, pf.c, K)) return rc;
   HIP_TRY(ctx, hipEventSynchronize(ws.ev_result));
-  stamp("device done", 0);
-  if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
+  if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, kFinalCarry);
   if (pf.curve == TE_MSM_CURVE_BLS12_377_G1) te377_host::horner_to_affine(ws.h_partials, pf.c, (int)pf.logB, pf.W, out);
   else te_host::horner_to_affine(ws.h_partials, pf.c, (int)pf.logB, pf.W, out);
-  stamp("host tail done", 0);
+  return 0;
+}
+
+// te_msm_run on a context of D > 1 devices: POINT sharding.  Points and scalars are cut into contiguous slices, one per
+// device; one host thread per device stages its slice over that device's own PCIe link (pageable copies block the thread
+// that issues them) and runs ALL windows on its n/D points (enqueue_host_slice, itself in pieces for large slices); the D x W
+// rows are linear in the bucket contents, so the host tail folds their sum (horner_to_affine_multi).  Every device pays the
+// reduction of all W x B buckets -- which is why device-resident inputs (te_msm_run_device, one process per GPU) shard
+// the WINDOWS instead -- but on this boundary the cost is the link: 1.85 of 2.47 ms at n = 2^20 on one device.  The window size
+// follows the slice (all slices share it).  Reference: compute_msm uploads inside the call (cuzk/gpu.ts:33-46,
+// submission.ts:73-78); multi-device is its README's future work (README.md:551).
+int run_host_sharded(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_scalars, uint64_t n, uint8_t* out) {
+  const size_t nd = ctx->devs.size();
+  uint64_t per_min = ctx->opt_host_shard_min > 0 ? (uint64_t)ctx->opt_host_shard_min : 1;
+  size_t D = (size_t)std::min<uint64_t>(nd, std::max<uint64_t>(1, n / per_min));
+  const uint64_t per = (n + D - 1) / D;
+  plan_t p0; make_plan(ctx, ctx->devs[0], per, p0);          // geometry of every slice's rows (window bits from the slice size)
+  const curve_sizes sz = sizes_of(p0.curve);
+  const int K = host_pieces(ctx, per);
+  while (ctx->workers.size() + 1 < D) {
+    ctx->workers.emplace_back(new worker_t());
+    worker_t* w = ctx->workers.back().get();
+    w->th = std::thread([w] { w->loop(); });
+  }
+  struct saved_t { int first, step; };
+  std::vector<saved_t> saved(nd);
+  for (size_t i = 0; i < nd; i++) { saved[i] = {ctx->devs[i].w_first, ctx->devs[i].w_step}; ctx->devs[i].w_first = 0; ctx->devs[i].w_step = 1; }
+  auto slice = [&](size_t i) -> int {
+    const uint64_t lo = std::min<uint64_t>(n, per * i), hi = std::min<uint64_t>(n, lo + per);
+    gpu_t& d = ctx->devs[i];
+    if (hi == lo) return 0;
+    if (int rc = enqueue_host_slice(ctx, d, d.ws[0], src_points + lo * sz.point_in, src_scalars + lo * sz.scalar_in, hi - lo, p0.c, K)) return rc;
+    HIP_TRY(ctx, hipEventSynchronize(d.ws[0].ev_result));
+    return 0;
+  };
+  for (size_t i = 1; i < D; i++) ctx->workers[i - 1]->start([&slice, i] { return slice(i); });
+  int rc = slice(0);
+  for (size_t i = 1; i < D; i++) { const int r = ctx->workers[i - 1]->wait(); if (!rc) rc = r; }
+  for (size_t i = 0; i < nd; i++) { ctx->devs[i].w_first = saved[i].first; ctx->devs[i].w_step = saved[i].step; }
+  if (rc) return rc;
+  std::vector<const uint8_t*> sets;
+  for (size_t i = 0; i < D; i++) {
+    if (per * i >= n) break;
+    workset_t& ws = ctx->devs[i].ws[0];
+    if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, kFinalCarry);
+    sets.push_back(ws.h_partials);
+  }
+  if (p0.curve == TE_MSM_CURVE_BLS12_377_G1) te377_host::horner_to_affine_multi(sets.data(), (int)sets.size(), p0.c, (int)p0.logB, p0.W, out);
+  else te_host::horner_to_affine_multi(sets.data(), (int)sets.size(), p0.c, (int)p0.logB, p0.W, out);
   return 0;
 }
 
@@ -911,13 +1029,13 @@ int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, boo
   }
   if (!src_points || !src_scalars) return set_err(ctx, TE_MSM_EINVAL, "null input buffer");
   const size_t nd = ctx->devs.size();
+  // host buffers on several devices: slices of the points, one upload thread per device (device-resident inputs: window shards, below)
+  if (src_is_host && nd > 1) return run_host_sharded(ctx, static_cast<const uint8_t*>(src_points), static_cast<const uint8_t*>(src_scalars), n, out);
   if (src_is_host && nd == 1 && !ctx->opt_profile && ctx->opt_workset == 0 &&
-      ctx->devs[0].w_step == 1 && ctx->devs[0].next_ticket == ctx->devs[0].next_collect) {
+      ctx->devs[0].w_step == 1 && ctx->devs[0].in_flight == 0) {
     // no tickets in flight, no stage timing requested: every work set is free for the pieces
-    // measured (tools/sweep_host_chunks.py, ms for 1 / 2 / 3 pieces): 2^17 0.672 / 0.659 / 0.773, 2^18 1.005 / 0.927 / 1.001,
-    // 2^19 1.642 / 1.407 / 1.424, 2^20 2.991 / 2.464 / 2.380
-    const int K = ctx->opt_host_chunks ? ctx->opt_host_chunks : (n >= (3ull << 18) ? 3 : n >= (1ull << 17) ? 2 : 1);
-    if (K > 1 && n >= (uint64_t)K) return run_host_chunked(ctx, static_cast<const uint8_t*>(src_points), static_cast<const uint8_t*>(src_scalars), n, K, out);
+    const int K = host_pieces(ctx, n);
+    if (K > 1) return run_host_chunked(ctx, static_cast<const uint8_t*>(src_points), static_cast<const uint8_t*>(src_scalars), n, K, out);
   }
   // the work set this call runs on: the selected one, unless a submitted MSM still owns it (tickets exist on
   // single-device contexts only) -- then any free one; with every set owned by a ticket the call is refused
@@ -936,29 +1054,22 @@ int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, boo
     HIP_TRY(ctx, hipSetDevice(d.device));
     const void *dp = src_points, *ds = src_scalars;
     if (src_is_host || i > 0) {
-      if (n > d.cap_in) {
-        if (d.d_in_points) HIP_TRY(ctx, hipFree(d.d_in_points));
-        if (d.d_in_scalars) HIP_TRY(ctx, hipFree(d.d_in_scalars));
-        d.d_in_points = d.d_in_scalars = nullptr;
-        HIP_TRY(ctx, hipMalloc(&d.d_in_points, n * 96));           // sized for the larger wire format (BLS12-377)
-        HIP_TRY(ctx, hipMalloc(&d.d_in_scalars, n * 48));
-        d.cap_in = n;
-      }
+      if (int rc = ensure_staging(ctx, ws, n * sz.point_in, n * sz.scalar_in)) return rc;
       if (src_is_host) {
         // scalars first; the points follow from inside enqueue_partial (pageable copies return when the data has left
         // the caller's buffer, so the scalar-only stages enqueued in between run while the points are still in flight)
-        HIP_TRY(ctx, hipMemcpyAsync(d.d_in_scalars, src_scalars, n * sz.scalar_in, hipMemcpyHostToDevice, ws.stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ws.d_in_scalars, src_scalars, n * sz.scalar_in, hipMemcpyHostToDevice, ws.stream));
       } else {
         // inputs live on device 0's memory: wait for nothing (caller's data is ready), copy peer-to-peer
-        HIP_TRY(ctx, hipMemcpyPeerAsync(d.d_in_points, d.device, src_points, ctx->devs[0].device, n * sz.point_in, ws.stream));
-        HIP_TRY(ctx, hipMemcpyPeerAsync(d.d_in_scalars, d.device, src_scalars, ctx->devs[0].device, n * sz.scalar_in, ws.stream));
+        HIP_TRY(ctx, hipMemcpyPeerAsync(ws.d_in_points, d.device, src_points, ctx->devs[0].device, n * sz.point_in, ws.stream));
+        HIP_TRY(ctx, hipMemcpyPeerAsync(ws.d_in_scalars, d.device, src_scalars, ctx->devs[0].device, n * sz.scalar_in, ws.stream));
         ctx->stat_peer_copies += 2;
       }
-      dp = d.d_in_points; ds = d.d_in_scalars;
+      dp = ws.d_in_points; ds = ws.d_in_scalars;
     }
     const std::function<int(hipStream_t)> upload_points = [&](hipStream_t side) -> int {
       // on the side stream, beside the scalar-only kernels on ws.stream; the conversion to records follows it there
-      HIP_TRY(ctx, hipMemcpyAsync(d.d_in_points, src_points, n * sz.point_in, hipMemcpyHostToDevice, side));
+      HIP_TRY(ctx, hipMemcpyAsync(ws.d_in_points, src_points, n * sz.point_in, hipMemcpyHostToDevice, side));
       return 0;
     };
     if (int rc = enqueue_partial(ctx, d, ws, dp, ds, n, nullptr, ws.stream, src_is_host ? &upload_points : nullptr)) return rc;
@@ -970,7 +1081,7 @@ int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, boo
     workset_t& ws = d.ws[wsel];
     HIP_TRY(ctx, hipSetDevice(d.device));
     HIP_TRY(ctx, hipEventSynchronize(ws.ev_result));
-    if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
+    if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, kFinalCarry);
     for (int w = d.w_first; w < p0.W; w += d.w_step)
       memcpy(&merged[(size_t)w * sz.row], ws.h_partials + (size_t)w * sz.row, sz.row);
   }
@@ -997,6 +1108,11 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
   }
   te_ctx* ctx = new te_ctx();
   if (const char* e = getenv("TE_MSM_FUSE_PREP")) ctx->opt_fuse_prep = e[0] != '0';      // A/B measurements; option "fuse_prep"
+  if (const char* e = getenv("TE_MSM_QUEUE_PROBE")) ctx->opt_queue_probe = e[0] != '0';  // option "queue_probe"
+  if (const char* e = getenv("TE_MSM_HOST_SPLIT")) {                                     // relative piece weights "w0,w1,..." (experiments)
+    const char* q = e;
+    while (*q) { char* end = nullptr; const double v = strtod(q, &end); if (end == q) break; ctx->host_split.push_back(v > 0 ? v : 1.0); q = *end == ',' ? end + 1 : end; }
+  }
   ctx->devs.resize(n_dev);
   for (int i = 0; i < n_dev; i++) {
     gpu_t& d = ctx->devs[i];
@@ -1032,7 +1148,16 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
 
 void te_msm_destroy(te_ctx* ctx) {
   if (!ctx) return;
-  for (auto& d : ctx->devs) { (void)hipSetDevice(d.device); (void)hipDeviceSynchronize(); free_dev(d); }
+  ctx->workers.clear();                 // joins the per-device host threads (idle between calls)
+  for (auto& d : ctx->devs) {
+    (void)hipSetDevice(d.device);
+    for (workset_t& ws : d.ws) {        // this context's streams only: other work of the process is none of its business
+      if (ws.stream) (void)hipStreamSynchronize(ws.stream);
+      if (ws.copy_stream) (void)hipStreamSynchronize(ws.copy_stream);
+      if (ws.last_stream && ws.last_stream != ws.stream && ws.ev_done) (void)hipEventSynchronize(ws.ev_done);
+    }
+    free_dev(d);
+  }
   delete ctx;
 }
 
@@ -1046,27 +1171,67 @@ int te_msm_run_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_sca
   return run_common(ctx, d_points_xy_le, d_scalars_le, false, n, out_xy_le);
 }
 
+namespace {
+// the lowest-numbered free work set (each has its own stream: the MSMs overlap on the device).  Not ticket % sets: with
+// fewer MSMs in flight than sets only as many sets as needed are ever touched -- no buffer allocation in the middle
+// of a run, and a smaller footprint in the Infinity Cache.
+int take_free_workset(te_ctx* ctx, gpu_t& d) {
+  if (d.in_flight >= TE_MSM_WORKSETS) return set_err(ctx, TE_MSM_ESTATE, "every work set has an MSM in flight: collect one first");
+  if (!d.queues_probed && ctx->opt_queue_probe) spread_streams_over_queues(d);      // once per context, with nothing of it in flight
+  d.streams_final = true;
+  int wi = 0;
+  while (wi < TE_MSM_WORKSETS && d.ws[wi].pending_ticket) wi++;
+  if (wi == TE_MSM_WORKSETS) return set_err(ctx, TE_MSM_ESTATE, "every work set has an MSM in flight: collect one first");
+  return wi;
+}
+void hand_out_ticket(gpu_t& d, workset_t& ws, uint64_t* ticket) {
+  *ticket = d.next_ticket++;
+  __atomic_store_n(&ws.pending_ticket, *ticket, __ATOMIC_RELEASE); d.in_flight++;      // te_msm_ticket_wait reads it from other threads
+}
+workset_t* workset_of_ticket(gpu_t& d, uint64_t ticket) {
+  if (!ticket) return nullptr;
+  for (workset_t& ws : d.ws) if (__atomic_load_n(&ws.pending_ticket, __ATOMIC_ACQUIRE) == ticket) return &ws;
+  return nullptr;
+}
+}  // namespace
+
 int te_msm_submit_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_scalars_le, uint64_t n, uint64_t* ticket) {
   if (!ctx || !ticket) return TE_MSM_EINVAL;
   if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_submit_device needs a single-device context");
   if (!d_points_xy_le || !d_scalars_le || n == 0 || n >= (1ull << 31)) return set_err(ctx, TE_MSM_EINVAL, "bad arguments");
   gpu_t& d = ctx->devs[0];
-  if (d.next_ticket - d.next_collect >= TE_MSM_WORKSETS) return set_err(ctx, TE_MSM_ESTATE, "every work set has an MSM in flight: collect one first");
-  // the lowest-numbered free work set (each has its own stream: the MSMs overlap on the device).  Not ticket % sets: with
-  // fewer MSMs in flight than sets only as many sets as needed are ever touched -- no buffer allocation in the middle
-  // of a run, and a smaller footprint in the Infinity Cache.
   HIP_TRY(ctx, hipSetDevice(d.device));
-  if (!d.queues_probed) spread_streams_over_queues(d);      // once per context, with nothing in flight
-  int wi = 0;
-  while (wi < TE_MSM_WORKSETS && d.ws[wi].pending_ticket) wi++;
-  if (wi == TE_MSM_WORKSETS) return set_err(ctx, TE_MSM_ESTATE, "every work set has an MSM in flight: collect one first");
+  const int wi = take_free_workset(ctx, d);
+  if (wi < 0) return wi;
   workset_t& ws = d.ws[wi];
-  HIP_TRY(ctx, hipSetDevice(d.device));
   if (int rc = enqueue_partial(ctx, d, ws, d_points_xy_le, d_scalars_le, n, nullptr, ws.stream)) return rc;
   if (int rc = fetch_rows(ctx, ws, ws.stream)) return rc;
-  *ticket = d.next_ticket++;
-  ws.pending_ticket = *ticket;
-  d.ticket_ws[*ticket % TE_MSM_WORKSETS] = wi;
+  hand_out_ticket(d, ws, ticket);
+  return 0;
+}
+
+int te_msm_submit(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars_le, uint64_t n, uint64_t* ticket) {
+  if (!ctx || !ticket) return TE_MSM_EINVAL;
+  if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_submit needs a single-device context");
+  if (!points_xy_le || !scalars_le || n == 0 || n >= (1ull << 31)) return set_err(ctx, TE_MSM_EINVAL, "bad arguments");
+  gpu_t& d = ctx->devs[0];
+  if (d.w_step != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_submit computes whole MSMs: reset the window shard first");
+  HIP_TRY(ctx, hipSetDevice(d.device));
+  const int wi = take_free_workset(ctx, d);
+  if (wi < 0) return wi;
+  workset_t& ws = d.ws[wi];
+  plan_t pf; make_plan(ctx, d, n, pf);
+  if (int rc = enqueue_host_slice(ctx, d, ws, points_xy_le, scalars_le, n, pf.c, host_pieces(ctx, n))) return rc;
+  hand_out_ticket(d, ws, ticket);
+  return 0;
+}
+
+int te_msm_ticket_wait(te_ctx* ctx, uint64_t ticket) {
+  if (!ctx) return TE_MSM_EINVAL;
+  if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "tickets exist on single-device contexts");
+  workset_t* ws = workset_of_ticket(ctx->devs[0], ticket);
+  if (!ws) return set_err(ctx, TE_MSM_ESTATE, "no such ticket in flight");
+  HIP_TRY(ctx, hipEventSynchronize(ws->ev_result));
   return 0;
 }
 
@@ -1074,15 +1239,47 @@ int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]) {
   if (!ctx || !out_xy_le) return TE_MSM_EINVAL;
   if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_collect needs a single-device context");
   gpu_t& d = ctx->devs[0];
-  if (ticket != d.next_collect || ticket >= d.next_ticket) return set_err(ctx, TE_MSM_ESTATE, "tickets must be collected in submission order");
-  workset_t& ws = d.ws[d.ticket_ws[ticket % TE_MSM_WORKSETS]];
+  workset_t* wsp = workset_of_ticket(d, ticket);
+  if (!wsp) return set_err(ctx, TE_MSM_ESTATE, "no such ticket in flight (already collected, or never handed out)");
+  workset_t& ws = *wsp;
   HIP_TRY(ctx, hipEventSynchronize(ws.ev_result));   // on failure the ticket stays collectable
   (void)collect_stage_ms(ctx, ws);
-  d.next_collect++; ws.pending_ticket = 0;           // the MSM is over, with a result or with a scalar-range error
-  if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
+  d.in_flight--; __atomic_store_n(&ws.pending_ticket, (uint64_t)0, __ATOMIC_RELEASE);   // the MSM is over, with a result or with a scalar-range error
+  if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, kFinalCarry);
   if (ws.plan.curve == TE_MSM_CURVE_BLS12_377_G1) te377_host::horner_to_affine(ws.h_partials, ws.plan.c, (int)ws.plan.logB, ws.plan.W, out_xy_le);
   else te_host::horner_to_affine(ws.h_partials, ws.plan.c, (int)ws.plan.logB, ws.plan.W, out_xy_le);
   return 0;
+}
+
+int te_msm_probe_queues(te_ctx* ctx) {
+  if (!ctx) return TE_MSM_EINVAL;
+  int classes = 0;
+  for (gpu_t& d : ctx->devs) {
+    if (d.in_flight) return set_err(ctx, TE_MSM_ESTATE, "te_msm_probe_queues: collect the MSMs in flight first");
+    HIP_TRY(ctx, hipSetDevice(d.device));
+    spread_streams_over_queues(d);
+    d.streams_final = true;
+    int c = -1; for (const workset_t& ws : d.ws) c = std::max(c, ws.hw_queue_class);
+    classes = std::max(classes, c + 1);
+  }
+  return classes;          // 0: the measurement was not accepted (its two passes disagreed): creation order kept
+}
+
+int te_msm_trim(te_ctx* ctx, int keep_worksets) {
+  if (!ctx || keep_worksets < 0) return TE_MSM_EINVAL;
+  int freed = 0;
+  for (gpu_t& d : ctx->devs) {
+    HIP_TRY(ctx, hipSetDevice(d.device));
+    for (int i = keep_worksets; i < TE_MSM_WORKSETS; i++) {
+      workset_t& ws = d.ws[i];
+      if (ws.pending_ticket || !(ws.d_recs || ws.d_in_points || ws.d_zero)) continue;       // owned by a ticket, or nothing to free
+      if (ws.used) HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));
+      if (ws.copy_stream) HIP_TRY(ctx, hipStreamSynchronize(ws.copy_stream));
+      free_workset_buffers(ws);
+      freed++;
+    }
+  }
+  return freed;
 }
 
 int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
@@ -1101,6 +1298,8 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   if (!strcmp(key, "host_chunks")) { if (value < 0 || value > 64) return set_err(ctx, TE_MSM_EINVAL, "host_chunks out of range"); ctx->opt_host_chunks = (int)value; return 0; }
   if (!strcmp(key, "workset")) { if (value < 0 || value >= TE_MSM_WORKSETS) return set_err(ctx, TE_MSM_EINVAL, "workset out of range"); ctx->opt_workset = (int)value; return 0; }
   if (!strcmp(key, "segment_len")) { if (value < 0 || value > 1000000) return set_err(ctx, TE_MSM_EINVAL, "segment_len must be 0 (from n) or in [1, 1e6]"); ctx->opt_seg_len = (int)value; return 0; }
+  if (!strcmp(key, "host_shard_min")) { if (value < 1 || value > (1ll << 30)) return set_err(ctx, TE_MSM_EINVAL, "host_shard_min out of range"); ctx->opt_host_shard_min = (int)value; return 0; }
+  if (!strcmp(key, "queue_probe")) { ctx->opt_queue_probe = value ? 1 : 0; return 0; }
   return set_err(ctx, TE_MSM_EINVAL, "unknown option");
 }
 
@@ -1120,6 +1319,15 @@ int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value) {
   if (!strcmp(key, "prezero")) { *value = ctx->opt_prezero; return 0; }
   if (!strcmp(key, "fuse_prep")) { *value = ctx->opt_fuse_prep; return 0; }
   if (!strcmp(key, "host_chunks")) { *value = ctx->opt_host_chunks; return 0; }
+  if (!strcmp(key, "host_shard_min")) { *value = ctx->opt_host_shard_min; return 0; }
+  if (!strcmp(key, "queue_probe")) { *value = ctx->opt_queue_probe; return 0; }
+  if (!strcmp(key, "streams_final")) { *value = ctx->devs[0].streams_final ? 1 : 0; return 0; }
+  if (!strcmp(key, "in_flight")) { *value = ctx->devs[0].in_flight; return 0; }
+  if (!strcmp(key, "device_bytes")) {      // device memory this context holds in work-set buffers (te_msm_trim gives it back)
+    int64_t tot = 0;
+    for (const gpu_t& d : ctx->devs) for (const workset_t& ws : d.ws) { for (size_t cb : ws.cap) tot += (int64_t)cb; tot += (int64_t)(ws.cap_in_points + ws.cap_in_scalars); }
+    *value = tot; return 0;
+  }
   return set_err(ctx, TE_MSM_EINVAL, "unknown option");
 }
 
@@ -1250,6 +1458,21 @@ int te_msm_finalize_gathered_curve(int curve, const uint8_t* gathered, int world
   for (int w = 0; w < num_windows; w++)
     memcpy(&merged[(size_t)w * row], gathered + ((size_t)(w % world) * num_windows + w) * row, row);
   return te_msm_finalize_host_curve(curve, merged.data(), window_bits, bucket_bits, num_windows, out_xy_le);
+}
+
+int te_msm_finalize_sum_curve(int curve, const uint8_t* const* row_sets, int sets, int window_bits, int bucket_bits, int num_windows, uint8_t* out_xy_le) {
+  if (curve != TE_MSM_CURVE_TE_BLS12 && curve != TE_MSM_CURVE_BLS12_377_G1) return TE_MSM_EINVAL;
+  if (!row_sets || sets < 1 || sets > 4096 || !out_xy_le || window_bits < 2 || window_bits > 16 || num_windows < 1 || num_windows > 128) return TE_MSM_EINVAL;
+  if (bucket_bits != window_bits && bucket_bits != window_bits - 1) return TE_MSM_EINVAL;
+  for (int i = 0; i < sets; i++) if (!row_sets[i]) return TE_MSM_EINVAL;
+  if (curve == TE_MSM_CURVE_BLS12_377_G1) {
+    if (!te377_host::tail_selftest()) return TE_MSM_ESTATE;
+    te377_host::horner_to_affine_multi(row_sets, sets, window_bits, bucket_bits, num_windows, out_xy_le);
+  } else {
+    if (!te_host::tail_selftest()) return TE_MSM_ESTATE;
+    te_host::horner_to_affine_multi(row_sets, sets, window_bits, bucket_bits, num_windows, out_xy_le);
+  }
+  return 0;
 }
 
 int te_msm_stage_ms(te_ctx* ctx, float* ms, const char** names, int max_stages) {

@@ -6,18 +6,33 @@
 // (submission/submission.ts:73-78).  The MSM runs on a libuv worker thread (napi_create_async_work), so the
 // JS event loop is not blocked -- the reference's call is async for the same reason (ui/Benchmark.tsx:32).
 // Errors reject the promise, as the reference's `throw`s do (implementation/cuzk/gpu.ts:19-22).
+//
+// Devices: TE_MSM_DEVICES="0,1,2,3" (or setDevices([0,1,2,3])) shards every call over several GPUs of the node --
+// te_msm_run on an n_dev > 1 context: point slices, one upload thread and PCIe link per device (include/te_msm.h).
+// Default: device 0.
+// Concurrency: promises in flight at the same time (a prover that does not await each call) are mapped onto the
+// engine's work sets -- te_msm_submit under the lock, te_msm_ticket_wait outside it, te_msm_collect under it again --
+// so the upload of one MSM overlaps the device work of the previous ones; as many as libuv has pool threads (4 unless
+// UV_THREADPOOL_SIZE says otherwise, at most TE_MSM_WORKSETS) are in flight.  Multi-device contexts run one call at a
+// time (each call already uses every device).
 #include <node_api.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
+#include <condition_variable>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/te_msm.h"
 
 namespace {
 
-std::mutex g_mu;            // one context, one MSM at a time (the engine context is not thread-safe)
+std::mutex g_mu;            // guards the context (it is not thread-safe) and the fields below
+std::condition_variable g_cv;   // a work set became free / the context went idle
 te_ctx* g_ctx = nullptr;
+std::vector<int> g_devices;     // empty: TE_MSM_DEVICES, else device 0
+int g_busy = 0;                 // Execute() calls that are using g_ctx right now (resetContext / setDevices wait for 0)
 
 struct Job {
   napi_async_work work = nullptr;
@@ -29,16 +44,63 @@ struct Job {
   uint8_t out[64];
 };
 
+std::vector<int> devices_from_env() {
+  std::vector<int> ids;
+  const char* e = getenv("TE_MSM_DEVICES");
+  if (e && *e) {
+    const char* q = e;
+    while (*q) { char* end = nullptr; const long v = strtol(q, &end, 10); if (end == q) break; ids.push_back((int)v); q = *end == ',' ? end + 1 : end; }
+  }
+  if (ids.empty()) ids.push_back(0);
+  return ids;
+}
+
+// with g_mu held
+int ensure_context(std::string& err) {
+  if (g_ctx) return 0;
+  const std::vector<int> ids = g_devices.empty() ? devices_from_env() : g_devices;
+  const int rc = te_msm_init(ids.data(), (int)ids.size(), &g_ctx);
+  if (rc) { err = te_msm_last_error(nullptr); g_ctx = nullptr; return rc; }
+  // the lazy hardware-queue measurement (16 ms at the first submit) only pays off for many small device-resident MSMs in flight;
+  // a host-buffer caller is bound by its uploads.  TE_MSM_QUEUE_PROBE=1 asks for it.
+  const char* qp = getenv("TE_MSM_QUEUE_PROBE");
+  if (!(qp && qp[0] == '1')) te_msm_set_option(g_ctx, "queue_probe", 0);
+  return 0;
+}
+
 void Execute(napi_env, void* data) {
   Job* j = static_cast<Job*>(data);
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ctx) {
-    int dev = 0;
-    j->rc = te_msm_init(&dev, 1, &g_ctx);
-    if (j->rc) { j->err = te_msm_last_error(nullptr); g_ctx = nullptr; return; }
+  std::unique_lock<std::mutex> lk(g_mu);
+  if ((j->rc = ensure_context(j->err))) return;
+  te_ctx* const ctx = g_ctx;
+  g_busy++;
+  int64_t ndev = 1;
+  te_msm_get_option(ctx, "num_devices", &ndev);
+  if (ndev > 1 || j->n == 0) {
+    j->rc = te_msm_run(ctx, j->points, j->scalars, j->n, j->out);       // every device works on this one call
+    if (j->rc) j->err = te_msm_last_error(ctx);
+  } else {
+    uint64_t ticket = 0;
+    for (;;) {
+      j->rc = te_msm_submit(ctx, j->points, j->scalars, j->n, &ticket);
+      if (j->rc != TE_MSM_ESTATE) break;
+      int64_t fl = 0; te_msm_get_option(ctx, "in_flight", &fl);
+      if (fl == 0) break;                                                // not a capacity problem
+      g_cv.wait(lk);                                                     // every work set is taken: wait for a collect
+    }
+    if (j->rc) {
+      j->err = te_msm_last_error(ctx);
+    } else {
+      lk.unlock();
+      const int wrc = te_msm_ticket_wait(ctx, ticket);                   // the one call that may run beside others
+      lk.lock();
+      j->rc = te_msm_collect(ctx, ticket, j->out);
+      if (j->rc) j->err = te_msm_last_error(ctx);
+      else if (wrc) { j->rc = wrc; j->err = "te_msm_ticket_wait failed"; }
+    }
   }
-  j->rc = te_msm_run(g_ctx, j->points, j->scalars, j->n, j->out);
-  if (j->rc) j->err = te_msm_last_error(g_ctx);
+  g_busy--;
+  g_cv.notify_all();
 }
 
 void Complete(napi_env env, napi_status, void* data) {
@@ -85,19 +147,58 @@ napi_value MsmNative(napi_env env, napi_callback_info info) {
   return promise;
 }
 
+// with g_mu held by lk: waits until no Execute() uses the context, then drops it
+void drop_context(std::unique_lock<std::mutex>& lk) {
+  g_cv.wait(lk, [] { return g_busy == 0; });
+  if (g_ctx) { te_msm_destroy(g_ctx); g_ctx = nullptr; }
+}
+
 // resetContext(): drops the cached engine context (compute_msm's force_recompile)
 napi_value ResetContext(napi_env env, napi_callback_info) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (g_ctx) { te_msm_destroy(g_ctx); g_ctx = nullptr; }
+  std::unique_lock<std::mutex> lk(g_mu);
+  drop_context(lk);
   napi_value u; napi_get_undefined(env, &u); return u;
 }
 
+// setDevices([0, 1, ...]): the GPUs later calls are sharded over (overrides TE_MSM_DEVICES; [] = back to the environment)
+napi_value SetDevices(napi_env env, napi_callback_info info) {
+  size_t argc = 1; napi_value argv[1];
+  napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+  bool is_arr = false;
+  if (argc >= 1) napi_is_array(env, argv[0], &is_arr);
+  if (!is_arr) { napi_throw_type_error(env, nullptr, "setDevices(ids: number[])"); return nullptr; }
+  uint32_t len = 0; napi_get_array_length(env, argv[0], &len);
+  if (len > 64) { napi_throw_range_error(env, nullptr, "setDevices: at most 64 devices"); return nullptr; }
+  std::vector<int> ids;
+  for (uint32_t i = 0; i < len; i++) {
+    napi_value v; int32_t id = 0;
+    napi_get_element(env, argv[0], i, &v);
+    if (napi_get_value_int32(env, v, &id) != napi_ok || id < 0) { napi_throw_type_error(env, nullptr, "setDevices: device ids are non-negative integers"); return nullptr; }
+    ids.push_back(id);
+  }
+  std::unique_lock<std::mutex> lk(g_mu);
+  drop_context(lk);
+  g_devices = ids;
+  napi_value u; napi_get_undefined(env, &u); return u;
+}
+
+// getDevices(): the device list the next context is (or the current one was) created with
+napi_value GetDevices(napi_env env, napi_callback_info) {
+  std::vector<int> ids;
+  { std::lock_guard<std::mutex> lk(g_mu); ids = g_devices.empty() ? devices_from_env() : g_devices; }
+  napi_value arr; napi_create_array_with_length(env, ids.size(), &arr);
+  for (size_t i = 0; i < ids.size(); i++) { napi_value v; napi_create_int32(env, ids[i], &v); napi_set_element(env, arr, (uint32_t)i, v); }
+  return arr;
+}
+
 napi_value Init(napi_env env, napi_value exports) {
-  napi_value f1, f2;
-  napi_create_function(env, "msmNative", NAPI_AUTO_LENGTH, MsmNative, nullptr, &f1);
-  napi_set_named_property(env, exports, "msmNative", f1);
-  napi_create_function(env, "resetContext", NAPI_AUTO_LENGTH, ResetContext, nullptr, &f2);
-  napi_set_named_property(env, exports, "resetContext", f2);
+  const struct { const char* name; napi_callback fn; } fns[] = {
+      {"msmNative", MsmNative}, {"resetContext", ResetContext}, {"setDevices", SetDevices}, {"getDevices", GetDevices}};
+  for (const auto& f : fns) {
+    napi_value v;
+    napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &v);
+    napi_set_named_property(env, exports, f.name, v);
+  }
   return exports;
 }
 

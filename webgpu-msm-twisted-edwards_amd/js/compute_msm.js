@@ -47,4 +47,9 @@ const compute_msm = async (bufferPoints, bufferScalars, log_result = true, force
   return result;
 };
 
-module.exports = { compute_msm };
+// Not part of the reference's interface: which GPUs a call is sharded over (default TE_MSM_DEVICES, else device 0).
+// Promises in flight at the same time overlap on the engine's work sets (js/addon.cc).
+const setDevices = (ids) => native.setDevices(ids);
+const getDevices = () => native.getDevices();
+
+module.exports = { compute_msm, setDevices, getDevices };

@@ -7,3 +7,6 @@ export declare const compute_msm: (
   log_result?: boolean,
   force_recompile?: boolean,
 ) => Promise<{ x: bigint; y: bigint }>;
+// Not in the reference: the GPUs a call is sharded over (default: TE_MSM_DEVICES, else device 0).
+export declare const setDevices: (ids: number[]) => void;
+export declare const getDevices: () => number[];
