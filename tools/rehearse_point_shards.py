@@ -1,0 +1,48 @@
+"""Rehearsal of te_msm_run on D devices (point shards) on a ONE-GPU box: what ONE device of D does -- its slice of n / D points
+from host buffers, all windows (te_msm_run of n / D points) -- next to the whole call on one device, plus the in-process
+multi-"device" call with the one GPU named D times (D threads, D uploads sharing ONE link and one GPU: correctness and the
+host-side overhead of threads and the D-set host tail, not a speed-up).  Also the node-visible pipelined form:
+k te_msm_submit tickets in flight.   Run on the GPU box:  python tools/rehearse_point_shards.py [log2n]"""
+import importlib, sys, time
+sys.path.insert(0, '.')
+pkg = importlib.import_module("webgpu-msm-twisted-edwards_amd")
+lg = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+n = 1 << lg
+pts, sc = pkg.synth_inputs(0x5EED0000 + lg, n)
+
+
+def timed(f, reps=9):
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); r = f(); ts.append((time.perf_counter() - t0) * 1e3)
+    ts.sort()
+    return r, ts[0], ts[len(ts) // 2]
+
+
+with pkg.MsmContext((0,)) as c:
+    ref = c.run(pts, sc)
+    _, best, med = timed(lambda: c.run(pts, sc))
+    print("n = 2^%d  one device, whole call: best %.3f ms, median %.3f ms" % (lg, best, med))
+    whole = med
+    for D in (2, 4, 8):
+        m = n // D
+        c.run(pts[:64 * m], sc[:32 * m])
+        _, best, med = timed(lambda: c.run(pts[:64 * m], sc[:32 * m]))
+        cb, W = c.plan(m)
+        print("  one device's share at D = %d: %7d points, %d-bit windows: best %.3f ms, median %.3f ms  -> %.2fx the whole call (before the D-set host tail)"
+              % (D, m, cb, best, med, whole / med))
+    # tickets in flight from host buffers (what concurrent compute_msm promises get)
+    for k in (1, 2, 4):
+        def go():
+            ts = [c.submit(pts, sc) for _ in range(k)]
+            return [c.collect(t) for t in ts]
+        go()
+        r, best, med = timed(go, 7)
+        assert all(x == ref for x in r)
+        print("  %d te_msm_submit ticket(s) in flight: best %.3f ms, median %.3f ms per MSM" % (k, best / k, med / k))
+
+for D in (2, 4, 8):
+    with pkg.MsmContext((0,) * D) as c:
+        assert c.run(pts, sc) == ref
+        _, best, med = timed(lambda: c.run(pts, sc), 7)
+        print("in-process te_msm_run, the one GPU named %d times (D uploads share one link): best %.3f ms, median %.3f ms" % (D, best, med))
