@@ -48,17 +48,20 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-def measured_traffic(log2n, c, world, default_workload=True):
-    """HBM bytes per k_accumulate launch from the committed rocprofv3 PMC passes (tools/profile_bench.sh ->
-    profiles/pmc_traffic.json).  Counters cannot be read from inside the process, so the figure applies to the profiled
-    workload only (n = 2^20, c = 16, one GPU) and to the kernel sources it was profiled with: the JSON records their
-    hash and the commit; when the sources have changed since, the figure is withheld (null) and flagged stale."""
+def measured_traffic(log2n, c, world, default_workload=True, config=None):
+    """HBM bytes per k_accumulate launch from the committed rocprofv3 PMC passes (tools/profile_bench.sh and, for the side
+    configs, tools/profile_configs.sh -> profiles/pmc_traffic.json).  Counters cannot be read from inside the process, so
+    the figure applies to the profiled workloads only (n = 2^20, c = 16, one GPU: the default line under "kernels", the
+    side configs under "configs") and to the kernel sources they were profiled with: the JSON records their hash and the
+    commit; when the sources have changed since, the figure is withheld (null) and flagged stale."""
     info = {"file": os.path.relpath(TRAFFIC_JSON, ROOT), "sources_sha_now": kernel_sources_sha()}
-    if not (log2n == 20 and c == 16 and world == 1 and default_workload and os.path.exists(TRAFFIC_JSON)):
+    if not (log2n == 20 and c == 16 and world == 1 and (default_workload or config) and os.path.exists(TRAFFIC_JSON)):
         return None, info
     try:
         j = json.load(open(TRAFFIC_JSON))
-        k = j["kernels"]["k_accumulate"]
+        k = (j["configs"][config]["kernels"] if config else j["kernels"])["k_accumulate"]
+        if config:
+            info["profiled_workload"] = j["configs"][config].get("workload")
     except (KeyError, ValueError):
         return None, info
     info.update({"profiled_at_commit": j.get("commit"), "sources_sha_profiled": j.get("kernel_sources_sha"),
@@ -149,7 +152,7 @@ def roofline_block(acc_bytes, alone, timed, bls, waves, traffic=None, traffic_in
     return out
 
 
-def side_config(pkg, dev, name, curve, digits, log2n, depth, threads, steps, expect=None, inputs=None):
+def side_config(pkg, dev, name, curve, digits, log2n, depth, threads, steps, expect=None, inputs=None, workload_note=""):
     """a short pass of another BASELINE config on a fresh context: pipelined throughput, latency, the dominant kernel alone,
     parity against the config's oracle (timed: its cpu_baseline)"""
     import torch
@@ -183,10 +186,11 @@ def side_config(pkg, dev, name, curve, digits, log2n, depth, threads, steps, exp
         elapsed, result = pipelined_pass(cx, dp, ds, n, steps, depth)
         alone = alone_pass(cx, lambda: cx.run_device(dp, ds, n), 4)
     whole, acc_bytes = algorithmic_bytes(n, W, B, bls)
-    out = {"workload": "n=2^%d %s MSM, %d-bit %s windows (%d windows x %d buckets), inputs resident in HBM" % (
-               log2n, "BLS12-377 G1" if bls else "TE-BLS12", c, digits, W, B),
+    traffic, traffic_info = measured_traffic(log2n, c, 1, False, name)
+    out = {"workload": "n=2^%d %s MSM, %d-bit %s windows (%d windows x %d buckets)%s, inputs resident in HBM" % (
+               log2n, "BLS12-377 G1" if bls else "TE-BLS12", c, digits, W, B, workload_note),
            "value": steps / elapsed, "unit": "MSM/s", "steps": steps, "ms_per_step": elapsed * 1e3 / steps, "latency_ms": min(lat),
-           "roofline": roofline_block(acc_bytes, alone, None, bls, W * n / 64.0),
+           "roofline": roofline_block(acc_bytes, alone, None, bls, W * n / 64.0, traffic, traffic_info),
            "msm_algorithmic_bytes": whole}
     if expect is None:
         t0 = time.perf_counter()
@@ -215,7 +219,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log2n", type=int, default=20)
     ap.add_argument("--window-bits", type=int, default=16)
-    ap.add_argument("--points", choices=["chain", "fixed"], default="chain", help="chain: distinct points (a+i*b)G; fixed: harness mode")
+    ap.add_argument("--points", choices=["random", "chain", "fixed"], default="random",
+                    help="random: n independent seeded-random a_i*G (SURVEY 8d set (R), default); chain: the arithmetic progression (a+i*b)G; "
+                         "fixed: harness mode (H), one point replicated (ui/AllBenchmarks.tsx:105-112)")
     ap.add_argument("--scalars", choices=["uniform", "equal", "small"], default="uniform",
                     help="uniform: the harness's distribution; equal: one scalar repeated (worst-case skew); small: 64-bit scalars")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -237,6 +243,7 @@ def main():
                          "engine converts it once per launch sequence) or each its own copy")
     ap.add_argument("--no-pipeline", action="store_true", help="N=1: await every MSM before submitting the next (latency mode)")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--repeats", type=int, default=3, help="timed passes of --steps steps each; value = the median pass")
     args = ap.parse_args()
 
     import torch
@@ -246,6 +253,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     force_dist = os.environ.get("TE_BENCH_FORCE_DIST") == "1"      # rehearsal: run the N > 1 code path with one rank over RCCL
+    cpu_group = None
     share = os.environ.get("TE_BENCH_SHARE_GPU") == "1"            # rehearsal on a one-GPU box: every rank on cuda:0, exchange over gloo
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d); got WORLD_SIZE=%d"
@@ -263,6 +271,9 @@ def main():
                                  % (rank, local_rank, torch.cuda.device_count()))
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # a CPU-side group: the ranks that wait while rank 0 drives all GPUs from its own process (host-buffer figure
+            # below) must wait on the host -- an RCCL barrier is a kernel spinning on their GPUs
+            cpu_group = dist.new_group(backend="gloo") if world > 1 else None
         if dist.get_world_size() != args.gpus:
             raise SystemExit("process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
     dev = local_rank if world > 1 else 0
@@ -289,7 +300,7 @@ def main():
 
     def make_inputs(log2n):
         n = 1 << log2n
-        pts, sc = pkg.synth_inputs(0x5EED0000 + log2n, n, fixed_point=(args.points != "chain"),      # the engine's own harness inputs
+        pts, sc = pkg.synth_inputs(0x5EED0000 + log2n, n, fixed_point=("chain" if (bls and args.points == "random") else args.points),   # the engine's own harness inputs
                                    curve=pkg.CURVE_BLS12_377_G1 if bls else pkg.CURVE_TE_BLS12)
         if args.scalars == "equal":
             sc = sc[:sb] * n
@@ -408,36 +419,51 @@ def main():
         return el, k, res
 
     distinct_line = None
-    if pipelined and sharded:
-        elapsed, last, result = sharded_pass(batch_inputs)
-        note_stage()                                   # events of the last launch sequence (`last` MSMs): a sample, not the mean
-        if batch > 1 and len(base_copies) == 1:
-            # the same again with a point buffer of its own per MSM of a batch (same bytes at distinct addresses): a shared
-            # buffer is converted once per launch sequence, distinct ones once each -- both figures belong in the line
-            copies = [d_pts] + [d_pts.clone() for _ in range(batch - 1)]
-            torch.cuda.synchronize()
-            el2, _, res2 = sharded_pass(lambda k: [(copies[m], d_sc) for m in range(k)])
-            assert res2 == result
-            distinct_line = {"ms_per_step": el2 * 1e3 / args.steps, "value": args.steps / el2,
-                             "note": "every MSM of a batch names its own copy of the point buffer: %d conversions per launch sequence instead of one" % batch}
-            del copies
-    else:
+
+    def timed_pass():
+        """EXACTLY args.steps MSMs, bracketed by barrier + synchronize on both sides, max over ranks: (seconds, result)"""
+        if pipelined and sharded:
+            el, k, res = sharded_pass(batch_inputs)
+            return el, res, k
         sync()
         t0 = time.perf_counter()
         if pipelined:
             # K independent MSMs back to back, `depth` in flight on as many streams: host tail and device work of consecutive
             # MSMs overlap, and on the GPU the gaps and latency-bound tail of one are filled by the wide kernels of another
-            _, result = pipelined_pass(ctx, d_pts.data_ptr(), d_sc.data_ptr(), n, args.steps, depth, note_stage)
+            _, res = pipelined_pass(ctx, d_pts.data_ptr(), d_sc.data_ptr(), n, args.steps, depth, note_stage)
         else:
+            res = None
             for _ in range(args.steps):
-                result = step()
+                res = step()
                 note_stage()
         sync()
-        elapsed = time.perf_counter() - t0
+        el = time.perf_counter() - t0
         if sharded:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() != "gloo" else "cpu")
+            t = torch.tensor([el], dtype=torch.float64, device="cuda" if dist.get_backend() != "gloo" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            el = float(t.item())
+        return el, res, 1
+
+    # The timed region runs args.repeats (3) times, each EXACTLY args.steps steps; `value` / `ms_per_step` are the MEDIAN pass
+    # (the driver's 20 steps are 20 ms of GPU time: one pass alone carries the box's clock wobble straight into `value`); all
+    # passes are in "passes_ms_per_step".
+    passes = []
+    for _ in range(max(1, args.repeats)):
+        el, result, last = timed_pass()
+        passes.append(el)
+    if pipelined and sharded:
+        note_stage()                                   # events of the last launch sequence (`last` MSMs): a sample, not the mean
+    elapsed = sorted(passes)[len(passes) // 2]
+    if pipelined and sharded and batch > 1 and len(base_copies) == 1:
+        # the same again with a point buffer of its own per MSM of a batch (same bytes at distinct addresses): a shared
+        # buffer is converted once per launch sequence, distinct ones once each -- both figures belong in the line
+        copies = [d_pts] + [d_pts.clone() for _ in range(batch - 1)]
+        torch.cuda.synchronize()
+        el2, _, res2 = sharded_pass(lambda k: [(copies[m], d_sc) for m in range(k)])
+        assert res2 == result
+        distinct_line = {"ms_per_step": el2 * 1e3 / args.steps, "value": args.steps / el2,
+                         "note": "every MSM of a batch names its own copy of the point buffer: %d conversions per launch sequence instead of one" % batch}
+        del copies
 
     ms_per_step = elapsed * 1e3 / args.steps
     # the dominant kernel in the timed region, per LAUNCH (a launch carries `last` MSMs in a window-sharded batch): means over
@@ -457,7 +483,7 @@ def main():
     acc_bytes_rank = acc_bytes / div                      # windows are sharded
     traffic, traffic_info = (None, None) if bls else measured_traffic(
         args.log2n, c, world if not rehearse else rehearse,
-        args.digits == "signed" and args.scalars == "uniform" and args.points == "chain" and not args.segment_len)
+        args.digits == "signed" and args.scalars == "uniform" and args.points == "random" and not args.segment_len)
 
     out = {
         "metric": "MSMs/sec at n=2^%d %s (pipelined throughput = 1000/ms_per_step; single-MSM latency in latency_ms)" % (args.log2n, "BLS12-377 G1" if bls else "Twisted-Edwards BLS12"),
@@ -467,6 +493,8 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        "passes_ms_per_step": [e * 1e3 / args.steps for e in passes],
+        "value_is": "median of %d timed passes of %d steps each" % (len(passes), args.steps),
         "latency_ms": min(lat),
         "latency_ms_single_msm": min(lat),
         "host_buffers_ms": None,
@@ -478,9 +506,9 @@ def main():
         "data": "synthetic",
         "config": {"workload": "n=2^%d %s MSM, %d-bit %s windows (%d windows x %d buckets), points=%s, scalars=%s, inputs resident in HBM"
                                % (args.log2n, "BLS12-377 G1" if bls else "TE-BLS12", c, args.digits, W, B, args.points, args.scalars),
-                   "points_note": ("chain = n distinct subgroup points (a + i*b)*G, an arithmetic progression generated by te_msm_synth_inputs "
-                                   "(SURVEY 8d asks for seeded-random a_i*G: performance-equivalent -- every point is a distinct, "
-                                   "uniformly spread field element; tests/ use the oracle's seeded-random points)") if args.points == "chain" else "harness mode: one fixed point replicated",
+                   "points_note": {"random": "SURVEY 8d set (R): n independent subgroup points a_i*G, a_i seeded-random (te_msm_synth_inputs, fixed-base table on the host cores)",
+                                   "chain": "n distinct subgroup points (a + i*b)*G, an arithmetic progression (te_msm_synth_inputs)",
+                                   "fixed": "harness mode (H): one fixed point replicated (ui/AllBenchmarks.tsx:105-112)"}[args.points],
                    "parallelism": "windows sharded over %d rank(s), one %s all-gather of %d B partial sums per launch sequence of %d MSM(s), %s point buffers"
                                   % (world, "RCCL" if (world > 1 and dist.get_backend() == "nccl") else "gloo (rehearsal: ranks share one GPU)", batch * W * 720, batch,
                                      "one shared" if len(base_copies) == 1 else "distinct") if world > 1 else "single GPU"},
@@ -525,6 +553,22 @@ def main():
                                     "from 3 * 2^18 points, 2 from 2^17, whole below)" % ctx.get_option("host_chunks"))
         out["host_buffers_gbps"] = (len(pts) + len(sc)) / (hb * 1e-3) / 1e9
         assert r_host == result
+        # the same boundary with several calls in flight (te_msm_submit: what concurrent compute_msm promises map onto): the upload
+        # of MSM k+1 overlaps the device work of MSM k -- bound by the one PCIe link
+        ctx.set_option("profile", 0)
+        for t in [ctx.submit(pts, sc) for _ in range(depth)]:
+            assert ctx.collect(t) == result
+        t1 = time.perf_counter()
+        tk = []
+        for _ in range(12):
+            tk.append(ctx.submit(pts, sc))
+            if len(tk) >= depth:
+                assert ctx.collect(tk.pop(0)) == result
+        while tk:
+            assert ctx.collect(tk.pop(0)) == result
+        out["host_buffers_in_flight_ms"] = (time.perf_counter() - t1) * 1e3 / 12
+        out["host_buffers_in_flight_note"] = "12 te_msm_submit calls from pageable host buffers, %d in flight, per MSM" % depth
+        ctx.set_option("profile", 1)
         out["sizes"] = {str(args.log2n): {"ms_per_step": ms_per_step, "latency_ms": min(lat), "host_buffers_ms": hb, "window_bits": c,
                                           "core_clock_ghz": stage_ms.get("accumulate_core_clock_ghz")}}
         if not args.no_sizes and not bls and args.log2n == 20:
@@ -556,6 +600,33 @@ def main():
                                          "core_clock_ghz": sx.stage_ms().get("accumulate_core_clock_ghz")}
             sx.set_option("window_bits", args.window_bits)
             sx.set_option("profile", 1)
+    if world > 1 and not share and not rehearse and not bls and not args.no_host_buffers:
+        # compute_msm(Buffer, Buffer) on all N GPUs from ONE process: rank 0 opens an n_dev = N context (te_msm_run: point
+        # slices, one upload thread and PCIe link per device) while the other ranks wait -- the reference's boundary (host buffers,
+        # upload inside the call: cuzk/gpu.ts:33-46) on N devices.  PCIe-inclusive: reported, never `value`.
+        sync()
+        if rank == 0 and torch.cuda.device_count() >= world and cpu_group is not None:
+            try:
+                with pkg.MsmContext((dev,)) as one:
+                    one.set_option("signed_digits", 1 if args.digits == "signed" else 0)
+                    one.run(pts, sc)
+                    hb1, r1 = host_buffer_ms(one, pts, sc, reps=5)
+                with pkg.MsmContext(tuple(range(world))) as mc:
+                    mc.set_option("signed_digits", 1 if args.digits == "signed" else 0)
+                    mc.run(pts, sc)                               # buffers, staging areas, the per-device host threads
+                    hb, r_host = host_buffer_ms(mc, pts, sc, reps=7)
+                    cb, Wb = mc.plan((n + world - 1) // world)
+                out["host_buffers_ms"] = hb
+                out["pcie_inclusive_ms_host_buffers"] = hb
+                out["host_buffers_ms_one_device"] = hb1
+                out["host_buffers_path"] = ("te_msm_run on ONE n_dev = %d context in rank 0's process: %d point slices of %d points, %d-bit windows, "
+                                            "one host thread + PCIe link per device, rows summed in the host tail" % (world, world, (n + world - 1) // world, cb))
+                out["host_buffers_parity"] = "identical to the window-sharded result" if (r_host == result and r1 == result) else "MISMATCH"
+            except pkg.MsmError as e:
+                out["host_buffers_error"] = str(e)
+        if cpu_group is not None:
+            dist.barrier(group=cpu_group)                         # ranks 1.. wait here, on the host
+        sync()
     exp = None
     if rank == 0 and world == 1 and not sharded and not args.no_cpu_baseline:
         t0 = time.perf_counter()
@@ -567,8 +638,19 @@ def main():
             exp = oracle.msm(pts, sc, c=16 if n >= 65536 else 4, bpr_mode=1, threads=threads)
         cpu_s = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "MSM/s", "cores": threads, "kind": "port",
+                               "host_cpu_count": os.cpu_count(),
                                "sample": "1 full MSM at n=2^%d (C restatement of the reference pipeline, oracle/%s), %.1f s"
                                          % (args.log2n, "bls377_oracle.c; parity unpinned by the reference" if bls else "te_oracle.c", cpu_s)}
+        if not bls and args.log2n >= 18:
+            # the same restatement on ONE core ("also on 1 core"), on a bounded sample: the first 2^18 points of the
+            # workload (a whole 2^20 MSM is ~15 s of one core); the per-window bucket reduction (2 x 2^15 additions against
+            # 2^18) is then counted 2^(log2n - 18) times when scaled to n: a slight under-estimate of the one-core rate
+            m1 = 1 << 18
+            t0 = time.perf_counter()
+            oracle.msm(pts[:64 * m1], sc[:32 * m1], c=16, bpr_mode=1, threads=1)
+            one_s = time.perf_counter() - t0
+            out["cpu_baseline"]["one_core"] = {"value": 1.0 / (one_s * (n / m1)), "unit": "MSM/s", "cores": 1,
+                                               "sample": "first 2^18 points of the workload, 1 thread: %.2f s; x%d to n=2^%d" % (one_s, n // m1, args.log2n)}
         out["parity"] = "bit-exact vs oracle" if exp == result else "MISMATCH vs oracle"
         if exp != result:
             print(json.dumps(out))
@@ -576,7 +658,7 @@ def main():
     if "parity" not in out and not sharded:
         out["parity"] = "not checked (--no-cpu-baseline)"
     default_run = (rank == 0 and world == 1 and not sharded and not bls and args.log2n == 20 and args.digits == "signed"
-                   and args.scalars == "uniform" and args.points == "chain" and pipelined)
+                   and args.scalars == "uniform" and args.points == "random" and pipelined)
     if default_run and not args.no_configs and not args.no_cpu_baseline:
         # BASELINE configs 2 and 5 in the driver's one line: short passes, each checked against its oracle
         ctx.close()
@@ -591,6 +673,26 @@ def main():
         out["configs"]["bls12_377"] = cb
         if not ok:
             bad.append("bls12_377")
+        # harness mode (H): the UI's random mode replicates ONE point n times (ui/AllBenchmarks.tsx:105-112), same scalars
+        ph, _ = pkg.synth_inputs(0x5EED0000 + 20, n, fixed_point="fixed", scalars=False)
+        chh, ok = side_config(pkg, dev, "harness_fixed_point", "te", "signed", 20, depth, threads, 40, inputs=(ph, sc),
+                              workload_note=", harness mode: one fixed point replicated")
+        out["configs"]["harness_fixed_point"] = chh
+        if not ok:
+            bad.append("harness_fixed_point")
+        # set (R) against the arithmetic progression the earlier rounds timed: the same kernels on equally spread field elements
+        pc, _ = pkg.synth_inputs(0x5EED0000 + 20, n, fixed_point="chain", scalars=False)
+        dpc = torch.frombuffer(bytearray(pc), dtype=torch.uint8).cuda()
+        torch.cuda.synchronize()
+        with pkg.MsmContext((dev,)) as cx:
+            cx.set_option("window_bits", args.window_bits)
+            for t in [cx.submit_device(dpc.data_ptr(), d_sc.data_ptr(), n) for _ in range(depth)]:
+                cx.collect(t)
+            elc, _ = pipelined_pass(cx, dpc.data_ptr(), d_sc.data_ptr(), n, 40, depth)
+            elr, _ = pipelined_pass(cx, d_pts.data_ptr(), d_sc.data_ptr(), n, 40, depth)
+        out["points_chain_vs_random"] = {"chain_ms_per_step": elc * 1e3 / 40, "random_ms_per_step": elr * 1e3 / 40,
+                                         "note": "40 steps each on one fresh context, back to back: the arithmetic-progression points of rounds 1-3 and set (R) time the same"}
+        del dpc
         if bad:
             print(json.dumps(out))
             raise SystemExit("GPU result differs from the oracle in configs: %s" % bad)

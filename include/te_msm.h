@@ -227,8 +227,13 @@ int te_msm_finalize_sum_curve(int curve, const uint8_t* const* row_sets, int set
 
 /* ---- harness inputs (host code, no device needed).  The reference's harness generates its own random inputs when the
  * ZPrize files are not used (ui/AllBenchmarks.tsx:99-131, reference/webgpu/utils.ts:81-88,118-124): seeded scalars =
- * 256 random bits reduced mod p; points = n distinct subgroup points (a + i*b)*G, or, with fixed_point != 0, the harness's
- * one fixed point replicated n times.  Either output pointer may be NULL. */
+ * 256 random bits reduced mod p; points, by `fixed_point`: 0 = n distinct subgroup points (a + i*b)*G (an arithmetic
+ * progression: one addition per point), 1 = the harness's one fixed point replicated n times (ui/AllBenchmarks.tsx:105-112),
+ * 2 = n independent points a_i * G with seeded-random a_i ("random points", SURVEY.md 8d set (R); fixed-base table, all host
+ * threads: about a second per 2^20).  Either output pointer may be NULL. */
+#define TE_MSM_SYNTH_CHAIN  0
+#define TE_MSM_SYNTH_FIXED  1
+#define TE_MSM_SYNTH_RANDOM 2
 int te_msm_synth_inputs(uint64_t seed, uint64_t n, int fixed_point, uint8_t* points_xy_le, uint8_t* scalars_le);
 /* The same scheme for BLS12-377 G1: 96-byte points (a + i*b)*G, 48-byte scalar records (values below r). */
 int te_msm_synth_inputs_bls12_377(uint64_t seed, uint64_t n, uint8_t* points_xy_le, uint8_t* scalars_le);

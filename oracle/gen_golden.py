@@ -38,11 +38,13 @@ CASES = [  # (name, seed, n, mode)
     # --only <names>, which keeps every record already in the fixture)
     ("chain_n1048576", 0x5EED0100000, 1 << 20, "chain"),
     ("fixed_n262144", 0x5EED0040001, 1 << 18, "fixed"),
+    ("random_n1000", 0x5EED03E9, 1000, "random"),              # SURVEY 8d set (R): independent seeded-random a_i * G
+    ("random_n65536", 0x5EED0010002, 65536, "random"),
 ]
 
 
 def make_inputs(seed: int, n: int, mode: str):
-    pts = oracle.gen_points_fixed(n) if mode == "fixed" else oracle.gen_points(seed, n)
+    pts = oracle.gen_points_fixed(n) if mode == "fixed" else oracle.gen_points_random(seed, n) if mode == "random" else oracle.gen_points(seed, n)
     sc = oracle.gen_scalars(seed, n)
     if mode == "edge":
         sc = model.scalars_to_bytes(edge_scalars(seed, n))

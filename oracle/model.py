@@ -177,6 +177,16 @@ def gen_points(seed: int, n: int):
 
 
 # ------------------------------------------------------------------ the reference pipeline, tiny sizes
+def gen_points_random(seed: int, n: int):
+    """Mirror of ora_gen_points_random: P_i = a_i * G, a_i from the splitmix64 stream of seed ^ 0x5A5A5A5AA5A5A5A5."""
+    s = (seed ^ 0x5A5A5A5AA5A5A5A5) & MASK64
+    out = []
+    for _ in range(n):
+        s, a = _rand_mod_p(s)
+        out.append(scalar_mul(a, (GX, GY)))
+    return out
+
+
 def to_words_le(val: int, num_words: int, word_size: int):
     """utils.ts:440-465"""
     mask = (1 << word_size) - 1

@@ -43,6 +43,8 @@ def lib() -> ctypes.CDLL:
         L.ora_set_generator.argtypes = [u8p]
         L.ora_gen_points.argtypes = [u64, u64, u8p]
         L.ora_gen_points.restype = c_int
+        L.ora_gen_points_random.argtypes = [u64, u64, u8p, c_int]
+        L.ora_gen_points_random.restype = c_int
         L.ora_decompose_scalars_signed.argtypes = [u8p, u64, c_int, c_int, ctypes.c_void_p]
         L.ora_decompose_scalars_signed.restype = c_int
         L.ora_transpose.argtypes = [ctypes.c_void_p, u64, ctypes.c_uint32, c_int, ctypes.c_void_p, ctypes.c_void_p]
@@ -116,6 +118,15 @@ def gen_points(seed: int, n: int) -> bytes:
     rc = lib().ora_gen_points(seed, n, out)
     if rc:
         raise RuntimeError(f"ora_gen_points failed: {rc}")
+    return out.raw[: 64 * n]
+
+
+def gen_points_random(seed: int, n: int, threads: int = 8) -> bytes:
+    """SURVEY 8d set (R): n independent points a_i * G, a_i seeded-random (plain double-and-add per point: ~0.1 ms each)."""
+    out = ctypes.create_string_buffer(64 * n) if n else ctypes.create_string_buffer(1)
+    rc = lib().ora_gen_points_random(seed, n, out, threads)
+    if rc:
+        raise RuntimeError(f"ora_gen_points_random failed: {rc}")
     return out.raw[: 64 * n]
 
 

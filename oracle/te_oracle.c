@@ -466,3 +466,41 @@ int ora_gen_points(uint64_t seed, uint64_t n, uint8_t *points_xy_le) {
   free(pts); free(pre);
   return 0;
 }
+
+/* Set (R) of SURVEY.md 8d: n INDEPENDENT points P_i = a_i * G, a_i = the i-th value of the splitmix64 stream of
+ * (seed ^ 0x5A5A5A5AA5A5A5A5), 256 bits reduced mod p.  Restated here with the plain double-and-add of pt_mul_raw (the
+ * product generates the same points with a fixed-base table: tests compare the two); pthreads over ranges of i. */
+typedef struct { const uint64_t (*ks)[4]; pt *pts; const pt *g; uint64_t lo, hi; } rnd_job;
+static void *rnd_worker(void *arg) {
+  rnd_job *j = (rnd_job *)arg;
+  for (uint64_t i = j->lo; i < j->hi; i++) pt_mul_raw(&j->pts[i], j->g, j->ks[i]);
+  return NULL;
+}
+int ora_gen_points_random(uint64_t seed, uint64_t n, uint8_t *points_xy_le, int threads) {
+  init_once();
+  if (!g_have_gen) return -2;
+  if (n == 0) return 0;
+  if (threads < 1) threads = 1;
+  if (threads > 64) threads = 64;
+  uint64_t (*ks)[4] = (uint64_t (*)[4])malloc(sizeof(uint64_t[4]) * n);
+  pt *pts = (pt *)malloc(sizeof(pt) * n);
+  uint64_t s = seed ^ 0x5A5A5A5AA5A5A5A5ULL;
+  for (uint64_t i = 0; i < n; i++) rand_mod_p(ks[i], &s);
+  pt g; pt_from_affine_raw(&g, g_gx, g_gy);
+  rnd_job jobs[64]; pthread_t th[64];
+  const uint64_t per = (n + (uint64_t)threads - 1) / (uint64_t)threads;
+  for (int t = 0; t < threads; t++) {
+    uint64_t lo = per * (uint64_t)t; if (lo > n) lo = n;
+    uint64_t hi = lo + per; if (hi > n) hi = n;
+    jobs[t].ks = (const uint64_t (*)[4])ks; jobs[t].pts = pts; jobs[t].g = &g; jobs[t].lo = lo; jobs[t].hi = hi;
+    if (threads == 1) rnd_worker(&jobs[t]); else pthread_create(&th[t], NULL, rnd_worker, &jobs[t]);
+  }
+  if (threads > 1) for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+  for (uint64_t i = 0; i < n; i++) {
+    uint64_t x[4], y[4];
+    pt_to_affine_raw(x, y, &pts[i]);
+    raw_to_le(points_xy_le + 64 * i, x); raw_to_le(points_xy_le + 64 * i + 32, y);
+  }
+  free(ks); free(pts);
+  return 0;
+}

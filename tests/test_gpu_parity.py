@@ -463,9 +463,11 @@ def test_multi_device_host_point_shards(pkg, model, ora, wasm_golden, ids):
         n = 100003
         pts, sc = ora.gen_points(56, n), ora.gen_scalars(56, n)
         bad = bytearray(sc); bad[32 * (n - 3):32 * (n - 3) + 32] = b"\xff" * 32          # lands in the last device's slice
+        c.set_option("window_bits", 16)                                  # 16 x 16 bits: 2^256 - 1 leaves a final carry (18 x 15 would hold it)
         with pytest.raises(pkg.MsmError) as e:
             c.run(pts, bytes(bad))
         assert e.value.code == -3
+        c.set_option("window_bits", 0)
         assert c.run(pts, sc) == ora.msm(pts, sc, threads=8)              # the context is usable afterwards
         c.set_option("host_shard_min", 4096)                             # default: small inputs use fewer devices
         pts, sc = ora.gen_points(57, 5000), ora.gen_scalars(57, 5000)

@@ -5,6 +5,7 @@ REPO="$(cd "$(dirname "$0")/.." && pwd)"; cd "$REPO"
 F=gpurun_out/final; rm -rf $F; mkdir -p $F
 export TE_COMMIT=${TE_COMMIT:-unknown}
 bash tools/profile_bench.sh > $F/profile_bench.txt 2>&1 || { echo "profile_bench failed"; tail -5 $F/profile_bench.txt; exit 1; }
+bash tools/profile_configs.sh > $F/profile_configs.txt 2>&1 || { echo "profile_configs failed"; tail -5 $F/profile_configs.txt; exit 1; }
 cp gpurun_out/prof/summary.txt $F/rocprofv3_summary.txt; cp gpurun_out/prof/traffic.json $F/pmc_traffic.json
 cp $(find gpurun_out/prof/trace -name "*kernel_stats.csv" | head -1) $F/rocprofv3_kernel_stats.csv
 rm -rf gpurun_out/prof_pipe; cp -r gpurun_out/prof/trace gpurun_out/prof_pipe

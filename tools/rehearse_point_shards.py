@@ -26,8 +26,9 @@ with pkg.MsmContext((0,)) as c:
     whole = med
     for D in (2, 4, 8):
         m = n // D
-        c.run(pts[:64 * m], sc[:32 * m])
-        _, best, med = timed(lambda: c.run(pts[:64 * m], sc[:32 * m]))
+        p1, s1 = pts[:64 * m], sc[:32 * m]                 # sliced once, outside the timed call
+        c.run(p1, s1)
+        _, best, med = timed(lambda: c.run(p1, s1))
         cb, W = c.plan(m)
         print("  one device's share at D = %d: %7d points, %d-bit windows: best %.3f ms, median %.3f ms  -> %.2fx the whole call (before the D-set host tail)"
               % (D, m, cb, best, med, whole / med))

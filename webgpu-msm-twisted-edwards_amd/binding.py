@@ -329,15 +329,18 @@ def finalize_sum(row_sets, window_bits: int, num_windows: int, bucket_bits: int 
     return out.raw[:96 if curve == CURVE_BLS12_377_G1 else 64]
 
 
-def synth_inputs(seed: int, n: int, fixed_point: bool = False, points: bool = True, scalars: bool = True, curve: int = CURVE_TE_BLS12):
+def synth_inputs(seed: int, n: int, fixed_point=False, points: bool = True, scalars: bool = True, curve: int = CURVE_TE_BLS12):
     """Seeded harness inputs in compute_msm's wire format (te_msm_synth_inputs): (points 64n bytes, scalars 32n bytes)
-    -- 96n / 48n bytes for curve = CURVE_BLS12_377_G1; a part not asked for is None.  Host code only."""
+    -- 96n / 48n bytes for curve = CURVE_BLS12_377_G1; a part not asked for is None.  Host code only.
+    fixed_point: False / "chain" = (a + i*b)*G, True / "fixed" = the harness's one point replicated, "random" = independent
+    seeded-random a_i*G (SURVEY 8d set (R))."""
+    fixed_point = {"chain": 0, "fixed": 1, "random": 2}.get(fixed_point, fixed_point)
     bls = curve == CURVE_BLS12_377_G1
     pb = ctypes.create_string_buffer((96 if bls else 64) * n) if points else None
     sb = ctypes.create_string_buffer((48 if bls else 32) * n) if scalars else None
     pp = ctypes.cast(pb, ctypes.c_void_p) if pb is not None else None
     sp = ctypes.cast(sb, ctypes.c_void_p) if sb is not None else None
-    rc = _lib().te_msm_synth_inputs_bls12_377(seed, n, pp, sp) if bls else _lib().te_msm_synth_inputs(seed, n, 1 if fixed_point else 0, pp, sp)
+    rc = _lib().te_msm_synth_inputs_bls12_377(seed, n, pp, sp) if bls else _lib().te_msm_synth_inputs(seed, n, int(fixed_point), pp, sp)
     if rc:
         raise MsmError(rc, "te_msm_synth_inputs failed")
     return (pb.raw if pb is not None else None), (sb.raw if sb is not None else None)

@@ -7,6 +7,7 @@
 // harness's replicated point is not.
 #pragma once
 #include <vector>
+#include <thread>
 #include "host_tail.hpp"
 #include "host_tail377.hpp"
 
@@ -54,6 +55,61 @@ static inline void synth_points(uint64_t seed, uint64_t n, uint8_t* out) {
   std::vector<Pt> pts(n);
   pts[0] = pmul(g, a, k2d);
   for (uint64_t i = 1; i < n; i++) pts[i] = padd(pts[i - 1], q, k2d);
+  std::vector<Fe> pre(n);
+  Fe acc = ONE_M;
+  for (uint64_t i = 0; i < n; i++) { pre[i] = acc; acc = mul(acc, pts[i].z); }
+  Fe iv = inv(acc);
+  for (uint64_t i = n; i-- > 0;) {
+    const Fe zi = mul(iv, pre[i]);
+    iv = mul(iv, pts[i].z);
+    const Fe x = from_mont(mul(pts[i].x, zi)), y = from_mont(mul(pts[i].y, zi));
+    memcpy(out + 64 * i, x.l, 32); memcpy(out + 64 * i + 32, y.l, 32);
+  }
+}
+
+// Set (R) of SURVEY.md 8d: P_i = a_i * G with a_i seeded-random (the splitmix64 stream of seed ^ 0x5A5A..., 256 bits reduced
+// mod p, as the scalars are) -- n INDEPENDENT subgroup points, what "random points" means for a benchmark of a general MSM;
+// the chain above is an arithmetic progression.  Fixed-base method: a table of v * 2^(8 j) * G (j < 32, v < 256) built once,
+// then 31 additions per point; points are independent, so they are spread over the host's threads (2^20 points: ~7 s of one
+// core).  The a_i come from ONE sequential stream (thread t re-derives its share by skipping), so the output does not depend
+// on the thread count.
+static inline void synth_points_random(uint64_t seed, uint64_t n, uint8_t* out, unsigned threads = 0) {
+  if (n == 0) return;
+  const Fe gx = {{0x137e82844bbe49c5ULL, 0xe7608833a9dd83f3ULL, 0x16b294b80d905006ULL, 0x036824eb02475007ULL}};
+  const Fe gy = {{0xd50dce7d8bcda9d4ULL, 0x7f6758f4c08bc255ULL, 0x37c0a81e810abce5ULL, 0x11b1d8d5c1d897a3ULL}};
+  const Fe d2 = {{2 * 3021, 0, 0, 0}};
+  const Fe k2d = to_mont(d2);
+  Pt g; g.x = to_mont(gx); g.y = to_mont(gy); g.z = ONE_M; g.t = mul(g.x, g.y);
+  std::vector<Pt> table(32 * 256);
+  {
+    Pt base = g;                                    // 2^(8 j) * G
+    for (int j = 0; j < 32; j++) {
+      table[(size_t)j * 256] = identity();
+      for (int v = 1; v < 256; v++) table[(size_t)j * 256 + v] = padd(table[(size_t)j * 256 + v - 1], base, k2d);
+      base = padd(table[(size_t)j * 256 + 255], base, k2d);
+    }
+  }
+  std::vector<Fe> ks(n);
+  { uint64_t s = seed ^ 0x5A5A5A5AA5A5A5A5ULL; for (uint64_t i = 0; i < n; i++) ks[i] = rand_mod_p(s); }
+  std::vector<Pt> pts(n);
+  if (!threads) { threads = std::thread::hardware_concurrency(); if (threads > 32) threads = 32; }
+  if (threads < 1 || n < 4096) threads = 1;
+  auto work = [&](uint64_t lo, uint64_t hi) {
+    for (uint64_t i = lo; i < hi; i++) {
+      const uint8_t* kb = reinterpret_cast<const uint8_t*>(ks[i].l);
+      Pt acc = table[kb[0]];
+      for (int j = 1; j < 32; j++) acc = padd(acc, table[(size_t)j * 256 + kb[j]], k2d);
+      pts[i] = acc;
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    const uint64_t per = (n + threads - 1) / threads;
+    for (unsigned t = 1; t < threads; t++) { const uint64_t lo = std::min<uint64_t>(n, per * t), hi = std::min<uint64_t>(n, lo + per); if (hi > lo) th.emplace_back(work, lo, hi); }
+    work(0, std::min<uint64_t>(n, per));
+    for (auto& t : th) t.join();
+  }
+  // one batched inversion of the z coordinates (a_i = 0 mod l would give the neutral element, z != 0 all the same)
   std::vector<Fe> pre(n);
   Fe acc = ONE_M;
   for (uint64_t i = 0; i < n; i++) { pre[i] = acc; acc = mul(acc, pts[i].z); }

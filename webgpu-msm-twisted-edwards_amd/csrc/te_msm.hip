@@ -1489,7 +1489,12 @@ int te_msm_stage_ms(te_ctx* ctx, float* ms, const char** names, int max_stages) 
 int te_msm_synth_inputs(uint64_t seed, uint64_t n, int fixed_point, uint8_t* points_xy_le, uint8_t* scalars_le) {
   if (n >= (1ull << 31) || !te_host::tail_selftest()) return TE_MSM_EINVAL;
   if (scalars_le) te_host::synth_scalars(seed, n, scalars_le);
-  if (points_xy_le) { if (fixed_point) te_host::synth_points_fixed(n, points_xy_le); else te_host::synth_points(seed, n, points_xy_le); }
+  if (points_xy_le) {
+    if (fixed_point == 1) te_host::synth_points_fixed(n, points_xy_le);
+    else if (fixed_point == 2) te_host::synth_points_random(seed, n, points_xy_le);
+    else if (fixed_point == 0) te_host::synth_points(seed, n, points_xy_le);
+    else return TE_MSM_EINVAL;
+  }
   return 0;
 }
 
