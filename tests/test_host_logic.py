@@ -194,6 +194,23 @@ def test_point_shards_merge(fpcheck, pkg, ora):
         pkg.finalize_sum([], c, W)
 
 
+def test_synth_random_points_match_the_oracle(pkg, model, ora):
+    """SURVEY 8d set (R): the engine's harness generator (fixed-base table, threads) and the oracle's independent restatement
+    (plain double-and-add) produce the same n independent points a_i * G; the pure-Python model agrees on the first few; the
+    output does not depend on the thread split (n above and below the threading threshold); scalars are unchanged"""
+    for n in (1, 7, 5000):
+        p, s = pkg.synth_inputs(0xABCDE, n, "random")
+        assert p == ora.gen_points_random(0xABCDE, n) and s == ora.gen_scalars(0xABCDE, n)
+    p5000 = pkg.synth_inputs(0xABCDE, 5000, "random", scalars=False)[0]
+    assert pkg.synth_inputs(0xABCDE, 7, "random", scalars=False)[0] == p5000[:7 * 64]
+    assert model.points_to_bytes(model.gen_points_random(0xABCDE, 3)) == p5000[:3 * 64]
+    assert len({p5000[64 * i:64 * i + 64] for i in range(5000)}) == 5000
+    assert all(ora.on_curve(p5000[64 * i:64 * i + 64]) for i in range(0, 5000, 97))
+    assert pkg.synth_inputs(3, 10, "chain")[0] == ora.gen_points(3, 10) and pkg.synth_inputs(3, 10, True)[0] == ora.gen_points_fixed(10)
+    with pytest.raises(pkg.MsmError):
+        pkg.synth_inputs(3, 10, 7)
+
+
 def test_devices_from_env(pkg, monkeypatch):
     monkeypatch.delenv("TE_MSM_DEVICES", raising=False)
     assert pkg.devices_from_env() == (0,)
