@@ -698,6 +698,7 @@ def test_pipelined_host_submit(pkg, model, ora):
         bad = bytearray(sc); bad[32 * (n - 2):32 * (n - 2) + 32] = b"\xff" * 32
         dp, ds = _dev(pts), _dev(sc)
         torch.cuda.synchronize()
+        c.set_option("window_bits", 16)                                        # 16 x 16 bits: 2^256 - 1 leaves a final carry
         for chunks in (0, 1, 3):
             c.set_option("host_chunks", chunks)
             t1, t2, t3, t4 = c.submit(pts, sc), c.submit(pts, bytes(bad)), c.submit_device(dp.data_ptr(), ds.data_ptr(), n), c.submit(pts, sc)
@@ -708,6 +709,7 @@ def test_pipelined_host_submit(pkg, model, ora):
             assert e.value.code == -3
             assert c.collect(t3) == want and c.collect(t1) == want
         c.set_option("host_chunks", 0)
+        c.set_option("window_bits", 0)
         # capacity: WORKSETS tickets, then ESTATE until one is collected
         ts = [c.submit(pts, sc) for _ in range(pkg.WORKSETS)]
         with pytest.raises(pkg.MsmError):
