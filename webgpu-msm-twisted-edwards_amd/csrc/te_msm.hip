@@ -79,19 +79,22 @@ struct workset_t {
   uint32_t *d_counts1 = nullptr, *d_part_start = nullptr, *d_part_count = nullptr, *d_part_idx = nullptr, *d_seg_part_base = nullptr;
   uint32_t *d_bucket_count = nullptr, *d_bucket_start = nullptr, *d_bucket_cursor = nullptr, *d_sorted = nullptr;
   uint32_t *d_seg_base = nullptr, *d_seg_bucket = nullptr, *d_seg_lenv = nullptr, *d_order = nullptr;
-  uint32_t *d_split_list = nullptr, *d_large_list = nullptr, *d_chunk_list = nullptr;
+  uint32_t *d_split_list = nullptr, *d_chunk_list = nullptr;
   uint8_t *d_seg_out = nullptr, *d_buckets = nullptr, *d_red[4] = {};   // accumulators of the plan's curve (te::ete_t<N>); d_red: ping/pong of the two fold chains
   // ONE zeroed block per MSM (a single memset), words: [0] final-carry flag, [1] number of segments, [2..4] split / giant
   // bucket counters, [Z_ROWS..) the partial rows of the MSM (so that flag and rows come back in ONE device-to-host copy),
   // [Z_HIST..) segment-length histogram (TE_HIST_COPIES copies), [Z_CURSOR..) reservation cursors of the schedule, [Z_END..) the level-1 histogram
-  // counts1[window][chunk][partition], then bucket_count[window][bucket].  d_err .. d_bucket_count point into d_zero.
+  // counts1[window][chunk][partition], then bucket_count[window][bucket], then part_ticket[window][partition].  d_err .. d_part_ticket point into d_zero.
   uint32_t *d_zero = nullptr; size_t zero_words = 0;
   size_t zero_clean_words = 0;        // words of d_zero known to be zero on the set's stream: the block is cleared AFTER an MSM's read-back
                                       // (finish_sequence), so that the next MSM on the set starts with its first kernel, not a fill
   uint32_t *d_err = nullptr, *d_num_seg = nullptr, *d_size_hist = nullptr, *d_size_cursor = nullptr;
+  uint32_t* d_part_ticket = nullptr;  // [window][partition]: level-2 pieces counted so far (k_l2_count_plan), behind bucket_count in the zeroed block
   uint8_t* d_partials = nullptr;      // = d_zero + Z_ROWS: TE_MAX_WINDOWS rows
   uint32_t* h_err = nullptr;          // pinned: mirror of d_zero[0 .. Z_ROWS + rows)
   uint8_t* h_partials = nullptr;      // = h_err + Z_ROWS
+  uint32_t* h_err_dev = nullptr;      // the device-visible address of h_err: k_reduce_tail writes flag words and rows there itself
+  bool rows_on_host = false;          // the last launch sequence did so: fetch_rows has nothing to copy
   hipEvent_t ev_done = nullptr;       // the set is free again (everything of its last MSM, the clearing of the zeroed block included)
   hipEvent_t ev_result = nullptr;     // flag + rows of its last MSM are in host memory (recorded before the clearing: what a caller waits for)
   hipEvent_t ev[ST_COUNT + 1] = {};
@@ -268,11 +271,11 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, workset_t& ws, uint64_t n, const plan_
   if ((rc = ensure(ctx, ws, ws.d_sorted, ws.cap[2], nd))) return rc;
   {
     const size_t c1 = (size_t)p.nw * p.CH * p.P;
-    ws.zero_words = Z_END + c1 + wb;
+    ws.zero_words = Z_END + c1 + wb + (size_t)p.nw * p.P;
     { const uint32_t* before = ws.d_zero; if ((rc = ensure(ctx, ws, ws.d_zero, ws.cap[3], ws.zero_words))) return rc; if (ws.d_zero != before) ws.zero_clean_words = 0; }
     ws.d_err = ws.d_zero; ws.d_num_seg = ws.d_zero + 1; ws.d_size_hist = ws.d_zero + Z_HIST; ws.d_size_cursor = ws.d_zero + Z_CURSOR;
     ws.d_partials = reinterpret_cast<uint8_t*>(ws.d_zero + Z_ROWS);
-    ws.d_counts1 = ws.d_zero + Z_END; ws.d_bucket_count = ws.d_counts1 + c1;
+    ws.d_counts1 = ws.d_zero + Z_END; ws.d_bucket_count = ws.d_counts1 + c1; ws.d_part_ticket = ws.d_bucket_count + wb;
   }
   if ((rc = ensure(ctx, ws, ws.d_bucket_start, ws.cap[5], wb))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_bucket_cursor, ws.cap[16], wb))) return rc;
@@ -284,7 +287,6 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, workset_t& ws, uint64_t n, const plan_
   if ((rc = ensure(ctx, ws, ws.d_seg_out, ws.cap[22], smax * ab))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_seg_base, ws.cap[23], wb + 1))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_split_list, ws.cap[24], wb + 1))) return rc;
-  if ((rc = ensure(ctx, ws, ws.d_large_list, ws.cap[25], wb + 1))) return rc;
   // a giant bucket contributes one chunk per 1024 parts: at most one per bucket plus one per 1024 segments
   if ((rc = ensure(ctx, ws, ws.d_chunk_list, ws.cap[26], 2 * (wb + smax / 1024 + 2)))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_part_start, ws.cap[6], (size_t)p.nw * p.P))) return rc;
@@ -315,6 +317,13 @@ struct msm_launch {
   hipStream_t stream;
   bool own_rows = false;          // rows go to ws.d_partials: the caller fetches flag + rows with one copy
   bool onto = false;              // a later piece of a host-buffer MSM: keep the final-carry flag, add onto the buckets
+  bool host_rows = false;         // own rows go straight to the work set's pinned host block, written by k_reduce_tail (no copy at all)
+  // Own rows of a context that computes ALL windows can be written to host memory by the tail kernel (every row slot is
+  // rewritten by every MSM).  Not with window shards (rows of foreign windows must read as zero: they come from the cleared
+  // device block), not with captured graphs (fixed pointers), not with "prezero" = 0 (stage verifiers read the device rows).
+  static bool rows_to_host(const te_ctx* ctx, const gpu_t& d, const plan_t& p, bool own_rows) {
+    return own_rows && p.nw > 0 && p.batch == 1 && d.w_first == 0 && d.w_step == 1 && ctx->opt_prezero && !ctx->opt_graph;
+  }
   uint32_t n32() const { return (uint32_t)n; }
   uint32_t total() const { return (uint32_t)p.nw * p.B; }
   uint32_t smax() const { return total() + (uint32_t)((uint64_t)p.nw * (n / p.seg_len)); }
@@ -421,15 +430,17 @@ struct msm_launch {
       }
     }
     mark(ST_BSORT);
-    const uint32_t total = this->total();
     if (p.nw > 0) {
       const uint32_t nslices = (p.nst + p.slice - 1u) / p.slice;
-      hipLaunchKernelGGL(te::k_l2_count, dim3(nslices, p.nw), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx, ws.d_part_start,
-                         ws.d_part_count, ws.d_bucket_count, sg);
-      // d_num_seg[1..3] = split / giant bucket counters, zeroed with the rest
-      hipLaunchKernelGGL(te::k_seg_plan, dim3(p.P, p.nw), dim3(p.S), 0, stream, ws.d_bucket_count, ws.d_part_start, ws.d_part_count, ws.d_seg_part_base,
-                         ws.d_bucket_start, ws.d_bucket_cursor, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv, ws.d_size_hist, ws.d_split_list,
-                         ws.d_num_seg + 1, ws.d_large_list, ws.d_chunk_list, p.B, p.S, p.seg_len, cap_w, total, chunk_cap());
+      // level-2 count + the segment plan (by the block that completes a partition) in one launch; d_num_seg[1..3] = split / giant
+      // bucket counters, zeroed with the rest
+      te::plan_args pa;
+      pa.bucket_count = ws.d_bucket_count; pa.part_start = ws.d_part_start; pa.part_count = ws.d_part_count; pa.seg_part_base = ws.d_seg_part_base;
+      pa.bucket_start = ws.d_bucket_start; pa.bucket_cursor = ws.d_bucket_cursor; pa.seg_base = ws.d_seg_base; pa.seg_bucket = ws.d_seg_bucket;
+      pa.seg_lenv = ws.d_seg_lenv; pa.size_hist = ws.d_size_hist; pa.split_list = ws.d_split_list; pa.split_count = ws.d_num_seg + 1;
+      pa.chunk_list = ws.d_chunk_list; pa.part_ticket = ws.d_part_ticket; pa.seg_len = p.seg_len; pa.cap_w = cap_w; pa.chunk_cap = chunk_cap();
+      hipLaunchKernelGGL(te::k_l2_count_plan, dim3(nslices, p.nw), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx, ws.d_part_start,
+                         ws.d_part_count, ws.d_bucket_count, sg, pa);
       // level-2 placement + the segment schedule (counts the valid segments, d_num_seg[0]; with "sort_buckets" = 0 the
       // schedule is simply not used) in one launch
       te::order_args oa;
@@ -461,15 +472,13 @@ struct msm_launch {
   int accumulate() { return bls() ? accumulate_t<14>() : accumulate_t<9>(); }
 
   // sums of the buckets that were accumulated in several parts: buckets cut into 2..16 parts (quads) and the 1024-part runs
-  // of giant buckets (blocks) in one launch, then the giant buckets' second stage (empty lists for well-spread digits: a
-  // near-empty launch)
+  // of giant buckets (blocks; the block that finishes a bucket's last run adds the runs up) in one launch
   template <int N> int combine_t() {
     if (p.nw <= 0) return 0;
     using E = te::ete_t<N>;
     hipLaunchKernelGGL(te::k_seg_combine_all<N>, dim3(256 + 512), dim3(256), 0, stream, ws.d_split_list, ws.d_num_seg + 1, ws.d_chunk_list,
-                       ws.d_bucket_count, ws.d_seg_base, reinterpret_cast<E*>(ws.d_seg_out), reinterpret_cast<E*>(ws.d_buckets), p.seg_len, chunk_cap(), 256u);
-    hipLaunchKernelGGL(te::k_seg_combine_large2<N>, dim3(256), dim3(256), 0, stream, ws.d_large_list, ws.d_num_seg + 1, ws.d_bucket_count, ws.d_seg_base,
-                       reinterpret_cast<const E*>(ws.d_seg_out), reinterpret_cast<E*>(ws.d_buckets), p.seg_len, total());
+                       ws.d_bucket_count, ws.d_seg_base, reinterpret_cast<E*>(ws.d_seg_out), reinterpret_cast<E*>(ws.d_buckets), p.seg_len, chunk_cap(), 256u,
+                       ws.d_bucket_start, ws.d_bucket_cursor);
     return 0;
   }
   int combine() { return bls() ? combine_t<14>() : combine_t<9>(); }
@@ -527,7 +536,10 @@ struct msm_launch {
       tp.xin = ch[0].cur; tp.yin = ch[1].cur; tp.rx = ch[0].r; tp.ry = ch[1].r;
       tp.x_per_window = ch[0].n; tp.y_per_window = ch[1].n;
       tp.w[0] = w0; tp.w[1] = w1; tp.w[2] = w2; tp.w[3] = w3;
-      tp.rows = reinterpret_cast<E*>(d_partials_out) + (size_t)d.w_first * 5; tp.row_stride = (uint32_t)d.w_step * 5u;
+      // host_rows: the rows (and the flag words in front of them) are written to the pinned host block by the kernel itself
+      uint8_t* const rows_base = host_rows ? reinterpret_cast<uint8_t*>(ws.h_err_dev + Z_ROWS) : static_cast<uint8_t*>(d_partials_out);
+      tp.flag_src = host_rows ? ws.d_zero : nullptr; tp.flag_dst = host_rows ? ws.h_err_dev : nullptr; tp.flag_words = (uint32_t)Z_ROWS;
+      tp.rows = reinterpret_cast<E*>(rows_base) + (size_t)d.w_first * 5; tp.row_stride = (uint32_t)d.w_step * 5u;
       tp.win_per_msm = (uint32_t)p.nw1; tp.msm_stride = (uint32_t)p.W * 5u;          // batch: MSM m's W rows follow MSM m-1's
       const size_t lds_bytes = (size_t)(std::max(H, L) + 16u) * sizeof(E);
       hipLaunchKernelGGL(te::k_reduce_tail<N>, dim3(4, p.nw), dim3(1024), lds_bytes, stream, tp);
@@ -700,6 +712,8 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, 
   // profile 1: two events around the dominant kernel only (what bench.py times live); 2: every stage boundary
   // (an event between two kernels costs ~4 us of idle stream time, 11 of them ~2 % of a 2^20 MSM)
   msm_launch L{ctx, d, ws, p, d_points, d_scalars, n, d_partials_out, ctx->opt_profile, stream, own_rows};
+  L.host_rows = msm_launch::rows_to_host(ctx, d, p, own_rows);
+  ws.rows_on_host = L.host_rows;
   if (ctx->opt_graph && ctx->opt_profile < 2 && !upload_points && batch == 1) {
     // the graphs hold pointers and geometry: re-captured when any of them changes (including a buffer reallocation);
     // the captured front always clears the zeroed block itself
@@ -755,7 +769,9 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, 
 // one device-to-host copy: final-carry flag + the W rows of the work set's own row buffer (enqueue_partial with nullptr);
 // ends the launch sequence
 int fetch_rows(te_ctx* ctx, workset_t& ws, hipStream_t stream) {
-  HIP_TRY(ctx, hipMemcpyAsync(ws.h_err, ws.d_zero, Z_ROWS * 4 + (size_t)ws.plan.W * sizes_of(ws.plan.curve).row, hipMemcpyDeviceToHost, stream));
+  // (nothing to copy when k_reduce_tail wrote flag words and rows to the pinned block itself)
+  if (!ws.rows_on_host)
+    HIP_TRY(ctx, hipMemcpyAsync(ws.h_err, ws.d_zero, Z_ROWS * 4 + (size_t)ws.plan.W * sizes_of(ws.plan.curve).row, hipMemcpyDeviceToHost, stream));
   return finish_sequence(ctx, ws, stream);
 }
 
@@ -808,12 +824,12 @@ void free_workset_buffers(workset_t& ws) {      // the big device buffers of a w
   void** ptrs[] = {(void**)&ws.d_recs, (void**)&ws.d_digits, (void**)&ws.d_part_keys, (void**)&ws.d_zero, (void**)&ws.d_part_start, (void**)&ws.d_part_count,
                    (void**)&ws.d_part_idx, (void**)&ws.d_seg_part_base, (void**)&ws.d_bucket_start, (void**)&ws.d_bucket_cursor, (void**)&ws.d_sorted,
                    (void**)&ws.d_seg_base, (void**)&ws.d_seg_bucket, (void**)&ws.d_seg_lenv, (void**)&ws.d_order, (void**)&ws.d_split_list,
-                   (void**)&ws.d_large_list, (void**)&ws.d_chunk_list, (void**)&ws.d_seg_out, (void**)&ws.d_buckets, (void**)&ws.d_red[0], (void**)&ws.d_red[1],
+                   (void**)&ws.d_chunk_list, (void**)&ws.d_seg_out, (void**)&ws.d_buckets, (void**)&ws.d_red[0], (void**)&ws.d_red[1],
                    (void**)&ws.d_red[2], (void**)&ws.d_red[3], &ws.d_in_points, &ws.d_in_scalars};
   for (void** q : ptrs) if (*q) { (void)hipFree(*q); *q = nullptr; }
   memset(ws.cap, 0, sizeof ws.cap); ws.cap_in_points = ws.cap_in_scalars = 0;
   ws.zero_words = ws.zero_clean_words = 0;
-  ws.d_err = ws.d_num_seg = ws.d_size_hist = ws.d_size_cursor = ws.d_counts1 = ws.d_bucket_count = nullptr; ws.d_partials = nullptr;
+  ws.d_err = ws.d_num_seg = ws.d_size_hist = ws.d_size_cursor = ws.d_counts1 = ws.d_bucket_count = ws.d_part_ticket = nullptr; ws.d_partials = nullptr;
   if (ws.g_front) { (void)hipGraphExecDestroy(ws.g_front); ws.g_front = nullptr; }
   if (ws.g_back) { (void)hipGraphExecDestroy(ws.g_back); ws.g_back = nullptr; }
   ws.generation++; ws.used = false;
@@ -933,6 +949,8 @@ int enqueue_host_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* src_
     make_plan(ctx, d, m, p, pf.c, 1, seg_all);
     if (int rc = ensure_buffers(ctx, d, ws, m, p)) return rc;              // no reallocation: only the pointers into the zeroed block move
     msm_launch L{ctx, d, ws, p, dpts + lo * sz.point_in, dscs + lo * sz.scalar_in, m, ws.d_partials, 0, ws.stream, true, !first};
+    L.host_rows = msm_launch::rows_to_host(ctx, d, p, true);
+    ws.rows_on_host = L.host_rows;
     first = false;
     if (!scalars_first) {
       HIP_TRY(ctx, hipMemcpyAsync(dscs + lo * sz.scalar_in, src_scalars + lo * sz.scalar_in, m * sz.scalar_in, hipMemcpyHostToDevice, ws.copy_stream));
@@ -1131,6 +1149,7 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
       if (er == hipSuccess) er = hipEventCreateWithFlags(&ws.ev_start, hipEventDisableTiming);
       if (er == hipSuccess) er = hipHostMalloc((void**)&ws.h_err, Z_ROWS * 4 + (size_t)TE_MAX_WINDOWS * TE_MAX_ROW_BYTES, hipHostMallocDefault);
       if (er == hipSuccess) ws.h_partials = reinterpret_cast<uint8_t*>(ws.h_err + Z_ROWS);
+      if (er == hipSuccess) er = hipHostGetDevicePointer((void**)&ws.h_err_dev, ws.h_err, 0);
       if (er == hipSuccess) er = hipEventCreateWithFlags(&ws.ev_done, hipEventDisableTiming);
       if (er == hipSuccess) er = hipEventCreateWithFlags(&ws.ev_result, hipEventDisableTiming);
       for (auto& evn : ws.ev) if (er == hipSuccess) er = hipEventCreate(&evn);
