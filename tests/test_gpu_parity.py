@@ -568,6 +568,10 @@ def test_full_benchmarks_protocol(pkg, ora):
         r = res[power]
         assert len(r["subsequent_runs"]) == 2 and r["first_run_elapsed"] > 0
         assert abs(r["full_average"] - (r["first_run_elapsed"] + sum(r["subsequent_runs"])) / 3) < 1e-9
+    # the harness's CSV export (ui/CSVExportButton.tsx:8-23, rows of ui/AllBenchmarks.tsx:45-52): quoted cells, one row per timed call
+    lines = fb.to_csv(fb.csv_rows(res)).split("\n")
+    assert lines[0] == '"InputSize","MSM Func","Time (MS)"' and len(lines) == 1 + 2 * 3
+    assert lines[1].startswith('"10","Submission","') and lines[4].startswith('"12","Submission","')
     pts, sc = pkg.synth_inputs(0x5EED0000 + 10, 1 << 10)
     out = pkg.compute_msm(pts, sc, log_result=False)
     assert out["x"] == int.from_bytes(ora.msm(pts, sc)[:32], "little")

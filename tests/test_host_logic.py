@@ -211,6 +211,15 @@ def test_synth_random_points_match_the_oracle(pkg, model, ora):
         pkg.synth_inputs(3, 10, 7)
 
 
+def test_csv_export_format(pkg):
+    """ui/CSVExportButton.tsx:9-11: every cell quoted, ',' between cells, newline between rows; header of ui/AllBenchmarks.tsx:45"""
+    import importlib
+    fb = importlib.import_module(pkg.__name__ + ".full_benchmarks")
+    res = {17: {"first_run_elapsed": 3.5, "subsequent_runs": [1.25, 1.5]}, 16: {"first_run_elapsed": 9.0, "subsequent_runs": [0.5]}}
+    assert fb.to_csv(fb.csv_rows(res)) == ('"InputSize","MSM Func","Time (MS)"\n"16","Submission","9.0"\n"16","Submission","0.5"\n'
+                                           '"17","Submission","3.5"\n"17","Submission","1.25"\n"17","Submission","1.5"')
+
+
 def test_devices_from_env(pkg, monkeypatch):
     monkeypatch.delenv("TE_MSM_DEVICES", raising=False)
     assert pkg.devices_from_env() == (0,)

@@ -7,6 +7,9 @@ the same Markdown table: | MSM size | 1st run | Run 1..5 | Average (incl 1st) | 
 Inputs: the ZPrize files if `--data DIR` (or $TE_ZPRIZE_DATA) holds them (test-data/testCases.ts:35-52; results are
 then compared with the five expected points), else the engine's seeded synthetic inputs (te_msm_synth_inputs).
 
+`--csv FILE` also writes the harness's export (ui/CSVExportButton.tsx:8-23 over the rows ui/AllBenchmarks.tsx:45-52
+collects): a header row "InputSize","MSM Func","Time (MS)" and one quoted row per timed call.
+
     python -m webgpu-msm-twisted-edwards_amd.full_benchmarks        (python full_benchmarks.py works too)
 """
 from __future__ import annotations
@@ -21,6 +24,23 @@ import time
 DELAY_MS = 100          # full_benchmarks.ts:10
 NUM_RUNS = 5            # full_benchmarks.ts:11
 START_POWER, END_POWER = 16, 20
+CSV_HEADER = ["InputSize", "MSM Func", "Time (MS)"]          # ui/AllBenchmarks.tsx:45
+MSM_FUNC_NAME = "Submission"                                  # the name the harness gives compute_msm (ui/AllBenchmarks.tsx:213-222)
+
+
+def to_csv(rows) -> str:
+    """convertToCSV of ui/CSVExportButton.tsx:9-11: every cell in double quotes, cells joined by ',', rows by newline"""
+    return "\n".join(",".join('"%s"' % cell for cell in row) for row in rows)
+
+
+def csv_rows(all_results):
+    """the rows postResult collects (ui/AllBenchmarks.tsx:49-52): [input size (the power), function name, time in ms]"""
+    rows = [list(CSV_HEADER)]
+    for power in sorted(all_results):
+        r = all_results[power]
+        for t in [r["first_run_elapsed"]] + list(r["subsequent_runs"]):
+            rows.append([power, MSM_FUNC_NAME, t])
+    return rows
 
 
 def _pkg():
@@ -87,8 +107,12 @@ def main():
     ap.add_argument("--end", type=int, default=END_POWER)
     ap.add_argument("--runs", type=int, default=NUM_RUNS)
     ap.add_argument("--json", action="store_true", help="also print the results as one JSON line")
+    ap.add_argument("--csv", default=None, help="write the harness's CSV export (InputSize, MSM Func, Time (MS)) to this file")
     args = ap.parse_args()
     res = run(list(range(args.start, args.end + 1)), args.data, args.runs)
+    if args.csv:
+        with open(args.csv, "w") as f:
+            f.write(to_csv(csv_rows(res)))
     if args.json:
         print(json.dumps(res))
 
