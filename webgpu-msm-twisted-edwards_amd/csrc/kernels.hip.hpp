@@ -204,6 +204,19 @@ __device__ __forceinline__ bool digit_bucket(uint32_t stored, uint32_t half, uin
   return true;
 }
 
+// Hand-offs between blocks of ONE launch ("the block that finishes last does the next step").  The L2 caches of the eight XCDs
+// are not coherent with each other: a device-scope fence (__threadfence) writes back and invalidates the issuing XCD's whole
+// L2 -- measured at ~60 us per fence inside a streaming kernel (the first version of k_l2_count_plan took 663 us instead of
+// 20).  So the handed-over DATA travels through device-scope atomic accesses (performed at the memory side, past the L2s),
+// the producer only waits for its own accesses to be acknowledged (s_waitcnt), and no cache is flushed.
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// every memory access this wave has issued is complete (acknowledged by the memory side for device-scope accesses)
+__device__ __forceinline__ void wait_own_accesses() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);
+}
+
 // block-wide exclusive scan of one value per thread (blockDim.x <= 1024, multiple of 64 or < 64)
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds /*>= 17 words*/, uint32_t& block_total) {
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -543,7 +556,7 @@ __device__ __forceinline__ void seg_plan_block(uint32_t p, uint32_t k, const sor
   if (t == 0) L.n_giant = 0u;
   const bool mine = t < S;
   const uint32_t g = k * B + p * S + (mine ? t : 0u);
-  const uint32_t cnt = mine ? a.bucket_count[g] : 0u;
+  const uint32_t cnt = mine ? ld_agent(a.bucket_count + g) : 0u;       // other blocks' atomic adds: read past the (incoherent) L2
   const uint32_t nparts = mine ? max(1u, (cnt + seg_len - 1u) / seg_len) : 0u;
   uint32_t bt, bt2;
   const uint32_t ex = block_excl_scan(cnt, sm, bt);
@@ -594,7 +607,7 @@ __device__ __forceinline__ void seg_plan_block(uint32_t p, uint32_t k, const sor
 // rounds -- 9 us between two launch boundaries on every MSM's critical path).  grid (nslices, nw), block 256: a block counts
 // the pieces of its slice per bucket (LDS, then one global atomicAdd per touched bucket), and the block that completes a
 // partition -- its pieces are counted in part_ticket -- plans it: all the partition's bucket counts are final at that moment
-// (release fence before the ticket, acquire fence after).  Empty partitions have no piece: the block whose walk passes their
+// (they are only ever touched by device-scope atomics; see ld_agent above: no fence, no cache flush).  Empty partitions have no piece: the block whose walk passes their
 // position plans them -- inside its slice, at its end (s1 == part_start), or, at position 0, block 0 (which therefore never
 // leaves early: a window whose digits are all zero has nothing but empty partitions).
 __global__ void __launch_bounds__(256) k_l2_count_plan(const uint16_t* __restrict__ part_keys, const uint32_t* __restrict__ part_idx,
@@ -631,14 +644,11 @@ __global__ void __launch_bounds__(256) k_l2_count_plan(const uint16_t* __restric
     if (c0) atomicAdd(&bucket_count[(size_t)k * g.B + (size_t)p * g.S + t], c0);
     // pieces of this partition: the slices its range [pb, pe) touches
     const uint32_t pieces = (pe - 1u) / g.slice - pb / g.slice + 1u;
-    __threadfence();                                    // this piece's counts are visible device-wide before it is counted as done
+    wait_own_accesses();                                // this piece's atomic adds have been performed before it is counted as done
     __syncthreads();
     if (t == 0) is_last = (atomicAdd(&pa.part_ticket[k * g.P + p], 1u) + 1u == pieces) ? 1u : 0u;
     __syncthreads();
-    if (is_last) {                                      // uniform
-      __threadfence();
-      seg_plan_block(p, k, g, pa, PL);
-    }
+    if (is_last) seg_plan_block(p, k, g, pa, PL);       // uniform; the plan reads the counts with device-scope loads
     s0 = e1; p++;
   }
   // empty partitions at the end of the slice (the next slice's walk starts behind them)
@@ -974,12 +984,21 @@ template <int N> __device__ __forceinline__ uint32_t* words(ete_t<N>* p) { retur
 
 // block-wide sum of cnt points src[0], src[stride], ... by 64 quads: strided serial team additions, then an LDS tree.
 // Returns the sum in quad 0.  blockDim.x must be 256; lds holds 64 points.
-template <int N> __device__ __forceinline__ fel<N> block_sum_points(const ete_t<N>* __restrict__ src, uint32_t stride, uint32_t cnt, uint32_t* lds) {
+template <int N> __device__ __forceinline__ fel<N> load_coord_agent(const uint32_t* p) { fel<N> r;
+#pragma unroll
+  for (int i = 0; i < N; i++) r.v[i] = ld_agent(p + i);
+  return r; }
+template <int N> __device__ __forceinline__ void store_coord_agent(uint32_t* p, const fel<N>& a) {
+#pragma unroll
+  for (int i = 0; i < N; i++) st_agent(p + i, a.v[i]);
+}
+// COHERENT: the inputs were written by other blocks of this launch (store_coord_agent): read them past the L2
+template <int N, bool COHERENT = false> __device__ __forceinline__ fel<N> block_sum_points(const ete_t<N>* __restrict__ src, uint32_t stride, uint32_t cnt, uint32_t* lds) {
   constexpr uint32_t PW = geo<N>::PW;
   const uint32_t i = threadIdx.x >> 2, q = threadIdx.x & 3u, w = team_word<N>(q);
   fel<N> acc = identity_coord<N>(q);
   for (uint32_t j = i; j < cnt; j += 64u) {       // quad-uniform trip count differs between quads: DPP stays inside a quad
-    const fel<N> e = load_coord<N>(words<N>(src + (size_t)j * stride) + w);
+    const fel<N> e = COHERENT ? load_coord_agent<N>(words<N>(src + (size_t)j * stride) + w) : load_coord<N>(words<N>(src + (size_t)j * stride) + w);
     acc = j == i ? e : ete_add_team<N>(acc, e, q);
   }
   for (uint32_t s = 32; s > 0; s >>= 1) {
@@ -1031,14 +1050,13 @@ __global__ void __launch_bounds__(256) k_seg_combine_all(const uint32_t* __restr
       __syncthreads();
       continue;
     }
-    if ((threadIdx.x >> 2) == 0) store_coord<N>(words<N>(base) + wq, r);
-    __threadfence();                                       // the run's sum is visible device-wide before the arrival is counted
+    if ((threadIdx.x >> 2) == 0) store_coord_agent<N>(words<N>(base) + wq, r);      // past the L2: another XCD's block may add the runs up
+    wait_own_accesses();                                   // ... and performed before the arrival is counted
     __syncthreads();
     if (threadIdx.x == 0) arrived = atomicAdd(&bucket_cursor[g], 1u) - (bucket_start[g] + bucket_count[g]);
     __syncthreads();
     if (arrived + 1u == nchunks) {                         // uniform: this block finished the bucket's last run
-      __threadfence();
-      const fel<N> t = block_sum_points<N>(seg_out + seg_base[g], 1024u, nchunks, lds);
+      const fel<N> t = block_sum_points<N, true>(seg_out + seg_base[g], 1024u, nchunks, lds);
       if ((threadIdx.x >> 2) == 0) store_coord<N>(words<N>(buckets + g) + wq, t);
     }
     __syncthreads();
