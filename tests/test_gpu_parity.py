@@ -138,11 +138,27 @@ def test_stages_against_oracle(ctx, fpcheck, model, ora, n, c):
 
 # ------------------------------------------------------------------ end to end, golden fixtures
 def test_wasm_golden_cases(ctx, wasm_golden, model):
+    """the HIP path against outputs of the reference's own CPU MSM (Aleo WASM Address.msm, reference/reference.ts:29-39) -- up to
+    the headline size n = 2^20, chain / harness-mode / random points; the large cases also with the 16-bit windows of BASELINE
+    configs 2 and 3 (unsigned and signed digits) and from device-resident inputs"""
+    import torch
     ctx.set_option("window_bits", 0)
+    assert max(g["n"] for g in wasm_golden) == 1 << 20, "the reference-generated golden at the headline size is missing"
     for g in wasm_golden:
         pts, sc = make_inputs(g["seed"], g["n"], g["mode"])
-        got = model.xy_from_bytes(ctx.run(pts, sc))
-        assert got == (int(g["x"]), int(g["y"])), g["name"]
+        want = (int(g["x"]), int(g["y"]))
+        assert model.xy_from_bytes(ctx.run(pts, sc)) == want, g["name"]
+        if g["n"] >= 65536:
+            dp, ds = _dev(pts), _dev(sc)
+            torch.cuda.synchronize()
+            ctx.set_option("window_bits", 16)
+            for signed in (1, 0):
+                ctx.set_option("signed_digits", signed)
+                assert model.xy_from_bytes(ctx.run_device(dp.data_ptr(), ds.data_ptr(), g["n"])) == want, (g["name"], signed)
+                assert model.xy_from_bytes(ctx.run(pts, sc)) == want, (g["name"], signed)
+            ctx.set_option("signed_digits", 1)
+            ctx.set_option("window_bits", 0)
+            del dp, ds
 
 
 @pytest.mark.parametrize("c", [4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
