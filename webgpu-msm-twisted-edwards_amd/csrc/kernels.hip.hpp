@@ -607,9 +607,7 @@ __device__ __forceinline__ void seg_plan_block(uint32_t p, uint32_t k, const sor
 // rounds -- 9 us between two launch boundaries on every MSM's critical path).  grid (nslices, nw), block 256: a block counts
 // the pieces of its slice per bucket (LDS, then one global atomicAdd per touched bucket), and the block that completes a
 // partition -- its pieces are counted in part_ticket -- plans it: all the partition's bucket counts are final at that moment
-// (they are only ever touched by device-scope atomics; see ld_agent above: no fence, no cache flush).  Empty partitions have no piece: the block whose walk passes their
-// position plans them -- inside its slice, at its end (s1 == part_start), or, at position 0, block 0 (which therefore never
-// leaves early: a window whose digits are all zero has nothing but empty partitions).
+// (they are only ever touched by device-scope atomics; see ld_agent above: no fence, no cache flush).
 __global__ void __launch_bounds__(256) k_l2_count_plan(const uint16_t* __restrict__ part_keys, const uint32_t* __restrict__ part_idx,
                                                        const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ part_count,
                                                        uint32_t* __restrict__ bucket_count, sort_geom g, plan_args pa) {
@@ -619,16 +617,20 @@ __global__ void __launch_bounds__(256) k_l2_count_plan(const uint16_t* __restric
   const uint32_t k = blockIdx.y, t = threadIdx.x;
   const uint32_t* ps = part_start + k * g.P; const uint32_t* pc = part_count + k * g.P;
   const uint32_t row_total = ps[g.P - 1] + pc[g.P - 1];
+  // empty partitions have no piece: they are dealt over the blocks of the window by index (a 253-bit scalar leaves the upper
+  // 109 of the top window's 128 partitions empty -- and whole windows at 15 bits: planned one after the other by the block
+  // whose slice they border, they made this kernel 300 us long)
+  for (uint32_t q = blockIdx.x; q < g.P; q += gridDim.x) if (pc[q] == 0u) seg_plan_block(q, k, g, pa, PL);     // uniform
   uint32_t s0 = blockIdx.x * g.slice;
   const uint32_t s1 = min(row_total, s0 + g.slice);
-  if (s0 >= s1 && blockIdx.x != 0u) return;
+  if (s0 >= s1) return;
   const uint16_t* keys_row = part_keys + (size_t)k * g.nst; const uint32_t* idx_row = part_idx + (size_t)k * g.nst;
-  uint32_t p = blockIdx.x == 0u ? 0u : find_partition(ps, pc, g.P, s0);
+  uint32_t p = find_partition(ps, pc, g.P, s0);
   cnt_s[t] = 0u;
   __syncthreads();
   while (s0 < s1) {
     const uint32_t pb = ps[p], pe = pb + pc[p], e1 = min(s1, pe);
-    if (e1 <= s0) { if (pc[p] == 0u) seg_plan_block(p, k, g, pa, PL); p++; continue; }      // empty partition (uniform branch): planned here
+    if (e1 <= s0) { p++; continue; }                 // empty partition (uniform branch): planned above
     piece_regs r; uint32_t head, total;
     load_piece(keys_row, idx_row, s0, e1, t, false, r, head, total);
 #pragma unroll
@@ -651,8 +653,6 @@ __global__ void __launch_bounds__(256) k_l2_count_plan(const uint16_t* __restric
     if (is_last) seg_plan_block(p, k, g, pa, PL);       // uniform; the plan reads the counts with device-scope loads
     s0 = e1; p++;
   }
-  // empty partitions at the end of the slice (the next slice's walk starts behind them)
-  while (p < g.P && pc[p] == 0u && ps[p] == s1) { seg_plan_block(p, k, g, pa, PL); p++; }
 }
 
 // Counting sort of the valid segment ids by descending length: block `ob` of `nob` (256 threads; lds: 2 * 1024 + 17 words);
