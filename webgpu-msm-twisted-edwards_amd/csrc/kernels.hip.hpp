@@ -206,8 +206,8 @@ __device__ __forceinline__ bool digit_bucket(uint32_t stored, uint32_t half, uin
 
 // Hand-offs between blocks of ONE launch ("the block that finishes last does the next step").  The L2 caches of the eight XCDs
 // are not coherent with each other: a device-scope fence (__threadfence) writes back and invalidates the issuing XCD's whole
-// L2 -- measured at ~60 us per fence inside a streaming kernel (the first version of k_l2_count_plan took 663 us instead of
-// 20).  So the handed-over DATA travels through device-scope atomic accesses (performed at the memory side, past the L2s),
+// L2 -- measured at ~60 us per fence inside a streaming kernel (a fused count + plan kernel built that way took 663 us instead
+// of 20).  So the handed-over DATA travels through device-scope atomic accesses (performed at the memory side, past the L2s),
 // the producer only waits for its own accesses to be acknowledged (s_waitcnt), and no cache is flushed.
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -449,6 +449,42 @@ __device__ __forceinline__ uint32_t find_partition(const uint32_t* __restrict__ 
   return lo;
 }
 
+// grid (nslices, nw), block 256
+__global__ void __launch_bounds__(256) k_l2_count(const uint16_t* __restrict__ part_keys, const uint32_t* __restrict__ part_idx,
+                                                  const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ part_count,
+                                                  uint32_t* __restrict__ bucket_count, sort_geom g) {
+  __shared__ uint32_t cnt_s[256];
+  const uint32_t k = blockIdx.y, t = threadIdx.x;
+  const uint32_t* ps = part_start + k * g.P; const uint32_t* pc = part_count + k * g.P;
+  const uint32_t row_total = ps[g.P - 1] + pc[g.P - 1];
+  uint32_t s0 = blockIdx.x * g.slice;
+  const uint32_t s1 = min(row_total, s0 + g.slice);
+  if (s0 >= s1) return;
+  const uint16_t* keys_row = part_keys + (size_t)k * g.nst; const uint32_t* idx_row = part_idx + (size_t)k * g.nst;
+  uint32_t p = find_partition(ps, pc, g.P, s0);
+  cnt_s[t] = 0u;
+  __syncthreads();
+  while (s0 < s1) {
+    const uint32_t pe = ps[p] + pc[p], e1 = min(s1, pe);
+    if (e1 <= s0) { p++; continue; }                 // empty partition (uniform branch)
+    piece_regs r; uint32_t head, total;
+    load_piece(keys_row, idx_row, s0, e1, t, false, r, head, total);
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+      uint32_t kv[8]; unpack8(r.k[c], kv);
+      const uint32_t e0 = ((uint32_t)c * 256u + t) * 8u;
+#pragma unroll
+      for (int e = 0; e < 8; e++) { const uint32_t pos = e0 + (uint32_t)e; if (pos >= head && pos < total) atomicAdd(&cnt_s[kv[e] & 0x7fffu], 1u); }
+    }
+    __syncthreads();
+    const uint32_t c0 = cnt_s[t];
+    cnt_s[t] = 0u;                                      // for the block's next piece (two barriers per piece, not three)
+    if (c0) atomicAdd(&bucket_count[(size_t)k * g.B + (size_t)p * g.S + t], c0);
+    __syncthreads();
+    s0 = e1; p++;
+  }
+}
+
 // LDS of one level-2 placement block, in words: four 256-entry tables, the piece's entries and their buckets, scan scratch
 #define TE_PLACE_LDS_WORDS (4u * 256u + (TE_SLICE + 8u) + (TE_SLICE + 8u) / 4u + 2u + 17u)
 // slice `slice_id` of local window k (block of 256 threads; lds: TE_PLACE_LDS_WORDS words)
@@ -538,121 +574,69 @@ __device__ __forceinline__ void l2_place_block(uint32_t slice_id, uint32_t k, ui
 // The histogram of segment lengths is kept in TE_HIST_COPIES copies (block b adds to copy b mod copies; k_order_scatter sums
 // them): 2048 blocks adding to the same ~60 hot addresses cost 28 us of serialised atomics with a single copy.
 #define TE_HIST_COPIES 32u
-// Segment plan of partition p of local window k, by one block of 256 threads (threads t >= S idle along: S < 256 only for
-// windows of fewer than 9 bits).  Called by the level-2 count block that finishes the partition's LAST piece (k_l2_count_plan).
-struct plan_args {
-  const uint32_t* bucket_count; const uint32_t* part_start; const uint32_t* part_count; const uint32_t* seg_part_base;
-  uint32_t *bucket_start, *bucket_cursor, *seg_base, *seg_bucket, *seg_lenv, *size_hist, *split_list;
-  uint32_t* split_count;    // [0] small, [1] large buckets, [2] large chunks
-  uint32_t* chunk_list;     // pairs (bucket, first part)
-  uint32_t* part_ticket;    // [window][partition], zeroed per MSM: pieces of the partition counted so far
-  uint32_t seg_len, cap_w, chunk_cap;
-};
-struct plan_lds { uint32_t h[1024]; uint32_t sm[17]; uint32_t giant[256 * 3]; uint32_t n_giant; };
-__device__ __forceinline__ void seg_plan_block(uint32_t p, uint32_t k, const sort_geom& sg, const plan_args& a, plan_lds& L) {
-  const uint32_t t = threadIdx.x, P = sg.P, S = sg.S, B = sg.B, seg_len = a.seg_len;
-  uint32_t* const h = L.h; uint32_t* const sm = L.sm; uint32_t* const giant = L.giant;
-  for (uint32_t j = t; j < 1024u; j += 256u) h[j] = 0u;
-  if (t == 0) L.n_giant = 0u;
-  const bool mine = t < S;
-  const uint32_t g = k * B + p * S + (mine ? t : 0u);
-  const uint32_t cnt = mine ? ld_agent(a.bucket_count + g) : 0u;       // other blocks' atomic adds: read past the (incoherent) L2
-  const uint32_t nparts = mine ? max(1u, (cnt + seg_len - 1u) / seg_len) : 0u;
+// (Round 4 measured the count and the plan as ONE launch -- the block that counts a partition's last piece plans it, hand-over
+// through device-scope atomics: 32.8 us against 12 + 9 at n = 2^20, 24.3 against 6.8 + 6.0 at 2^16.  A block then runs
+// "count, wait for its atomics, plan" twice in a row where two launches run 2048 + 2048 blocks side by side; the launch boundary
+// is cheaper.  profiles/r04_count_plan_fusion_experiment.txt.)
+// grid (P, nw), block S (= buckets per partition, <= 256)
+__global__ void __launch_bounds__(256) k_seg_plan(const uint32_t* __restrict__ bucket_count, const uint32_t* __restrict__ part_start,
+                                                  const uint32_t* __restrict__ part_count, const uint32_t* __restrict__ seg_part_base,
+                                                  uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ bucket_cursor,
+                                                  uint32_t* __restrict__ seg_base, uint32_t* __restrict__ seg_bucket, uint32_t* __restrict__ seg_lenv,
+                                                  uint32_t* __restrict__ size_hist, uint32_t* __restrict__ split_list,
+                                                  uint32_t* __restrict__ split_count /* [0] small, [1] large buckets, [2] large chunks */,
+                                                  uint32_t* __restrict__ chunk_list /* pairs (bucket, first part) */,
+                                                  uint32_t B, uint32_t S, uint32_t seg_len, uint32_t cap_w, uint32_t chunk_cap) {
+  __shared__ uint32_t h[1024];
+  __shared__ uint32_t sm[17];
+  __shared__ uint32_t giant[256 * 3];                   // (bucket, first segment id, count) of the buckets cut into > 16 parts
+  __shared__ uint32_t n_giant;
+  const uint32_t p = blockIdx.x, k = blockIdx.y, t = threadIdx.x, P = gridDim.x;
+  for (uint32_t j = t; j < 1024u; j += blockDim.x) h[j] = 0u;
+  if (t == 0) n_giant = 0u;
+  const uint32_t g = k * B + p * S + t;
+  const uint32_t cnt = bucket_count[g];
+  const uint32_t nparts = max(1u, (cnt + seg_len - 1u) / seg_len);
   uint32_t bt, bt2;
   const uint32_t ex = block_excl_scan(cnt, sm, bt);
   const uint32_t ex2 = block_excl_scan(nparts, sm, bt2);
-  const uint32_t bs = a.part_start[k * P + p] + ex, sb = a.seg_part_base[k * P + p] + ex2;
-  if (mine) {
-    a.bucket_start[g] = bs; a.bucket_cursor[g] = bs; a.seg_base[g] = sb;
-    if (nparts <= TE_COMBINE_SMALL) {
-      for (uint32_t part = 0; part < nparts; part++) {
-        const uint32_t len = cnt > part * seg_len ? min(seg_len, cnt - part * seg_len) : 0u;
-        a.seg_bucket[sb + part] = g; a.seg_lenv[sb + part] = len;
-        atomicAdd(&h[min(len, 1023u)], 1u);
-      }
-      if (nparts > 1u) a.split_list[atomicAdd(&a.split_count[0], 1u)] = g;
-    } else {
-      const uint32_t j = atomicAdd(&L.n_giant, 1u);
-      giant[3 * j] = g; giant[3 * j + 1] = sb; giant[3 * j + 2] = cnt;
-      atomicAdd(&a.split_count[1], 1u);
+  const uint32_t bs = part_start[k * P + p] + ex, sb = seg_part_base[k * P + p] + ex2;
+  bucket_start[g] = bs; bucket_cursor[g] = bs; seg_base[g] = sb;
+  if (nparts <= TE_COMBINE_SMALL) {
+    for (uint32_t part = 0; part < nparts; part++) {
+      const uint32_t len = cnt > part * seg_len ? min(seg_len, cnt - part * seg_len) : 0u;
+      seg_bucket[sb + part] = g; seg_lenv[sb + part] = len;
+      atomicAdd(&h[min(len, 1023u)], 1u);
     }
+    if (nparts > 1u) split_list[atomicAdd(&split_count[0], 1u)] = g;
+  } else {
+    const uint32_t j = atomicAdd(&n_giant, 1u);
+    giant[3 * j] = g; giant[3 * j + 1] = sb; giant[3 * j + 2] = cnt;
+    atomicAdd(&split_count[1], 1u);
   }
   // ids this partition does not use: [first + segments, first + S + floor(part_count / seg_len))
   {
     // (the last partition also covers the rest of the window's id range, up to (k + 1) * cap_w)
-    const uint32_t first = a.seg_part_base[k * P + p], used = bt2;
-    const uint32_t cap = p + 1u == P ? (k + 1u) * a.cap_w - first : S + a.part_count[k * P + p] / seg_len;
-    for (uint32_t j = used + t; j < cap; j += 256u) { a.seg_bucket[first + j] = TE_SEG_INVALID; a.seg_lenv[first + j] = TE_SEG_INVALID; }
+    const uint32_t first = seg_part_base[k * P + p], used = bt2;
+    const uint32_t cap = p + 1u == P ? (k + 1u) * cap_w - first : S + part_count[k * P + p] / seg_len;
+    for (uint32_t j = used + t; j < cap; j += blockDim.x) { seg_bucket[first + j] = TE_SEG_INVALID; seg_lenv[first + j] = TE_SEG_INVALID; }
   }
   __syncthreads();
   // giant buckets: the whole block writes their segment records; one chunk entry per 1024 parts (k_seg_combine_all)
-  const uint32_t ng = L.n_giant;
+  const uint32_t ng = n_giant;
   for (uint32_t j = 0; j < ng; j++) {
     const uint32_t gg = giant[3 * j], sb0 = giant[3 * j + 1], c0 = giant[3 * j + 2];
     const uint32_t np = (c0 + seg_len - 1u) / seg_len;
-    for (uint32_t part = t; part < np; part += 256u) {
+    for (uint32_t part = t; part < np; part += blockDim.x) {
       const uint32_t len = min(seg_len, c0 - part * seg_len);
-      a.seg_bucket[sb0 + part] = gg; a.seg_lenv[sb0 + part] = len;
+      seg_bucket[sb0 + part] = gg; seg_lenv[sb0 + part] = len;
       atomicAdd(&h[min(len, 1023u)], 1u);
-      if ((part & 1023u) == 0) { const uint32_t ci = atomicAdd(&a.split_count[2], 1u); if (ci < a.chunk_cap) { a.chunk_list[2 * ci] = gg; a.chunk_list[2 * ci + 1] = part; } }
+      if ((part & 1023u) == 0) { const uint32_t ci = atomicAdd(&split_count[2], 1u); if (ci < chunk_cap) { chunk_list[2 * ci] = gg; chunk_list[2 * ci + 1] = part; } }
     }
   }
   __syncthreads();
-  uint32_t* my_hist = a.size_hist + ((k * P + p) % TE_HIST_COPIES) * 1024u;
-  for (uint32_t j = t; j < 1024u; j += 256u) if (h[j]) atomicAdd(&my_hist[j], h[j]);
-  __syncthreads();                                       // L is reused by the block's next plan
-}
-
-// Level-2 count AND the segment plan in one launch (until round 4 two: the plan is one block per partition of a few dependent
-// rounds -- 9 us between two launch boundaries on every MSM's critical path).  grid (nslices, nw), block 256: a block counts
-// the pieces of its slice per bucket (LDS, then one global atomicAdd per touched bucket), and the block that completes a
-// partition -- its pieces are counted in part_ticket -- plans it: all the partition's bucket counts are final at that moment
-// (they are only ever touched by device-scope atomics; see ld_agent above: no fence, no cache flush).
-__global__ void __launch_bounds__(256) k_l2_count_plan(const uint16_t* __restrict__ part_keys, const uint32_t* __restrict__ part_idx,
-                                                       const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ part_count,
-                                                       uint32_t* __restrict__ bucket_count, sort_geom g, plan_args pa) {
-  __shared__ uint32_t cnt_s[256];
-  __shared__ plan_lds PL;
-  __shared__ uint32_t is_last;
-  const uint32_t k = blockIdx.y, t = threadIdx.x;
-  const uint32_t* ps = part_start + k * g.P; const uint32_t* pc = part_count + k * g.P;
-  const uint32_t row_total = ps[g.P - 1] + pc[g.P - 1];
-  // empty partitions have no piece: they are dealt over the blocks of the window by index (a 253-bit scalar leaves the upper
-  // 109 of the top window's 128 partitions empty -- and whole windows at 15 bits: planned one after the other by the block
-  // whose slice they border, they made this kernel 300 us long)
-  for (uint32_t q = blockIdx.x; q < g.P; q += gridDim.x) if (pc[q] == 0u) seg_plan_block(q, k, g, pa, PL);     // uniform
-  uint32_t s0 = blockIdx.x * g.slice;
-  const uint32_t s1 = min(row_total, s0 + g.slice);
-  if (s0 >= s1) return;
-  const uint16_t* keys_row = part_keys + (size_t)k * g.nst; const uint32_t* idx_row = part_idx + (size_t)k * g.nst;
-  uint32_t p = find_partition(ps, pc, g.P, s0);
-  cnt_s[t] = 0u;
-  __syncthreads();
-  while (s0 < s1) {
-    const uint32_t pb = ps[p], pe = pb + pc[p], e1 = min(s1, pe);
-    if (e1 <= s0) { p++; continue; }                 // empty partition (uniform branch): planned above
-    piece_regs r; uint32_t head, total;
-    load_piece(keys_row, idx_row, s0, e1, t, false, r, head, total);
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-      uint32_t kv[8]; unpack8(r.k[c], kv);
-      const uint32_t e0 = ((uint32_t)c * 256u + t) * 8u;
-#pragma unroll
-      for (int e = 0; e < 8; e++) { const uint32_t pos = e0 + (uint32_t)e; if (pos >= head && pos < total) atomicAdd(&cnt_s[kv[e] & 0x7fffu], 1u); }
-    }
-    __syncthreads();
-    const uint32_t c0 = cnt_s[t];
-    cnt_s[t] = 0u;                                      // for the block's next piece
-    if (c0) atomicAdd(&bucket_count[(size_t)k * g.B + (size_t)p * g.S + t], c0);
-    // pieces of this partition: the slices its range [pb, pe) touches
-    const uint32_t pieces = (pe - 1u) / g.slice - pb / g.slice + 1u;
-    wait_own_accesses();                                // this piece's atomic adds have been performed before it is counted as done
-    __syncthreads();
-    if (t == 0) is_last = (atomicAdd(&pa.part_ticket[k * g.P + p], 1u) + 1u == pieces) ? 1u : 0u;
-    __syncthreads();
-    if (is_last) seg_plan_block(p, k, g, pa, PL);       // uniform; the plan reads the counts with device-scope loads
-    s0 = e1; p++;
-  }
+  uint32_t* my_hist = size_hist + ((blockIdx.y * gridDim.x + blockIdx.x) % TE_HIST_COPIES) * 1024u;
+  for (uint32_t j = t; j < 1024u; j += blockDim.x) if (h[j]) atomicAdd(&my_hist[j], h[j]);
 }
 
 // Counting sort of the valid segment ids by descending length: block `ob` of `nob` (256 threads; lds: 2 * 1024 + 17 words);

@@ -84,12 +84,11 @@ struct workset_t {
   // ONE zeroed block per MSM (a single memset), words: [0] final-carry flag, [1] number of segments, [2..4] split / giant
   // bucket counters, [Z_ROWS..) the partial rows of the MSM (so that flag and rows come back in ONE device-to-host copy),
   // [Z_HIST..) segment-length histogram (TE_HIST_COPIES copies), [Z_CURSOR..) reservation cursors of the schedule, [Z_END..) the level-1 histogram
-  // counts1[window][chunk][partition], then bucket_count[window][bucket], then part_ticket[window][partition].  d_err .. d_part_ticket point into d_zero.
+  // counts1[window][chunk][partition], then bucket_count[window][bucket].  d_err .. d_bucket_count point into d_zero.
   uint32_t *d_zero = nullptr; size_t zero_words = 0;
   size_t zero_clean_words = 0;        // words of d_zero known to be zero on the set's stream: the block is cleared AFTER an MSM's read-back
                                       // (finish_sequence), so that the next MSM on the set starts with its first kernel, not a fill
   uint32_t *d_err = nullptr, *d_num_seg = nullptr, *d_size_hist = nullptr, *d_size_cursor = nullptr;
-  uint32_t* d_part_ticket = nullptr;  // [window][partition]: level-2 pieces counted so far (k_l2_count_plan), behind bucket_count in the zeroed block
   uint8_t* d_partials = nullptr;      // = d_zero + Z_ROWS: TE_MAX_WINDOWS rows
   uint32_t* h_err = nullptr;          // pinned: mirror of d_zero[0 .. Z_ROWS + rows)
   uint8_t* h_partials = nullptr;      // = h_err + Z_ROWS
@@ -271,11 +270,11 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, workset_t& ws, uint64_t n, const plan_
   if ((rc = ensure(ctx, ws, ws.d_sorted, ws.cap[2], nd))) return rc;
   {
     const size_t c1 = (size_t)p.nw * p.CH * p.P;
-    ws.zero_words = Z_END + c1 + wb + (size_t)p.nw * p.P;
+    ws.zero_words = Z_END + c1 + wb;
     { const uint32_t* before = ws.d_zero; if ((rc = ensure(ctx, ws, ws.d_zero, ws.cap[3], ws.zero_words))) return rc; if (ws.d_zero != before) ws.zero_clean_words = 0; }
     ws.d_err = ws.d_zero; ws.d_num_seg = ws.d_zero + 1; ws.d_size_hist = ws.d_zero + Z_HIST; ws.d_size_cursor = ws.d_zero + Z_CURSOR;
     ws.d_partials = reinterpret_cast<uint8_t*>(ws.d_zero + Z_ROWS);
-    ws.d_counts1 = ws.d_zero + Z_END; ws.d_bucket_count = ws.d_counts1 + c1; ws.d_part_ticket = ws.d_bucket_count + wb;
+    ws.d_counts1 = ws.d_zero + Z_END; ws.d_bucket_count = ws.d_counts1 + c1;
   }
   if ((rc = ensure(ctx, ws, ws.d_bucket_start, ws.cap[5], wb))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_bucket_cursor, ws.cap[16], wb))) return rc;
@@ -432,15 +431,12 @@ struct msm_launch {
     mark(ST_BSORT);
     if (p.nw > 0) {
       const uint32_t nslices = (p.nst + p.slice - 1u) / p.slice;
-      // level-2 count + the segment plan (by the block that completes a partition) in one launch; d_num_seg[1..3] = split / giant
-      // bucket counters, zeroed with the rest
-      te::plan_args pa;
-      pa.bucket_count = ws.d_bucket_count; pa.part_start = ws.d_part_start; pa.part_count = ws.d_part_count; pa.seg_part_base = ws.d_seg_part_base;
-      pa.bucket_start = ws.d_bucket_start; pa.bucket_cursor = ws.d_bucket_cursor; pa.seg_base = ws.d_seg_base; pa.seg_bucket = ws.d_seg_bucket;
-      pa.seg_lenv = ws.d_seg_lenv; pa.size_hist = ws.d_size_hist; pa.split_list = ws.d_split_list; pa.split_count = ws.d_num_seg + 1;
-      pa.chunk_list = ws.d_chunk_list; pa.part_ticket = ws.d_part_ticket; pa.seg_len = p.seg_len; pa.cap_w = cap_w; pa.chunk_cap = chunk_cap();
-      hipLaunchKernelGGL(te::k_l2_count_plan, dim3(nslices, p.nw), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx, ws.d_part_start,
-                         ws.d_part_count, ws.d_bucket_count, sg, pa);
+      hipLaunchKernelGGL(te::k_l2_count, dim3(nslices, p.nw), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx, ws.d_part_start,
+                         ws.d_part_count, ws.d_bucket_count, sg);
+      // d_num_seg[1..3] = split / giant bucket counters, zeroed with the rest
+      hipLaunchKernelGGL(te::k_seg_plan, dim3(p.P, p.nw), dim3(p.S), 0, stream, ws.d_bucket_count, ws.d_part_start, ws.d_part_count, ws.d_seg_part_base,
+                         ws.d_bucket_start, ws.d_bucket_cursor, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv, ws.d_size_hist, ws.d_split_list,
+                         ws.d_num_seg + 1, ws.d_chunk_list, p.B, p.S, p.seg_len, cap_w, chunk_cap());
       // level-2 placement + the segment schedule (counts the valid segments, d_num_seg[0]; with "sort_buckets" = 0 the
       // schedule is simply not used) in one launch
       te::order_args oa;
@@ -829,7 +825,7 @@ void free_workset_buffers(workset_t& ws) {      // the big device buffers of a w
   for (void** q : ptrs) if (*q) { (void)hipFree(*q); *q = nullptr; }
   memset(ws.cap, 0, sizeof ws.cap); ws.cap_in_points = ws.cap_in_scalars = 0;
   ws.zero_words = ws.zero_clean_words = 0;
-  ws.d_err = ws.d_num_seg = ws.d_size_hist = ws.d_size_cursor = ws.d_counts1 = ws.d_bucket_count = ws.d_part_ticket = nullptr; ws.d_partials = nullptr;
+  ws.d_err = ws.d_num_seg = ws.d_size_hist = ws.d_size_cursor = ws.d_counts1 = ws.d_bucket_count = nullptr; ws.d_partials = nullptr;
   if (ws.g_front) { (void)hipGraphExecDestroy(ws.g_front); ws.g_front = nullptr; }
   if (ws.g_back) { (void)hipGraphExecDestroy(ws.g_back); ws.g_back = nullptr; }
   ws.generation++; ws.used = false;
