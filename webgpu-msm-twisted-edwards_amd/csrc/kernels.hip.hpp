@@ -297,15 +297,17 @@ struct scatter_args {
   const uint16_t* digits; const uint32_t* counts1; uint16_t* part_keys; uint32_t* part_idx;
   uint32_t *part_start, *part_count, *seg_part_base; uint32_t seg_len, cap_w; sort_geom g;
 };
-// LDS of one level-1 block in words: the tile's indices, keys and partitions, three 512-entry tables, scan scratch
-#define TE_SCATTER_LDS_WORDS (TE_TILE + TE_TILE / 2u + TE_TILE / 2u + 3u * 512u + 17u)
+// LDS of one level-1 block in words: one packed word per entry of the tile, four 512-entry tables, scan scratch.
+// Packed entry: source slot in the tile (12 bits) | partition << 12 (8 bits: P <= 256) | bucket low bits << 20 (8) | sign << 28 --
+// index, key and partition in ONE LDS store and ONE load per entry (round 3 staged a u32 index and two u16 words: three
+// stores, and five loads in the copy-out with the two offset tables; LDS instructions per thread and tile 72 -> 32).
+#define TE_SCATTER_LDS_WORDS (TE_TILE + 4u * 512u + 17u)
 // chunk `ch` of local window `k` (block of 512 threads; lds: TE_SCATTER_LDS_WORDS words)
 __device__ __forceinline__ void part_scatter_block(uint32_t ch, uint32_t k, uint32_t* __restrict__ lds, const scatter_args& a) {
-  uint32_t* const st_idx = lds;
-  uint16_t* const st_key = reinterpret_cast<uint16_t*>(lds + TE_TILE);
-  uint16_t* const st_part = reinterpret_cast<uint16_t*>(lds + TE_TILE + TE_TILE / 2u);
-  uint32_t* const tile_cnt = lds + 2u * TE_TILE; uint32_t* const tile_off = tile_cnt + 512; uint32_t* const run_base = tile_cnt + 1024;
-  uint32_t* const sm = tile_cnt + 1536;
+  uint32_t* const st = lds;
+  uint32_t* const tile_cnt = lds + TE_TILE; uint32_t* const tile_off = tile_cnt + 512; uint32_t* const run_base = tile_cnt + 1024;
+  uint32_t* const gdelta = tile_cnt + 1536;            // run_base - tile_off of the current tile: global position of LDS slot s = s + gdelta[partition]
+  uint32_t* const sm = tile_cnt + 2048;
   const uint16_t* __restrict__ digits = a.digits; const uint32_t* __restrict__ counts1 = a.counts1;
   uint16_t* __restrict__ part_keys = a.part_keys; uint32_t* __restrict__ part_idx = a.part_idx;
   uint32_t* __restrict__ part_start = a.part_start; uint32_t* __restrict__ part_count = a.part_count; uint32_t* __restrict__ seg_part_base = a.seg_part_base;
@@ -366,18 +368,17 @@ __device__ __forceinline__ void part_scatter_block(uint32_t ch, uint32_t k, uint
     wave0_excl_scan(tile_cnt, tile_off, g.P, &sm[16]);
     __syncthreads();
     const uint32_t tile_total = sm[16];
+    if (t < g.P) gdelta[t] = run_base[t] - tile_off[t];
 #pragma unroll
     for (int e = 0; e < 8; e++) {
-      if (part[e] != 0xffffffffu) {
-        const uint32_t slot = tile_off[part[e]] + rank[e];
-        st_idx[slot] = i0 + (uint32_t)e; st_key[slot] = (uint16_t)key[e]; st_part[slot] = (uint16_t)part[e];
-      }
+      if (part[e] != 0xffffffffu)
+        st[tile_off[part[e]] + rank[e]] = (t * 8u + (uint32_t)e) | (part[e] << 12) | ((key[e] & 0xffu) << 20) | ((key[e] >> 15) << 28);
     }
     __syncthreads();
     for (uint32_t s = t; s < tile_total; s += 512u) {
-      const uint32_t p = st_part[s];
-      const uint32_t gpos = run_base[p] + (s - tile_off[p]);
-      ok[gpos] = st_key[s]; oi[gpos] = st_idx[s];
+      const uint32_t w = st[s];
+      const uint32_t gpos = s + gdelta[(w >> 12) & 0xffu];
+      ok[gpos] = (uint16_t)(((w >> 20) & 0xffu) | ((w >> 28) << 15)); oi[gpos] = base + (w & 0xfffu);
     }
     __syncthreads();
     for (uint32_t p = t; p < g.P; p += 512u) { run_base[p] += tile_cnt[p]; tile_cnt[p] = 0u; }
@@ -527,6 +528,7 @@ __device__ __forceinline__ void l2_place_block(uint32_t slice_id, uint32_t k, ui
     }
     __syncthreads();
     off_s[t] = lex_s[t];
+    gbase_s[t] -= lex_s[t];                             // global position of LDS slot s of bucket t: s + gbase_s[t]
     cnt_s[t] = 0u;                                      // for the block's next piece
     __syncthreads();
 #pragma unroll
@@ -545,7 +547,7 @@ __device__ __forceinline__ void l2_place_block(uint32_t slice_id, uint32_t k, ui
       }
     }
     __syncthreads();
-    for (uint32_t s = t; s < len; s += 256u) { const uint32_t b = list_b[s]; out[gbase_s[b] + (s - lex_s[b])] = list[s]; }
+    for (uint32_t s = t; s < len; s += 256u) out[gbase_s[list_b[s]] + s] = list[s];
     __syncthreads();
     s0 = e1; p++;
   }
