@@ -231,6 +231,29 @@ def test_giant_buckets_and_host_pieces(bls):
     bls.set_option("host_chunks", 0)
 
 
+def test_multi_device_point_shards_and_host_tickets(pkg):
+    """BLS12-377 through the round-4 host paths: te_msm_run on an n_dev = 3 context (point slices, rows of 1120 bytes summed in
+    this curve's host tail) and te_msm_submit tickets (scalars travel piece by piece with their points on this curve)"""
+    from oracle import oracle377
+    n = 50021
+    pts, sc = oracle377.gen_points(91, n), oracle377.gen_scalars(91, n)
+    exp = oracle377.msm(pts, sc, threads=8)
+    with pkg.MsmContext((0, 0, 0)) as c:
+        c.set_option("curve", pkg.CURVE_BLS12_377_G1)
+        c.set_option("host_shard_min", 1)
+        for chunks in (0, 2):
+            c.set_option("host_chunks", chunks)
+            assert c.run(pts, sc) == exp, chunks
+        assert c.run(pts[:96 * 2], sc[:48 * 2]) == oracle377.msm(pts[:96 * 2], sc[:48 * 2])        # fewer points than devices
+    with pkg.MsmContext((0,)) as c:
+        c.set_option("curve", pkg.CURVE_BLS12_377_G1)
+        for chunks in (0, 3):
+            c.set_option("host_chunks", chunks)
+            ts = [c.submit(pts, sc) for _ in range(3)]
+            assert [c.collect(t) for t in reversed(ts)] == [exp] * 3
+        assert pkg.finalize_sum([bytes(16 * 1120)], 16, 16, curve=pkg.CURVE_BLS12_377_G1) == bytes(96)   # no rows at all: the point at infinity
+
+
 def test_one_context_serves_both_curves(pkg, ora):
     n = 3000
     with pkg.MsmContext((0,)) as c:

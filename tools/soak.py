@@ -20,6 +20,10 @@ done = 0
 te = pkg.MsmContext((0,))
 bls = pkg.MsmContext((0,))
 bls.set_option("curve", pkg.CURVE_BLS12_377_G1)
+# multi-"device" contexts (the one GPU named several times): te_msm_run shards the POINTS over them, one host thread each
+multi = {d: pkg.MsmContext((0,) * d) for d in (2, 3, 4)}
+multi_bls = pkg.MsmContext((0, 0))
+multi_bls.set_option("curve", pkg.CURVE_BLS12_377_G1)
 while time.time() < t_end:
     ctx, orc, pb, sb = (te, oracle, 64, 32) if rnd.random() < 0.75 else (bls, oracle377, 96, 48)
     opts = {}
@@ -29,7 +33,12 @@ while time.time() < t_end:
                  ("fuse_prep", rnd.choice([1, 1, 0]))):
         ctx.set_option(k, v)
         opts[k] = v
-    mode = rnd.choice(["run", "run", "tickets", "tickets", "shards", "batch"])
+    mode = rnd.choice(["run", "run", "tickets", "tickets", "shards", "batch", "host_tickets", "host_tickets", "multi"])
+    if mode == "multi":
+        ctx = multi_bls if ctx is bls else multi[rnd.choice([2, 3, 4])]
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        ctx.set_option("host_shard_min", rnd.choice([1, 1, 4096]))
     batch, n_common = [], int(2 ** rnd.uniform(0, 17.5))
     for _ in range(rnd.randint(1, pkg.WORKSETS)):
         n = n_common if mode == "batch" else int(2 ** rnd.uniform(0, 20.2 if rnd.random() < 0.05 else 17.5))      # one launch sequence takes MSMs of one size
@@ -43,8 +52,16 @@ while time.time() < t_end:
             sc = sc[:sb] * n
         batch.append((pts, sc, n))
     exp = [orc.msm(p, s, threads=8) for p, s, _ in batch]
-    if mode == "run":
+    if mode in ("run", "multi"):
         got = [ctx.run(p, s) for p, s, _ in batch]
+    elif mode == "host_tickets":
+        # te_msm_submit: host buffers, tickets collected in random order, now and then beside a synchronous call
+        tickets = [ctx.submit(p, s) if n else None for p, s, n in batch]
+        got = [None] * len(batch)
+        for i in rnd.sample(range(len(batch)), len(batch)):
+            got[i] = ctx.collect(tickets[i]) if tickets[i] is not None else ctx.run(batch[i][0], batch[i][1])
+        if rnd.random() < 0.3:
+            ctx.trim(rnd.choice([0, 1, 4]))
     elif mode == "shards":
         world = rnd.choice([2, 3, 5, 8])
         got = []
@@ -92,7 +109,7 @@ while time.time() < t_end:
         tickets = [ctx.submit_device(a.data_ptr(), b.data_ptr(), n) for a, b, n in dev]
         got = [ctx.collect(t) for t in tickets]
     if got != exp:
-        print("MISMATCH", "bls" if ctx is bls else "te", opts, mode, [(n, g == e) for (_, _, n), g, e in zip(batch, got, exp)], flush=True)
+        print("MISMATCH", "bls" if ctx in (bls, multi_bls) else "te", opts, mode, [(n, g == e) for (_, _, n), g, e in zip(batch, got, exp)], flush=True)
         raise SystemExit(1)
     done += len(batch)
     if done % 50 < len(batch):

@@ -4,8 +4,8 @@
 //   K1 convert_point_coords_and_decompose_scalars (wgsl/cuzk/convert_point_coords_and_decompose_scalars
 //      .template.wgsl:37-123)                    -> k_prep_points + k_digits<C>
 //   K2 transpose (wgsl/cuzk/transpose.wgsl:32-76; 16 threads in total)
-//                                                -> (histogram in k_digits) k_part_scatter / k_l2_count / k_seg_plan / k_l2_place_order
-//                                                   (two-level counting sort, all stores coalesced; the segment schedule rides along)
+//                                                -> (histogram in k_digits) k_part_scatter / k_l2_local / k_l2_place_order
+//                                                   (two-level counting sort, all stores coalesced; segment plan and schedule ride along)
 //   K3 smvp (wgsl/cuzk/smvp.template.wgsl:58-152) -> k_accumulate (7-product mixed additions)
 //   K4/K5 bpr stage_1/2 (wgsl/cuzk/bpr.template.wgsl:73-171) + the CPU sum of 4096 points
 //      (submission.ts:362-393)                   -> k_sum_groups[_team] (fold levels) + k_reduce_tail (digit marginals, weighted sums)
@@ -266,14 +266,12 @@ __device__ __forceinline__ void wave0_excl_scan(const uint32_t* in, uint32_t* ou
 //   level 1  partition = bucket >> logS (P = B/S partitions per window, ~n/P entries each):
 //            histogram (in k_digits) -> k_part_scatter (4096-entry tiles sorted by partition in LDS,
 //            written out as contiguous runs: u16 key = bucket low bits | sign << 15, u32 index)
-//   level 2  k_l2_count -> k_seg_plan -> k_l2_place: blocks take fixed-size slices of the level-1 output, count per
-//            bucket in LDS, reserve ranges with one global atomic per touched bucket, and write each bucket's run
-//            contiguously -- balanced for any digit distribution.
+//   level 2  k_l2_local: one block per partition counts, plans and places it from one load (pieces of over-long partitions:
+//            counted there, placed by k_l2_place_order) -- balanced for any digit distribution.
 struct sort_geom {
   uint32_t n, nst;       // entries per window; row stride of digits / part_keys / part_idx (multiple of 8, >= n)
   uint32_t B, logS, S, P, CH, chunk_len;   // chunk_len is a multiple of TE_TILE
   uint32_t half;         // stored code of digit 0 (see digit_bucket)
-  uint32_t slice;        // level 2: entries per block, <= TE_SLICE (multiple of 8)
 };
 #define TE_TILE 4096u
 
@@ -410,23 +408,26 @@ __global__ void __launch_bounds__(512) k_part_scatter_prep(scatter_args a, uint3
   }
 }
 
-// level 2, work split by SLICES of the level-1 output (TE_SLICE consecutive entries of a window), not by
-// partition: every block has the same amount of work whatever the digit distribution.  (The top window of a
-// 253-bit scalar has only ~4.8k of its 32k buckets occupied, 219 entries each: with one block per partition,
-// 19 blocks sorted 55k entries each while the rest of the chip idled -- 200 us of tail.)
-// A slice is cut into pieces at partition boundaries; a piece touches at most S (<= 256) buckets.
-//   k_l2_count : LDS count per bucket of each piece -> global atomicAdd into bucket_count (<= S per piece)
-//   k_seg_plan : per partition: bucket_start = bucket_cursor = part_start + scan of the partition's bucket counts (and the
-//                segment schedule, see below)
-//   k_l2_place : LDS count again, reserve [base, base+c) in every touched bucket with one atomicAdd on
-//                bucket_cursor, sort the piece by bucket in LDS and copy each run to its reserved range.
-// The slice length follows n: a slice is cut into pieces at partition boundaries and a block works its pieces off one after
-// the other (loads, LDS rounds, a returning global atomic: 4-5 us each), so a slice should hold about ONE partition's worth of
-// entries -- n / P -- not more: with 8192 at n = 2^16 (1024 entries per partition) every block ran eight pieces in a row
-// and k_l2_place took 37 us for 7 MB.
-#define TE_SLICE 8192u
+// level 2: one block per PARTITION of a window sorts it by bucket -- count, segment plan and placement in ONE pass over the
+// partition's ~n/P entries, held in registers from the single load: no global atomics, no second read of the keys, no launch
+// boundary between count, plan and placement (rounds 1-3: three launches -- k_l2_count / k_seg_plan / k_l2_place, blocks taking
+// fixed-size slices of the level-1 output, every partition cut in two by a slice boundary, ranges reserved with a returning
+// global atomic per touched bucket).  The sorted run of a partition occupies the same range [part_start, part_start + count)
+// as its level-1 run, in bucket order: the copy-out is one coalesced stream.
+// Work stays balanced for any digit distribution: a block takes at most TE_L2_CAP entries.  A partition with more (the top
+// window of a 253-bit scalar has only ~4.8k of its 32k buckets occupied -- 19 partitions of 55k entries; skewed scalars in
+// general) is cut into PIECES of TE_L2_CAP entries, piece 0 for the partition's own block, the others for the "extra" blocks
+// behind the P partition blocks of the grid (block P + x takes the x-th overflow piece of the window: it finds it by scanning
+// the P partition counts).  Pieces of such a partition are counted into bucket_count with global atomics, the block that
+// counts the last piece plans the partition (hand-over through device-scope accesses, see ld_agent), and their placement --
+// ranges reserved with one returning atomic per touched bucket -- happens in the next launch (k_l2_place_order), beside
+// the segment schedule.  With well-spread digits only the top window has such partitions.
+//   k_l2_local       : grid (P + X, nw), X = n / TE_L2_CAP + 1 extra blocks
+//   k_l2_place_order : grid (order_cols + P + X, nw): segment schedule + placement of the pieces of multi-piece partitions
+#define TE_L2_CAP 9208u          // entries per piece (multiple of 8); n/P = 8192 at n = 2^20: +11 sigma of its Poisson spread
+#define TE_L2_LIST (TE_L2_CAP + 8u)
 
-// loads the 16-byte groups covering entries [a, b) of a row (<= TE_SLICE + 8 entries), 5 groups per thread
+// loads the 16-byte groups covering entries [a, b) of a row (<= TE_L2_CAP + 8 entries), 5 groups per thread
 struct piece_regs { uint4 k[5], ia[5], ib[5]; };
 __device__ __forceinline__ void load_piece(const uint16_t* __restrict__ keys_row, const uint32_t* __restrict__ idx_row, uint32_t a, uint32_t b,
                                            uint32_t t, bool with_idx, piece_regs& r, uint32_t& head, uint32_t& total) {
@@ -442,115 +443,24 @@ __device__ __forceinline__ void load_piece(const uint16_t* __restrict__ keys_row
     if (with_idx) { r.ia[c] = i4[2 * gi]; r.ib[c] = i4[2 * gi + 1]; }
   }
 }
+static_assert(5u * 256u * 8u >= TE_L2_CAP + 8u, "five groups per thread hold a piece");
 
-// first partition whose end lies beyond position s (partitions are back to back: start[p+1] = start[p] + count[p])
-__device__ __forceinline__ uint32_t find_partition(const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ pcount, uint32_t P, uint32_t s) {
-  uint32_t lo = 0, hi = P;          // invariant: end(lo-1) <= s
-  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (pstart[mid] + pcount[mid] <= s) lo = mid + 1; else hi = mid; }
-  return lo;
-}
-
-// grid (nslices, nw), block 256
-__global__ void __launch_bounds__(256) k_l2_count(const uint16_t* __restrict__ part_keys, const uint32_t* __restrict__ part_idx,
-                                                  const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ part_count,
-                                                  uint32_t* __restrict__ bucket_count, sort_geom g) {
-  __shared__ uint32_t cnt_s[256];
-  const uint32_t k = blockIdx.y, t = threadIdx.x;
-  const uint32_t* ps = part_start + k * g.P; const uint32_t* pc = part_count + k * g.P;
-  const uint32_t row_total = ps[g.P - 1] + pc[g.P - 1];
-  uint32_t s0 = blockIdx.x * g.slice;
-  const uint32_t s1 = min(row_total, s0 + g.slice);
-  if (s0 >= s1) return;
-  const uint16_t* keys_row = part_keys + (size_t)k * g.nst; const uint32_t* idx_row = part_idx + (size_t)k * g.nst;
-  uint32_t p = find_partition(ps, pc, g.P, s0);
-  cnt_s[t] = 0u;
+// Which piece does block bx of a window's grid row work on?  bx < P: piece 0 of partition bx.  bx >= P: the (bx - P)-th overflow
+// piece of the window -- pieces 1.. of the partitions with more than TE_L2_CAP entries, in partition order; false when there
+// are fewer.  All 256 threads call (block scan inside); pj: 2 words of LDS, sm: 17.
+__device__ __forceinline__ bool l2_piece_of_block(uint32_t bx, const uint32_t* __restrict__ pc, uint32_t P, uint32_t* sm, uint32_t* pj, uint32_t& p, uint32_t& j) {
+  if (bx < P) { p = bx; j = 0u; return true; }
+  const uint32_t t = threadIdx.x, x = bx - P;
+  const uint32_t c = t < P ? pc[t] : 0u;
+  const uint32_t ov = c ? (c + TE_L2_CAP - 1u) / TE_L2_CAP - 1u : 0u;
+  uint32_t tot;
+  const uint32_t ex = block_excl_scan(ov, sm, tot);
+  if (x >= tot) return false;                              // uniform
+  if (x >= ex && x < ex + ov) { pj[0] = t; pj[1] = x - ex + 1u; }
   __syncthreads();
-  while (s0 < s1) {
-    const uint32_t pe = ps[p] + pc[p], e1 = min(s1, pe);
-    if (e1 <= s0) { p++; continue; }                 // empty partition (uniform branch)
-    piece_regs r; uint32_t head, total;
-    load_piece(keys_row, idx_row, s0, e1, t, false, r, head, total);
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-      uint32_t kv[8]; unpack8(r.k[c], kv);
-      const uint32_t e0 = ((uint32_t)c * 256u + t) * 8u;
-#pragma unroll
-      for (int e = 0; e < 8; e++) { const uint32_t pos = e0 + (uint32_t)e; if (pos >= head && pos < total) atomicAdd(&cnt_s[kv[e] & 0x7fffu], 1u); }
-    }
-    __syncthreads();
-    const uint32_t c0 = cnt_s[t];
-    cnt_s[t] = 0u;                                      // for the block's next piece (two barriers per piece, not three)
-    if (c0) atomicAdd(&bucket_count[(size_t)k * g.B + (size_t)p * g.S + t], c0);
-    __syncthreads();
-    s0 = e1; p++;
-  }
-}
-
-// LDS of one level-2 placement block, in words: four 256-entry tables, the piece's entries and their buckets, scan scratch
-#define TE_PLACE_LDS_WORDS (4u * 256u + (TE_SLICE + 8u) + (TE_SLICE + 8u) / 4u + 2u + 17u)
-// slice `slice_id` of local window k (block of 256 threads; lds: TE_PLACE_LDS_WORDS words)
-__device__ __forceinline__ void l2_place_block(uint32_t slice_id, uint32_t k, uint32_t* __restrict__ lds,
-                                               const uint16_t* __restrict__ part_keys, const uint32_t* __restrict__ part_idx,
-                                               const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ part_count,
-                                               uint32_t* __restrict__ bucket_cursor, uint32_t* __restrict__ sorted, const sort_geom& g) {
-  uint32_t* const cnt_s = lds; uint32_t* const lex_s = lds + 256; uint32_t* const off_s = lds + 512; uint32_t* const gbase_s = lds + 768;
-  uint32_t* const list = lds + 1024;
-  uint8_t* const list_b = reinterpret_cast<uint8_t*>(list + (TE_SLICE + 8u));
-  uint32_t* const sm = list + (TE_SLICE + 8u) + (TE_SLICE + 8u) / 4u + 2u;
-  const uint32_t t = threadIdx.x;
-  const uint32_t* ps = part_start + k * g.P; const uint32_t* pc = part_count + k * g.P;
-  const uint32_t row_total = ps[g.P - 1] + pc[g.P - 1];
-  uint32_t s0 = slice_id * g.slice;
-  const uint32_t s1 = min(row_total, s0 + g.slice);
-  if (s0 >= s1) return;
-  const uint16_t* keys_row = part_keys + (size_t)k * g.nst; const uint32_t* idx_row = part_idx + (size_t)k * g.nst;
-  uint32_t* out = sorted + (size_t)k * g.n;
-  uint32_t p = find_partition(ps, pc, g.P, s0);
-  cnt_s[t] = 0u;
+  p = pj[0]; j = pj[1];
   __syncthreads();
-  while (s0 < s1) {
-    const uint32_t pe = ps[p] + pc[p], e1 = min(s1, pe), len = e1 - s0;
-    if (e1 <= s0) { p++; continue; }                 // empty partition (uniform branch)
-    piece_regs r; uint32_t head, total;
-    load_piece(keys_row, idx_row, s0, e1, t, true, r, head, total);
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-      uint32_t kv[8]; unpack8(r.k[c], kv);
-      const uint32_t e0 = ((uint32_t)c * 256u + t) * 8u;
-#pragma unroll
-      for (int e = 0; e < 8; e++) { const uint32_t pos = e0 + (uint32_t)e; if (pos >= head && pos < total) atomicAdd(&cnt_s[kv[e] & 0x7fffu], 1u); }
-    }
-    __syncthreads();
-    wave0_excl_scan(cnt_s, lex_s, 256u, &sm[16]);      // the first wave scans the 256 bucket counts; five barriers per piece, not eight
-    {
-      const uint32_t c0 = cnt_s[t];                    // (reserving the output ranges needs only the counts: it overlaps the scan)
-      gbase_s[t] = c0 ? atomicAdd(&bucket_cursor[(size_t)k * g.B + (size_t)p * g.S + t], c0) : 0u;
-    }
-    __syncthreads();
-    off_s[t] = lex_s[t];
-    gbase_s[t] -= lex_s[t];                             // global position of LDS slot s of bucket t: s + gbase_s[t]
-    cnt_s[t] = 0u;                                      // for the block's next piece
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-      uint32_t kv[8]; unpack8(r.k[c], kv);
-      const uint32_t iv[8] = {r.ia[c].x, r.ia[c].y, r.ia[c].z, r.ia[c].w, r.ib[c].x, r.ib[c].y, r.ib[c].z, r.ib[c].w};
-      const uint32_t e0 = ((uint32_t)c * 256u + t) * 8u;
-#pragma unroll
-      for (int e = 0; e < 8; e++) {
-        const uint32_t pos = e0 + (uint32_t)e;
-        if (pos >= head && pos < total) {
-          const uint32_t b = kv[e] & 0x7fffu;
-          const uint32_t slot = atomicAdd(&off_s[b], 1u);      // (keeping the ranks of the counting round instead was measured: no gain, 168 VGPRs)
-          list[slot] = iv[e] | ((kv[e] >> 15) << 31); list_b[slot] = (uint8_t)b;
-        }
-      }
-    }
-    __syncthreads();
-    for (uint32_t s = t; s < len; s += 256u) out[gbase_s[list_b[s]] + s] = list[s];
-    __syncthreads();
-    s0 = e1; p++;
-  }
+  return true;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -562,7 +472,7 @@ __device__ __forceinline__ void l2_place_block(uint32_t slice_id, uint32_t k, ui
 //    duration on its own -- every 253-bit scalar does this: its top window has only ~4.8k occupied buckets of ~219
 //    entries (1.13 ms of serial additions against ~1 ms for everything else); skewed scalars do it in general.
 // Buckets split into several segments are summed afterwards by k_seg_combine*.
-//   k_seg_plan     : one block per level-1 partition, one thread per bucket, after k_l2_count: bucket_start / bucket_cursor
+//   seg_plan_block : one block per level-1 partition, one thread per bucket, inside k_l2_local: bucket_start / bucket_cursor
 //                    (= part_start + scan of the partition's counts -- no scan across blocks), seg_base (= seg_part_base +
 //                    scan of the segments per bucket), the segment records (bucket, length), the histogram of the
 //                    lengths and the lists of split buckets.  Segment ids are dense inside a partition; the ids between
@@ -576,69 +486,144 @@ __device__ __forceinline__ void l2_place_block(uint32_t slice_id, uint32_t k, ui
 // The histogram of segment lengths is kept in TE_HIST_COPIES copies (block b adds to copy b mod copies; k_order_scatter sums
 // them): 2048 blocks adding to the same ~60 hot addresses cost 28 us of serialised atomics with a single copy.
 #define TE_HIST_COPIES 32u
-// (Round 4 measured the count and the plan as ONE launch -- the block that counts a partition's last piece plans it, hand-over
-// through device-scope atomics: 32.8 us against 12 + 9 at n = 2^20, 24.3 against 6.8 + 6.0 at 2^16.  A block then runs
-// "count, wait for its atomics, plan" twice in a row where two launches run 2048 + 2048 blocks side by side; the launch boundary
-// is cheaper.  profiles/r04_count_plan_fusion_experiment.txt.)
-// grid (P, nw), block S (= buckets per partition, <= 256)
-__global__ void __launch_bounds__(256) k_seg_plan(const uint32_t* __restrict__ bucket_count, const uint32_t* __restrict__ part_start,
-                                                  const uint32_t* __restrict__ part_count, const uint32_t* __restrict__ seg_part_base,
-                                                  uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ bucket_cursor,
-                                                  uint32_t* __restrict__ seg_base, uint32_t* __restrict__ seg_bucket, uint32_t* __restrict__ seg_lenv,
-                                                  uint32_t* __restrict__ size_hist, uint32_t* __restrict__ split_list,
-                                                  uint32_t* __restrict__ split_count /* [0] small, [1] large buckets, [2] large chunks */,
-                                                  uint32_t* __restrict__ chunk_list /* pairs (bucket, first part) */,
-                                                  uint32_t B, uint32_t S, uint32_t seg_len, uint32_t cap_w, uint32_t chunk_cap) {
-  __shared__ uint32_t h[1024];
-  __shared__ uint32_t sm[17];
-  __shared__ uint32_t giant[256 * 3];                   // (bucket, first segment id, count) of the buckets cut into > 16 parts
-  __shared__ uint32_t n_giant;
-  const uint32_t p = blockIdx.x, k = blockIdx.y, t = threadIdx.x, P = gridDim.x;
-  for (uint32_t j = t; j < 1024u; j += blockDim.x) h[j] = 0u;
-  if (t == 0) n_giant = 0u;
-  const uint32_t g = k * B + p * S + t;
-  const uint32_t cnt = bucket_count[g];
-  const uint32_t nparts = max(1u, (cnt + seg_len - 1u) / seg_len);
+// Segment plan of partition p of local window k by one block of 256 threads, thread t holding the count of bucket t of the
+// partition (threads t >= S idle along: S < 256 only for windows of fewer than 9 bits).  Returns the bucket's start inside the
+// partition (the exclusive scan of the counts).  L may alias memory the caller uses before and after: the function starts and
+// ends with the block in step.
+struct plan_args {
+  const uint32_t* part_start; const uint32_t* part_count; const uint32_t* seg_part_base;
+  uint32_t *bucket_start, *bucket_cursor, *seg_base, *seg_bucket, *seg_lenv, *size_hist, *split_list;
+  uint32_t* split_count;    // [0] small, [1] large buckets, [2] large chunks
+  uint32_t* chunk_list;     // pairs (bucket, first part)
+  uint32_t seg_len, cap_w, chunk_cap;
+};
+struct plan_lds { uint32_t h[1024]; uint32_t sm[17]; uint32_t giant[256 * 3]; uint32_t n_giant; };
+__device__ __forceinline__ uint32_t seg_plan_block(uint32_t p, uint32_t k, uint32_t cnt_in, const sort_geom& sg, const plan_args& a, plan_lds& L) {
+  const uint32_t t = threadIdx.x, P = sg.P, S = sg.S, B = sg.B, seg_len = a.seg_len;
+  uint32_t* const h = L.h; uint32_t* const sm = L.sm; uint32_t* const giant = L.giant;
+  __syncthreads();                                       // the caller is done with whatever L aliases
+  for (uint32_t j = t; j < 1024u; j += 256u) h[j] = 0u;
+  if (t == 0) L.n_giant = 0u;
+  const bool mine = t < S;
+  const uint32_t g = k * B + p * S + (mine ? t : 0u);
+  const uint32_t cnt = mine ? cnt_in : 0u;
+  const uint32_t nparts = mine ? max(1u, (cnt + seg_len - 1u) / seg_len) : 0u;
   uint32_t bt, bt2;
   const uint32_t ex = block_excl_scan(cnt, sm, bt);
   const uint32_t ex2 = block_excl_scan(nparts, sm, bt2);
-  const uint32_t bs = part_start[k * P + p] + ex, sb = seg_part_base[k * P + p] + ex2;
-  bucket_start[g] = bs; bucket_cursor[g] = bs; seg_base[g] = sb;
-  if (nparts <= TE_COMBINE_SMALL) {
-    for (uint32_t part = 0; part < nparts; part++) {
-      const uint32_t len = cnt > part * seg_len ? min(seg_len, cnt - part * seg_len) : 0u;
-      seg_bucket[sb + part] = g; seg_lenv[sb + part] = len;
-      atomicAdd(&h[min(len, 1023u)], 1u);
+  const uint32_t bs = a.part_start[k * P + p] + ex, sb = a.seg_part_base[k * P + p] + ex2;
+  if (mine) {
+    a.bucket_start[g] = bs; a.bucket_cursor[g] = bs; a.seg_base[g] = sb;
+    if (nparts <= TE_COMBINE_SMALL) {
+      for (uint32_t part = 0; part < nparts; part++) {
+        const uint32_t len = cnt > part * seg_len ? min(seg_len, cnt - part * seg_len) : 0u;
+        a.seg_bucket[sb + part] = g; a.seg_lenv[sb + part] = len;
+        atomicAdd(&h[min(len, 1023u)], 1u);
+      }
+      if (nparts > 1u) a.split_list[atomicAdd(&a.split_count[0], 1u)] = g;
+    } else {
+      const uint32_t j = atomicAdd(&L.n_giant, 1u);
+      giant[3 * j] = g; giant[3 * j + 1] = sb; giant[3 * j + 2] = cnt;
+      atomicAdd(&a.split_count[1], 1u);
     }
-    if (nparts > 1u) split_list[atomicAdd(&split_count[0], 1u)] = g;
-  } else {
-    const uint32_t j = atomicAdd(&n_giant, 1u);
-    giant[3 * j] = g; giant[3 * j + 1] = sb; giant[3 * j + 2] = cnt;
-    atomicAdd(&split_count[1], 1u);
   }
   // ids this partition does not use: [first + segments, first + S + floor(part_count / seg_len))
   {
     // (the last partition also covers the rest of the window's id range, up to (k + 1) * cap_w)
-    const uint32_t first = seg_part_base[k * P + p], used = bt2;
-    const uint32_t cap = p + 1u == P ? (k + 1u) * cap_w - first : S + part_count[k * P + p] / seg_len;
-    for (uint32_t j = used + t; j < cap; j += blockDim.x) { seg_bucket[first + j] = TE_SEG_INVALID; seg_lenv[first + j] = TE_SEG_INVALID; }
+    const uint32_t first = a.seg_part_base[k * P + p], used = bt2;
+    const uint32_t cap = p + 1u == P ? (k + 1u) * a.cap_w - first : S + a.part_count[k * P + p] / seg_len;
+    for (uint32_t j = used + t; j < cap; j += 256u) { a.seg_bucket[first + j] = TE_SEG_INVALID; a.seg_lenv[first + j] = TE_SEG_INVALID; }
   }
   __syncthreads();
   // giant buckets: the whole block writes their segment records; one chunk entry per 1024 parts (k_seg_combine_all)
-  const uint32_t ng = n_giant;
+  const uint32_t ng = L.n_giant;
   for (uint32_t j = 0; j < ng; j++) {
     const uint32_t gg = giant[3 * j], sb0 = giant[3 * j + 1], c0 = giant[3 * j + 2];
     const uint32_t np = (c0 + seg_len - 1u) / seg_len;
-    for (uint32_t part = t; part < np; part += blockDim.x) {
+    for (uint32_t part = t; part < np; part += 256u) {
       const uint32_t len = min(seg_len, c0 - part * seg_len);
-      seg_bucket[sb0 + part] = gg; seg_lenv[sb0 + part] = len;
+      a.seg_bucket[sb0 + part] = gg; a.seg_lenv[sb0 + part] = len;
       atomicAdd(&h[min(len, 1023u)], 1u);
-      if ((part & 1023u) == 0) { const uint32_t ci = atomicAdd(&split_count[2], 1u); if (ci < chunk_cap) { chunk_list[2 * ci] = gg; chunk_list[2 * ci + 1] = part; } }
+      if ((part & 1023u) == 0) { const uint32_t ci = atomicAdd(&a.split_count[2], 1u); if (ci < a.chunk_cap) { a.chunk_list[2 * ci] = gg; a.chunk_list[2 * ci + 1] = part; } }
     }
   }
   __syncthreads();
-  uint32_t* my_hist = size_hist + ((blockIdx.y * gridDim.x + blockIdx.x) % TE_HIST_COPIES) * 1024u;
-  for (uint32_t j = t; j < 1024u; j += blockDim.x) if (h[j]) atomicAdd(&my_hist[j], h[j]);
+  uint32_t* my_hist = a.size_hist + ((k * P + p) % TE_HIST_COPIES) * 1024u;
+  for (uint32_t j = t; j < 1024u; j += 256u) if (h[j]) atomicAdd(&my_hist[j], h[j]);
+  __syncthreads();                                       // L is free again
+  return ex;
+}
+
+struct l2_args {
+  const uint16_t* part_keys; const uint32_t* part_idx; const uint32_t* part_start; const uint32_t* part_count;
+  uint32_t* bucket_count; uint32_t* sorted;
+  uint32_t* part_ticket;    // [window][partition], zeroed per MSM: pieces of a multi-piece partition counted so far
+  sort_geom g; plan_args pa;
+};
+// LDS of a k_l2_local block, in words: three 256-entry tables, scan scratch, the piece's sorted entries (the plan's tables
+// alias them: the plan runs between the count and the placement)
+#define TE_L2A_LDS_WORDS (3u * 256u + 32u + TE_L2_LIST)
+static_assert(sizeof(plan_lds) <= TE_L2_LIST * 4u, "the plan's LDS fits into the list area");
+// grid (P + X, nw), block 256: see "level 2" above
+__global__ void __launch_bounds__(256, 3) k_l2_local(l2_args a) {
+  __shared__ uint32_t lds[TE_L2A_LDS_WORDS];
+  uint32_t* const cnt_s = lds; uint32_t* const off_s = lds + 256; uint32_t* const sm = lds + 768; uint32_t* const pj = lds + 768 + 17;
+  uint32_t* const list = lds + 768 + 32;
+  plan_lds& PL = *reinterpret_cast<plan_lds*>(list);
+  const sort_geom& g = a.g;
+  const uint32_t k = blockIdx.y, t = threadIdx.x;
+  const uint32_t* ps = a.part_start + k * g.P; const uint32_t* pc = a.part_count + k * g.P;
+  uint32_t p, j;
+  if (!l2_piece_of_block(blockIdx.x, pc, g.P, sm, pj, p, j)) return;
+  const uint32_t cntp = pc[p], pb = ps[p];
+  if (cntp == 0u) { (void)seg_plan_block(p, k, 0u, g, a.pa, PL); return; }       // an empty partition: its buckets' (empty) segments
+  const bool single = cntp <= TE_L2_CAP;                                         // uniform
+  const uint32_t a0 = pb + j * TE_L2_CAP, b0 = min(pb + cntp, a0 + TE_L2_CAP);
+  const uint16_t* keys_row = a.part_keys + (size_t)k * g.nst; const uint32_t* idx_row = a.part_idx + (size_t)k * g.nst;
+  cnt_s[t] = 0u;
+  __syncthreads();
+  piece_regs r; uint32_t head, total;
+  load_piece(keys_row, idx_row, a0, b0, t, single, r, head, total);
+#pragma unroll
+  for (int c = 0; c < 5; c++) {
+    uint32_t kv[8]; unpack8(r.k[c], kv);
+    const uint32_t e0 = ((uint32_t)c * 256u + t) * 8u;
+#pragma unroll
+    for (int e = 0; e < 8; e++) { const uint32_t pos = e0 + (uint32_t)e; if (pos >= head && pos < total) atomicAdd(&cnt_s[kv[e] & 0x7fffu], 1u); }
+  }
+  __syncthreads();
+  const uint32_t c0 = cnt_s[t];
+  const size_t gb = (size_t)k * g.B + (size_t)p * g.S + t;        // bucket t of the partition (t < S)
+  if (!single) {
+    // a piece of a multi-piece partition: counts to memory, the block that counts the last piece plans the partition
+    if (c0) atomicAdd(&a.bucket_count[gb], c0);
+    wait_own_accesses();                                // the atomic adds have been performed before the piece is counted as done
+    __syncthreads();
+    if (t == 0) pj[2] = (atomicAdd(&a.part_ticket[k * g.P + p], 1u) + 1u == (cntp + TE_L2_CAP - 1u) / TE_L2_CAP) ? 1u : 0u;
+    __syncthreads();
+    if (pj[2]) (void)seg_plan_block(p, k, t < g.S ? ld_agent(a.bucket_count + gb) : 0u, g, a.pa, PL);      // uniform
+    return;
+  }
+  // the whole partition is in this block's registers: plan it from the counts at hand, then place it
+  if (t < g.S) a.bucket_count[gb] = c0;
+  const uint32_t ex = seg_plan_block(p, k, c0, g, a.pa, PL);
+  if (t < g.S) a.pa.bucket_cursor[gb] = pb + ex + c0;   // "everything placed" (the arrival counter of k_seg_combine_all starts from there)
+  off_s[t] = ex;                                        // next free LDS slot of bucket t
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 5; c++) {
+    uint32_t kv[8]; unpack8(r.k[c], kv);
+    const uint32_t iv[8] = {r.ia[c].x, r.ia[c].y, r.ia[c].z, r.ia[c].w, r.ib[c].x, r.ib[c].y, r.ib[c].z, r.ib[c].w};
+    const uint32_t e0 = ((uint32_t)c * 256u + t) * 8u;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const uint32_t pos = e0 + (uint32_t)e;
+      if (pos >= head && pos < total) list[atomicAdd(&off_s[kv[e] & 0x7fffu], 1u)] = iv[e] | ((kv[e] >> 15) << 31);
+    }
+  }
+  __syncthreads();
+  uint32_t* out = a.sorted + (size_t)k * g.n + pb;      // the partition's sorted run: same range as its level-1 run, in bucket order
+  for (uint32_t s = t; s < cntp; s += 256u) out[s] = list[s];
 }
 
 // Counting sort of the valid segment ids by descending length: block `ob` of `nob` (256 threads; lds: 2 * 1024 + 17 words);
@@ -681,19 +666,82 @@ __device__ __forceinline__ void order_scatter_block(uint32_t ob, uint32_t nob, u
   }
 }
 
-// Level-2 placement and the segment schedule in ONE launch: both need only k_seg_plan's output and neither needs the other,
-// and the schedule is latency-bound (a few dependent rounds over 3 MB: 20 us as a launch of its own, between k_l2_place
-// and the record conversion on one MSM's critical path).  grid (order_cols + nslices, nw), block 256: blocks with
-// blockIdx.x < order_cols sort segments (order_cols * nw of them, dispatched first), the others place a slice each.
+// Placement of ONE piece [a0, b0) of a multi-piece partition p of local window k (block of 256 threads; lds: TE_PLACE_LDS_WORDS
+// words): LDS count, reserve [base, base + c) in every touched bucket with one returning atomicAdd on bucket_cursor, sort the
+// piece by bucket in LDS and copy each run to its reserved range.
+#define TE_PLACE_LDS_WORDS (4u * 256u + TE_L2_LIST + TE_L2_LIST / 4u + 2u + 17u)
+__device__ __forceinline__ void l2_place_piece(uint32_t p, uint32_t k, uint32_t a0, uint32_t b0, uint32_t* __restrict__ lds,
+                                               const uint16_t* __restrict__ part_keys, const uint32_t* __restrict__ part_idx,
+                                               uint32_t* __restrict__ bucket_cursor, uint32_t* __restrict__ sorted, const sort_geom& g) {
+  uint32_t* const cnt_s = lds; uint32_t* const lex_s = lds + 256; uint32_t* const off_s = lds + 512; uint32_t* const gbase_s = lds + 768;
+  uint32_t* const list = lds + 1024;
+  uint8_t* const list_b = reinterpret_cast<uint8_t*>(list + TE_L2_LIST);
+  uint32_t* const sm = list + TE_L2_LIST + TE_L2_LIST / 4u + 2u;
+  const uint32_t t = threadIdx.x, len = b0 - a0;
+  const uint16_t* keys_row = part_keys + (size_t)k * g.nst; const uint32_t* idx_row = part_idx + (size_t)k * g.nst;
+  uint32_t* out = sorted + (size_t)k * g.n;
+  cnt_s[t] = 0u;
+  __syncthreads();
+  piece_regs r; uint32_t head, total;
+  load_piece(keys_row, idx_row, a0, b0, t, true, r, head, total);
+#pragma unroll
+  for (int c = 0; c < 5; c++) {
+    uint32_t kv[8]; unpack8(r.k[c], kv);
+    const uint32_t e0 = ((uint32_t)c * 256u + t) * 8u;
+#pragma unroll
+    for (int e = 0; e < 8; e++) { const uint32_t pos = e0 + (uint32_t)e; if (pos >= head && pos < total) atomicAdd(&cnt_s[kv[e] & 0x7fffu], 1u); }
+  }
+  __syncthreads();
+  wave0_excl_scan(cnt_s, lex_s, 256u, &sm[16]);        // the first wave scans the 256 bucket counts
+  {
+    const uint32_t c0 = cnt_s[t];                      // (reserving the output ranges needs only the counts: it overlaps the scan)
+    gbase_s[t] = c0 ? atomicAdd(&bucket_cursor[(size_t)k * g.B + (size_t)p * g.S + t], c0) : 0u;
+  }
+  __syncthreads();
+  off_s[t] = lex_s[t];
+  gbase_s[t] -= lex_s[t];                               // global position of LDS slot s of bucket t: s + gbase_s[t]
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 5; c++) {
+    uint32_t kv[8]; unpack8(r.k[c], kv);
+    const uint32_t iv[8] = {r.ia[c].x, r.ia[c].y, r.ia[c].z, r.ia[c].w, r.ib[c].x, r.ib[c].y, r.ib[c].z, r.ib[c].w};
+    const uint32_t e0 = ((uint32_t)c * 256u + t) * 8u;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const uint32_t pos = e0 + (uint32_t)e;
+      if (pos >= head && pos < total) {
+        const uint32_t b = kv[e] & 0x7fffu;
+        const uint32_t slot = atomicAdd(&off_s[b], 1u);
+        list[slot] = iv[e] | ((kv[e] >> 15) << 31); list_b[slot] = (uint8_t)b;
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t s = t; s < len; s += 256u) out[gbase_s[list_b[s]] + s] = list[s];
+}
+
+// The segment schedule and the placement of the multi-piece partitions in ONE launch: both need the plans of k_l2_local, neither
+// needs the other, and the schedule is latency-bound (a few dependent rounds over 3 MB: 20 us as a launch of its own).
+// grid (order_cols + P + X, nw), block 256: blocks with blockIdx.x < order_cols sort segments (order_cols * nw of them,
+// dispatched first); the others take the pieces of k_l2_local's grid and leave at once unless theirs belongs to a partition of
+// more than TE_L2_CAP entries (with well-spread digits: the top window's ~115 pieces).
 struct order_args { const uint32_t* lenv; uint32_t ids; const uint32_t* size_hist; uint32_t* rel_cursor; uint32_t* order; uint32_t* num_segments; uint32_t order_cols; };
 __global__ void __launch_bounds__(256, 3) k_l2_place_order(const uint16_t* __restrict__ part_keys, const uint32_t* __restrict__ part_idx,
                                                            const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ part_count,
                                                            uint32_t* __restrict__ bucket_cursor, uint32_t* __restrict__ sorted, sort_geom g, order_args oa) {
   __shared__ uint32_t lds[TE_PLACE_LDS_WORDS];
-  if (blockIdx.x < oa.order_cols)
+  if (blockIdx.x < oa.order_cols) {
     order_scatter_block(blockIdx.y * oa.order_cols + blockIdx.x, gridDim.y * oa.order_cols, lds, oa.lenv, oa.ids, oa.size_hist, oa.rel_cursor, oa.order, oa.num_segments);
-  else
-    l2_place_block(blockIdx.x - oa.order_cols, blockIdx.y, lds, part_keys, part_idx, part_start, part_count, bucket_cursor, sorted, g);
+    return;
+  }
+  const uint32_t k = blockIdx.y;
+  const uint32_t* pc = part_count + k * g.P;
+  uint32_t p, j;
+  if (!l2_piece_of_block(blockIdx.x - oa.order_cols, pc, g.P, lds, lds + 32, p, j)) return;
+  const uint32_t cntp = pc[p], pb = part_start[k * g.P + p];
+  if (cntp <= TE_L2_CAP) return;                         // sorted by its own block of k_l2_local (uniform)
+  const uint32_t a0 = pb + j * TE_L2_CAP;
+  l2_place_piece(p, k, a0, min(pb + cntp, a0 + TE_L2_CAP), lds, part_keys, part_idx, bucket_cursor, sorted, g);
 }
 
 // ================================================================================================

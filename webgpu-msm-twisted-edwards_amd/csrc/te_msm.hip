@@ -61,7 +61,6 @@ struct plan_t {
   uint32_t CH = 0, chunk_len = 0, nst = 0;   // level-1 chunks per window (chunk_len multiple of 4096); padded row stride
   uint32_t seg_len = 64;
   uint32_t S = 0, logS = 0, P = 0;   // level-1 partition: S buckets each, P = B/S partitions per window
-  uint32_t slice = 0;                // level 2: entries per block (about one partition's worth, 1024..TE_SLICE)
 };
 
 struct graph_key { const void *pts, *sc, *out; uint64_t n, generation; int c, w_first, w_step, seg_len, sort; };
@@ -89,6 +88,7 @@ struct workset_t {
   size_t zero_clean_words = 0;        // words of d_zero known to be zero on the set's stream: the block is cleared AFTER an MSM's read-back
                                       // (finish_sequence), so that the next MSM on the set starts with its first kernel, not a fill
   uint32_t *d_err = nullptr, *d_num_seg = nullptr, *d_size_hist = nullptr, *d_size_cursor = nullptr;
+  uint32_t* d_part_ticket = nullptr;  // [window][partition]: pieces of a multi-piece partition counted so far (k_l2_local), behind bucket_count in the zeroed block
   uint8_t* d_partials = nullptr;      // = d_zero + Z_ROWS: TE_MAX_WINDOWS rows
   uint32_t* h_err = nullptr;          // pinned: mirror of d_zero[0 .. Z_ROWS + rows)
   uint8_t* h_partials = nullptr;      // = h_err + Z_ROWS
@@ -242,11 +242,6 @@ void make_plan(const te_ctx* ctx, const gpu_t& d, uint64_t n, plan_t& p, int for
     p.seg_len = (uint32_t)s2;
   }
   p.P = p.B / p.S; p.logS = ilog2(p.S);
-  {
-    uint64_t per = (n + p.P - 1) / p.P;                         // entries of one partition for well-spread digits
-    per = (per + 1023u) & ~(uint64_t)1023u;
-    p.slice = (uint32_t)std::min<uint64_t>(TE_SLICE, std::max<uint64_t>(1024u, per));
-  }
 }
 
 template <typename T> int ensure(te_ctx* ctx, workset_t& ws, T*& ptr, size_t& cap_bytes, size_t need_elems) {
@@ -270,11 +265,11 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, workset_t& ws, uint64_t n, const plan_
   if ((rc = ensure(ctx, ws, ws.d_sorted, ws.cap[2], nd))) return rc;
   {
     const size_t c1 = (size_t)p.nw * p.CH * p.P;
-    ws.zero_words = Z_END + c1 + wb;
+    ws.zero_words = Z_END + c1 + wb + (size_t)p.nw * p.P;
     { const uint32_t* before = ws.d_zero; if ((rc = ensure(ctx, ws, ws.d_zero, ws.cap[3], ws.zero_words))) return rc; if (ws.d_zero != before) ws.zero_clean_words = 0; }
     ws.d_err = ws.d_zero; ws.d_num_seg = ws.d_zero + 1; ws.d_size_hist = ws.d_zero + Z_HIST; ws.d_size_cursor = ws.d_zero + Z_CURSOR;
     ws.d_partials = reinterpret_cast<uint8_t*>(ws.d_zero + Z_ROWS);
-    ws.d_counts1 = ws.d_zero + Z_END; ws.d_bucket_count = ws.d_counts1 + c1;
+    ws.d_counts1 = ws.d_zero + Z_END; ws.d_bucket_count = ws.d_counts1 + c1; ws.d_part_ticket = ws.d_bucket_count + wb;
   }
   if ((rc = ensure(ctx, ws, ws.d_bucket_start, ws.cap[5], wb))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_bucket_cursor, ws.cap[16], wb))) return rc;
@@ -384,7 +379,7 @@ struct msm_launch {
     ws.zero_clean_words = 0;
     mark(ST_DIGITS);
     te::sort_geom sg;
-    sg.n = n32; sg.nst = p.nst; sg.B = p.B; sg.logS = p.logS; sg.S = p.S; sg.P = p.P; sg.CH = p.CH; sg.chunk_len = p.chunk_len; sg.half = p.signed_digits ? p.B : 0u; sg.slice = p.slice;
+    sg.n = n32; sg.nst = p.nst; sg.B = p.B; sg.logS = p.logS; sg.S = p.S; sg.P = p.P; sg.CH = p.CH; sg.chunk_len = p.chunk_len; sg.half = p.signed_digits ? p.B : 0u;
     if (p.nw > 0) {
       te::digits_params prm; memset(&prm, 0, sizeof prm);
       if (p.signed_digits) for (int w = 0; w < p.W; w++) { const int bit = w * p.c + p.c - 1; if (bit < 320) prm.half[bit >> 5] |= 1u << (bit & 31); }
@@ -430,19 +425,23 @@ struct msm_launch {
     }
     mark(ST_BSORT);
     if (p.nw > 0) {
-      const uint32_t nslices = (p.nst + p.slice - 1u) / p.slice;
-      hipLaunchKernelGGL(te::k_l2_count, dim3(nslices, p.nw), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx, ws.d_part_start,
-                         ws.d_part_count, ws.d_bucket_count, sg);
-      // d_num_seg[1..3] = split / giant bucket counters, zeroed with the rest
-      hipLaunchKernelGGL(te::k_seg_plan, dim3(p.P, p.nw), dim3(p.S), 0, stream, ws.d_bucket_count, ws.d_part_start, ws.d_part_count, ws.d_seg_part_base,
-                         ws.d_bucket_start, ws.d_bucket_cursor, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv, ws.d_size_hist, ws.d_split_list,
-                         ws.d_num_seg + 1, ws.d_chunk_list, p.B, p.S, p.seg_len, cap_w, chunk_cap());
-      // level-2 placement + the segment schedule (counts the valid segments, d_num_seg[0]; with "sort_buckets" = 0 the
-      // schedule is simply not used) in one launch
+      // level 2: one block per partition (+ extra blocks for the pieces of over-long partitions) counts, plans and places
+      // it; d_num_seg[1..3] = split / giant bucket counters, zeroed with the rest
+      const uint32_t l2_blocks = p.P + n32 / TE_L2_CAP + 1u;
+      te::l2_args la;
+      la.part_keys = ws.d_part_keys; la.part_idx = ws.d_part_idx; la.part_start = ws.d_part_start; la.part_count = ws.d_part_count;
+      la.bucket_count = ws.d_bucket_count; la.sorted = ws.d_sorted; la.part_ticket = ws.d_part_ticket; la.g = sg;
+      la.pa.part_start = ws.d_part_start; la.pa.part_count = ws.d_part_count; la.pa.seg_part_base = ws.d_seg_part_base;
+      la.pa.bucket_start = ws.d_bucket_start; la.pa.bucket_cursor = ws.d_bucket_cursor; la.pa.seg_base = ws.d_seg_base; la.pa.seg_bucket = ws.d_seg_bucket;
+      la.pa.seg_lenv = ws.d_seg_lenv; la.pa.size_hist = ws.d_size_hist; la.pa.split_list = ws.d_split_list; la.pa.split_count = ws.d_num_seg + 1;
+      la.pa.chunk_list = ws.d_chunk_list; la.pa.seg_len = p.seg_len; la.pa.cap_w = cap_w; la.pa.chunk_cap = chunk_cap();
+      hipLaunchKernelGGL(te::k_l2_local, dim3(l2_blocks, p.nw), dim3(256), 0, stream, la);
+      // the segment schedule (counts the valid segments, d_num_seg[0]; with "sort_buckets" = 0 the schedule is simply not used)
+      // + the placement of the pieces of over-long partitions in one launch
       te::order_args oa;
       oa.lenv = ws.d_seg_lenv; oa.ids = smax(); oa.size_hist = ws.d_size_hist; oa.rel_cursor = ws.d_size_cursor; oa.order = ws.d_order; oa.num_segments = ws.d_num_seg;
       oa.order_cols = (uint32_t)std::min(64, std::max(1, 128 / p.nw));
-      hipLaunchKernelGGL(te::k_l2_place_order, dim3(oa.order_cols + nslices, p.nw), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx, ws.d_part_start,
+      hipLaunchKernelGGL(te::k_l2_place_order, dim3(oa.order_cols + l2_blocks, p.nw), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx, ws.d_part_start,
                          ws.d_part_count, ws.d_bucket_cursor, ws.d_sorted, sg, oa);
     }
     mark(ST_ORDER);
@@ -825,7 +824,7 @@ void free_workset_buffers(workset_t& ws) {      // the big device buffers of a w
   for (void** q : ptrs) if (*q) { (void)hipFree(*q); *q = nullptr; }
   memset(ws.cap, 0, sizeof ws.cap); ws.cap_in_points = ws.cap_in_scalars = 0;
   ws.zero_words = ws.zero_clean_words = 0;
-  ws.d_err = ws.d_num_seg = ws.d_size_hist = ws.d_size_cursor = ws.d_counts1 = ws.d_bucket_count = nullptr; ws.d_partials = nullptr;
+  ws.d_err = ws.d_num_seg = ws.d_size_hist = ws.d_size_cursor = ws.d_counts1 = ws.d_bucket_count = ws.d_part_ticket = nullptr; ws.d_partials = nullptr;
   if (ws.g_front) { (void)hipGraphExecDestroy(ws.g_front); ws.g_front = nullptr; }
   if (ws.g_back) { (void)hipGraphExecDestroy(ws.g_back); ws.g_back = nullptr; }
   ws.generation++; ws.used = false;
