@@ -726,12 +726,26 @@ __device__ __forceinline__ void l2_place_piece(uint32_t p, uint32_t k, uint32_t 
 // dispatched first); the others take the pieces of k_l2_local's grid and leave at once unless theirs belongs to a partition of
 // more than TE_L2_CAP entries (with well-spread digits: the top window's ~115 pieces).
 struct order_args { const uint32_t* lenv; uint32_t ids; const uint32_t* size_hist; uint32_t* rel_cursor; uint32_t* order; uint32_t* num_segments; uint32_t order_cols; };
+// ... and, for device-resident Twisted-Edwards inputs, the points -> records conversion as a third kind of block behind them
+// (prep.blocks of them, dealt over the grid rows): it needs nothing of the sort, is bound by memory and four products per
+// point, and hides the latency-bound schedule completely (rounds 2-3 had it share the launch of the sort's FIRST level, where
+// both want the memory system: 84 us together against 53 + 39 apart; beside the schedule the pair costs ~45 instead of 26 + 39).
+struct prep_args { batch_ptrs in; batch_slabs row_slab; pnt_slot* recs; uint32_t n, blocks_per_row, blocks; };
 __global__ void __launch_bounds__(256, 3) k_l2_place_order(const uint16_t* __restrict__ part_keys, const uint32_t* __restrict__ part_idx,
                                                            const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ part_count,
-                                                           uint32_t* __restrict__ bucket_cursor, uint32_t* __restrict__ sorted, sort_geom g, order_args oa) {
-  __shared__ uint32_t lds[TE_PLACE_LDS_WORDS];
+                                                           uint32_t* __restrict__ bucket_cursor, uint32_t* __restrict__ sorted, sort_geom g, order_args oa,
+                                                           uint32_t l2_blocks, prep_args prep) {
+  __shared__ uint4 lds4[(TE_PLACE_LDS_WORDS + 3u) / 4u > 256u * 8u ? (TE_PLACE_LDS_WORDS + 3u) / 4u : 256u * 8u];
+  uint32_t* const lds = reinterpret_cast<uint32_t*>(lds4);
   if (blockIdx.x < oa.order_cols) {
     order_scatter_block(blockIdx.y * oa.order_cols + blockIdx.x, gridDim.y * oa.order_cols, lds, oa.lenv, oa.ids, oa.size_hist, oa.rel_cursor, oa.order, oa.num_segments);
+    return;
+  }
+  if (blockIdx.x >= oa.order_cols + l2_blocks) {         // conversion blocks (only when the launch carries them)
+    const uint32_t q = (blockIdx.x - oa.order_cols - l2_blocks) * gridDim.y + blockIdx.y;
+    if (q >= prep.blocks) return;
+    const uint32_t row = q / prep.blocks_per_row, blk = q - row * prep.blocks_per_row;
+    prep_points_block(blk, lds4, prep.in.p[row], prep.recs + (size_t)prep.row_slab.s[row] * prep.n, prep.n);
     return;
   }
   const uint32_t k = blockIdx.y;
