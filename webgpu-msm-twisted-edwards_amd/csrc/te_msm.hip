@@ -443,14 +443,12 @@ struct msm_launch {
       oa.lenv = ws.d_seg_lenv; oa.ids = smax(); oa.size_hist = ws.d_size_hist; oa.rel_cursor = ws.d_size_cursor; oa.order = ws.d_order; oa.num_segments = ws.d_num_seg;
       oa.order_cols = (uint32_t)std::min(64, std::max(1, 128 / p.nw));
       te::prep_args pr; memset(&pr, 0, sizeof pr);
-      uint32_t prep_cols = 0;
       if (with_prep == 2) {                                      // the record conversion as further blocks of this launch
         const uint32_t rows = (uint32_t)prep_rows(pr.in, pr.row_slab);
         pr.recs = reinterpret_cast<te::pnt_slot*>(ws.d_recs); pr.n = n32; pr.blocks_per_row = (n32 + 255u) / 256u; pr.blocks = rows * pr.blocks_per_row;
-        prep_cols = (pr.blocks + (uint32_t)p.nw - 1u) / (uint32_t)p.nw;
       }
-      hipLaunchKernelGGL(te::k_l2_place_order, dim3(oa.order_cols + l2_blocks + prep_cols, p.nw), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx, ws.d_part_start,
-                         ws.d_part_count, ws.d_bucket_cursor, ws.d_sorted, sg, oa, l2_blocks, pr);
+      hipLaunchKernelGGL(te::k_l2_place_order, dim3((oa.order_cols + l2_blocks) * (uint32_t)p.nw + pr.blocks), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx,
+                         ws.d_part_start, ws.d_part_count, ws.d_bucket_cursor, ws.d_sorted, sg, oa, l2_blocks, (uint32_t)p.nw, pr);
     }
     mark(ST_ORDER);
     return 0;
