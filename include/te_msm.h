@@ -133,9 +133,8 @@ int te_msm_ticket_wait(te_ctx* ctx, uint64_t ticket);
  *   "prezero"       1 (default) = a work set's block of counters is cleared BEHIND an MSM's read-back, for its next MSM
  *                   (the next MSM starts with its first kernel instead of a fill); 0 = cleared in front of every MSM --
  *                   te_msm_debug_read of "bucket_count" / "num_segments" / "partials" needs 0 (it refuses otherwise)
- *   "fuse_prep"     device-resident Twisted-Edwards inputs: the points -> records conversion shares a launch of the sort --
- *                   2 (default) = the segment schedule's, 1 = the first level's (rounds 2-3); 0 = a launch of its own
- *                   (A/B measurements; env TE_MSM_FUSE_PREP) */
+ *   "fuse_prep"     1 (default) = device-resident Twisted-Edwards inputs: the points -> records conversion shares the launch
+ *                   of the sort's first level; 0 = a launch of its own (A/B measurements; env TE_MSM_FUSE_PREP) */
 int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value);
 int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value);
 

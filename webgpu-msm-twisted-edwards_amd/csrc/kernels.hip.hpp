@@ -722,39 +722,22 @@ __device__ __forceinline__ void l2_place_piece(uint32_t p, uint32_t k, uint32_t 
 
 // The segment schedule and the placement of the multi-piece partitions in ONE launch: both need the plans of k_l2_local, neither
 // needs the other, and the schedule is latency-bound (a few dependent rounds over 3 MB: 20 us as a launch of its own).
-// Blocks of 256 threads: order_cols * nw of them sort segments; (P + X) * nw take the pieces of k_l2_local's grid and leave at once unless theirs belongs to a partition of
+// grid (order_cols + P + X, nw), block 256: blocks with blockIdx.x < order_cols sort segments (order_cols * nw of them,
+// dispatched first); the others take the pieces of k_l2_local's grid and leave at once unless theirs belongs to a partition of
 // more than TE_L2_CAP entries (with well-spread digits: the top window's ~115 pieces).
 struct order_args { const uint32_t* lenv; uint32_t ids; const uint32_t* size_hist; uint32_t* rel_cursor; uint32_t* order; uint32_t* num_segments; uint32_t order_cols; };
-// ... and, for device-resident Twisted-Edwards inputs, the points -> records conversion as a third kind of block behind them
-// (prep.blocks of them, dealt over the grid rows): it needs nothing of the sort, is bound by memory and four products per
-// point, and hides the latency-bound schedule completely (rounds 2-3 had it share the launch of the sort's FIRST level, where
-// both want the memory system: 84 us together against 53 + 39 apart; beside the schedule the pair costs ~45 instead of 26 + 39).
-struct prep_args { batch_ptrs in; batch_slabs row_slab; pnt_slot* recs; uint32_t n, blocks_per_row, blocks; };
-// 1-D grid so that the dispatch order is explicit: first the order_cols * nw schedule blocks (each a chain of dependent rounds:
-// they must start at once -- behind a 2-D grid's earlier rows of conversion blocks they started ~35 us late and the launch took
-// 65 us instead of 45), then the (P + X) * nw piece blocks, then the conversion blocks.
 __global__ void __launch_bounds__(256, 3) k_l2_place_order(const uint16_t* __restrict__ part_keys, const uint32_t* __restrict__ part_idx,
                                                            const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ part_count,
-                                                           uint32_t* __restrict__ bucket_cursor, uint32_t* __restrict__ sorted, sort_geom g, order_args oa,
-                                                           uint32_t l2_blocks, uint32_t nw, prep_args prep) {
-  __shared__ uint4 lds4[(TE_PLACE_LDS_WORDS + 3u) / 4u > 256u * 8u ? (TE_PLACE_LDS_WORDS + 3u) / 4u : 256u * 8u];
-  uint32_t* const lds = reinterpret_cast<uint32_t*>(lds4);
-  const uint32_t n_order = oa.order_cols * nw, n_piece = l2_blocks * nw;
-  if (blockIdx.x < n_order) {
-    order_scatter_block(blockIdx.x, n_order, lds, oa.lenv, oa.ids, oa.size_hist, oa.rel_cursor, oa.order, oa.num_segments);
+                                                           uint32_t* __restrict__ bucket_cursor, uint32_t* __restrict__ sorted, sort_geom g, order_args oa) {
+  __shared__ uint32_t lds[TE_PLACE_LDS_WORDS];
+  if (blockIdx.x < oa.order_cols) {
+    order_scatter_block(blockIdx.y * oa.order_cols + blockIdx.x, gridDim.y * oa.order_cols, lds, oa.lenv, oa.ids, oa.size_hist, oa.rel_cursor, oa.order, oa.num_segments);
     return;
   }
-  if (blockIdx.x >= n_order + n_piece) {                   // conversion blocks (only when the launch carries them)
-    const uint32_t q = blockIdx.x - n_order - n_piece;
-    if (q >= prep.blocks) return;
-    const uint32_t row = q / prep.blocks_per_row, blk = q - row * prep.blocks_per_row;
-    prep_points_block(blk, lds4, prep.in.p[row], prep.recs + (size_t)prep.row_slab.s[row] * prep.n, prep.n);
-    return;
-  }
-  const uint32_t q = blockIdx.x - n_order, k = q % nw, bx = q / nw;
+  const uint32_t k = blockIdx.y;
   const uint32_t* pc = part_count + k * g.P;
   uint32_t p, j;
-  if (!l2_piece_of_block(bx, pc, g.P, lds, lds + 32, p, j)) return;
+  if (!l2_piece_of_block(blockIdx.x - oa.order_cols, pc, g.P, lds, lds + 32, p, j)) return;
   const uint32_t cntp = pc[p], pb = part_start[k * g.P + p];
   if (cntp <= TE_L2_CAP) return;                         // sorted by its own block of k_l2_local (uniform)
   const uint32_t a0 = pb + j * TE_L2_CAP;

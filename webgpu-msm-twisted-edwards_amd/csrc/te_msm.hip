@@ -167,8 +167,7 @@ struct te_ctx {
   int opt_host_chunks = 0;     // te_msm_run: pieces a large host buffer is uploaded and processed in (0 = choose from n)
   int opt_graph = 0;           // replay the launch sequence around k_accumulate as HIP graphs
   int opt_workset = 0;         // work set used by te_msm_run* / te_msm_partial_device
-  int opt_fuse_prep = 2;       // device-resident inputs: convert the points inside a launch of the sort -- 2: beside the segment schedule
-                               // (k_l2_place_order), 1: beside the first level (k_part_scatter_prep, rounds 2-3), 0: a launch of its own
+  int opt_fuse_prep = 1;       // device-resident inputs: convert the points in the launch of the sort's first level (k_part_scatter_prep)
   int opt_prezero = 1;         // clear a work set's zeroed block behind an MSM's read-back instead of in front of the next MSM's first kernel
   float stage_ms[ST_COUNT + 2] = {};
   bool have_stage_ms = false;
@@ -330,7 +329,7 @@ struct msm_launch {
   // device-resident inputs, no per-stage timing: the record conversion rides in the launch of the sort's first level
   bool can_fuse_prep() const { return ctx->opt_fuse_prep && p.curve == TE_MSM_CURVE_TE_BLS12 && prof < 2 && p.nw > 0; }
   int front() {
-    if (can_fuse_prep()) return front_scalars(ctx->opt_fuse_prep);
+    if (can_fuse_prep()) return front_scalars(true);
     if (int rc = front_scalars()) return rc;
     return front_points();
   }
@@ -370,8 +369,8 @@ struct msm_launch {
   }
 
   // scalars -> digits, two-level counting sort, segment schedule (needs only the scalars); with_prep: the points -> records
-  // conversion shares a launch of the sort -- 2: the segment schedule's (k_l2_place_order), 1: the first level's (k_part_scatter_prep)
-  int front_scalars(int with_prep = 0) {
+  // conversion shares the launch of the sort's first level (k_part_scatter_prep)
+  int front_scalars(bool with_prep = false) {
     const uint32_t n32 = this->n32();
     // flags, counters, histograms, bucket counts (a later piece of the same MSM keeps word 0, the final-carry flag)
     // -- unless the block is still clean from the clearing that followed the set's previous MSM (finish_sequence)
@@ -415,7 +414,7 @@ struct msm_launch {
       te::scatter_args sa;
       sa.digits = ws.d_digits; sa.counts1 = ws.d_counts1; sa.part_keys = ws.d_part_keys; sa.part_idx = ws.d_part_idx; sa.part_start = ws.d_part_start;
       sa.part_count = ws.d_part_count; sa.seg_part_base = ws.d_seg_part_base; sa.seg_len = p.seg_len; sa.cap_w = cap_w; sa.g = sg;
-      if (with_prep == 1) {
+      if (with_prep) {
         te::batch_ptrs tab; te::batch_slabs row_slab;
         const uint32_t rows = (uint32_t)prep_rows(tab, row_slab), per_row = (n32 + 255u) / 256u, sblocks = p.CH * (uint32_t)p.nw;
         hipLaunchKernelGGL(te::k_part_scatter_prep, dim3(sblocks + rows * per_row), dim3(512), 0, stream, sa, sblocks, tab, row_slab,
@@ -442,13 +441,8 @@ struct msm_launch {
       te::order_args oa;
       oa.lenv = ws.d_seg_lenv; oa.ids = smax(); oa.size_hist = ws.d_size_hist; oa.rel_cursor = ws.d_size_cursor; oa.order = ws.d_order; oa.num_segments = ws.d_num_seg;
       oa.order_cols = (uint32_t)std::min(64, std::max(1, 128 / p.nw));
-      te::prep_args pr; memset(&pr, 0, sizeof pr);
-      if (with_prep == 2) {                                      // the record conversion as further blocks of this launch
-        const uint32_t rows = (uint32_t)prep_rows(pr.in, pr.row_slab);
-        pr.recs = reinterpret_cast<te::pnt_slot*>(ws.d_recs); pr.n = n32; pr.blocks_per_row = (n32 + 255u) / 256u; pr.blocks = rows * pr.blocks_per_row;
-      }
-      hipLaunchKernelGGL(te::k_l2_place_order, dim3((oa.order_cols + l2_blocks) * (uint32_t)p.nw + pr.blocks), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx,
-                         ws.d_part_start, ws.d_part_count, ws.d_bucket_cursor, ws.d_sorted, sg, oa, l2_blocks, (uint32_t)p.nw, pr);
+      hipLaunchKernelGGL(te::k_l2_place_order, dim3(oa.order_cols + l2_blocks, p.nw), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx, ws.d_part_start,
+                         ws.d_part_count, ws.d_bucket_cursor, ws.d_sorted, sg, oa);
     }
     mark(ST_ORDER);
     return 0;
@@ -722,7 +716,7 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, 
     graph_key key; memset(&key, 0, sizeof key);          // padding bytes take part in the memcmp below
     key.pts = d_points; key.sc = d_scalars; key.out = d_partials_out; key.n = n; key.generation = ws.generation;
     key.c = p.c; key.w_first = d.w_first; key.w_step = d.w_step; key.seg_len = (int)p.seg_len;
-    key.sort = ctx->opt_sort | (ctx->opt_signed << 1) | (ctx->opt_curve << 2) | (ctx->opt_fuse_prep << 4);
+    key.sort = ctx->opt_sort | (ctx->opt_signed << 1) | (ctx->opt_curve << 2);
     if (!ws.g_front || !ws.g_back || memcmp(&key, &ws.g_key, sizeof key) != 0) {
       if (ws.g_front || ws.g_back) HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));   // a previous replay may still be running
       msm_launch C = L; C.stream = ws.stream; C.prof = 0;
@@ -1126,7 +1120,7 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
     return TE_MSM_EDEVICE;
   }
   te_ctx* ctx = new te_ctx();
-  if (const char* e = getenv("TE_MSM_FUSE_PREP")) ctx->opt_fuse_prep = e[0] == '0' ? 0 : e[0] == '1' ? 1 : 2;      // A/B measurements; option "fuse_prep"
+  if (const char* e = getenv("TE_MSM_FUSE_PREP")) ctx->opt_fuse_prep = e[0] != '0';      // A/B measurements; option "fuse_prep"
   if (const char* e = getenv("TE_MSM_QUEUE_PROBE")) ctx->opt_queue_probe = e[0] != '0';  // option "queue_probe"
   if (const char* e = getenv("TE_MSM_HOST_SPLIT")) {                                     // relative piece weights "w0,w1,..." (experiments)
     const char* q = e;
@@ -1314,7 +1308,7 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   if (!strcmp(key, "profile")) { ctx->opt_profile = value < 0 ? 0 : (value > 2 ? 2 : (int)value); ctx->have_stage_ms = false; return 0; }
   if (!strcmp(key, "graph")) { ctx->opt_graph = value ? 1 : 0; return 0; }
   if (!strcmp(key, "prezero")) { ctx->opt_prezero = value ? 1 : 0; return 0; }
-  if (!strcmp(key, "fuse_prep")) { if (value < 0 || value > 2) return set_err(ctx, TE_MSM_EINVAL, "fuse_prep must be 0, 1 or 2"); ctx->opt_fuse_prep = (int)value; return 0; }
+  if (!strcmp(key, "fuse_prep")) { ctx->opt_fuse_prep = value ? 1 : 0; return 0; }
   if (!strcmp(key, "host_chunks")) { if (value < 0 || value > 64) return set_err(ctx, TE_MSM_EINVAL, "host_chunks out of range"); ctx->opt_host_chunks = (int)value; return 0; }
   if (!strcmp(key, "workset")) { if (value < 0 || value >= TE_MSM_WORKSETS) return set_err(ctx, TE_MSM_EINVAL, "workset out of range"); ctx->opt_workset = (int)value; return 0; }
   if (!strcmp(key, "segment_len")) { if (value < 0 || value > 1000000) return set_err(ctx, TE_MSM_EINVAL, "segment_len must be 0 (from n) or in [1, 1e6]"); ctx->opt_seg_len = (int)value; return 0; }
