@@ -273,7 +273,13 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             # a CPU-side group: the ranks that wait while rank 0 drives all GPUs from its own process (host-buffer figure
             # below) must wait on the host -- an RCCL barrier is a kernel spinning on their GPUs
-            cpu_group = dist.new_group(backend="gloo") if world > 1 else None
+            cpu_group = None
+            if world > 1:
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node; the container's hostname may not resolve
+                try:
+                    cpu_group = dist.new_group(backend="gloo")
+                except Exception as e:                                  # the host-buffer leg is skipped, nothing else depends on it
+                    print("bench.py: no CPU-side group (%s): host_buffers_ms is not measured" % e, file=sys.stderr)
         if dist.get_world_size() != args.gpus:
             raise SystemExit("process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
     dev = local_rank if world > 1 else 0
@@ -600,18 +606,20 @@ def main():
                                          "core_clock_ghz": sx.stage_ms().get("accumulate_core_clock_ghz")}
             sx.set_option("window_bits", args.window_bits)
             sx.set_option("profile", 1)
-    if world > 1 and not share and not rehearse and not bls and not args.no_host_buffers:
+    if world > 1 and not rehearse and not bls and not args.no_host_buffers and (share or cpu_group is not None):
         # compute_msm(Buffer, Buffer) on all N GPUs from ONE process: rank 0 opens an n_dev = N context (te_msm_run: point
         # slices, one upload thread and PCIe link per device) while the other ranks wait -- the reference's boundary (host buffers,
         # upload inside the call: cuzk/gpu.ts:33-46) on N devices.  PCIe-inclusive: reported, never `value`.
         sync()
-        if rank == 0 and torch.cuda.device_count() >= world and cpu_group is not None:
+        # (rehearsal with every rank on one GPU, TE_BENCH_SHARE_GPU=1: the one device named `world` times -- the code path, not a speed-up)
+        host_ids = tuple([dev] * world) if share else tuple(range(world))
+        if rank == 0 and (share or torch.cuda.device_count() >= world):
             try:
                 with pkg.MsmContext((dev,)) as one:
                     one.set_option("signed_digits", 1 if args.digits == "signed" else 0)
                     one.run(pts, sc)
                     hb1, r1 = host_buffer_ms(one, pts, sc, reps=5)
-                with pkg.MsmContext(tuple(range(world))) as mc:
+                with pkg.MsmContext(host_ids) as mc:
                     mc.set_option("signed_digits", 1 if args.digits == "signed" else 0)
                     mc.run(pts, sc)                               # buffers, staging areas, the per-device host threads
                     hb, r_host = host_buffer_ms(mc, pts, sc, reps=7)
@@ -622,10 +630,13 @@ def main():
                 out["host_buffers_path"] = ("te_msm_run on ONE n_dev = %d context in rank 0's process: %d point slices of %d points, %d-bit windows, "
                                             "one host thread + PCIe link per device, rows summed in the host tail" % (world, world, (n + world - 1) // world, cb))
                 out["host_buffers_parity"] = "identical to the window-sharded result" if (r_host == result and r1 == result) else "MISMATCH"
+                out["host_buffers_devices"] = list(host_ids)
             except pkg.MsmError as e:
                 out["host_buffers_error"] = str(e)
         if cpu_group is not None:
             dist.barrier(group=cpu_group)                         # ranks 1.. wait here, on the host
+        elif share:
+            dist.barrier()                                        # gloo: a CPU-side wait already
         sync()
     exp = None
     if rank == 0 and world == 1 and not sharded and not args.no_cpu_baseline:
