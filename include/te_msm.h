@@ -133,6 +133,9 @@ int te_msm_ticket_wait(te_ctx* ctx, uint64_t ticket);
  *   "prezero"       1 (default) = a work set's block of counters is cleared BEHIND an MSM's read-back, for its next MSM
  *                   (the next MSM starts with its first kernel instead of a fill); 0 = cleared in front of every MSM --
  *                   te_msm_debug_read of "bucket_count" / "num_segments" / "partials" needs 0 (it refuses otherwise)
+ *   "packed_sort"   1 (default) = the sort's level-1 entries are one 32-bit word (index | key << 23 | sign << 31) where n <= 2^23:
+ *                   4 bytes per entry instead of 6; 0 = the general form (u16 key + u32 index; what larger n always uses).
+ *                   Same result (A/B measurements, tests; env TE_MSM_PACKED)
  *   "fuse_prep"     1 (default) = device-resident Twisted-Edwards inputs: the points -> records conversion shares the launch
  *                   of the sort's first level; 0 = a launch of its own (A/B measurements; env TE_MSM_FUSE_PREP) */
 int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value);

@@ -26,11 +26,12 @@ def _dev(buf: bytes):
 
 # ------------------------------------------------------------------ stage verifiers
 # (the reference's per-stage `debug` checks, submission.ts:892-1363)
-@pytest.mark.parametrize("n,c", [(1000, 8), (5003, 13), (70001, 16)])
-def test_stages_against_oracle(ctx, fpcheck, model, ora, n, c):
+@pytest.mark.parametrize("n,c,packed", [(1000, 8, 1), (5003, 13, 1), (70001, 16, 1), (70001, 16, 0), (5003, 13, 0)])
+def test_stages_against_oracle(ctx, fpcheck, model, ora, n, c, packed):
     pts, sc = ora.gen_points(500 + n, n), ora.gen_scalars(500 + n, n)
     ctx.set_option("window_bits", c)
     ctx.set_option("sort_buckets", 1)
+    ctx.set_option("packed_sort", packed)  # level-1 entries as one word (default where n <= 2^23) or as key + index (larger n)
     ctx.set_option("prezero", 0)           # keep counters and rows in the zeroed block for the checks below
     res = ctx.run(pts, sc)
     W, B = (256 + c - 1) // c, 1 << (c - 1)
@@ -130,6 +131,7 @@ def test_stages_against_oracle(ctx, fpcheck, model, ora, n, c):
     assert res == ora.msm(pts, sc, threads=8)
     ctx.set_option("window_bits", 0)
     ctx.set_option("prezero", 1)
+    ctx.set_option("packed_sort", 1)
     # with the default (the zeroed block is cleared behind the read-back) the same stages are refused, not read as zeros
     assert ctx.run(pts, sc) == res
     with pytest.raises(Exception):
@@ -511,6 +513,26 @@ def test_multi_device_full_size_against_the_reference(pkg, model, ora, wasm_gold
 
 
 # ------------------------------------------------------------------ BASELINE.json's full size
+def test_full_size_2_20_general_sort_entries(pkg, ora):
+    """n = 2^20 with the sort's level-1 entries in the general form (u16 key + u32 index; the default packs them into one
+    word where n <= 2^23): the form every n above 2^23 runs with, at the headline size, both digit forms, several in flight"""
+    import torch
+    n = 1 << 20
+    pts, sc = pkg.synth_inputs(0xFACE, n)
+    exp = ora.msm(pts, sc, threads=16)
+    dp, ds = _dev(pts), _dev(sc)
+    torch.cuda.synchronize()
+    with pkg.MsmContext((0,)) as c:
+        c.set_option("packed_sort", 0)
+        assert c.get_option("packed_sort") == 0
+        for signed in (1, 0):
+            c.set_option("signed_digits", signed)
+            ts = [c.submit_device(dp.data_ptr(), ds.data_ptr(), n) for _ in range(3)]
+            assert [c.collect(t) for t in ts] == [exp] * 3, signed
+        c.set_option("signed_digits", 1)
+        assert c.run(pts, sc) == exp
+
+
 def test_full_size_2_20(ctx, model, ora):
     n = 1 << 20
     pts, sc = ora.gen_points(0x5EED0014, n), ora.gen_scalars(0x5EED0014, n)
@@ -786,7 +808,8 @@ def test_random_configurations(pkg, ora):
         for it in range(40):
             n = rnd.choice([1, 2, 7, 64, 65, 300, 1023, 4096, 5000, 20011, 66000])
             cfg = {"window_bits": rnd.choice([0, 4, 6, 9, 12, 14, 15, 16]), "signed_digits": rnd.choice([0, 1]),
-                   "segment_len": rnd.choice([1, 2, 5, 64, 300]), "sort_buckets": rnd.choice([0, 1]), "host_chunks": rnd.choice([0, 1, 2, 5])}
+                   "segment_len": rnd.choice([1, 2, 5, 64, 300]), "sort_buckets": rnd.choice([0, 1]), "host_chunks": rnd.choice([0, 1, 2, 5]),
+                   "packed_sort": rnd.choice([1, 1, 0])}
             for k, v in cfg.items():
                 c.set_option(k, v)
             mode = rnd.choice(["uniform", "equal", "small", "fixed_point"])
@@ -938,3 +961,8 @@ def test_giant_buckets(ctx, model, ora):
         ctx.set_option("window_bits", c)
         assert ctx.run(pts, sc) == exp
     ctx.set_option("window_bits", 0)
+    # the same skew through the general (key + index) form of the sort's level-1 entries -- what n > 2^23 always uses: pieces of
+    # over-long partitions, counted with atomics, planned by the last arriver, placed by the schedule launch
+    ctx.set_option("packed_sort", 0)
+    assert ctx.run(pts, same) == ora.msm(pts, same, threads=16) and ctx.run(pts, sc) == exp
+    ctx.set_option("packed_sort", 1)

@@ -272,6 +272,7 @@ struct sort_geom {
   uint32_t n, nst;       // entries per window; row stride of digits / part_keys / part_idx (multiple of 8, >= n)
   uint32_t B, logS, S, P, CH, chunk_len;   // chunk_len is a multiple of TE_TILE
   uint32_t half;         // stored code of digit 0 (see digit_bucket)
+  uint32_t packed;       // level-1 entries as ONE word: index (23 bits) | bucket low bits << 23 (8) | sign << 31 (n <= 2^23; else u16 key + u32 index)
 };
 #define TE_TILE 4096u
 
@@ -373,10 +374,17 @@ __device__ __forceinline__ void part_scatter_block(uint32_t ch, uint32_t k, uint
         st[tile_off[part[e]] + rank[e]] = (t * 8u + (uint32_t)e) | (part[e] << 12) | ((key[e] & 0xffu) << 20) | ((key[e] >> 15) << 28);
     }
     __syncthreads();
-    for (uint32_t s = t; s < tile_total; s += 512u) {
-      const uint32_t w = st[s];
-      const uint32_t gpos = s + gdelta[(w >> 12) & 0xffu];
-      ok[gpos] = (uint16_t)(((w >> 20) & 0xffu) | ((w >> 28) << 15)); oi[gpos] = base + (w & 0xfffu);
+    if (g.packed) {                                       // uniform: key and index leave as one word (4 bytes per entry instead of 6)
+      for (uint32_t s = t; s < tile_total; s += 512u) {
+        const uint32_t w = st[s];
+        oi[s + gdelta[(w >> 12) & 0xffu]] = (base + (w & 0xfffu)) | (((w >> 20) & 0xffu) << 23) | ((w >> 28) << 31);
+      }
+    } else {
+      for (uint32_t s = t; s < tile_total; s += 512u) {
+        const uint32_t w = st[s];
+        const uint32_t gpos = s + gdelta[(w >> 12) & 0xffu];
+        ok[gpos] = (uint16_t)(((w >> 20) & 0xffu) | ((w >> 28) << 15)); oi[gpos] = base + (w & 0xfffu);
+      }
     }
     __syncthreads();
     for (uint32_t p = t; p < g.P; p += 512u) { run_base[p] += tile_cnt[p]; tile_cnt[p] = 0u; }
@@ -427,8 +435,10 @@ __global__ void __launch_bounds__(512) k_part_scatter_prep(scatter_args a, uint3
 #define TE_L2_CAP 9208u          // entries per piece (multiple of 8); n/P = 8192 at n = 2^20: +11 sigma of its Poisson spread
 #define TE_L2_LIST (TE_L2_CAP + 8u)
 
-// loads the 16-byte groups covering entries [a, b) of a row (<= TE_L2_CAP + 8 entries), 5 groups per thread
+// loads the 16-byte groups covering entries [a, b) of a row (<= TE_L2_CAP + 8 entries), 5 groups of 8 entries per thread.
+// PK: packed level-1 entries (one u32 each: the key lives in the index word, the key array does not exist)
 struct piece_regs { uint4 k[5], ia[5], ib[5]; };
+template <bool PK>
 __device__ __forceinline__ void load_piece(const uint16_t* __restrict__ keys_row, const uint32_t* __restrict__ idx_row, uint32_t a, uint32_t b,
                                            uint32_t t, bool with_idx, piece_regs& r, uint32_t& head, uint32_t& total) {
   const uint32_t a_al = a & ~7u;
@@ -439,8 +449,20 @@ __device__ __forceinline__ void load_piece(const uint16_t* __restrict__ keys_row
 #pragma unroll
   for (int c = 0; c < 5; c++) {
     const uint32_t gi = min((uint32_t)c * 256u + t, groups - 1u);
-    r.k[c] = k4[gi];
-    if (with_idx) { r.ia[c] = i4[2 * gi]; r.ib[c] = i4[2 * gi + 1]; }
+    if (!PK) r.k[c] = k4[gi];
+    if (PK || with_idx) { r.ia[c] = i4[2 * gi]; r.ib[c] = i4[2 * gi + 1]; }
+  }
+}
+// the 8 entries of group c as (key = bucket low bits | sign << 15, index)
+template <bool PK> __device__ __forceinline__ void piece_group(const piece_regs& r, int c, uint32_t (&kv)[8], uint32_t (&iv)[8]) {
+  const uint32_t w[8] = {r.ia[c].x, r.ia[c].y, r.ia[c].z, r.ia[c].w, r.ib[c].x, r.ib[c].y, r.ib[c].z, r.ib[c].w};
+  if (PK) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) { kv[e] = ((w[e] >> 23) & 0xffu) | ((w[e] >> 31) << 15); iv[e] = w[e] & 0x7fffffu; }
+  } else {
+    unpack8(r.k[c], kv);
+#pragma unroll
+    for (int e = 0; e < 8; e++) iv[e] = w[e];
   }
 }
 static_assert(5u * 256u * 8u >= TE_L2_CAP + 8u, "five groups per thread hold a piece");
@@ -565,6 +587,7 @@ struct l2_args {
 #define TE_L2A_LDS_WORDS (3u * 256u + 32u + TE_L2_LIST)
 static_assert(sizeof(plan_lds) <= TE_L2_LIST * 4u, "the plan's LDS fits into the list area");
 // grid (P + X, nw), block 256: see "level 2" above
+template <bool PK>
 __global__ void __launch_bounds__(256, 3) k_l2_local(l2_args a) {
   __shared__ uint32_t lds[TE_L2A_LDS_WORDS];
   uint32_t* const cnt_s = lds; uint32_t* const off_s = lds + 256; uint32_t* const sm = lds + 768; uint32_t* const pj = lds + 768 + 17;
@@ -583,10 +606,10 @@ __global__ void __launch_bounds__(256, 3) k_l2_local(l2_args a) {
   cnt_s[t] = 0u;
   __syncthreads();
   piece_regs r; uint32_t head, total;
-  load_piece(keys_row, idx_row, a0, b0, t, single, r, head, total);
+  load_piece<PK>(keys_row, idx_row, a0, b0, t, single, r, head, total);
 #pragma unroll
   for (int c = 0; c < 5; c++) {
-    uint32_t kv[8]; unpack8(r.k[c], kv);
+    uint32_t kv[8], iv[8]; piece_group<PK>(r, c, kv, iv);
     const uint32_t e0 = ((uint32_t)c * 256u + t) * 8u;
 #pragma unroll
     for (int e = 0; e < 8; e++) { const uint32_t pos = e0 + (uint32_t)e; if (pos >= head && pos < total) atomicAdd(&cnt_s[kv[e] & 0x7fffu], 1u); }
@@ -612,8 +635,7 @@ __global__ void __launch_bounds__(256, 3) k_l2_local(l2_args a) {
   __syncthreads();
 #pragma unroll
   for (int c = 0; c < 5; c++) {
-    uint32_t kv[8]; unpack8(r.k[c], kv);
-    const uint32_t iv[8] = {r.ia[c].x, r.ia[c].y, r.ia[c].z, r.ia[c].w, r.ib[c].x, r.ib[c].y, r.ib[c].z, r.ib[c].w};
+    uint32_t kv[8], iv[8]; piece_group<PK>(r, c, kv, iv);
     const uint32_t e0 = ((uint32_t)c * 256u + t) * 8u;
 #pragma unroll
     for (int e = 0; e < 8; e++) {
@@ -670,6 +692,7 @@ __device__ __forceinline__ void order_scatter_block(uint32_t ob, uint32_t nob, u
 // words): LDS count, reserve [base, base + c) in every touched bucket with one returning atomicAdd on bucket_cursor, sort the
 // piece by bucket in LDS and copy each run to its reserved range.
 #define TE_PLACE_LDS_WORDS (4u * 256u + TE_L2_LIST + TE_L2_LIST / 4u + 2u + 17u)
+template <bool PK>
 __device__ __forceinline__ void l2_place_piece(uint32_t p, uint32_t k, uint32_t a0, uint32_t b0, uint32_t* __restrict__ lds,
                                                const uint16_t* __restrict__ part_keys, const uint32_t* __restrict__ part_idx,
                                                uint32_t* __restrict__ bucket_cursor, uint32_t* __restrict__ sorted, const sort_geom& g) {
@@ -683,10 +706,10 @@ __device__ __forceinline__ void l2_place_piece(uint32_t p, uint32_t k, uint32_t 
   cnt_s[t] = 0u;
   __syncthreads();
   piece_regs r; uint32_t head, total;
-  load_piece(keys_row, idx_row, a0, b0, t, true, r, head, total);
+  load_piece<PK>(keys_row, idx_row, a0, b0, t, true, r, head, total);
 #pragma unroll
   for (int c = 0; c < 5; c++) {
-    uint32_t kv[8]; unpack8(r.k[c], kv);
+    uint32_t kv[8], iv[8]; piece_group<PK>(r, c, kv, iv);
     const uint32_t e0 = ((uint32_t)c * 256u + t) * 8u;
 #pragma unroll
     for (int e = 0; e < 8; e++) { const uint32_t pos = e0 + (uint32_t)e; if (pos >= head && pos < total) atomicAdd(&cnt_s[kv[e] & 0x7fffu], 1u); }
@@ -703,8 +726,7 @@ __device__ __forceinline__ void l2_place_piece(uint32_t p, uint32_t k, uint32_t 
   __syncthreads();
 #pragma unroll
   for (int c = 0; c < 5; c++) {
-    uint32_t kv[8]; unpack8(r.k[c], kv);
-    const uint32_t iv[8] = {r.ia[c].x, r.ia[c].y, r.ia[c].z, r.ia[c].w, r.ib[c].x, r.ib[c].y, r.ib[c].z, r.ib[c].w};
+    uint32_t kv[8], iv[8]; piece_group<PK>(r, c, kv, iv);
     const uint32_t e0 = ((uint32_t)c * 256u + t) * 8u;
 #pragma unroll
     for (int e = 0; e < 8; e++) {
@@ -726,6 +748,7 @@ __device__ __forceinline__ void l2_place_piece(uint32_t p, uint32_t k, uint32_t 
 // dispatched first); the others take the pieces of k_l2_local's grid and leave at once unless theirs belongs to a partition of
 // more than TE_L2_CAP entries (with well-spread digits: the top window's ~115 pieces).
 struct order_args { const uint32_t* lenv; uint32_t ids; const uint32_t* size_hist; uint32_t* rel_cursor; uint32_t* order; uint32_t* num_segments; uint32_t order_cols; };
+template <bool PK>
 __global__ void __launch_bounds__(256, 3) k_l2_place_order(const uint16_t* __restrict__ part_keys, const uint32_t* __restrict__ part_idx,
                                                            const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ part_count,
                                                            uint32_t* __restrict__ bucket_cursor, uint32_t* __restrict__ sorted, sort_geom g, order_args oa) {
@@ -741,7 +764,7 @@ __global__ void __launch_bounds__(256, 3) k_l2_place_order(const uint16_t* __res
   const uint32_t cntp = pc[p], pb = part_start[k * g.P + p];
   if (cntp <= TE_L2_CAP) return;                         // sorted by its own block of k_l2_local (uniform)
   const uint32_t a0 = pb + j * TE_L2_CAP;
-  l2_place_piece(p, k, a0, min(pb + cntp, a0 + TE_L2_CAP), lds, part_keys, part_idx, bucket_cursor, sorted, g);
+  l2_place_piece<PK>(p, k, a0, min(pb + cntp, a0 + TE_L2_CAP), lds, part_keys, part_idx, bucket_cursor, sorted, g);
 }
 
 // ================================================================================================

@@ -61,6 +61,7 @@ struct plan_t {
   uint32_t CH = 0, chunk_len = 0, nst = 0;   // level-1 chunks per window (chunk_len multiple of 4096); padded row stride
   uint32_t seg_len = 64;
   uint32_t S = 0, logS = 0, P = 0;   // level-1 partition: S buckets each, P = B/S partitions per window
+  uint32_t packed = 0;               // level-1 entries as one 32-bit word (index | key << 23 | sign << 31): n <= 2^23
 };
 
 struct graph_key { const void *pts, *sc, *out; uint64_t n, generation; int c, w_first, w_step, seg_len, sort; };
@@ -168,6 +169,7 @@ struct te_ctx {
   int opt_graph = 0;           // replay the launch sequence around k_accumulate as HIP graphs
   int opt_workset = 0;         // work set used by te_msm_run* / te_msm_partial_device
   int opt_fuse_prep = 1;       // device-resident inputs: convert the points in the launch of the sort's first level (k_part_scatter_prep)
+  int opt_packed = 1;          // level-1 sort entries as one 32-bit word where n <= 2^23 (make_plan)
   int opt_prezero = 1;         // clear a work set's zeroed block behind an MSM's read-back instead of in front of the next MSM's first kernel
   float stage_ms[ST_COUNT + 2] = {};
   bool have_stage_ms = false;
@@ -242,6 +244,9 @@ void make_plan(const te_ctx* ctx, const gpu_t& d, uint64_t n, plan_t& p, int for
     p.seg_len = (uint32_t)s2;
   }
   p.P = p.B / p.S; p.logS = ilog2(p.S);
+  // 4 bytes per level-1 entry instead of 6 (-32 MB written and -32 MB read per 2^20-point MSM) where the index fits 23 bits;
+  // option "packed_sort" = 0 (env TE_MSM_PACKED=0): the general form (A/B measurements, tests; what larger n uses)
+  p.packed = (ctx->opt_packed && n <= (1ull << 23)) ? 1u : 0u;
 }
 
 template <typename T> int ensure(te_ctx* ctx, workset_t& ws, T*& ptr, size_t& cap_bytes, size_t need_elems) {
@@ -286,7 +291,7 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, workset_t& ws, uint64_t n, const plan_
   if ((rc = ensure(ctx, ws, ws.d_part_start, ws.cap[6], (size_t)p.nw * p.P))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_buckets, ws.cap[8], wb * ab))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_part_count, ws.cap[9], (size_t)p.nw * p.P))) return rc;
-  if ((rc = ensure(ctx, ws, ws.d_part_keys, ws.cap[14], nd))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_part_keys, ws.cap[14], p.packed ? 8 : nd))) return rc;       // packed level-1 entries carry their key
   if ((rc = ensure(ctx, ws, ws.d_part_idx, ws.cap[15], nd))) return rc;
   // fold levels (by 8, 4 or 2): the first output is at most B/2 per window, the second at most B/4
   if ((rc = ensure(ctx, ws, ws.d_red[0], ws.cap[10], (wb / 2 + 1) * ab))) return rc;
@@ -379,7 +384,7 @@ struct msm_launch {
     ws.zero_clean_words = 0;
     mark(ST_DIGITS);
     te::sort_geom sg;
-    sg.n = n32; sg.nst = p.nst; sg.B = p.B; sg.logS = p.logS; sg.S = p.S; sg.P = p.P; sg.CH = p.CH; sg.chunk_len = p.chunk_len; sg.half = p.signed_digits ? p.B : 0u;
+    sg.n = n32; sg.nst = p.nst; sg.B = p.B; sg.logS = p.logS; sg.S = p.S; sg.P = p.P; sg.CH = p.CH; sg.chunk_len = p.chunk_len; sg.half = p.signed_digits ? p.B : 0u; sg.packed = p.packed;
     if (p.nw > 0) {
       te::digits_params prm; memset(&prm, 0, sizeof prm);
       if (p.signed_digits) for (int w = 0; w < p.W; w++) { const int bit = w * p.c + p.c - 1; if (bit < 320) prm.half[bit >> 5] |= 1u << (bit & 31); }
@@ -435,14 +440,19 @@ struct msm_launch {
       la.pa.bucket_start = ws.d_bucket_start; la.pa.bucket_cursor = ws.d_bucket_cursor; la.pa.seg_base = ws.d_seg_base; la.pa.seg_bucket = ws.d_seg_bucket;
       la.pa.seg_lenv = ws.d_seg_lenv; la.pa.size_hist = ws.d_size_hist; la.pa.split_list = ws.d_split_list; la.pa.split_count = ws.d_num_seg + 1;
       la.pa.chunk_list = ws.d_chunk_list; la.pa.seg_len = p.seg_len; la.pa.cap_w = cap_w; la.pa.chunk_cap = chunk_cap();
-      hipLaunchKernelGGL(te::k_l2_local, dim3(l2_blocks, p.nw), dim3(256), 0, stream, la);
+      if (p.packed) hipLaunchKernelGGL(te::k_l2_local<true>, dim3(l2_blocks, p.nw), dim3(256), 0, stream, la);
+      else hipLaunchKernelGGL(te::k_l2_local<false>, dim3(l2_blocks, p.nw), dim3(256), 0, stream, la);
       // the segment schedule (counts the valid segments, d_num_seg[0]; with "sort_buckets" = 0 the schedule is simply not used)
       // + the placement of the pieces of over-long partitions in one launch
       te::order_args oa;
       oa.lenv = ws.d_seg_lenv; oa.ids = smax(); oa.size_hist = ws.d_size_hist; oa.rel_cursor = ws.d_size_cursor; oa.order = ws.d_order; oa.num_segments = ws.d_num_seg;
       oa.order_cols = (uint32_t)std::min(64, std::max(1, 128 / p.nw));
-      hipLaunchKernelGGL(te::k_l2_place_order, dim3(oa.order_cols + l2_blocks, p.nw), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx, ws.d_part_start,
-                         ws.d_part_count, ws.d_bucket_cursor, ws.d_sorted, sg, oa);
+      if (p.packed)
+        hipLaunchKernelGGL(te::k_l2_place_order<true>, dim3(oa.order_cols + l2_blocks, p.nw), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx, ws.d_part_start,
+                           ws.d_part_count, ws.d_bucket_cursor, ws.d_sorted, sg, oa);
+      else
+        hipLaunchKernelGGL(te::k_l2_place_order<false>, dim3(oa.order_cols + l2_blocks, p.nw), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx, ws.d_part_start,
+                           ws.d_part_count, ws.d_bucket_cursor, ws.d_sorted, sg, oa);
     }
     mark(ST_ORDER);
     return 0;
@@ -716,7 +726,7 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, 
     graph_key key; memset(&key, 0, sizeof key);          // padding bytes take part in the memcmp below
     key.pts = d_points; key.sc = d_scalars; key.out = d_partials_out; key.n = n; key.generation = ws.generation;
     key.c = p.c; key.w_first = d.w_first; key.w_step = d.w_step; key.seg_len = (int)p.seg_len;
-    key.sort = ctx->opt_sort | (ctx->opt_signed << 1) | (ctx->opt_curve << 2);
+    key.sort = ctx->opt_sort | (ctx->opt_signed << 1) | (ctx->opt_curve << 2) | (ctx->opt_packed << 4);
     if (!ws.g_front || !ws.g_back || memcmp(&key, &ws.g_key, sizeof key) != 0) {
       if (ws.g_front || ws.g_back) HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));   // a previous replay may still be running
       msm_launch C = L; C.stream = ws.stream; C.prof = 0;
@@ -1122,6 +1132,7 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
   te_ctx* ctx = new te_ctx();
   if (const char* e = getenv("TE_MSM_FUSE_PREP")) ctx->opt_fuse_prep = e[0] != '0';      // A/B measurements; option "fuse_prep"
   if (const char* e = getenv("TE_MSM_QUEUE_PROBE")) ctx->opt_queue_probe = e[0] != '0';  // option "queue_probe"
+  if (const char* e = getenv("TE_MSM_PACKED")) ctx->opt_packed = e[0] != '0';            // option "packed_sort"
   if (const char* e = getenv("TE_MSM_HOST_SPLIT")) {                                     // relative piece weights "w0,w1,..." (experiments)
     const char* q = e;
     while (*q) { char* end = nullptr; const double v = strtod(q, &end); if (end == q) break; ctx->host_split.push_back(v > 0 ? v : 1.0); q = *end == ',' ? end + 1 : end; }
@@ -1314,6 +1325,7 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   if (!strcmp(key, "segment_len")) { if (value < 0 || value > 1000000) return set_err(ctx, TE_MSM_EINVAL, "segment_len must be 0 (from n) or in [1, 1e6]"); ctx->opt_seg_len = (int)value; return 0; }
   if (!strcmp(key, "host_shard_min")) { if (value < 1 || value > (1ll << 30)) return set_err(ctx, TE_MSM_EINVAL, "host_shard_min out of range"); ctx->opt_host_shard_min = (int)value; return 0; }
   if (!strcmp(key, "queue_probe")) { ctx->opt_queue_probe = value ? 1 : 0; return 0; }
+  if (!strcmp(key, "packed_sort")) { ctx->opt_packed = value ? 1 : 0; return 0; }
   return set_err(ctx, TE_MSM_EINVAL, "unknown option");
 }
 
@@ -1335,6 +1347,7 @@ int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value) {
   if (!strcmp(key, "host_chunks")) { *value = ctx->opt_host_chunks; return 0; }
   if (!strcmp(key, "host_shard_min")) { *value = ctx->opt_host_shard_min; return 0; }
   if (!strcmp(key, "queue_probe")) { *value = ctx->opt_queue_probe; return 0; }
+  if (!strcmp(key, "packed_sort")) { *value = ctx->opt_packed; return 0; }
   if (!strcmp(key, "streams_final")) { *value = ctx->devs[0].streams_final ? 1 : 0; return 0; }
   if (!strcmp(key, "in_flight")) { *value = ctx->devs[0].in_flight; return 0; }
   if (!strcmp(key, "device_bytes")) {      // device memory this context holds in work-set buffers (te_msm_trim gives it back)
@@ -1539,8 +1552,22 @@ int64_t te_msm_debug_read(te_ctx* ctx, const char* stage, void* dst, uint64_t ca
   else if (!strcmp(stage, "order")) { src = ws.d_order; bytes = ((uint64_t)p.nw * p.B + (uint64_t)p.nw * (n / p.seg_len)) * 4; }
   else if (!strcmp(stage, "part_start")) { src = ws.d_part_start; bytes = (uint64_t)p.nw * p.P * 4; }
   else if (!strcmp(stage, "part_count")) { src = ws.d_part_count; bytes = (uint64_t)p.nw * p.P * 4; }
-  else if (!strcmp(stage, "part_keys")) { src = ws.d_part_keys; bytes = (uint64_t)p.nw * p.nst * 2; }
-  else if (!strcmp(stage, "part_idx")) { src = ws.d_part_idx; bytes = (uint64_t)p.nw * p.nst * 4; }
+  else if (!strcmp(stage, "part_keys") && !p.packed) { src = ws.d_part_keys; bytes = (uint64_t)p.nw * p.nst * 2; }
+  else if (!strcmp(stage, "part_idx") && !p.packed) { src = ws.d_part_idx; bytes = (uint64_t)p.nw * p.nst * 4; }
+  else if (!strcmp(stage, "part_keys") || !strcmp(stage, "part_idx")) {
+    // packed level-1 entries (index | bucket low bits << 23 | sign << 31): taken apart here into the two views of the general form
+    const bool want_keys = stage[5] == 'k';
+    const uint64_t words = (uint64_t)p.nw * p.nst;
+    std::vector<uint32_t> pk(words);
+    HIP_TRY(ctx, hipSetDevice(d.device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemcpy(pk.data(), ws.d_part_idx, words * 4, hipMemcpyDeviceToHost));
+    uint64_t out_bytes = words * (want_keys ? 2 : 4);
+    if (out_bytes > cap) out_bytes = cap;
+    if (want_keys) { uint16_t* o = static_cast<uint16_t*>(dst); for (uint64_t i = 0; i < out_bytes / 2; i++) o[i] = (uint16_t)(((pk[i] >> 23) & 0xffu) | ((pk[i] >> 31) << 15)); }
+    else { uint32_t* o = static_cast<uint32_t*>(dst); for (uint64_t i = 0; i < out_bytes / 4; i++) o[i] = pk[i] & 0x7fffffu; }
+    return (int64_t)out_bytes;
+  }
   else if (!strcmp(stage, "buckets")) { src = ws.d_buckets; bytes = (uint64_t)p.nw * p.B * sizes_of(p.curve).acc; }
   else if (!strcmp(stage, "partials")) { src = ws.d_partials; bytes = (uint64_t)p.W * sizes_of(p.curve).row; }
   else return set_err(ctx, TE_MSM_EINVAL, "unknown stage");
