@@ -40,6 +40,11 @@ CASES = [  # (name, seed, n, mode)
     ("fixed_n262144", 0x5EED0040001, 1 << 18, "fixed"),
     ("random_n1000", 0x5EED03E9, 1000, "random"),              # SURVEY 8d set (R): independent seeded-random a_i * G
     ("random_n65536", 0x5EED0010002, 65536, "random"),
+    # every harness size 2^16 .. 2^20 (full_benchmarks.ts:13-15) has a reference-generated point, and the harness mode at the headline size
+    ("chain_n131072", 0x5EED0020000, 1 << 17, "chain"),
+    ("random_n262144", 0x5EED0040002, 1 << 18, "random"),
+    ("chain_n524288", 0x5EED0080000, 1 << 19, "chain"),
+    ("fixed_n1048576", 0x5EED0100001, 1 << 20, "fixed"),
 ]
 
 
