@@ -809,7 +809,7 @@ def test_random_configurations(pkg, ora):
             n = rnd.choice([1, 2, 7, 64, 65, 300, 1023, 4096, 5000, 20011, 66000])
             cfg = {"window_bits": rnd.choice([0, 4, 6, 9, 12, 14, 15, 16]), "signed_digits": rnd.choice([0, 1]),
                    "segment_len": rnd.choice([1, 2, 5, 64, 300]), "sort_buckets": rnd.choice([0, 1]), "host_chunks": rnd.choice([0, 1, 2, 5]),
-                   "packed_sort": rnd.choice([1, 1, 0])}
+                   "packed_sort": rnd.choice([1, 1, 0]), "fold_pairs": rnd.choice([1, 1, 0])}
             for k, v in cfg.items():
                 c.set_option(k, v)
             mode = rnd.choice(["uniform", "equal", "small", "fixed_point"])

@@ -30,7 +30,7 @@ while time.time() < t_end:
     for k, v in (("window_bits", rnd.choice([0, 0, 4, 7, 10, 13, 15, 16])), ("signed_digits", rnd.choice([1, 1, 0])),
                  ("segment_len", rnd.choice([0, 0, 64, 1, 7, 500])), ("sort_buckets", rnd.choice([1, 1, 0])), ("host_chunks", rnd.choice([0, 1, 3, 5])),
                  ("graph", rnd.choice([0, 0, 1])), ("profile", rnd.choice([0, 0, 1, 2])), ("prezero", rnd.choice([1, 1, 0])),
-                 ("fuse_prep", rnd.choice([1, 1, 0])), ("packed_sort", rnd.choice([1, 1, 0]))):
+                 ("fuse_prep", rnd.choice([1, 1, 0])), ("packed_sort", rnd.choice([1, 1, 0])), ("fold_pairs", rnd.choice([1, 1, 0]))):
         ctx.set_option(k, v)
         opts[k] = v
     mode = rnd.choice(["run", "run", "tickets", "tickets", "shards", "batch", "host_tickets", "host_tickets", "multi"])

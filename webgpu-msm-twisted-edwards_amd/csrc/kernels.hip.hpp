@@ -948,20 +948,44 @@ template <int N> struct sum_job_t {
   uint32_t in_per_window, out_per_window;
 };
 template <int N> struct sum_jobs_t { sum_job_t<N> j[4]; };
-template <int N>
+// PAIR: two adjacent lanes share an output -- each sums half of the K inputs, the even lane adds the odd lane's half (handed over
+// with DPP moves) and stores: K/2 dependent additions instead of K - 1 for the same number of additions in all.  For levels with
+// too few outputs to fill the machine (n <= 2^18: 73 728 outputs on 1024 SIMDs -- a lone wave issues a dependent chain at half
+// rate): 59 -> 3x us at n = 2^16.
+template <int N> __device__ __forceinline__ ete_t<N> pair_swap(const ete_t<N>& a) {        // the other lane of my pair (lanes 2i, 2i + 1)
+  ete_t<N> r;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    r.x.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.x.v[i], 0xb1, 0xf, 0xf, true);
+    r.y.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.y.v[i], 0xb1, 0xf, 0xf, true);
+    r.z.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.z.v[i], 0xb1, 0xf, 0xf, true);
+    r.t.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.t.v[i], 0xb1, 0xf, 0xf, true);
+  }
+  return r;
+}
+template <int N, bool PAIR>
 __global__ void __launch_bounds__(256, N == 9 ? 2 : 1) k_sum_groups(sum_jobs_t<N> js, uint32_t nw) {
   const sum_job_t<N>& j = js.j[blockIdx.y];
-  const uint32_t total = j.n_out * nw;
-  for (uint32_t g = blockIdx.x * 256u + threadIdx.x; g < total; g += gridDim.x * 256u) {
+  constexpr uint32_t TPO = PAIR ? 2u : 1u;                // threads per output
+  const uint32_t total = j.n_out * nw * TPO, Kt = j.K / TPO;      // PAIR needs an even K (the host folds by 8, 4 or 2)
+  for (uint32_t gt = blockIdx.x * 256u + threadIdx.x; gt < total; gt += gridDim.x * 256u) {      // pairs stay in adjacent lanes
+    const uint32_t g = gt / TPO, half = gt % TPO;
     const uint32_t k = g / j.n_out, o = g - k * j.n_out;
     const uint32_t outer = o / j.inner, q = o - outer * j.inner;
-    const ete_t<N>* src = j.in + (size_t)k * j.in_per_window + (size_t)outer * j.K * j.inner + q;
+    const ete_t<N>* src = j.in + (size_t)k * j.in_per_window + ((size_t)outer * j.K + (size_t)half * Kt) * j.inner + q;
     ete_t<N> acc = load_ete<N>(src);
-    ete_t<N> nxt = load_ete<N>(src + (size_t)j.inner);          // K >= 2: the next operand is in flight during the addition
-    for (uint32_t t = 1; t < j.K; t++) {
-      const ete_t<N> cur = nxt;
-      if (t + 1 < j.K) nxt = load_ete<N>(src + (size_t)(t + 1) * j.inner);
-      acc = ete_add<N>(acc, cur);
+    if (Kt > 1u) {
+      ete_t<N> nxt = load_ete<N>(src + (size_t)j.inner);        // the next operand is in flight during the addition
+      for (uint32_t t = 1; t < Kt; t++) {
+        const ete_t<N> cur = nxt;
+        if (t + 1 < Kt) nxt = load_ete<N>(src + (size_t)(t + 1) * j.inner);
+        acc = ete_add<N>(acc, cur);
+      }
+    }
+    if (PAIR) {
+      const ete_t<N> other = pair_swap<N>(acc);
+      acc = ete_add<N>(acc, other);                          // both lanes compute it (one instruction stream), the even one stores
+      if (half != 0u) continue;
     }
     store_ete<N>(j.out + (size_t)k * j.out_per_window + o, acc);
   }

@@ -169,6 +169,7 @@ struct te_ctx {
   int opt_graph = 0;           // replay the launch sequence around k_accumulate as HIP graphs
   int opt_workset = 0;         // work set used by te_msm_run* / te_msm_partial_device
   int opt_fuse_prep = 1;       // device-resident inputs: convert the points in the launch of the sort's first level (k_part_scatter_prep)
+  int opt_fold_pairs = 1;      // first fold level of small MSMs with two lanes per output (k_sum_groups<N, true>)
   int opt_packed = 1;          // level-1 sort entries as one 32-bit word where n <= 2^23 (make_plan)
   int opt_prezero = 1;         // clear a work set's zeroed block behind an MSM's read-back instead of in front of the next MSM's first kernel
   float stage_ms[ST_COUNT + 2] = {};
@@ -526,9 +527,14 @@ struct msm_launch {
         // 36864 outputs) the thread form is as fast for one MSM (0.344 against 0.346 ms) and leaves more of the VALU to the
         // other MSMs in flight: 0.1645 against 0.1785 ms per MSM at 2^16, 0.224 against 0.239 at 2^17.  16384 would also move
         // the second level of unsigned 16-bit windows (64 blocks of serial additions: slower for one MSM).
-        if (most >= 32768u) {
+        if (most >= 65536u || (most >= 32768u && !ctx->opt_fold_pairs)) {
           uint32_t blocks = (most + 255) / 256; if (blocks > 4096) blocks = 4096;
-          hipLaunchKernelGGL(te::k_sum_groups<N>, dim3(blocks, nj), dim3(256), 0, stream, js, (uint32_t)p.nw);
+          hipLaunchKernelGGL((te::k_sum_groups<N, false>), dim3(blocks, nj), dim3(256), 0, stream, js, (uint32_t)p.nw);
+        } else if (most >= 32768u) {
+          // too few outputs for one thread each to fill the machine (n <= 2^18: 36 864 per chain): two lanes per output, half
+          // the dependent additions (option "fold_pairs"; every level folds by 8, 4 or 2 -- K is even)
+          uint32_t blocks = (2 * most + 255) / 256; if (blocks > 4096) blocks = 4096;
+          hipLaunchKernelGGL((te::k_sum_groups<N, true>), dim3(blocks, nj), dim3(256), 0, stream, js, (uint32_t)p.nw);
         } else {                            // latency-bound level: four lanes per output.  (Sixteen lanes per output as a tree --
                                             // 3 dependent team additions instead of 7 -- was measured: 22.5 us against 18.5 at
                                             // n = 2^20: four times the lanes put four waves on every SIMD and each addition slows down.)
@@ -726,7 +732,7 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, 
     graph_key key; memset(&key, 0, sizeof key);          // padding bytes take part in the memcmp below
     key.pts = d_points; key.sc = d_scalars; key.out = d_partials_out; key.n = n; key.generation = ws.generation;
     key.c = p.c; key.w_first = d.w_first; key.w_step = d.w_step; key.seg_len = (int)p.seg_len;
-    key.sort = ctx->opt_sort | (ctx->opt_signed << 1) | (ctx->opt_curve << 2) | (ctx->opt_packed << 4);
+    key.sort = ctx->opt_sort | (ctx->opt_signed << 1) | (ctx->opt_curve << 2) | (ctx->opt_packed << 4) | (ctx->opt_fold_pairs << 5);
     if (!ws.g_front || !ws.g_back || memcmp(&key, &ws.g_key, sizeof key) != 0) {
       if (ws.g_front || ws.g_back) HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));   // a previous replay may still be running
       msm_launch C = L; C.stream = ws.stream; C.prof = 0;
@@ -1133,6 +1139,7 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
   if (const char* e = getenv("TE_MSM_FUSE_PREP")) ctx->opt_fuse_prep = e[0] != '0';      // A/B measurements; option "fuse_prep"
   if (const char* e = getenv("TE_MSM_QUEUE_PROBE")) ctx->opt_queue_probe = e[0] != '0';  // option "queue_probe"
   if (const char* e = getenv("TE_MSM_PACKED")) ctx->opt_packed = e[0] != '0';            // option "packed_sort"
+  if (const char* e = getenv("TE_MSM_FOLD_PAIRS")) ctx->opt_fold_pairs = e[0] != '0';    // option "fold_pairs"
   if (const char* e = getenv("TE_MSM_HOST_SPLIT")) {                                     // relative piece weights "w0,w1,..." (experiments)
     const char* q = e;
     while (*q) { char* end = nullptr; const double v = strtod(q, &end); if (end == q) break; ctx->host_split.push_back(v > 0 ? v : 1.0); q = *end == ',' ? end + 1 : end; }
@@ -1326,6 +1333,7 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   if (!strcmp(key, "host_shard_min")) { if (value < 1 || value > (1ll << 30)) return set_err(ctx, TE_MSM_EINVAL, "host_shard_min out of range"); ctx->opt_host_shard_min = (int)value; return 0; }
   if (!strcmp(key, "queue_probe")) { ctx->opt_queue_probe = value ? 1 : 0; return 0; }
   if (!strcmp(key, "packed_sort")) { ctx->opt_packed = value ? 1 : 0; return 0; }
+  if (!strcmp(key, "fold_pairs")) { ctx->opt_fold_pairs = value ? 1 : 0; return 0; }
   return set_err(ctx, TE_MSM_EINVAL, "unknown option");
 }
 
@@ -1348,6 +1356,7 @@ int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value) {
   if (!strcmp(key, "host_shard_min")) { *value = ctx->opt_host_shard_min; return 0; }
   if (!strcmp(key, "queue_probe")) { *value = ctx->opt_queue_probe; return 0; }
   if (!strcmp(key, "packed_sort")) { *value = ctx->opt_packed; return 0; }
+  if (!strcmp(key, "fold_pairs")) { *value = ctx->opt_fold_pairs; return 0; }
   if (!strcmp(key, "streams_final")) { *value = ctx->devs[0].streams_final ? 1 : 0; return 0; }
   if (!strcmp(key, "in_flight")) { *value = ctx->devs[0].in_flight; return 0; }
   if (!strcmp(key, "device_bytes")) {      // device memory this context holds in work-set buffers (te_msm_trim gives it back)
