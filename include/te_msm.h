@@ -136,9 +136,8 @@ int te_msm_ticket_wait(te_ctx* ctx, uint64_t ticket);
  *   "packed_sort"   1 (default) = the sort's level-1 entries are one 32-bit word (index | key << 23 | sign << 31) where n <= 2^23:
  *                   4 bytes per entry instead of 6; 0 = the general form (u16 key + u32 index; what larger n always uses).
  *                   Same result (A/B measurements, tests; env TE_MSM_PACKED)
- *   "fold_pairs"    1 (default) = fold levels of the bucket reduction that cannot fill the machine split every output's chain of
- *                   additions in two halves -- two lanes per output on a level of 32 768 .. 65 535 outputs (n <= 2^18), two quads
- *                   per output on the team levels: half the dependent additions; 0 = off (A/B measurements; env TE_MSM_FOLD_PAIRS)
+ *   "fold_pairs"    1 (default) = a fold level of the bucket reduction with 32 768 .. 65 535 outputs (n <= 2^18) runs two lanes per
+ *                   output -- half the dependent additions; 0 = one thread per output (A/B measurements; env TE_MSM_FOLD_PAIRS)
  *   "fuse_prep"     1 (default) = device-resident Twisted-Edwards inputs: the points -> records conversion shares the launch
  *                   of the sort's first level; 0 = a launch of its own (A/B measurements; env TE_MSM_FUSE_PREP) */
 int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value);

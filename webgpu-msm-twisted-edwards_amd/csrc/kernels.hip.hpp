@@ -951,7 +951,7 @@ template <int N> struct sum_jobs_t { sum_job_t<N> j[4]; };
 // PAIR: two adjacent lanes share an output -- each sums half of the K inputs, the even lane adds the odd lane's half (handed over
 // with DPP moves) and stores: K/2 dependent additions instead of K - 1 for the same number of additions in all.  For levels with
 // too few outputs to fill the machine (n <= 2^18: 73 728 outputs on 1024 SIMDs -- a lone wave issues a dependent chain at half
-// rate): 59 -> 3x us at n = 2^16.
+// rate): 60 -> 52 us at n = 2^16 and 2^18.
 template <int N> __device__ __forceinline__ ete_t<N> pair_swap(const ete_t<N>& a) {        // the other lane of my pair (lanes 2i, 2i + 1)
   ete_t<N> r;
 #pragma unroll
@@ -1144,29 +1144,19 @@ __global__ void __launch_bounds__(256) k_seg_combine_all(const uint32_t* __restr
   }
 }
 // k_sum_groups with a quad per output (levels where the grid is too small to fill the machine): 4 threads per output.
-// PAIR: TWO quads per output (lanes 8i .. 8i + 7): each sums half of the K inputs, the first adds the second's half (handed over
-// with ds_bpermute) and stores -- K/2 dependent team additions instead of K - 1 (these levels are chains of dependent additions
-// on a nearly idle machine: 18.6 -> ~12 us at n = 2^20).
-template <int N, bool PAIR>
+// (Two quads per output -- each half of the chain, handed over with ds_bpermute: K/2 dependent team additions instead of K - 1 --
+// was measured in round 4 and changes nothing: 17.8 against 18.0 us at n = 2^20, 16.4 against 16.3 at 2^16.)
+template <int N>
 __global__ void __launch_bounds__(256) k_sum_groups_team(sum_jobs_t<N> js, uint32_t nw) {
   const sum_job_t<N>& j = js.j[blockIdx.y];
-  constexpr uint32_t LPO = PAIR ? 8u : 4u;                 // lanes per output
   const uint32_t total = j.n_out * nw, q = threadIdx.x & 3u, wq = team_word<N>(q);
-  const uint32_t half = PAIR ? (threadIdx.x >> 2) & 1u : 0u, Kt = PAIR ? j.K / 2u : j.K;
-  for (uint32_t g = (blockIdx.x * 256u + threadIdx.x) / LPO; g < total; g += (gridDim.x * 256u) / LPO) {
+  for (uint32_t g = (blockIdx.x * 256u + threadIdx.x) >> 2; g < total; g += (gridDim.x * 256u) >> 2) {
     const uint32_t k = g / j.n_out, o = g - k * j.n_out;
     const uint32_t outer = o / j.inner, qq = o - outer * j.inner;
-    const ete_t<N>* src = j.in + (size_t)k * j.in_per_window + ((size_t)outer * j.K + (size_t)half * Kt) * j.inner + qq;
+    const ete_t<N>* src = j.in + (size_t)k * j.in_per_window + (size_t)outer * j.K * j.inner + qq;
     fel<N> acc = load_coord<N>(words<N>(src) + wq);
-    for (uint32_t t = 1; t < Kt; t++)
+    for (uint32_t t = 1; t < j.K; t++)
       acc = ete_add_team<N>(acc, load_coord<N>(words<N>(src + (size_t)t * j.inner) + wq), q);
-    if (PAIR) {
-      fel<N> other;
-#pragma unroll
-      for (int i = 0; i < N; i++) other.v[i] = (uint32_t)__shfl_xor((int)acc.v[i], 4, 64);      // the same coordinate of the other quad
-      acc = ete_add_team<N>(acc, other, q);
-      if (half != 0u) continue;
-    }
     store_coord<N>(words<N>(j.out + (size_t)k * j.out_per_window + o) + wq, acc);
   }
 }

@@ -538,12 +538,8 @@ struct msm_launch {
         } else {                            // latency-bound level: four lanes per output.  (Sixteen lanes per output as a tree --
                                             // 3 dependent team additions instead of 7 -- was measured: 22.5 us against 18.5 at
                                             // n = 2^20: four times the lanes put four waves on every SIMD and each addition slows down.)
-          // two quads per output (half the dependent team additions) where a level folds by 4 or 8 (option "fold_pairs")
-          bool pair = ctx->opt_fold_pairs != 0;
-          for (int i = 0; i < nj; i++) pair = pair && js.j[i].K >= 4u;
-          uint32_t blocks = (most * (pair ? 8u : 4u) + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
-          if (pair) hipLaunchKernelGGL((te::k_sum_groups_team<N, true>), dim3(blocks, nj), dim3(256), 0, stream, js, (uint32_t)p.nw);
-          else hipLaunchKernelGGL((te::k_sum_groups_team<N, false>), dim3(blocks, nj), dim3(256), 0, stream, js, (uint32_t)p.nw);
+          uint32_t blocks = (most * 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+          hipLaunchKernelGGL(te::k_sum_groups_team<N>, dim3(blocks, nj), dim3(256), 0, stream, js, (uint32_t)p.nw);
         }
       }
       mark(ST_WEIGHTED);
