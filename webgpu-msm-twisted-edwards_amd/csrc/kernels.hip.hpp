@@ -1114,7 +1114,12 @@ __global__ void __launch_bounds__(256) k_seg_combine_all(const uint32_t* __restr
       const uint32_t g = split_list[i];
       const uint32_t ns = (bucket_count[g] + seg_len - 1u) / seg_len, s0 = seg_base[g];
       fel<N> acc = load_coord<N>(words<N>(seg_out + s0) + wq);
-      for (uint32_t j = 1; j < ns; j++) acc = ete_add_team<N>(acc, load_coord<N>(words<N>(seg_out + s0 + j) + wq), q);
+      fel<N> nxt = load_coord<N>(words<N>(seg_out + s0 + 1u) + wq);                  // ns >= 2: the next part is in flight during the addition
+      for (uint32_t j = 1; j < ns; j++) {
+        const fel<N> cur = nxt;
+        if (j + 1u < ns) nxt = load_coord<N>(words<N>(seg_out + s0 + j + 1u) + wq);
+        acc = ete_add_team<N>(acc, cur, q);
+      }
       store_coord<N>(words<N>(buckets + g) + wq, acc);
     }
     return;
@@ -1154,9 +1159,14 @@ __global__ void __launch_bounds__(256) k_sum_groups_team(sum_jobs_t<N> js, uint3
     const uint32_t k = g / j.n_out, o = g - k * j.n_out;
     const uint32_t outer = o / j.inner, qq = o - outer * j.inner;
     const ete_t<N>* src = j.in + (size_t)k * j.in_per_window + (size_t)outer * j.K * j.inner + qq;
+    // the next operand is in flight during the addition (loaded when needed, every step of the chain paid a memory latency)
     fel<N> acc = load_coord<N>(words<N>(src) + wq);
-    for (uint32_t t = 1; t < j.K; t++)
-      acc = ete_add_team<N>(acc, load_coord<N>(words<N>(src + (size_t)t * j.inner) + wq), q);
+    fel<N> nxt = load_coord<N>(words<N>(src + (size_t)j.inner) + wq);                 // K >= 2
+    for (uint32_t t = 1; t < j.K; t++) {
+      const fel<N> cur = nxt;
+      if (t + 1 < j.K) nxt = load_coord<N>(words<N>(src + (size_t)(t + 1) * j.inner) + wq);
+      acc = ete_add_team<N>(acc, cur, q);
+    }
     store_coord<N>(words<N>(j.out + (size_t)k * j.out_per_window + o) + wq, acc);
   }
 }
