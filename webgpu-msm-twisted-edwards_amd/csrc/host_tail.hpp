@@ -226,35 +226,61 @@ static inline Pt pdbl_n(Pt a, int k) {
 // evaluated top-down; the c doublings per window are split around the digit terms, so no doubling is added.
 // `sets` row buffers are summed on the fly: the rows are linear in the bucket contents, so an MSM computed in pieces
 // (te_msm_run uploads and processes a large host buffer in chunks) folds as the sum of the pieces' rows.
-static inline void horner_to_affine_multi(const uint8_t* const* partials, int sets, int c, int bucket_bits, int W, uint8_t out_xy_le[64]) {
+static inline Fe tail_k2d() {
   const Fe d2 = {{2 * 3021, 0, 0, 0}};
   const Fe R2 = {{0x25d577bab861857bULL, 0xcc2c27b58860591fULL, 0xa7cc008fe5dc8593ULL, 0x011fdae7eff1c939ULL}};
-  const Fe k2d = mul(d2, R2);
+  return mul(d2, R2);
+}
+// Horner over the W windows; add_slot(w, slot, acc) adds the window's point(s) of that slot onto acc
+template <typename F> static inline void horner_core(F&& add_slot, int c, int bucket_bits, int W, uint8_t out_xy_le[64]) {
   int dw[4];
   for (int k = 0; k < 4; k++) dw[k] = (bucket_bits + 3 - k) / 4;
   const int s3 = dw[0] + dw[1] + dw[2];
   Pt acc = identity();
-  auto add_slot = [&](int w, int slot) {
-    for (int s = 0; s < sets; s++) {
-      const uint8_t* row = partials[s] + (size_t)w * TE_TAIL_ROW_BYTES;
-      if (!all_zero_bytes(row, TE_TAIL_ROW_BYTES)) acc = padd(acc, load_point(row + (size_t)slot * TE_TAIL_POINT_BYTES), k2d);
-    }
-  };
   for (int w = W - 1; w >= 0; w--) {
     acc = pdbl_n(acc, c - s3);
-    add_slot(w, 4);                                    // W3
+    add_slot(w, 4, acc);                               // W3
     acc = pdbl_n(acc, dw[2]);
-    add_slot(w, 3);                                    // W2
+    add_slot(w, 3, acc);                               // W2
     acc = pdbl_n(acc, dw[1]);
-    add_slot(w, 2);                                    // W1
+    add_slot(w, 2, acc);                               // W1
     acc = pdbl_n(acc, dw[0]);
-    add_slot(w, 1);                                    // W0
-    add_slot(w, 0);                                    // T
+    add_slot(w, 1, acc);                               // W0
+    add_slot(w, 0, acc);                               // T
   }
   const Fe zi = inv(acc.z);
   const Fe one_raw = {{1, 0, 0, 0}};
   const Fe x = mul(mul(acc.x, zi), one_raw), y = mul(mul(acc.y, zi), one_raw);
   memcpy(out_xy_le, x.l, 32); memcpy(out_xy_le + 32, y.l, 32);
+}
+static inline void horner_to_affine_multi(const uint8_t* const* partials, int sets, int c, int bucket_bits, int W, uint8_t out_xy_le[64]) {
+  const Fe k2d = tail_k2d();
+  horner_core([&](int w, int slot, Pt& acc) {
+    for (int s = 0; s < sets; s++) {
+      const uint8_t* row = partials[s] + (size_t)w * TE_TAIL_ROW_BYTES;
+      if (!all_zero_bytes(row, TE_TAIL_ROW_BYTES)) acc = padd(acc, load_point(row + (size_t)slot * TE_TAIL_POINT_BYTES), k2d);
+    }
+  }, c, bucket_bits, W, out_xy_le);
+}
+// The same in two steps, for the multi-device te_msm_run: the sets' rows of ONE window summed slot by slot (independent per
+// window: the devices' host threads share the windows), then Horner over the merged points.
+//   merged: W x 5 points, present[w] = 0 when no set holds the window
+static inline void merge_window_rows(const uint8_t* const* partials, int sets, int w, Pt* merged, uint8_t* present) {
+  const Fe k2d = tail_k2d();
+  present[w] = 0;
+  for (int s = 0; s < sets; s++) {
+    const uint8_t* row = partials[s] + (size_t)w * TE_TAIL_ROW_BYTES;
+    if (all_zero_bytes(row, TE_TAIL_ROW_BYTES)) continue;
+    for (int slot = 0; slot < 5; slot++) {
+      const Pt p = load_point(row + (size_t)slot * TE_TAIL_POINT_BYTES);
+      merged[(size_t)w * 5 + slot] = present[w] ? padd(merged[(size_t)w * 5 + slot], p, k2d) : p;
+    }
+    present[w] = 1;
+  }
+}
+static inline void horner_to_affine_points(const Pt* merged, const uint8_t* present, int c, int bucket_bits, int W, uint8_t out_xy_le[64]) {
+  const Fe k2d = tail_k2d();
+  horner_core([&](int w, int slot, Pt& acc) { if (present[w]) acc = padd(acc, merged[(size_t)w * 5 + slot], k2d); }, c, bucket_bits, W, out_xy_le);
 }
 static inline void horner_to_affine(const uint8_t* partials, int c, int bucket_bits, int W, uint8_t out_xy_le[64]) {
   horner_to_affine_multi(&partials, 1, c, bucket_bits, W, out_xy_le);

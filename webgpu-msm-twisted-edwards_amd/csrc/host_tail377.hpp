@@ -112,27 +112,21 @@ static inline Pt pdbl(const Pt& a) {
 
 // rows: W x 1120 B = [T | W0 | W1 | W2 | W3]; see host_tail.hpp for the identity behind the fold.  `sets` row buffers are
 // summed on the fly (an MSM computed in pieces).
-static inline void horner_to_affine_multi(const uint8_t* const* partials, int sets, int c, int bucket_bits, int W, uint8_t out_xy_le[96]) {
+template <typename F> static inline void horner_core(F&& add_slot, int c, int bucket_bits, int W, uint8_t out_xy_le[96]) {
   int dw[4];
   for (int k = 0; k < 4; k++) dw[k] = (bucket_bits + 3 - k) / 4;
   const int s3 = dw[0] + dw[1] + dw[2];
   Pt acc = identity();
-  auto add_slot = [&](int w, int slot) {
-    for (int s = 0; s < sets; s++) {
-      const uint8_t* row = partials[s] + (size_t)w * TE377_TAIL_ROW_BYTES;
-      if (!all_zero_bytes(row, TE377_TAIL_ROW_BYTES)) acc = padd(acc, load_point(row + (size_t)slot * TE377_TAIL_POINT_BYTES));
-    }
-  };
   for (int w = W - 1; w >= 0; w--) {
     for (int k = 0; k < c - s3; k++) acc = pdbl(acc);
-    add_slot(w, 4);                                    // W3
+    add_slot(w, 4, acc);                               // W3
     for (int k = 0; k < dw[2]; k++) acc = pdbl(acc);
-    add_slot(w, 3);                                    // W2
+    add_slot(w, 3, acc);                               // W2
     for (int k = 0; k < dw[1]; k++) acc = pdbl(acc);
-    add_slot(w, 2);                                    // W1
+    add_slot(w, 2, acc);                               // W1
     for (int k = 0; k < dw[0]; k++) acc = pdbl(acc);
-    add_slot(w, 1);                                    // W0
-    add_slot(w, 0);                                    // T
+    add_slot(w, 1, acc);                               // W0
+    add_slot(w, 0, acc);                               // T
   }
   // Edwards (X : Y : Z) -> Montgomery u = (Z + Y)/(Z - Y), v = f u Z / X -> Weierstrass x = sqrt(3) u - 1, y = sqrt(3) v.
   // X = 0: the neutral element (Y = Z; the point at infinity, 96 zero bytes) or the point of order two (Y = -Z; (-1, 0)).
@@ -148,6 +142,30 @@ static inline void horner_to_affine_multi(const uint8_t* const* partials, int se
   const Fe v = mul(mul(mul(zpy, acc.z), di), F_M);              // f (Z + Y) Z / ((Z - Y) X)
   const Fe x = mul(sub(mul(u, SQRT3_M), ONE_M), one_raw), y = mul(mul(v, SQRT3_M), one_raw);
   memcpy(out_xy_le, x.l, 48); memcpy(out_xy_le + 48, y.l, 48);
+}
+static inline void horner_to_affine_multi(const uint8_t* const* partials, int sets, int c, int bucket_bits, int W, uint8_t out_xy_le[96]) {
+  horner_core([&](int w, int slot, Pt& acc) {
+    for (int s = 0; s < sets; s++) {
+      const uint8_t* row = partials[s] + (size_t)w * TE377_TAIL_ROW_BYTES;
+      if (!all_zero_bytes(row, TE377_TAIL_ROW_BYTES)) acc = padd(acc, load_point(row + (size_t)slot * TE377_TAIL_POINT_BYTES));
+    }
+  }, c, bucket_bits, W, out_xy_le);
+}
+// two-step form for the multi-device te_msm_run (see host_tail.hpp)
+static inline void merge_window_rows(const uint8_t* const* partials, int sets, int w, Pt* merged, uint8_t* present) {
+  present[w] = 0;
+  for (int s = 0; s < sets; s++) {
+    const uint8_t* row = partials[s] + (size_t)w * TE377_TAIL_ROW_BYTES;
+    if (all_zero_bytes(row, TE377_TAIL_ROW_BYTES)) continue;
+    for (int slot = 0; slot < 5; slot++) {
+      const Pt p = load_point(row + (size_t)slot * TE377_TAIL_POINT_BYTES);
+      merged[(size_t)w * 5 + slot] = present[w] ? padd(merged[(size_t)w * 5 + slot], p) : p;
+    }
+    present[w] = 1;
+  }
+}
+static inline void horner_to_affine_points(const Pt* merged, const uint8_t* present, int c, int bucket_bits, int W, uint8_t out_xy_le[96]) {
+  horner_core([&](int w, int slot, Pt& acc) { if (present[w]) acc = padd(acc, merged[(size_t)w * 5 + slot]); }, c, bucket_bits, W, out_xy_le);
 }
 static inline void horner_to_affine(const uint8_t* partials, int c, int bucket_bits, int W, uint8_t out_xy_le[96]) {
   horner_to_affine_multi(&partials, 1, c, bucket_bits, W, out_xy_le);
