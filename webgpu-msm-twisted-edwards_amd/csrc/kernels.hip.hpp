@@ -844,9 +844,13 @@ template <int N> __device__ __forceinline__ ete_t<N> load_ete(const ete_t<N>* sr
 struct __attribute__((aligned(4))) idx4 { uint32_t v[4]; };      // 16 bytes at 4-byte alignment: one global_load_dwordx4
 #define TE_CLK_SLOTS 64u       // copies of k_accumulate's four profiling words (64-bit each), see the kernel
 #define TE_IDX_STRIP 16u       // sorted indices a lane fetches at a time (k_accumulate); d_sorted is padded by as many words
-// registers: N = 9 fits four waves per SIMD (128 VGPRs); N = 14 holds 56 + 2 x 56 words of points alone: two waves
+// registers: N = 9 fits four waves per SIMD in 128 VGPRs (six of them spilled) and ran that way in rounds 1-3; round 4 asks for
+// THREE (133 VGPRs, nothing spilled): the VALU is as busy with three waves per SIMD (0.93-0.94 of the issue estimate either way),
+// and boxes whose clock sags under this kernel sustain a higher one with fewer waves in flight -- 2.11-2.19 GHz against 2.00-2.07,
+// the kernel alone 0.77-0.79 ms against 0.82-0.85, +2-4 % MSM/s there, nothing lost on boxes that hold 2.15 GHz anyway
+// (profiles/r04_accumulate_occupancy_experiment.txt).  N = 14 holds 56 + 2 x 56 words of points alone: two waves
 template <int N>
-__global__ void __launch_bounds__(256, N == 9 ? 4 : 2) k_accumulate(const rec_slot<N>* __restrict__ recs, const uint32_t* __restrict__ sorted,
+__global__ void __launch_bounds__(256, N == 9 ? 3 : 2) k_accumulate(const rec_slot<N>* __restrict__ recs, const uint32_t* __restrict__ sorted,
                                                     const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ bucket_count,
                                                     const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ seg_bucket,
                                                     const uint32_t* __restrict__ seg_lenv, const uint32_t* __restrict__ order,
