@@ -66,6 +66,34 @@ def edge_scalars(seed: int, n: int):
     return [special[i] if i < len(special) else rnd[i] for i in range(n)]
 
 
+def special_point_inputs(seed: int, n: int):
+    """Inputs that exercise the exceptional cases of the group law (the reference's add-2008-hwcd with a = -1, d = 3021 a
+    non-square, is complete -- wgsl/curve/ec.template.wgsl:34-66 -- so every one of them has a defined result): the neutral
+    element (0, 1), the point of order two (0, -1), the two points of order four (+-sqrt(-1), 0), P and -P and P again under the
+    SAME scalar (one bucket receives P, -P, P: a sum that passes through the neutral element and a doubling), and subgroup
+    points shifted by low-order points.  Returns (points: list of (x, y), scalars: list of int); n >= 32."""
+    p = model.P
+    i4 = model.sqrt_mod_p(p - 1)
+    low = [(0, 1), (0, p - 1), (i4, 0), (p - i4, 0)]
+    g = (model.GX, model.GY)
+    rnd = model.gen_scalars(seed, n)
+    pts, ks = [], []
+    for j, a in enumerate((1, 2, 3, 5, 7)):
+        b = model.scalar_mul(a, g)
+        pts += [b, model.neg(b), b]
+        ks += [rnd[j]] * 3
+    for j, q in enumerate(low):
+        pts.append(q); ks.append(rnd[8 + j])
+        pts.append(model.add(model.scalar_mul(11 + j, g), q)); ks.append(rnd[12 + j])
+    pts += [low[0], low[1]]; ks += [0, p - 1]
+    base = model.gen_points(seed, n)
+    while len(pts) < n:
+        k = len(pts)
+        pts.append(base[k] if k % 5 else model.add(base[k], low[k % 4]))
+        ks.append(rnd[k])
+    return pts[:n], ks[:n]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--max-n", type=int, default=65536)

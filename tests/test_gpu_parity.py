@@ -263,6 +263,38 @@ def test_edge_scalars_and_harness_mode(ctx, model, ora):
     assert ctx.run(pts, same) == ora.msm(pts, same, threads=8)
 
 
+def test_exceptional_points(ctx, pkg, model, ora):
+    """The cases a unified addition must get right without a branch: the neutral element, the points of order 2 and 4 as INPUTS,
+    P, -P and P again in one bucket (a sum through the neutral element and a doubling), subgroup points shifted by low-order
+    points -- through the first-entry conversion, the mixed addition, the folds and the tail, for window sizes that put them in
+    one bucket or spread them; host buffers, device buffers and unsigned digits."""
+    from oracle.gen_golden import special_point_inputs
+    for seed, n in ((5, 32), (6, 200), (7, 5000)):
+        pts, ks = special_point_inputs(seed, n)
+        pb, sb = model.points_to_bytes(pts), model.scalars_to_bytes(ks)
+        exp = ora.msm(pb, sb, threads=8)
+        if n <= 200:
+            assert model.xy_from_bytes(exp) == model.msm_naive(pts, ks)
+        for c in (0, 4, 9, 13, 16):
+            ctx.set_option("window_bits", c)
+            assert ctx.run(pb, sb) == exp, (n, c)
+        ctx.set_option("window_bits", 0)
+        dp, ds = _dev(pb), _dev(sb)
+        import torch
+        torch.cuda.synchronize()
+        assert ctx.run_device(dp.data_ptr(), ds.data_ptr(), n) == exp
+        ctx.set_option("signed_digits", 0)
+        assert ctx.run(pb, sb) == exp
+        ctx.set_option("signed_digits", 1)
+    # nothing but low-order points and the neutral element: every bucket sum is a low-order point
+    p = model.P
+    i4 = model.sqrt_mod_p(p - 1)
+    low = [(0, 1), (0, p - 1), (i4, 0), (p - i4, 0)] * 16
+    ks = model.gen_scalars(9, len(low))
+    pb, sb = model.points_to_bytes(low), model.scalars_to_bytes(ks)
+    assert model.xy_from_bytes(ctx.run(pb, sb)) == model.msm_naive(low, ks)
+
+
 def test_non_canonical_coordinates_are_reduced(ctx, model, ora):
     """x + p and y + p are other 256-bit names of the same field elements."""
     n = 64

@@ -109,6 +109,20 @@ def test_cuzk_small_pipeline(model, ora):
     assert _xy(model, ora.msm_naive(pb, sb)) == expected
 
 
+def test_exceptional_points_oracle_against_the_bigint_model(model, ora):
+    """The neutral element, the points of order 2 and 4, P / -P / P in one bucket, subgroup points shifted by low-order points:
+    the C restatement (add-2008-hwcd, complete for this curve) against the affine bigint model, for several window sizes."""
+    from oracle.gen_golden import special_point_inputs
+    for seed, n in ((5, 32), (6, 200)):
+        pts, ks = special_point_inputs(seed, n)
+        assert all(model.on_curve(q) for q in pts)
+        exp = model.msm_naive(pts, ks)
+        pb, sb = model.points_to_bytes(pts), model.scalars_to_bytes(ks)
+        for c in (None, 4, 9, 13, 16):
+            assert _xy(model, ora.msm(pb, sb, c=c)) == exp
+        assert _xy(model, ora.msm(pb, sb, c=16, bpr_mode=0)) == exp
+
+
 def test_transpose_is_counting_sort(model, ora):
     import numpy as np
     sc = ora.gen_scalars(3, 500)

@@ -858,6 +858,10 @@ __global__ void __launch_bounds__(256, N == 9 ? 3 : 2) k_accumulate(const rec_sl
                                                     ete_t<N>* __restrict__ seg_out, uint32_t n, uint32_t logB, uint32_t seg_len, uint32_t ids, uint32_t onto,
                                                     uint32_t win_per_msm, batch_slabs slabs, unsigned long long* __restrict__ clk) {
   __shared__ uint32_t idx_strip[256 * TE_IDX_STRIP];
+#if defined(TE_ACC_TWO_WAVES)
+  // A/B builds only: naming a high register makes the kernel's VGPR allocation 176, i.e. two waves per SIMD without touching LDS
+  if constexpr (N == 9) asm volatile("" ::: "v175");
+#endif
   // profiling: ~clock of the first wave in and clock of the last wave out, by atomic max on zeroed words -- the kernel's
   // own duration on the device, which an event pair around the launch overstates when other streams' kernels hold the
   // CUs (te_msm_stage_ms "accumulate_on_device"); per-wave shader-clock and wall-clock ticks give the core clock it ran at.
@@ -1033,6 +1037,17 @@ template <int N> __device__ __forceinline__ fel<N> fp_select(bool c, const fel<N
   for (int i = 0; i < N; i++) r.v[i] = c ? a.v[i] : b.v[i];
   return r;
 }
+// per-lane choice among field elements, limb by limb under a lane mask (m = all ones: b, else a).  NOT written as `c ? b : a` on
+// the structs: that is a choice between two OBJECTS, which the compiler resolved for one limb of ete_add_team's operands by
+// storing both candidates to scratch memory and loading one back with a per-lane offset -- a store + load round trip through
+// the vector memory path inside every team addition of the latency-bound kernels (12 bytes of scratch per lane in
+// k_seg_combine_all, k_sum_groups_team and k_reduce_tail until round 4).
+template <int N> __device__ __forceinline__ fel<N> fe_pick(uint32_t m, const fel<N>& b, const fel<N>& a) {
+  fel<N> r;
+#pragma unroll
+  for (int i = 0; i < N; i++) r.v[i] = mask_select(m, b.v[i], a.v[i]);
+  return r;
+}
 // q = lane & 3 selects the coordinate this lane holds: 0 X, 1 Y, 2 T, 3 Z.  All four lanes of a quad must call.
 // Limb rule for N = 14: one operand of every product is normalised (lanes 0, 1: the first-point side of round 1; E, F, G).
 template <int N> __device__ __forceinline__ fel<N> ete_add_team(const fel<N>& m1, const fel<N>& m2, const uint32_t q) {
@@ -1040,17 +1055,18 @@ template <int N> __device__ __forceinline__ fel<N> ete_add_team(const fel<N>& m1
   // round 1 operands
   const fel<N> u0 = fe_norm(fe_sub<2>(o1, m1)), v0 = fe_sub<2>(o2, m2); // lane0: Y1-X1, Y2-X2
   const fel<N> u1 = fe_norm_if_needed(fe_add(m1, o1)), v1 = fe_add(m2, o2);   // lane1: Y1+X1, Y2+X2
-  const fel<N> u = q == 0 ? u0 : (q == 1 ? u1 : m1);
-  const fel<N> v = q == 0 ? v0 : (q == 1 ? v1 : m2);
+  const uint32_t q0 = q == 0u ? ~0u : 0u, q1 = q == 1u ? ~0u : 0u, q2 = q == 2u ? ~0u : 0u, q3 = q == 3u ? ~0u : 0u;     // lane masks
+  const fel<N> u = fe_pick<N>(q0, u0, fe_pick<N>(q1, u1, m1));
+  const fel<N> v = fe_pick<N>(q0, v0, fe_pick<N>(q1, v1, m2));
   const fel<N> s1 = fe_mul(u, v);                                       // A | B | T1T2 | Z1Z2
   // round 2
   const fel<N> s2 = fe_mul(s1, fe_k2d<N>());                            // meaningful on lane2 only
-  const fel<N> val = q == 2 ? s2 : (q == 3 ? fe_add(s1, s1) : s1);      // A | B | C | D
+  const fel<N> val = fe_pick<N>(q2, s2, fe_pick<N>(q3, fe_add(s1, s1), s1));      // A | B | C | D
   // round 3
   const fel<N> A = quad_bcast<N>(val, 0), B = quad_bcast<N>(val, 1), C = quad_bcast<N>(val, 2), D = quad_bcast<N>(val, 3);
   const fel<N> E = fe_norm(fe_sub<2>(B, A)), H = fe_add(B, A), F = fe_norm(fe_sub<2>(D, C)), G = fe_norm(fe_add(D, C));
-  const fel<N> uu = (q == 0 || q == 2) ? E : (q == 1 ? H : F);
-  const fel<N> vv = q == 0 ? F : (q == 2 ? H : G);
+  const fel<N> uu = fe_pick<N>(q0 | q2, E, fe_pick<N>(q1, H, F));
+  const fel<N> vv = fe_pick<N>(q0, F, fe_pick<N>(q2, H, G));
   return fe_mul(uu, vv);                                                // X3 | Y3 | T3 | Z3
 }
 // word offset of coordinate q inside a stored point (memory order x | y | z | t)
@@ -1245,6 +1261,10 @@ __global__ void __launch_bounds__(1024) k_reduce_tail(tail_params_t<N> prm) {
   for (uint32_t m = 1u << wo; m > 1u; m >>= 1) {
     const uint32_t half = m >> 1, total = nout * half;
     for (uint32_t it0 = 0; it0 < total; it0 += Q) {                            // uniform trip count
+      // A wave none of whose quads has an item skips the addition (quads never straddle waves, so the DPP exchanges inside it
+      // stay whole): until round 4 all sixteen waves of the block executed every level under lane masks -- four waves per SIMD
+      // issuing the ~1000 instructions of an addition for the one or two that had work, 6 us per level instead of 2-3.
+      if (it0 + ((threadIdx.x & ~63u) >> 2) >= total) continue;               // wave-uniform
       const uint32_t it = it0 + i;
       const bool act = it < total;
       const uint32_t o = act ? it / half : 0u, t = act ? it - o * half : 0u;
