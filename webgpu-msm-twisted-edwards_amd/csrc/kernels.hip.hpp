@@ -649,20 +649,42 @@ __global__ void __launch_bounds__(256, 3) k_l2_local(l2_args a) {
 }
 
 // Counting sort of the valid segment ids by descending length: block `ob` of `nob` (256 threads; lds: 2 * 1024 + 17 words);
-// `ids` = size of the segment id space (host-known); rel_cursor zeroed per MSM.
+// `ids` = size of the segment id space (host-known); rel_cursor zeroed per MSM; max_len = largest length a segment can have
+// (min(seg_len, 1023), host-known).
 // order[] receives the valid segment ids by descending length; block 0 writes their number to *num_segments.
+// The block is a chain of dependent memory round trips on one MSM's critical path (20 us as a launch of its own), so it is
+// written to have as few of them as possible (round 4: 26 -> see profiles/r04_single_msm_timeline.txt):
+//  * the block's slice of seg_lenv is loaded ONCE, all loads in flight together, and kept in registers for both passes
+//    (TE_ORDER_REGS entries per thread; a larger slice takes the two-pass loop);
+//  * of the four 256-entry chunks of the length histogram only those that can be non-empty are summed and scanned -- with
+//    segments of at most 64 entries that is one chunk, not four (each costs 32 loads per thread and a block scan);
+//  * the 32 copies of a histogram entry are fetched by one batch of loads.
+#define TE_ORDER_REGS 32u
 __device__ __forceinline__ void order_scatter_block(uint32_t ob, uint32_t nob, uint32_t* __restrict__ lds, const uint32_t* __restrict__ lenv, uint32_t ids,
                                                     const uint32_t* __restrict__ size_hist, uint32_t* __restrict__ rel_cursor,
-                                                    uint32_t* __restrict__ order, uint32_t* __restrict__ num_segments) {
+                                                    uint32_t* __restrict__ order, uint32_t* __restrict__ num_segments, uint32_t max_len) {
   uint32_t* const h = lds; uint32_t* const base = lds + 1024; uint32_t* const sm = lds + 2048;
+  // the block owns a contiguous slice so that each thread sees the same elements in both passes
+  const uint32_t per = (ids + nob - 1) / nob;
+  const uint32_t lo = min(ids, ob * per), hi = min(ids, lo + per);
+  const bool in_regs = per <= TE_ORDER_REGS * 256u;                  // uniform
+  uint32_t lv[TE_ORDER_REGS];
+  if (in_regs) {
+#pragma unroll
+    for (uint32_t j = 0; j < TE_ORDER_REGS; j++) { const uint32_t g = lo + j * 256u + threadIdx.x; lv[j] = g < hi ? lenv[g] : TE_SEG_INVALID; }
+  }
+  for (uint32_t j = threadIdx.x; j < 1024u; j += 256u) h[j] = 0;
   // descending start of every length: number of segments longer than s (each block scans the histogram itself)
   {
     uint32_t run = 0;
-    for (uint32_t c = 0; c < 4u; c++) {
+    for (uint32_t c = (1023u - min(max_len, 1023u)) >> 8; c < 4u; c++) {      // chunk c holds the lengths 1023 - 256 c .. 768 - 256 c
       const uint32_t s = 1023u - (c * 256u + threadIdx.x);        // thread 0 of chunk 0 handles the largest size
+      uint32_t part[TE_HIST_COPIES];
+#pragma unroll
+      for (uint32_t r = 0; r < TE_HIST_COPIES; r++) part[r] = size_hist[r * 1024u + s];
       uint32_t cnt_s = 0;
-#pragma unroll 8
-      for (uint32_t r = 0; r < TE_HIST_COPIES; r++) cnt_s += size_hist[r * 1024u + s];
+#pragma unroll
+      for (uint32_t r = 0; r < TE_HIST_COPIES; r++) cnt_s += part[r];
       uint32_t bt;
       const uint32_t ex = block_excl_scan(cnt_s, sm, bt);
       base[s] = run + ex;
@@ -670,21 +692,30 @@ __device__ __forceinline__ void order_scatter_block(uint32_t ob, uint32_t nob, u
     }
     if (ob == 0 && threadIdx.x == 0) *num_segments = run;
   }
-  for (uint32_t j = threadIdx.x; j < 1024u; j += 256u) h[j] = 0;
   __syncthreads();
-  // the block owns a contiguous slice so that each thread sees the same elements in both passes
-  const uint32_t per = (ids + nob - 1) / nob;
-  const uint32_t lo = min(ids, ob * per), hi = min(ids, lo + per);
-  for (uint32_t g = lo + threadIdx.x; g < hi; g += 256u) { const uint32_t l = lenv[g]; if (l != TE_SEG_INVALID) atomicAdd(&h[min(l, 1023u)], 1u); }
+  if (in_regs) {
+#pragma unroll
+    for (uint32_t j = 0; j < TE_ORDER_REGS; j++) if (lv[j] != TE_SEG_INVALID) atomicAdd(&h[min(lv[j], 1023u)], 1u);
+  } else {
+    for (uint32_t g = lo + threadIdx.x; g < hi; g += 256u) { const uint32_t l = lenv[g]; if (l != TE_SEG_INVALID) atomicAdd(&h[min(l, 1023u)], 1u); }
+  }
   __syncthreads();
   for (uint32_t j = threadIdx.x; j < 1024u; j += 256u) { base[j] += h[j] ? atomicAdd(&rel_cursor[j], h[j]) : 0u; h[j] = 0; }
   __syncthreads();
-  for (uint32_t g = lo + threadIdx.x; g < hi; g += 256u) {
-    const uint32_t l = lenv[g];
-    if (l == TE_SEG_INVALID) continue;
-    const uint32_t s = min(l, 1023u);
-    const uint32_t pos = base[s] + atomicAdd(&h[s], 1u);
-    order[pos] = g;
+  if (in_regs) {
+#pragma unroll
+    for (uint32_t j = 0; j < TE_ORDER_REGS; j++) {
+      if (lv[j] == TE_SEG_INVALID) continue;
+      const uint32_t sz = min(lv[j], 1023u);
+      order[base[sz] + atomicAdd(&h[sz], 1u)] = lo + j * 256u + threadIdx.x;
+    }
+  } else {
+    for (uint32_t g = lo + threadIdx.x; g < hi; g += 256u) {
+      const uint32_t l = lenv[g];
+      if (l == TE_SEG_INVALID) continue;
+      const uint32_t sz = min(l, 1023u);
+      order[base[sz] + atomicAdd(&h[sz], 1u)] = g;
+    }
   }
 }
 
@@ -747,14 +778,14 @@ __device__ __forceinline__ void l2_place_piece(uint32_t p, uint32_t k, uint32_t 
 // grid (order_cols + P + X, nw), block 256: blocks with blockIdx.x < order_cols sort segments (order_cols * nw of them,
 // dispatched first); the others take the pieces of k_l2_local's grid and leave at once unless theirs belongs to a partition of
 // more than TE_L2_CAP entries (with well-spread digits: the top window's ~115 pieces).
-struct order_args { const uint32_t* lenv; uint32_t ids; const uint32_t* size_hist; uint32_t* rel_cursor; uint32_t* order; uint32_t* num_segments; uint32_t order_cols; };
+struct order_args { const uint32_t* lenv; uint32_t ids; const uint32_t* size_hist; uint32_t* rel_cursor; uint32_t* order; uint32_t* num_segments; uint32_t order_cols, max_len; };
 template <bool PK>
 __global__ void __launch_bounds__(256, 3) k_l2_place_order(const uint16_t* __restrict__ part_keys, const uint32_t* __restrict__ part_idx,
                                                            const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ part_count,
                                                            uint32_t* __restrict__ bucket_cursor, uint32_t* __restrict__ sorted, sort_geom g, order_args oa) {
   __shared__ uint32_t lds[TE_PLACE_LDS_WORDS];
   if (blockIdx.x < oa.order_cols) {
-    order_scatter_block(blockIdx.y * oa.order_cols + blockIdx.x, gridDim.y * oa.order_cols, lds, oa.lenv, oa.ids, oa.size_hist, oa.rel_cursor, oa.order, oa.num_segments);
+    order_scatter_block(blockIdx.y * oa.order_cols + blockIdx.x, gridDim.y * oa.order_cols, lds, oa.lenv, oa.ids, oa.size_hist, oa.rel_cursor, oa.order, oa.num_segments, oa.max_len);
     return;
   }
   const uint32_t k = blockIdx.y;

@@ -447,7 +447,12 @@ struct msm_launch {
       // + the placement of the pieces of over-long partitions in one launch
       te::order_args oa;
       oa.lenv = ws.d_seg_lenv; oa.ids = smax(); oa.size_hist = ws.d_size_hist; oa.rel_cursor = ws.d_size_cursor; oa.order = ws.d_order; oa.num_segments = ws.d_num_seg;
-      oa.order_cols = (uint32_t)std::min(64, std::max(1, 128 / p.nw));
+      // ~128 schedule blocks, more where a block's slice of the id space would not fit its registers (TE_ORDER_REGS * 256 ids)
+      {
+        const uint32_t by_regs = (smax() + TE_ORDER_REGS * 256u * (uint32_t)p.nw - 1u) / (TE_ORDER_REGS * 256u * (uint32_t)p.nw);
+        oa.order_cols = std::min(64u, std::max(by_regs, (uint32_t)std::max(1, 128 / p.nw)));
+      }
+      oa.max_len = std::min(p.seg_len, 1023u);                     // no segment is longer: only the histogram chunks up to there are scanned
       if (p.packed)
         hipLaunchKernelGGL(te::k_l2_place_order<true>, dim3(oa.order_cols + l2_blocks, p.nw), dim3(256), 0, stream, ws.d_part_keys, ws.d_part_idx, ws.d_part_start,
                            ws.d_part_count, ws.d_bucket_cursor, ws.d_sorted, sg, oa);
