@@ -2,7 +2,7 @@
 """Instruction-class histogram of one kernel in the gfx950 ISA listing (`make -C csrc asm`).
 
 usage: tools/isa_hist.py <listing.s> <kernel-substring> [--loop]
-  --loop   restrict to the hottest loop: the basic blocks between the LAST backward branch target and that branch
+  --loop   restrict to the hottest loop: the first loop of the kernel that holds at least one field product
            (k_accumulate's per-point loop)
 Prints the count per mnemonic and per class, with the issue cost measured by tools/ubench.hip
 (profiles/r01_ubench_instruction_rates.txt, r02_ubench_instruction_rates.txt: cycles per wave instruction at 4 waves/SIMD).
@@ -67,13 +67,16 @@ def analyse(path, name, loop_only, quiet=False):
         instrs.append(s.split(";")[0].strip())
     lo, hi = 0, len(instrs)
     if loop_only:
+        # the per-point loop: the FIRST loop in program order that holds a field product's worth of multiply-accumulates (the
+        # loop that sums the parts of a split bucket at the end of k_accumulate is larger -- nine products -- and comes later)
         best = None
         for i, ins in enumerate(instrs):
             m = re.match(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", ins)
             if m and m.group(1) in labels and labels[m.group(1)] <= i:
-                span = i - labels[m.group(1)]
-                if best is None or span > best[2]:
-                    best = (labels[m.group(1)], i + 1, span)
+                start = labels[m.group(1)]
+                mads = sum(1 for x in instrs[start:i + 1] if x.startswith("v_mad_u64_u32"))
+                if mads >= 150 and (best is None or start < best[0]):
+                    best = (start, i + 1, i - start)
         if best is None:
             raise SystemExit("no backward branch found")
         lo, hi = best[0], best[1]
