@@ -73,8 +73,8 @@ def ete_add(a, b):
     tt, zz = mul(t1, t2), mul(z1, z2)
     C = mul(tt, N(1.0))
     D = add(zz, zz)
-    E, H = norm(sub(Bp, A, 2)), add(Bp, A)
-    F, G = norm(sub(D, C, 2)), norm(add(D, C))
+    E, H = sub(Bp, A, 2), add(Bp, A)                  # N = 9: E and G stay wide (curve.hpp, fe_norm_if_needed)
+    F, G = norm(sub(D, C, 2)), add(D, C)
     return mul(E, F), mul(H, G), mul(F, G), mul(E, H)
 
 

@@ -156,7 +156,11 @@ TE_HD ete_t<14> ete_from_pnt(const pnt_t<14>& b) {
 }
 
 // Full addition a + b of two accumulators (add-2008-hwcd-3 shape, k = 2d), 9 products.
-// One operand of each opening product and F, G, E are normalised so that no product sees two wide operands.
+// One operand of the opening product of two differences and F are normalised, so that no product sees two wide operands:
+// with F of class N the closing products are E F (difference x N), H G (sum x sum-of-a-sum, limbs 2^30 x 2^30.6: the same
+// "difference x sum" column bound as the mixed addition, 0.97 * 2^64 in tests/test_limb_bounds_te.py), E H and F G.  With 14
+// limbs one operand of EVERY product must be normalised: E and G are as well.  (Until round 4 all three were normalised for
+// N = 9 too: two carry chains of 27 dependent instructions per addition that nothing needed.)
 template <int N> TE_HD ete_t<N> ete_add(const ete_t<N>& a, const ete_t<N>& b) {
   const fel<N> in1[4] = {fe_norm(fe_sub<2>(a.y, a.x)), fe_norm_if_needed(fe_add(a.y, a.x)), a.t, a.z};
   const fel<N> in2[4] = {fe_sub<2>(b.y, b.x), fe_add(b.y, b.x), b.t, b.z};
@@ -165,10 +169,10 @@ template <int N> TE_HD ete_t<N> ete_add(const ete_t<N>& a, const ete_t<N>& b) {
   const fel<N> &A = p1[0], &B = p1[1];
   const fel<N> C = fe_mul(p1[2], fe_k2d<N>());
   const fel<N> D = fe_add(p1[3], p1[3]);
-  const fel<N> E = fe_norm(fe_sub<2>(B, A));
+  const fel<N> E = fe_norm_if_needed(fe_sub<2>(B, A));
   const fel<N> H = fe_add(B, A);
   const fel<N> F = fe_norm(fe_sub<2>(D, C));
-  const fel<N> G = fe_norm(fe_add(D, C));
+  const fel<N> G = fe_norm_if_needed(fe_add(D, C));
   const fel<N> l[4] = {E, H, E, F}, rr[4] = {F, G, H, G};
   fel<N> o[4];
   fe_mul_x<4>(l, rr, o);

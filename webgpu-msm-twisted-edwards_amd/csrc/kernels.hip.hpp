@@ -102,8 +102,12 @@ __global__ void __launch_bounds__(256) k_prep_points(batch_ptrs in, batch_slabs 
 // A block covers TE_DIG_BLOCK consecutive entries (it never straddles a level-1 chunk: chunk_len is a multiple of it) and
 // also builds the level-1 histogram of the sort for them -- counts1[window][chunk][partition] += ... -- in LDS, flushed with
 // one global atomic per non-zero counter.  (The first version re-read all digits in a separate histogram kernel.)
+#ifndef TE_DIG_BLOCK
 #define TE_DIG_BLOCK 2048u
+#endif
+#ifndef TE_DIG_THREADS
 #define TE_DIG_THREADS 512u
+#endif
 __device__ __forceinline__ bool digit_bucket(uint32_t stored, uint32_t half, uint32_t& bucket, uint32_t& neg);
 template <int C>
 __global__ void __launch_bounds__(TE_DIG_THREADS) k_digits(batch_ptrs in, uint16_t* __restrict__ digits,
@@ -1080,7 +1084,8 @@ template <int N> __device__ __forceinline__ fel<N> fe_pick(uint32_t m, const fel
   return r;
 }
 // q = lane & 3 selects the coordinate this lane holds: 0 X, 1 Y, 2 T, 3 Z.  All four lanes of a quad must call.
-// Limb rule for N = 14: one operand of every product is normalised (lanes 0, 1: the first-point side of round 1; E, F, G).
+// Limb rule: N = 9 normalises the first-point difference of round 1 and F (E F, H G, E H, F G then hold one narrow operand or are
+// "difference x sum"); N = 14 one operand of every product (lanes 0, 1: the first-point side of round 1; E, F, G).
 template <int N> __device__ __forceinline__ fel<N> ete_add_team(const fel<N>& m1, const fel<N>& m2, const uint32_t q) {
   const fel<N> o1 = quad_swap1<N>(m1), o2 = quad_swap1<N>(m2);          // lane0 sees Y, lane1 sees X (lanes 2,3: unused)
   // round 1 operands
@@ -1095,7 +1100,7 @@ template <int N> __device__ __forceinline__ fel<N> ete_add_team(const fel<N>& m1
   const fel<N> val = fe_pick<N>(q2, s2, fe_pick<N>(q3, fe_add(s1, s1), s1));      // A | B | C | D
   // round 3
   const fel<N> A = quad_bcast<N>(val, 0), B = quad_bcast<N>(val, 1), C = quad_bcast<N>(val, 2), D = quad_bcast<N>(val, 3);
-  const fel<N> E = fe_norm(fe_sub<2>(B, A)), H = fe_add(B, A), F = fe_norm(fe_sub<2>(D, C)), G = fe_norm(fe_add(D, C));
+  const fel<N> E = fe_norm_if_needed(fe_sub<2>(B, A)), H = fe_add(B, A), F = fe_norm(fe_sub<2>(D, C)), G = fe_norm_if_needed(fe_add(D, C));   // limb rule: see ete_add
   const fel<N> uu = fe_pick<N>(q0 | q2, E, fe_pick<N>(q1, H, F));
   const fel<N> vv = fe_pick<N>(q0, F, fe_pick<N>(q2, H, G));
   return fe_mul(uu, vv);                                                // X3 | Y3 | T3 | Z3
