@@ -4,9 +4,9 @@
 mkdir -p gpurun_out
 out=gpurun_out/sweep_n.txt
 echo "# n sweep, one MI355X, bench.py --inflight 4 --steps 100 (window bits 0 = automatic rule)" > $out
-for lg in 16 17 18 19 20; do
-  for c in 0 14 15 16; do
-    timeout -k 5 120 python bench.py --steps 100 --warmup 3 --no-cpu-baseline --no-sizes --no-host-buffers --log2n $lg --window-bits $c 2>/dev/null | tail -1 > gpurun_out/_sw.json || { echo "FAILED lg=$lg c=$c" >> $out; exit 1; }
+for lg in ${LGS:-16 17 18 19 20}; do
+  for c in ${CS:-0 14 15 16}; do
+    timeout -k 5 120 python bench.py --steps 100 --warmup 3 --no-cpu-baseline --no-sizes --no-host-buffers --no-configs --log2n $lg --window-bits $c 2>/dev/null | tail -1 > gpurun_out/_sw.json || { echo "FAILED lg=$lg c=$c" >> $out; exit 1; }
     python - $lg $c <<'PY' >> $out
 import json, sys
 d = json.load(open("gpurun_out/_sw.json"))

@@ -99,11 +99,14 @@ __global__ void __launch_bounds__(256) k_prep_points(batch_ptrs in, batch_slabs 
 // reference's "final carry is 1" error (utils.ts:80-83) and sets *err.
 // digits[k * n + i] (u16) for local window k.
 // Each thread decomposes TWO consecutive scalars per step and stores their digits as one packed u32 per window (nst is even).
-// A block covers TE_DIG_BLOCK consecutive entries (it never straddles a level-1 chunk: chunk_len is a multiple of it) and
+// A block covers TE_DIG_BLOCK consecutive entries (it never straddles a level-1 chunk: chunk_len is a multiple of it; 1024 = ONE
+// step of two scalars per thread -- measured at n = 2^20 / 2^16: 2048 entries (two steps) 24.3 / 13.8 us, 1024 21.5 / 9.3,
+// 4096 28.3 / 23.4; smaller blocks lose to the flush below: 512 entries 30.6 us, 256 entries 54.5 us at 2^20 -- about 6 us per
+// million global atomics) and
 // also builds the level-1 histogram of the sort for them -- counts1[window][chunk][partition] += ... -- in LDS, flushed with
 // one global atomic per non-zero counter.  (The first version re-read all digits in a separate histogram kernel.)
 #ifndef TE_DIG_BLOCK
-#define TE_DIG_BLOCK 2048u
+#define TE_DIG_BLOCK 1024u
 #endif
 #ifndef TE_DIG_THREADS
 #define TE_DIG_THREADS 512u

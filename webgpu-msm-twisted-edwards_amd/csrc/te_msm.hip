@@ -218,10 +218,16 @@ void make_plan(const te_ctx* ctx, const gpu_t& d, uint64_t n, plan_t& p, int for
   p.signed_digits = ctx->opt_signed;
   p.logB = (uint32_t)(p.signed_digits ? p.c - 1 : p.c); p.B = 1u << p.logB;
   for (int k = 0; k < 4; k++) p.dw[k] = (p.logB + 3u - (uint32_t)k) / 4u;       // 15 -> 4,4,4,3
-  uint32_t ch = p.nw > 0 ? 1024u / (uint32_t)p.nw : 1u;     // ~4 blocks of 512 threads per CU in k_part_scatter
+#ifndef TE_SCATTER_BLOCKS
+#define TE_SCATTER_BLOCKS 1024u       // measured at n = 2^20: 512 blocks 81.8 us, 1024 80.3, 2048 98.4, 4096 264 (every block sums P x CH counts)
+#endif
+  uint32_t ch = p.nw > 0 ? TE_SCATTER_BLOCKS / (uint32_t)p.nw : 1u;     // ~4 blocks of 512 threads per CU in k_part_scatter
   if (ch < 1) ch = 1;
   if (ch > 256) ch = 256;
-  const uint32_t by_n = (uint32_t)((n + 8191) / 8192);      // at least ~8k digits per chunk
+#ifndef TE_SCATTER_MINCHUNK
+#define TE_SCATTER_MINCHUNK 4096u      // one tile (8192: k_part_scatter_prep 12.1 -> 10.7 us at n = 2^16, equal from 2^18 on)
+#endif
+  const uint32_t by_n = (uint32_t)((n + TE_SCATTER_MINCHUNK - 1) / TE_SCATTER_MINCHUNK);      // at least one tile of digits per chunk
   if (ch > by_n) ch = by_n ? by_n : 1;
   p.nst = (uint32_t)((n + 7) & ~(uint64_t)7);
   p.chunk_len = (uint32_t)((p.nst + ch - 1) / ch);
