@@ -282,6 +282,9 @@ struct sort_geom {
   uint32_t packed;       // level-1 entries as ONE word: index (23 bits) | bucket low bits << 23 (8) | sign << 31 (n <= 2^23; else u16 key + u32 index)
 };
 #define TE_TILE 4096u
+// level 2 takes a partition in pieces of at most TE_L2_CAP entries (see k_l2_local)
+#define TE_L2_CAP 9208u          // entries per piece (multiple of 8); n/P = 8192 at n = 2^20: +11 sigma of its Poisson spread
+#define TE_L2_LIST (TE_L2_CAP + 8u)
 
 // All global loads in these kernels are 16 bytes per lane (8 u16 digits / keys, 4 u32 indices): with 2- or
 // 4-byte loads the level-2 kernel spent 160 of its 197 us just fetching 100 MB (the memory pipeline is
@@ -301,7 +304,7 @@ __device__ __forceinline__ void unpack8(const uint4& v, uint32_t (&d)[8]) {
 // by k_seg_plan).
 struct scatter_args {
   const uint16_t* digits; const uint32_t* counts1; uint16_t* part_keys; uint32_t* part_idx;
-  uint32_t *part_start, *part_count, *seg_part_base; uint32_t seg_len, cap_w; sort_geom g;
+  uint32_t *part_start, *part_count, *seg_part_base; uint32_t seg_len, cap_w, nw /* local windows of the launch sequence */; sort_geom g;
 };
 // LDS of one level-1 block in words: one packed word per entry of the tile, four 512-entry tables, scan scratch.
 // Packed entry: source slot in the tile (12 bits) | partition << 12 (8 bits: P <= 256) | bucket low bits << 20 (8) | sign << 28 --
@@ -343,6 +346,11 @@ __device__ __forceinline__ void part_scatter_block(uint32_t ch, uint32_t k, uint
         part_start[k * g.P + t] = start; part_count[k * g.P + t] = tot;
         seg_part_base[k * g.P + t] = k * cap_w + t * g.S + extra;
       }
+      // overflow pieces of the window (pieces 1.. of the partitions with more than TE_L2_CAP entries), behind the nw * P counts:
+      // an extra block of level 2 that has no piece leaves after ONE load instead of a scan over the partition counts
+      uint32_t ovt;
+      (void)block_excl_scan((t < g.P && tot) ? (tot + TE_L2_CAP - 1u) / TE_L2_CAP - 1u : 0u, sm, ovt);
+      if (t == 0) part_count[a.nw * g.P + k] = ovt;
     }
   }
   const uint32_t lo = ch * g.chunk_len, hi = min(g.nst, lo + g.chunk_len);
@@ -439,8 +447,6 @@ __global__ void __launch_bounds__(512) k_part_scatter_prep(scatter_args a, uint3
 // the segment schedule.  With well-spread digits only the top window has such partitions.
 //   k_l2_local       : grid (P + X, nw), X = n / TE_L2_CAP + 1 extra blocks
 //   k_l2_place_order : grid (order_cols + P + X, nw): segment schedule + placement of the pieces of multi-piece partitions
-#define TE_L2_CAP 9208u          // entries per piece (multiple of 8); n/P = 8192 at n = 2^20: +11 sigma of its Poisson spread
-#define TE_L2_LIST (TE_L2_CAP + 8u)
 
 // loads the 16-byte groups covering entries [a, b) of a row (<= TE_L2_CAP + 8 entries), 5 groups of 8 entries per thread.
 // PK: packed level-1 entries (one u32 each: the key lives in the index word, the key array does not exist)
@@ -476,10 +482,11 @@ static_assert(5u * 256u * 8u >= TE_L2_CAP + 8u, "five groups per thread hold a p
 
 // Which piece does block bx of a window's grid row work on?  bx < P: piece 0 of partition bx.  bx >= P: the (bx - P)-th overflow
 // piece of the window -- pieces 1.. of the partitions with more than TE_L2_CAP entries, in partition order; false when there
-// are fewer.  All 256 threads call (block scan inside); pj: 2 words of LDS, sm: 17.
-__device__ __forceinline__ bool l2_piece_of_block(uint32_t bx, const uint32_t* __restrict__ pc, uint32_t P, uint32_t* sm, uint32_t* pj, uint32_t& p, uint32_t& j) {
+// are fewer (overflow_pieces = their number in this window).  All 256 threads call (block scan inside); pj: 2 words of LDS, sm: 17.
+__device__ __forceinline__ bool l2_piece_of_block(uint32_t bx, const uint32_t* __restrict__ pc, uint32_t P, uint32_t overflow_pieces, uint32_t* sm, uint32_t* pj, uint32_t& p, uint32_t& j) {
   if (bx < P) { p = bx; j = 0u; return true; }
   const uint32_t t = threadIdx.x, x = bx - P;
+  if (x >= overflow_pieces) return false;                    // uniform (the window's count, written by k_part_scatter's chunk-0 block)
   const uint32_t c = t < P ? pc[t] : 0u;
   const uint32_t ov = c ? (c + TE_L2_CAP - 1u) / TE_L2_CAP - 1u : 0u;
   uint32_t tot;
@@ -601,10 +608,15 @@ __global__ void __launch_bounds__(256, 3) k_l2_local(l2_args a) {
   uint32_t* const list = lds + 768 + 32;
   plan_lds& PL = *reinterpret_cast<plan_lds*>(list);
   const sort_geom& g = a.g;
-  const uint32_t k = blockIdx.y, t = threadIdx.x;
+  // Dispatch order = chain length: the pieces of over-long partitions are the longest chains of the launch (count, global atomics,
+  // ticket, and the last one plans the partition), and with canonical scalars they all sit in the TOP window -- so the grid is read
+  // backwards: last window first, and inside a window the extra blocks before the P partition blocks.  (Blocks are dispatched in
+  // grid order; with the pieces at the end of the grid their chain started when everything else was done.)
+  const uint32_t k = gridDim.y - 1u - blockIdx.y, t = threadIdx.x;
+  const uint32_t extra = gridDim.x - g.P, bx = blockIdx.x < extra ? g.P + blockIdx.x : blockIdx.x - extra;
   const uint32_t* ps = a.part_start + k * g.P; const uint32_t* pc = a.part_count + k * g.P;
   uint32_t p, j;
-  if (!l2_piece_of_block(blockIdx.x, pc, g.P, sm, pj, p, j)) return;
+  if (!l2_piece_of_block(bx, pc, g.P, bx < g.P ? 0u : a.part_count[gridDim.y * g.P + k], sm, pj, p, j)) return;
   const uint32_t cntp = pc[p], pb = ps[p];
   if (cntp == 0u) { (void)seg_plan_block(p, k, 0u, g, a.pa, PL); return; }       // an empty partition: its buckets' (empty) segments
   const bool single = cntp <= TE_L2_CAP;                                         // uniform
@@ -795,10 +807,11 @@ __global__ void __launch_bounds__(256, 3) k_l2_place_order(const uint16_t* __res
     order_scatter_block(blockIdx.y * oa.order_cols + blockIdx.x, gridDim.y * oa.order_cols, lds, oa.lenv, oa.ids, oa.size_hist, oa.rel_cursor, oa.order, oa.num_segments, oa.max_len);
     return;
   }
-  const uint32_t k = blockIdx.y;
+  const uint32_t k = gridDim.y - 1u - blockIdx.y;        // as in k_l2_local: the top window's pieces first
+  const uint32_t px = blockIdx.x - oa.order_cols, extra = gridDim.x - oa.order_cols - g.P, bx = px < extra ? g.P + px : px - extra;
   const uint32_t* pc = part_count + k * g.P;
   uint32_t p, j;
-  if (!l2_piece_of_block(blockIdx.x - oa.order_cols, pc, g.P, lds, lds + 32, p, j)) return;
+  if (!l2_piece_of_block(bx, pc, g.P, bx < g.P ? 0u : part_count[gridDim.y * g.P + k], lds, lds + 32, p, j)) return;
   const uint32_t cntp = pc[p], pb = part_start[k * g.P + p];
   if (cntp <= TE_L2_CAP) return;                         // sorted by its own block of k_l2_local (uniform)
   const uint32_t a0 = pb + j * TE_L2_CAP;

@@ -297,7 +297,7 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, workset_t& ws, uint64_t n, const plan_
   if ((rc = ensure(ctx, ws, ws.d_chunk_list, ws.cap[26], 2 * (wb + smax / 1024 + 2)))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_part_start, ws.cap[6], (size_t)p.nw * p.P))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_buckets, ws.cap[8], wb * ab))) return rc;
-  if ((rc = ensure(ctx, ws, ws.d_part_count, ws.cap[9], (size_t)p.nw * p.P))) return rc;
+  if ((rc = ensure(ctx, ws, ws.d_part_count, ws.cap[9], (size_t)p.nw * p.P + (size_t)p.nw))) return rc;      // + the overflow pieces of each window
   if ((rc = ensure(ctx, ws, ws.d_part_keys, ws.cap[14], p.packed ? 8 : nd))) return rc;       // packed level-1 entries carry their key
   if ((rc = ensure(ctx, ws, ws.d_part_idx, ws.cap[15], nd))) return rc;
   // fold levels (by 8, 4 or 2): the first output is at most B/2 per window, the second at most B/4
@@ -425,7 +425,7 @@ struct msm_launch {
     if (p.nw > 0) {
       te::scatter_args sa;
       sa.digits = ws.d_digits; sa.counts1 = ws.d_counts1; sa.part_keys = ws.d_part_keys; sa.part_idx = ws.d_part_idx; sa.part_start = ws.d_part_start;
-      sa.part_count = ws.d_part_count; sa.seg_part_base = ws.d_seg_part_base; sa.seg_len = p.seg_len; sa.cap_w = cap_w; sa.g = sg;
+      sa.part_count = ws.d_part_count; sa.seg_part_base = ws.d_seg_part_base; sa.seg_len = p.seg_len; sa.cap_w = cap_w; sa.nw = (uint32_t)p.nw; sa.g = sg;
       if (with_prep) {
         te::batch_ptrs tab; te::batch_slabs row_slab;
         const uint32_t rows = (uint32_t)prep_rows(tab, row_slab), per_row = (n32 + 255u) / 256u, sblocks = p.CH * (uint32_t)p.nw;
