@@ -534,7 +534,10 @@ struct plan_args {
   uint32_t seg_len, cap_w, chunk_cap;
 };
 struct plan_lds { uint32_t h[1024]; uint32_t sm[17]; uint32_t giant[256 * 3]; uint32_t n_giant; };
-__device__ __forceinline__ uint32_t seg_plan_block(uint32_t p, uint32_t k, uint32_t cnt_in, const sort_geom& sg, const plan_args& a, plan_lds& L) {
+// pstart / pcount / sbase: part_start, part_count and seg_part_base of the partition, loaded by the caller together with its first
+// loads (read here, behind the scans, they were one more memory round trip in every block's chain)
+__device__ __forceinline__ uint32_t seg_plan_block(uint32_t p, uint32_t k, uint32_t cnt_in, const sort_geom& sg, const plan_args& a, plan_lds& L,
+                                                   uint32_t pstart, uint32_t pcount, uint32_t sbase) {
   const uint32_t t = threadIdx.x, P = sg.P, S = sg.S, B = sg.B, seg_len = a.seg_len;
   uint32_t* const h = L.h; uint32_t* const sm = L.sm; uint32_t* const giant = L.giant;
   __syncthreads();                                       // the caller is done with whatever L aliases
@@ -547,7 +550,7 @@ __device__ __forceinline__ uint32_t seg_plan_block(uint32_t p, uint32_t k, uint3
   uint32_t bt, bt2;
   const uint32_t ex = block_excl_scan(cnt, sm, bt);
   const uint32_t ex2 = block_excl_scan(nparts, sm, bt2);
-  const uint32_t bs = a.part_start[k * P + p] + ex, sb = a.seg_part_base[k * P + p] + ex2;
+  const uint32_t bs = pstart + ex, sb = sbase + ex2;
   if (mine) {
     a.bucket_start[g] = bs; a.bucket_cursor[g] = bs; a.seg_base[g] = sb;
     if (nparts <= TE_COMBINE_SMALL) {
@@ -566,8 +569,8 @@ __device__ __forceinline__ uint32_t seg_plan_block(uint32_t p, uint32_t k, uint3
   // ids this partition does not use: [first + segments, first + S + floor(part_count / seg_len))
   {
     // (the last partition also covers the rest of the window's id range, up to (k + 1) * cap_w)
-    const uint32_t first = a.seg_part_base[k * P + p], used = bt2;
-    const uint32_t cap = p + 1u == P ? (k + 1u) * a.cap_w - first : S + a.part_count[k * P + p] / seg_len;
+    const uint32_t first = sbase, used = bt2;
+    const uint32_t cap = p + 1u == P ? (k + 1u) * a.cap_w - first : S + pcount / seg_len;
     for (uint32_t j = used + t; j < cap; j += 256u) { a.seg_bucket[first + j] = TE_SEG_INVALID; a.seg_lenv[first + j] = TE_SEG_INVALID; }
   }
   __syncthreads();
@@ -617,15 +620,15 @@ __global__ void __launch_bounds__(256, 3) k_l2_local(l2_args a) {
   const uint32_t* ps = a.part_start + k * g.P; const uint32_t* pc = a.part_count + k * g.P;
   uint32_t p, j;
   if (!l2_piece_of_block(bx, pc, g.P, bx < g.P ? 0u : a.part_count[gridDim.y * g.P + k], sm, pj, p, j)) return;
-  const uint32_t cntp = pc[p], pb = ps[p];
-  if (cntp == 0u) { (void)seg_plan_block(p, k, 0u, g, a.pa, PL); return; }       // an empty partition: its buckets' (empty) segments
+  const uint32_t cntp = pc[p], pb = ps[p], sbp = a.pa.seg_part_base[k * g.P + p];
+  if (cntp == 0u) { (void)seg_plan_block(p, k, 0u, g, a.pa, PL, pb, cntp, sbp); return; }       // an empty partition: its buckets' (empty) segments
   const bool single = cntp <= TE_L2_CAP;                                         // uniform
   const uint32_t a0 = pb + j * TE_L2_CAP, b0 = min(pb + cntp, a0 + TE_L2_CAP);
   const uint16_t* keys_row = a.part_keys + (size_t)k * g.nst; const uint32_t* idx_row = a.part_idx + (size_t)k * g.nst;
+  piece_regs r; uint32_t head, total;
+  load_piece<PK>(keys_row, idx_row, a0, b0, t, single, r, head, total);      // in flight across the barrier
   cnt_s[t] = 0u;
   __syncthreads();
-  piece_regs r; uint32_t head, total;
-  load_piece<PK>(keys_row, idx_row, a0, b0, t, single, r, head, total);
 #pragma unroll
   for (int c = 0; c < 5; c++) {
     uint32_t kv[8], iv[8]; piece_group<PK>(r, c, kv, iv);
@@ -643,12 +646,12 @@ __global__ void __launch_bounds__(256, 3) k_l2_local(l2_args a) {
     __syncthreads();
     if (t == 0) pj[2] = (atomicAdd(&a.part_ticket[k * g.P + p], 1u) + 1u == (cntp + TE_L2_CAP - 1u) / TE_L2_CAP) ? 1u : 0u;
     __syncthreads();
-    if (pj[2]) (void)seg_plan_block(p, k, t < g.S ? ld_agent(a.bucket_count + gb) : 0u, g, a.pa, PL);      // uniform
+    if (pj[2]) (void)seg_plan_block(p, k, t < g.S ? ld_agent(a.bucket_count + gb) : 0u, g, a.pa, PL, pb, cntp, sbp);      // uniform
     return;
   }
   // the whole partition is in this block's registers: plan it from the counts at hand, then place it
   if (t < g.S) a.bucket_count[gb] = c0;
-  const uint32_t ex = seg_plan_block(p, k, c0, g, a.pa, PL);
+  const uint32_t ex = seg_plan_block(p, k, c0, g, a.pa, PL, pb, cntp, sbp);
   if (t < g.S) a.pa.bucket_cursor[gb] = pb + ex + c0;   // "everything placed" (the arrival counter of k_seg_combine_all starts from there)
   off_s[t] = ex;                                        // next free LDS slot of bucket t
   __syncthreads();
