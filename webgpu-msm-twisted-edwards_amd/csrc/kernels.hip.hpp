@@ -418,7 +418,10 @@ __global__ void __launch_bounds__(512) k_part_scatter(scatter_args a) {
 // point -- side by side they fill each other's gaps, back to back they cost 56 + 39 us on one MSM's critical path.
 // 1-D grid of scatter_blocks + prep_blocks blocks of 512 threads, the two kinds interleaved evenly (Bresenham); a
 // conversion block works with its first 256 threads (the other four waves only meet the barriers).
-__global__ void __launch_bounds__(512) k_part_scatter_prep(scatter_args a, uint32_t scatter_blocks, batch_ptrs in, batch_slabs row_slab,
+#ifndef TE_SCATTER_PREP_WAVES
+#define TE_SCATTER_PREP_WAVES 8      // 64 VGPRs, nothing spilled: four 512-thread blocks per CU (80 VGPRs, three blocks: 81.1 -> 77.9 us at n = 2^20)
+#endif
+__global__ void __launch_bounds__(512, TE_SCATTER_PREP_WAVES) k_part_scatter_prep(scatter_args a, uint32_t scatter_blocks, batch_ptrs in, batch_slabs row_slab,
                                                            pnt_slot* __restrict__ recs, uint32_t n, uint32_t prep_blocks_per_row, uint32_t prep_blocks) {
   __shared__ uint4 lds4[(TE_SCATTER_LDS_WORDS + 3u) / 4u > 256u * 8u ? (TE_SCATTER_LDS_WORDS + 3u) / 4u : 256u * 8u];
   const uint64_t tot = (uint64_t)scatter_blocks + prep_blocks, b = blockIdx.x;
