@@ -222,8 +222,8 @@ def main():
     ap.add_argument("--points", choices=["random", "chain", "fixed"], default="random",
                     help="random: n independent seeded-random a_i*G (SURVEY 8d set (R), default); chain: the arithmetic progression (a+i*b)G; "
                          "fixed: harness mode (H), one point replicated (ui/AllBenchmarks.tsx:105-112)")
-    ap.add_argument("--scalars", choices=["uniform", "equal", "small"], default="uniform",
-                    help="uniform: the harness's distribution; equal: one scalar repeated (worst-case skew); small: 64-bit scalars")
+    ap.add_argument("--scalars", choices=["uniform", "equal", "small", "mixed"], default="uniform",
+                    help="uniform: the harness distribution; equal: one scalar repeated (worst-case skew); small: 64-bit scalars; mixed: a quarter zeros, a quarter ones, the rest uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sizes", action="store_true", help="skip the n = 2^16..2^19 side table")
     ap.add_argument("--no-configs", action="store_true", help="skip the short passes of BASELINE configs 2 and 5 (unsigned windows, BLS12-377 G1)")
@@ -312,6 +312,15 @@ def main():
             sc = sc[:sb] * n
         elif args.scalars == "small":
             sc = b"".join(sc[sb * i:sb * i + 8] + bytes(sb - 8) for i in range(n))
+        elif args.scalars == "mixed":
+            # a prover's witness: a quarter zeros, a quarter ones, the rest uniform -- bucket 0 of window 0
+            # holds n / 4 points, every other bucket the usual few dozen
+            import numpy as np
+            a = np.frombuffer(sc, dtype=np.uint8).reshape(n, sb).copy()
+            a[0::4] = 0
+            a[1::4] = 0
+            a[1::4, 0] = 1
+            sc = a.tobytes()
         return pts, sc
 
     n = 1 << args.log2n
@@ -691,6 +700,18 @@ def main():
         out["configs"]["harness_fixed_point"] = chh
         if not ok:
             bad.append("harness_fixed_point")
+        # SURVEY 8f rank 3, a prover's witness: a quarter zeros, a quarter ones, the rest uniform (bucket 0 of window 0 holds n / 4 points)
+        import numpy as np
+        aw = np.frombuffer(sc, dtype=np.uint8).reshape(n, sb).copy()
+        aw[0::4] = 0
+        aw[1::4] = 0
+        aw[1::4, 0] = 1
+        cw, ok = side_config(pkg, dev, "witness_scalars", "te", "signed", 20, depth, threads, 40, inputs=(pts, aw.tobytes()),
+                             workload_note=", scalars: a quarter zeros, a quarter ones, the rest uniform")
+        out["configs"]["witness_scalars"] = cw
+        if not ok:
+            bad.append("witness_scalars")
+        del aw
         # set (R) against the arithmetic progression the earlier rounds timed: the same kernels on equally spread field elements
         pc, _ = pkg.synth_inputs(0x5EED0000 + 20, n, fixed_point="chain", scalars=False)
         dpc = torch.frombuffer(bytearray(pc), dtype=torch.uint8).cuda()

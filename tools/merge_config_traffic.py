@@ -10,7 +10,8 @@ from collections import defaultdict
 
 WORKLOADS = {"unsigned": "bench.py --digits unsigned (n = 2^20, 16-bit unsigned windows, one GPU)",
              "bls12_377": "bench.py --curve bls12-377 (n = 2^20, BLS12-377 G1, 16-bit signed windows, one GPU)",
-             "harness_fixed_point": "bench.py --points fixed (n = 2^20, one fixed point replicated, 16-bit signed windows, one GPU)"}
+             "harness_fixed_point": "bench.py --points fixed (n = 2^20, one fixed point replicated, 16-bit signed windows, one GPU)",
+             "witness_scalars": "bench.py --scalars mixed (n = 2^20, a quarter zeros, a quarter ones, the rest uniform, 16-bit signed windows, one GPU)"}
 
 
 def short(k):

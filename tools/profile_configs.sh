@@ -9,7 +9,7 @@ OUT="$REPO/gpurun_out/prof"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 COMMON="--steps 6 --warmup 1 --repeats 1 --no-cpu-baseline --no-sizes --no-host-buffers --no-configs"
-for spec in "unsigned|--digits unsigned" "bls12_377|--curve bls12-377" "harness_fixed_point|--points fixed"; do
+for spec in "unsigned|--digits unsigned" "bls12_377|--curve bls12-377" "harness_fixed_point|--points fixed" "witness_scalars|--scalars mixed"; do
   name="${spec%%|*}"; flags="${spec#*|}"
   for ctr in FETCH_SIZE WRITE_SIZE; do
     d="$OUT/cfg_${name}_${ctr}"; rm -rf "$d"

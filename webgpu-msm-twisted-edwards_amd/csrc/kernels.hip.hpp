@@ -521,6 +521,10 @@ __device__ __forceinline__ bool l2_piece_of_block(uint32_t bx, const uint32_t* _
 //   k_order_scatter: counting sort of the valid segment ids by descending length; every block scans the 1024-entry
 //                    histogram itself.
 #define TE_COMBINE_SMALL 16u
+// a giant bucket's parts are summed in runs of TE_GIANT_RUN by one block each, then the runs by the block that finishes the last one.
+// 256 (1024 until round 4): a block works a run off as 64 quads x (run / 64) serial team additions + a 6-level tree, so a prover's
+// witness with a quarter of ones (bucket 0 of window 0: 4096 parts at n = 2^20) took 16 + 6 + 3 levels of ~2.6 us; now 4 + 6 + 5
+#define TE_GIANT_RUN 256u
 #define TE_SEG_INVALID 0xffffffffu
 // The histogram of segment lengths is kept in TE_HIST_COPIES copies (block b adds to copy b mod copies; k_order_scatter sums
 // them): 2048 blocks adding to the same ~60 hot addresses cost 28 us of serialised atomics with a single copy.
@@ -577,7 +581,7 @@ __device__ __forceinline__ uint32_t seg_plan_block(uint32_t p, uint32_t k, uint3
     for (uint32_t j = used + t; j < cap; j += 256u) { a.seg_bucket[first + j] = TE_SEG_INVALID; a.seg_lenv[first + j] = TE_SEG_INVALID; }
   }
   __syncthreads();
-  // giant buckets: the whole block writes their segment records; one chunk entry per 1024 parts (k_seg_combine_all)
+  // giant buckets: the whole block writes their segment records; one chunk entry per TE_GIANT_RUN parts (k_seg_combine_all)
   const uint32_t ng = L.n_giant;
   for (uint32_t j = 0; j < ng; j++) {
     const uint32_t gg = giant[3 * j], sb0 = giant[3 * j + 1], c0 = giant[3 * j + 2];
@@ -586,7 +590,7 @@ __device__ __forceinline__ uint32_t seg_plan_block(uint32_t p, uint32_t k, uint3
       const uint32_t len = min(seg_len, c0 - part * seg_len);
       a.seg_bucket[sb0 + part] = gg; a.seg_lenv[sb0 + part] = len;
       atomicAdd(&h[min(len, 1023u)], 1u);
-      if ((part & 1023u) == 0) { const uint32_t ci = atomicAdd(&a.split_count[2], 1u); if (ci < a.chunk_cap) { a.chunk_list[2 * ci] = gg; a.chunk_list[2 * ci + 1] = part; } }
+      if ((part & (TE_GIANT_RUN - 1u)) == 0) { const uint32_t ci = atomicAdd(&a.split_count[2], 1u); if (ci < a.chunk_cap) { a.chunk_list[2 * ci] = gg; a.chunk_list[2 * ci + 1] = part; } }
     }
   }
   __syncthreads();
@@ -1156,23 +1160,32 @@ template <int N, bool COHERENT = false> __device__ __forceinline__ fel<N> block_
   constexpr uint32_t PW = geo<N>::PW;
   const uint32_t i = threadIdx.x >> 2, q = threadIdx.x & 3u, w = team_word<N>(q);
   fel<N> acc = identity_coord<N>(q);
-  for (uint32_t j = i; j < cnt; j += 64u) {       // quad-uniform trip count differs between quads: DPP stays inside a quad
-    const fel<N> e = COHERENT ? load_coord_agent<N>(words<N>(src + (size_t)j * stride) + w) : load_coord<N>(words<N>(src + (size_t)j * stride) + w);
-    acc = j == i ? e : ete_add_team<N>(acc, e, q);
+  auto fetch = [&](uint32_t j) { return COHERENT ? load_coord_agent<N>(words<N>(src + (size_t)j * stride) + w) : load_coord<N>(words<N>(src + (size_t)j * stride) + w); };
+  if (i < cnt) {                                  // quad-uniform trip count differs between quads: DPP stays inside a quad
+    acc = fetch(i);
+    fel<N> nxt = fetch(min(i + 64u, cnt - 1u));   // the next operand is in flight during the addition
+    for (uint32_t j = i + 64u; j < cnt; j += 64u) {
+      const fel<N> cur = nxt;
+      if (j + 64u < cnt) nxt = fetch(j + 64u);
+      acc = ete_add_team<N>(acc, cur, q);
+    }
   }
   for (uint32_t s = 32; s > 0; s >>= 1) {
+    if (s >= cnt) continue;                                 // uniform: no quad beyond s holds a value
     if (i >= s && i < 2 * s) store_coord<N>(lds + (size_t)i * PW + w, acc);
     __syncthreads();
-    const bool act = i < s && i + s < cnt;
-    const fel<N> other = act ? load_coord<N>(lds + (size_t)(i + s) * PW + w) : identity_coord<N>(q);
-    const fel<N> sum = ete_add_team<N>(acc, other, q);
-    acc = fp_select<N>(act, sum, acc);
+    if (((threadIdx.x & ~63u) >> 2) < s) {                  // a wave all of whose quads are beyond s has nothing to add (wave-uniform)
+      const bool act = i < s && i + s < cnt;
+      const fel<N> other = act ? load_coord<N>(lds + (size_t)(i + s) * PW + w) : identity_coord<N>(q);
+      const fel<N> sum = ete_add_team<N>(acc, other, q);
+      acc = fp_select<N>(act, sum, acc);
+    }
     __syncthreads();
   }
   return acc;
 }
 // sums the parts of split buckets.  Blocks [0, quad_blocks) sum the buckets cut into 2..16 parts, one quad (team addition)
-// per entry of the split list; the remaining blocks sum the runs of 1024 parts of GIANT buckets (skewed scalars, or a top
+// per entry of the split list; the remaining blocks sum the runs of TE_GIANT_RUN parts of GIANT buckets (skewed scalars, or a top
 // window with one or two occupied buckets) into the first slot of each run, and the block that finishes a bucket's LAST run
 // sums those slots into the bucket (until round 4 a second launch, k_seg_combine_large2, near-empty for well-spread digits:
 // 5 us on every MSM's critical path).  The arrival counter of a bucket is its bucket_cursor word, dead since the placement:
@@ -1203,12 +1216,13 @@ __global__ void __launch_bounds__(256) k_seg_combine_all(const uint32_t* __restr
     return;
   }
   const uint32_t items = min(counts[2], chunk_cap), nb = gridDim.x - quad_blocks;
+  constexpr uint32_t run = TE_GIANT_RUN;
   for (uint32_t it = blockIdx.x - quad_blocks; it < items; it += nb) {
     const uint32_t g = chunk_list[2 * it], part = chunk_list[2 * it + 1];
-    const uint32_t ns = (bucket_count[g] + seg_len - 1u) / seg_len, cnt = min(1024u, ns - part);
+    const uint32_t ns = (bucket_count[g] + seg_len - 1u) / seg_len, cnt = min(run, ns - part);
     ete_t<N>* base = seg_out + seg_base[g] + part;
     const fel<N> r = block_sum_points<N>(base, 1u, cnt, lds);
-    const uint32_t nchunks = (ns + 1023u) >> 10;
+    const uint32_t nchunks = (ns + run - 1u) / run;
     if (nchunks == 1u) {                                  // (cannot happen: a giant bucket has more than 16 parts; kept exact)
       if ((threadIdx.x >> 2) == 0) store_coord<N>(words<N>(buckets + g) + wq, r);
       __syncthreads();
@@ -1220,7 +1234,7 @@ __global__ void __launch_bounds__(256) k_seg_combine_all(const uint32_t* __restr
     if (threadIdx.x == 0) arrived = atomicAdd(&bucket_cursor[g], 1u) - (bucket_start[g] + bucket_count[g]);
     __syncthreads();
     if (arrived + 1u == nchunks) {                         // uniform: this block finished the bucket's last run
-      const fel<N> t = block_sum_points<N, true>(seg_out + seg_base[g], 1024u, nchunks, lds);
+      const fel<N> t = block_sum_points<N, true>(seg_out + seg_base[g], run, nchunks, lds);
       if ((threadIdx.x >> 2) == 0) store_coord<N>(words<N>(buckets + g) + wq, t);
     }
     __syncthreads();

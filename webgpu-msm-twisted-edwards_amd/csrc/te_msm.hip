@@ -293,8 +293,8 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, workset_t& ws, uint64_t n, const plan_
   if ((rc = ensure(ctx, ws, ws.d_seg_out, ws.cap[22], smax * ab))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_seg_base, ws.cap[23], wb + 1))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_split_list, ws.cap[24], wb + 1))) return rc;
-  // a giant bucket contributes one chunk per 1024 parts: at most one per bucket plus one per 1024 segments
-  if ((rc = ensure(ctx, ws, ws.d_chunk_list, ws.cap[26], 2 * (wb + smax / 1024 + 2)))) return rc;
+  // a giant bucket contributes one chunk per TE_GIANT_RUN parts: at most one per bucket plus one per TE_GIANT_RUN segments
+  if ((rc = ensure(ctx, ws, ws.d_chunk_list, ws.cap[26], 2 * (wb + smax / TE_GIANT_RUN + 2)))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_part_start, ws.cap[6], (size_t)p.nw * p.P))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_buckets, ws.cap[8], wb * ab))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_part_count, ws.cap[9], (size_t)p.nw * p.P + (size_t)p.nw))) return rc;      // + the overflow pieces of each window
@@ -333,7 +333,7 @@ struct msm_launch {
   uint32_t n32() const { return (uint32_t)n; }
   uint32_t total() const { return (uint32_t)p.nw * p.B; }
   uint32_t smax() const { return total() + (uint32_t)((uint64_t)p.nw * (n / p.seg_len)); }
-  uint32_t chunk_cap() const { return total() + smax() / 1024u + 2u; }     // entries of d_chunk_list (pairs), see ensure_buffers
+  uint32_t chunk_cap() const { return total() + smax() / TE_GIANT_RUN + 2u; }     // entries of d_chunk_list (pairs), see ensure_buffers
   const void* points_of(int m) const { return p.batch > 1 ? static_cast<const void* const*>(d_points)[m] : d_points; }
   const void* scalars_of(int m) const { return p.batch > 1 ? static_cast<const void* const*>(d_scalars)[m] : d_scalars; }
   void mark(int i) const { if (prof >= 2 || (prof == 1 && (i == ST_ACCUM || i == ST_ACCUM + 1))) (void)hipEventRecord(ws.ev[i], stream); }
@@ -493,7 +493,7 @@ struct msm_launch {
   template <int N> int combine_t() {
     if (p.nw <= 0) return 0;
     using E = te::ete_t<N>;
-    hipLaunchKernelGGL(te::k_seg_combine_all<N>, dim3(256 + 512), dim3(256), 0, stream, ws.d_split_list, ws.d_num_seg + 1, ws.d_chunk_list,
+    hipLaunchKernelGGL(te::k_seg_combine_all<N>, dim3(256 + 1024), dim3(256), 0, stream, ws.d_split_list, ws.d_num_seg + 1, ws.d_chunk_list,
                        ws.d_bucket_count, ws.d_seg_base, reinterpret_cast<E*>(ws.d_seg_out), reinterpret_cast<E*>(ws.d_buckets), p.seg_len, chunk_cap(), 256u,
                        ws.d_bucket_start, ws.d_bucket_cursor);
     return 0;
