@@ -157,6 +157,32 @@ def test_emulated_stages_plus_host_tail(fpcheck, pkg, model, ora, n, c, mode):
     assert fpcheck.fpc_bound_violations() == 0
 
 
+def test_host_tail_forms_agree(fpcheck, pkg, model, ora, tmp_path):
+    """The host tail has two accumulators -- scalar (mulx / adcx products) and AVX-512 IFMA (the point's coordinates in vector
+    lanes) -- chosen by the CPU.  Whatever this machine chooses is what the tests above ran; here the OTHER choices run in fresh
+    processes (the choice is made once per process) on rows with edge scalars and must return the same 64 bytes as the oracle."""
+    import subprocess, sys
+    n, c = 300, 16
+    pts, sc = ora.gen_points(77, n), model.scalars_to_bytes(edge_scalars(77, n))
+    W = (256 + c - 1) // c
+    buf = ctypes.create_string_buffer(W * 720)
+    assert fpcheck.fpc_partial_rows(pts, sc, n, c, 0, 1, buf) == 0
+    exp = ora.msm(pts, sc, threads=4)
+    assert pkg.finalize_host(buf.raw, c, W) == exp
+    rows = tmp_path / "rows.bin"
+    rows.write_bytes(buf.raw)
+    prog = ("import importlib, sys; sys.path.insert(0, %r); p = importlib.import_module('webgpu-msm-twisted-edwards_amd'); "
+            "print(p.host_tail_features(), p.finalize_host(open(%r, 'rb').read(), %d, %d).hex())" % (ROOT, str(rows), c, W))
+    seen = {pkg.host_tail_features()}
+    for env in ({"TE_MSM_HOST_TAIL": "scalar"}, {"TE_MSM_HOST_MUL": "c"}, {}):
+        r = subprocess.run([sys.executable, "-c", prog], env={**os.environ, **env}, capture_output=True, timeout=300)
+        assert r.returncode == 0, r.stderr.decode()[-400:]
+        feat, hexout = r.stdout.decode().split()
+        assert bytes.fromhex(hexout) == exp, (env, feat)
+        seen.add(int(feat))
+    assert 0 in seen                                  # the portable form ran
+
+
 def test_window_shards_merge(fpcheck, pkg, ora):
     n, c = 200, 9
     pts, sc = ora.gen_points(9, n), ora.gen_scalars(9, n)

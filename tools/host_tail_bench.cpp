@@ -21,6 +21,23 @@ int main() {
   auto t4 = std::chrono::steady_clock::now();
   for (int i = 0; i < 2000; i++) horner_to_affine(rows, 16, 15, 16, out);
   auto t5 = std::chrono::steady_clock::now();
+  {
+    // the two accumulators of Horner's rule on the same rows (the product chooses IfmaAcc when the CPU has AVX-512 IFMA)
+    auto pts = [&](int w, int slot, auto& emit) { emit(load_point(rows + (size_t)w * 720 + (size_t)slot * 144)); };
+    uint8_t o1[64], o2[64];
+    auto a0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < 2000; i++) horner_with<ScalarAcc>(pts, 16, 15, 16, o1);
+    auto a1 = std::chrono::steady_clock::now();
+    double ifma_us = -1;
+#if defined(__x86_64__)
+    if (ifma::available()) {
+      for (int i = 0; i < 2000; i++) horner_with<IfmaAcc>(pts, 16, 15, 16, o2);
+      ifma_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a1).count() / 2000.0;
+    }
+#endif
+    printf("Horner over 16 x 16-bit rows: scalar accumulator %.1f us, AVX-512 IFMA accumulator %.1f us (results equal: %d)\n",
+           std::chrono::duration<double, std::micro>(a1 - a0).count() / 2000.0, ifma_us, ifma_us < 0 ? -1 : (int)(memcmp(o1, o2, 64) == 0));
+  }
   printf("doubling %.1f ns   product (dependent chain) %.1f ns, portable form %.1f ns   whole tail (16 windows of 16 bits) %.1f us   (%llu)\n",
          std::chrono::duration<double, std::nano>(t1 - t0).count() / 400000.0, std::chrono::duration<double, std::nano>(t2 - t1).count() / 4000000.0,
          std::chrono::duration<double, std::nano>(t3 - t2).count() / 4000000.0, std::chrono::duration<double, std::micro>(t5 - t4).count() / 2000.0,

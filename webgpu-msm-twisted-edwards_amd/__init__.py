@@ -15,6 +15,7 @@ from .binding import (  # noqa: F401
     MsmError,
     compute_msm,
     finalize_host,
+    host_tail_features,
     finalize_gathered,
     finalize_sum,
     devices_from_env,

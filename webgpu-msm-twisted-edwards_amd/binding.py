@@ -118,6 +118,8 @@ def _lib() -> ctypes.CDLL:
         L.te_msm_finalize.restype = ci
         L.te_msm_finalize_host.argtypes = [cp, ci, ci, cp]
         L.te_msm_finalize_host.restype = ci
+        L.te_msm_host_tail_features.argtypes = []
+        L.te_msm_host_tail_features.restype = ci
         L.te_msm_finalize_host_ex.argtypes = [cp, ci, ci, ci, cp]
         L.te_msm_finalize_host_ex.restype = ci
         L.te_msm_finalize_gathered.argtypes = [vp, ci, ci, ci, ci, cp]
@@ -294,6 +296,11 @@ class MsmContext:
 
 def partial_bytes(curve: int = CURVE_TE_BLS12) -> int:
     return PARTIAL_BYTES_BLS12_377 if curve == CURVE_BLS12_377_G1 else PARTIAL_BYTES
+
+
+def host_tail_features() -> int:
+    """te_msm_host_tail_features: bit 0 = mulx/adcx field product, bit 1 = AVX-512 IFMA accumulator in the host tail"""
+    return int(_lib().te_msm_host_tail_features())
 
 
 def finalize_host(partials: bytes, window_bits: int, num_windows: int, bucket_bits: int | None = None, curve: int = CURVE_TE_BLS12) -> bytes:

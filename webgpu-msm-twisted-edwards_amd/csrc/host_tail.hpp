@@ -219,6 +219,10 @@ static inline Pt pdbl_n(Pt a, int k) {
   return a;
 }
 
+}  // namespace te_host
+#include "host_tail_ifma.hpp"
+namespace te_host {
+
 // partials: W rows of 720 B = [T | W0 | W1 | W2 | W3]: T = sum of the window's buckets, Wk = sum_v v * M_k[v] for digit k of
 // the bucket index (bucket_bits = c - 1 for signed digits, c for unsigned; digit widths w_k = (bucket_bits + 3 - k) / 4,
 // e.g. 4,4,4,3 for 15 bits).  Window value
@@ -231,34 +235,66 @@ static inline Fe tail_k2d() {
   const Fe R2 = {{0x25d577bab861857bULL, 0xcc2c27b58860591fULL, 0xa7cc008fe5dc8593ULL, 0x011fdae7eff1c939ULL}};
   return mul(d2, R2);
 }
-// Horner over the W windows; add_slot(w, slot, acc) adds the window's point(s) of that slot onto acc
-template <typename F> static inline void horner_core(F&& add_slot, int c, int bucket_bits, int W, uint8_t out_xy_le[64]) {
-  int dw[4];
-  for (int k = 0; k < 4; k++) dw[k] = (bucket_bits + 3 - k) / 4;
-  const int s3 = dw[0] + dw[1] + dw[2];
-  Pt acc = identity();
-  for (int w = W - 1; w >= 0; w--) {
-    acc = pdbl_n(acc, c - s3);
-    add_slot(w, 4, acc);                               // W3
-    acc = pdbl_n(acc, dw[2]);
-    add_slot(w, 3, acc);                               // W2
-    acc = pdbl_n(acc, dw[1]);
-    add_slot(w, 2, acc);                               // W1
-    acc = pdbl_n(acc, dw[0]);
-    add_slot(w, 1, acc);                               // W0
-    add_slot(w, 0, acc);                               // T
-  }
+// The accumulator of Horner's rule in two forms with one interface (identity, k doublings, + a point, -> affine x | y):
+// ScalarAcc: four 64-bit limbs, mulx / adcx products one after the other (any x86-64, and the reference for the other form);
+// IfmaAcc (host_tail_ifma.hpp): the four coordinates in the lanes of AVX-512 registers, two vector products per doubling.
+static inline void affine_out(const Pt& acc, uint8_t out_xy_le[64]) {
   const Fe zi = inv(acc.z);
   const Fe one_raw = {{1, 0, 0, 0}};
   const Fe x = mul(mul(acc.x, zi), one_raw), y = mul(mul(acc.y, zi), one_raw);
   memcpy(out_xy_le, x.l, 32); memcpy(out_xy_le + 32, y.l, 32);
 }
+struct ScalarAcc {
+  Pt acc; Fe k2d;
+  ScalarAcc() : acc(identity()), k2d(tail_k2d()) {}
+  void dbl_n(int k) { acc = pdbl_n(acc, k); }
+  void add_point(const Pt& q) { acc = padd(acc, q, k2d); }
+  void to_affine(uint8_t out_xy_le[64]) const { affine_out(acc, out_xy_le); }
+};
+#if defined(__x86_64__)
+struct IfmaAcc {
+  ifma::V acc; Fe k2d;
+  __attribute__((target("avx512f,avx512ifma,avx512dq,avx512vl"))) IfmaAcc() : acc(ifma::videntity()), k2d(tail_k2d()) {}
+  __attribute__((target("avx512f,avx512ifma,avx512dq,avx512vl"))) void dbl_n(int k) { for (int i = 0; i < k; i++) acc = ifma::vdbl(acc); }
+  __attribute__((target("avx512f,avx512ifma,avx512dq,avx512vl"))) void add_point(const Pt& q) { acc = ifma::vaddp(acc, ifma::prepare(q, k2d)); }
+  __attribute__((target("avx512f,avx512ifma,avx512dq,avx512vl"))) void to_affine(uint8_t out_xy_le[64]) const {
+    Fe c[4]; ifma::to_fes(acc, c);
+    Pt r; r.x = c[0]; r.y = c[1]; r.z = c[2]; r.t = c[3];
+    affine_out(r, out_xy_le);
+  }
+};
+#endif
+// Horner over the W windows; points_of(w, slot, emit) calls emit(point) for every point of that window and slot
+template <typename Acc, typename F> static inline void horner_with(F&& points_of, int c, int bucket_bits, int W, uint8_t out_xy_le[64]) {
+  int dw[4];
+  for (int k = 0; k < 4; k++) dw[k] = (bucket_bits + 3 - k) / 4;
+  const int s3 = dw[0] + dw[1] + dw[2];
+  Acc acc;
+  auto emit = [&](const Pt& q) { acc.add_point(q); };
+  for (int w = W - 1; w >= 0; w--) {
+    acc.dbl_n(c - s3);
+    points_of(w, 4, emit);                             // W3
+    acc.dbl_n(dw[2]);
+    points_of(w, 3, emit);                             // W2
+    acc.dbl_n(dw[1]);
+    points_of(w, 2, emit);                             // W1
+    acc.dbl_n(dw[0]);
+    points_of(w, 1, emit);                             // W0
+    points_of(w, 0, emit);                             // T
+  }
+  acc.to_affine(out_xy_le);
+}
+template <typename F> static inline void horner_core(F&& points_of, int c, int bucket_bits, int W, uint8_t out_xy_le[64]) {
+#if defined(__x86_64__)
+  if (ifma::available()) { horner_with<IfmaAcc>(points_of, c, bucket_bits, W, out_xy_le); return; }
+#endif
+  horner_with<ScalarAcc>(points_of, c, bucket_bits, W, out_xy_le);
+}
 static inline void horner_to_affine_multi(const uint8_t* const* partials, int sets, int c, int bucket_bits, int W, uint8_t out_xy_le[64]) {
-  const Fe k2d = tail_k2d();
-  horner_core([&](int w, int slot, Pt& acc) {
+  horner_core([&](int w, int slot, auto& emit) {
     for (int s = 0; s < sets; s++) {
       const uint8_t* row = partials[s] + (size_t)w * TE_TAIL_ROW_BYTES;
-      if (!all_zero_bytes(row, TE_TAIL_ROW_BYTES)) acc = padd(acc, load_point(row + (size_t)slot * TE_TAIL_POINT_BYTES), k2d);
+      if (!all_zero_bytes(row, TE_TAIL_ROW_BYTES)) emit(load_point(row + (size_t)slot * TE_TAIL_POINT_BYTES));
     }
   }, c, bucket_bits, W, out_xy_le);
 }
@@ -279,8 +315,7 @@ static inline void merge_window_rows(const uint8_t* const* partials, int sets, i
   }
 }
 static inline void horner_to_affine_points(const Pt* merged, const uint8_t* present, int c, int bucket_bits, int W, uint8_t out_xy_le[64]) {
-  const Fe k2d = tail_k2d();
-  horner_core([&](int w, int slot, Pt& acc) { if (present[w]) acc = padd(acc, merged[(size_t)w * 5 + slot], k2d); }, c, bucket_bits, W, out_xy_le);
+  horner_core([&](int w, int slot, auto& emit) { if (present[w]) emit(merged[(size_t)w * 5 + slot]); }, c, bucket_bits, W, out_xy_le);
 }
 static inline void horner_to_affine(const uint8_t* partials, int c, int bucket_bits, int W, uint8_t out_xy_le[64]) {
   horner_to_affine_multi(&partials, 1, c, bucket_bits, W, out_xy_le);
@@ -300,6 +335,28 @@ static inline bool tail_selftest() {
   }
   const Fe top = {{MOD[0] - 1, MOD[1], MOD[2], MOD[3]}};           // p - 1: the widest operands
   { const Fe c = mul(top, top), d = mul_c(top, top); if (memcmp(c.l, d.l, 32) != 0) return false; }
+#if defined(__x86_64__)
+  if (ifma::available()) {
+    // the two accumulators over the same sequence of doublings and additions (the generator, its multiples as they come out of the
+    // scalar form, the neutral element, a point with the widest coordinates): the affine results must be the same 64 bytes
+    const Fe R2 = {{0x25d577bab861857bULL, 0xcc2c27b58860591fULL, 0xa7cc008fe5dc8593ULL, 0x011fdae7eff1c939ULL}};
+    Pt g; g.x = Fe{{0x137e82844bbe49c5ULL, 0xe7608833a9dd83f3ULL, 0x16b294b80d905006ULL, 0x036824eb02475007ULL}};
+    g.y = Fe{{0xd50dce7d8bcda9d4ULL, 0x7f6758f4c08bc255ULL, 0x37c0a81e810abce5ULL, 0x11b1d8d5c1d897a3ULL}};
+    g.z = one_raw; g.t = mul(mul(g.x, g.y), R2);                   // x y as a plain integer
+    ScalarAcc a; IfmaAcc b;
+    Pt q = g;
+    for (int round = 0; round < 12; round++) {
+      a.add_point(q); b.add_point(q);
+      a.dbl_n(1 + round % 5); b.dbl_n(1 + round % 5);
+      if (round == 3) { const Pt id = identity(); a.add_point(id); b.add_point(id); }
+      if (round == 7) { Pt w = q; w.x = top; w.y = top; w.z = top; w.t = top; a.add_point(w); b.add_point(w); }     // not a curve point: the formulas are polynomial identities
+      q = a.acc;                                                    // the next operand: a projective point with general Z
+      uint8_t oa[64], ob[64];
+      a.to_affine(oa); b.to_affine(ob);
+      if (memcmp(oa, ob, 64) != 0) return false;
+    }
+  }
+#endif
   return true;
 }
 

@@ -1486,6 +1486,14 @@ int te_msm_finalize(te_ctx* ctx, const uint8_t* partials, int window_bits, int n
   return 0;
 }
 
+int te_msm_host_tail_features(void) {
+  int f = te_host::have_adx() ? 1 : 0;
+#if defined(__x86_64__)
+  if (te_host::ifma::available()) f |= 2;
+#endif
+  return f;
+}
+
 int te_msm_finalize_host(const uint8_t* partials, int window_bits, int num_windows, uint8_t out_xy_le[64]) {
   if (!partials || !out_xy_le || window_bits < 2 || window_bits > 16 || num_windows < 1 || num_windows > 128) return TE_MSM_EINVAL;
   return te_msm_finalize_host_ex(partials, window_bits, window_bits - 1, num_windows, out_xy_le);
