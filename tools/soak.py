@@ -48,8 +48,17 @@ while time.time() < t_end:
         else:
             pts = orc.gen_points(seed, n)
         sc = orc.gen_scalars(seed, n)
-        if rnd.random() < 0.2:
-            sc = sc[:sb] * n
+        r = rnd.random()
+        if r < 0.2:
+            sc = sc[:sb] * n                                            # all scalars equal: one giant bucket per window
+        elif r < 0.35:
+            # a prover's witness: zeros, ones and small values among uniform scalars (one giant bucket in window 0, empty digits)
+            a = bytearray(sc)
+            for i in range(n):
+                q = rnd.random()
+                if q < 0.5:
+                    a[sb * i:sb * (i + 1)] = (0 if q < 0.2 else 1 if q < 0.4 else rnd.randrange(1 << 20)).to_bytes(sb, "little")
+            sc = bytes(a)
         batch.append((pts, sc, n))
     exp = [orc.msm(p, s, threads=8) for p, s, _ in batch]
     if mode in ("run", "multi"):
