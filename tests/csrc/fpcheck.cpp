@@ -43,6 +43,8 @@ int fpc_bound_violations() { return g_bound_violations; }
 void fpc_mont_mul(const uint32_t a[9], const uint32_t b[9], uint32_t out[9]) {
   fp x, y; memcpy(x.v, a, 36); memcpy(y.v, b, 36); fp r = mont_mul(x, y); memcpy(out, r.v, 36);
 }
+void fpc_mul_k2d(const uint32_t a[9], uint32_t out[9]) { fp x; memcpy(x.v, a, 36); fp r = fp_mul_k2d(x); memcpy(out, r.v, 36); }
+uint32_t fpc_k2d_q() { return K2D_Q; }
 void fpc_norm(const uint32_t a[9], uint32_t out[9]) { fp x; memcpy(x.v, a, 36); fp r = fp_norm(x); memcpy(out, r.v, 36); }
 void fpc_sub2(const uint32_t a[9], const uint32_t b[9], uint32_t out[9]) { fp x, y; memcpy(x.v, a, 36); memcpy(y.v, b, 36); fp r = fp_sub<2>(x, y); memcpy(out, r.v, 36); }
 void fpc_from_words32(const uint32_t w[8], uint32_t out[9]) { uint32_t t[8]; memcpy(t, w, 32); fp r = fp_from_words32(t); memcpy(out, r.v, 36); }

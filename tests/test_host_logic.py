@@ -50,6 +50,40 @@ def test_field_constants(fpcheck, model):
     assert 16 * P > 1 << 256                              # y - x + 16p >= 0 for any 256-bit x
 
 
+def test_small_constant_product(fpcheck, model):
+    """fp_mul_k2d (csrc/fp.hpp): a * 2d as  6042 a - q p  with q estimated from a's top 32 bits -- the residue, the value bound
+    (below 1.0001 p + nothing) and the limb class for random class-N operands below 2^254 and for the operands at which the
+    estimate is tightest; the estimate's constant re-derived from p."""
+    P, rnd = model.P, random.Random(21)
+    K = 2 * model.D
+    assert K == 6042
+    fpcheck.fpc_k2d_q.restype = ctypes.c_uint32
+    assert int(fpcheck.fpc_k2d_q()) == (K << 49) // ((P >> 222) + 1) < 1 << 32
+    out = (ctypes.c_uint32 * NL)()
+
+    def lim(v):                                            # class N: 8 limbs of 29 bits, the rest in the top limb
+        return [(v >> (29 * i)) & LM for i in range(8)] + [v >> 232]
+
+    def check(v):
+        fpcheck.fpc_mul_k2d(raw(lim(v)), out)
+        r = val(out)
+        assert r % P == K * v % P
+        assert 0 <= r < P + (P >> 13)                      # below 1.0002 p: offset subtractions with 2p are safe
+        assert all(int(out[i]) <= LM for i in range(NL - 1)) and int(out[NL - 1]) < 1 << 22
+
+    edge = [0, 1, P - 1, P, P + 1, 2 * P - 1, 2 * P, (1 << 254) - 1, 1 << 253, (1 << 232) - 1, 1 << 232, (1 << 222) - 1, 1 << 222]
+    for q in range(1, 6100, 97):                           # values where 6042 a crosses a multiple of p
+        for d in (-1, 0, 1):
+            edge.append(max(0, (q * P + K - 1) // K + d))
+    for v in edge:
+        if v < 1 << 254:
+            check(v)
+    for _ in range(20000):
+        check(rnd.randrange(1 << 254))
+    for _ in range(5000):
+        check(rnd.randrange(P + P // 8))                   # the range product outputs live in
+
+
 def test_mont_mul_values_and_limb_classes(fpcheck, model):
     """exactness for normalised operands and for the widest limb classes the formulas use (S x D)"""
     P, rnd = model.P, random.Random(11)

@@ -167,7 +167,7 @@ template <int N> TE_HD ete_t<N> ete_add(const ete_t<N>& a, const ete_t<N>& b) {
   fel<N> p1[4];
   fe_mul_x<4>(in1, in2, p1);
   const fel<N> &A = p1[0], &B = p1[1];
-  const fel<N> C = fe_mul(p1[2], fe_k2d<N>());
+  const fel<N> C = fe_mul_k2d(p1[2]);                 // N = 9: the 13-bit constant applied limb-wise, not a product
   const fel<N> D = fe_add(p1[3], p1[3]);
   const fel<N> E = fe_norm_if_needed(fe_sub<2>(B, A));
   const fel<N> H = fe_add(B, A);

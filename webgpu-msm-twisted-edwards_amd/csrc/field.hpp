@@ -34,6 +34,11 @@ template <> TE_HD fel<14> fe_one<14>() { return te377::fq_R1(); }
 template <> TE_HD fel<9> fe_k2d<9>() { return fp_K2D_MONT(); }
 template <> TE_HD fel<14> fe_k2d<14>() { return te377::fq_K2D_MONT(); }
 
+// a * 2d: a full product with the constant in Montgomery form -- except on the Twisted-Edwards BLS12 curve, whose 2d = 6042 is 13
+// bits wide (fp_mul_k2d: two multiply-accumulates per limb).  Result: class N, value below 1.1 p either way.
+TE_HD fel<9> fe_mul_k2d(const fel<9>& a) { return fp_mul_k2d(a); }
+TE_HD fel<14> fe_mul_k2d(const fel<14>& a) { return fe_mul(a, fe_k2d<14>()); }
+
 // may a product take a difference in offset form (limbs < 2^30.6) times a sum (limbs < 2^30)?  9 * 2^60.6 + 8 * 2^58 < 2^64
 // holds, 14 * 2^60.6 does not (fq377.hpp: one operand normalised, the other below 2^30.8)
 template <int N> constexpr bool fe_wide_ok() { return N <= 9; }

@@ -163,6 +163,33 @@ template <int M> TE_HD void mont_mul_x(const fp (&a)[M], const fp (&b)[M], fp (&
   for (int m = 0; m < M; m++) r[m].v[NL - 1] = (uint32_t)acc[m];
 }
 
+// a * 2d mod p (plus at most one p) for the curve constant 2d = 6042 of add-2008-hwcd-3 -- NOT a Montgomery product: the constant
+// is 13 bits wide, so  6042 a - q p  with q = floor(6042 a / p) estimated from a's top 32 bits costs two multiply-accumulates
+// per limb instead of a 153-mad product (about 50 instructions against 190; every full addition of the bucket reduction has one,
+// and in a team addition it is a whole round of the dependent chain).  The factor is applied to the Montgomery form directly
+// (a stands for a' R, 6042 a for 6042 a' R): no constant in Montgomery form is involved.
+//   a: class N with value below 2^254 (product outputs are below 1.1 p).  Returns class N, value below 1.0001 p + 0:
+//   h = a >> 222 (32 bits);  q = (h * K2D_Q) >> 49 with K2D_Q = floor(6042 * 2^49 / (floor(p / 2^222) + 1))  never exceeds
+//   6042 a / p and falls short of it by less than 1 + 2^-15, so 0 <= 6042 a - q p < 1.0001 p.  One signed pass over the limbs:
+//   acc += 6042 a_i - q p_i (|acc| < 2^43), the subtraction as  q (2^32 - p_i) - q 2^32  in unsigned 64-bit arithmetic.
+constexpr uint32_t K2D_SMALL = 6042u;            // 2 d, d = 3021 (reference/params/AleoConstants.ts:2-4)
+constexpr uint32_t K2D_Q = 0xa1d088f6u;          // checked against bigints in tests/test_host_logic.py::test_small_constant_product
+TE_HD fp fp_mul_k2d(const fp& a) {
+  const uint32_t h = (a.v[8] << 10) | (a.v[7] >> 19);
+  const uint32_t q = (uint32_t)(((uint64_t)h * K2D_Q) >> 49);
+  fp r;
+  uint64_t acc = 0;                              // a signed value in two's complement
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    acc += (uint64_t)a.v[i] * K2D_SMALL;
+    acc += (uint64_t)q * (0u - p_limb(i));       // q (2^32 - p_i) ...
+    acc -= (uint64_t)q << 32;                    // ... - q 2^32 = - q p_i
+    if (i < NL - 1) { r.v[i] = (uint32_t)acc & LM; acc = (uint64_t)((int64_t)acc >> LB); }
+    else r.v[i] = (uint32_t)acc;
+  }
+  return r;
+}
+
 // limb-wise a + b (N + N -> S).  No carries.
 TE_HD fp fp_add(const fp& a, const fp& b) {
   fp r;
