@@ -321,7 +321,7 @@ static inline void horner_to_affine(const uint8_t* partials, int c, int bucket_b
   horner_to_affine_multi(&partials, 1, c, bucket_bits, W, out_xy_le);
 }
 
-static inline bool tail_selftest() {
+static inline bool tail_selftest_run() {
   if ((uint64_t)(MOD[0] * MOD_NEG_INV) != ~0ULL) return false;     // p * (-p^-1) = -1 mod 2^64
   const Fe one_raw = {{1, 0, 0, 0}};
   const Fe t = mul(ONE_M, one_raw);                                // R * 1 / R = 1
@@ -359,5 +359,7 @@ static inline bool tail_selftest() {
 #endif
   return true;
 }
+// run once per process: the context-free entry points (te_msm_finalize_host*, every MSM of a window-sharded pipeline) ask every time
+static inline bool tail_selftest() { static const bool ok = tail_selftest_run(); return ok; }
 
 }  // namespace te_host

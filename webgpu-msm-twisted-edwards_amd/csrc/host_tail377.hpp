@@ -171,11 +171,13 @@ static inline void horner_to_affine(const uint8_t* partials, int c, int bucket_b
   horner_to_affine_multi(&partials, 1, c, bucket_bits, W, out_xy_le);
 }
 
-static inline bool tail_selftest() {
+static inline bool tail_selftest_run() {
   if ((uint64_t)(MOD[0] * MOD_NEG_INV) != ~0ULL) return false;
   Fe one_raw; memset(&one_raw, 0, sizeof one_raw); one_raw.l[0] = 1;
   const Fe t = mul(ONE_M, one_raw);
   return t.l[0] == 1 && !(t.l[1] | t.l[2] | t.l[3] | t.l[4] | t.l[5]);
 }
+// once per process (the context-free entry points ask on every call)
+static inline bool tail_selftest() { static const bool ok = tail_selftest_run(); return ok; }
 
 }  // namespace te377_host
