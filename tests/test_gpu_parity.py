@@ -831,6 +831,45 @@ def test_many_parts_per_bucket(ctx, ora):
         ctx.set_option("segment_len", 0)
 
 
+def test_schedule_slices_beyond_the_register_form(ctx, ora):
+    """k_l2_place_order's schedule block keeps its slice of the segment ids in registers (32 per thread); with more than
+    64 x 8192 ids per window -- n = 2^19 points in segments of ONE entry -- a slice does not fit and the two-pass loop runs.
+    Also: buckets of 17..256 parts, i.e. giant buckets that are a single run of the combine."""
+    n = 1 << 19
+    pts, sc = ora.gen_points(19, n), ora.gen_scalars(19, n)
+    exp = ora.msm(pts, sc, threads=8)
+    ctx.set_option("window_bits", 16)
+    try:
+        for seg in (1, 2):
+            ctx.set_option("segment_len", seg)
+            assert ctx.run(pts, sc) == exp, seg
+    finally:
+        ctx.set_option("window_bits", 0)
+        ctx.set_option("segment_len", 0)
+
+
+def test_witness_like_scalars(ctx, model, ora):
+    """SURVEY 8f rank 3, what a prover feeds: zeros, ones, small values and uniform scalars mixed -- one bucket of window 0 holds a
+    large share of the points (runs of the giant-bucket combine), the high windows of many scalars are empty."""
+    import random
+    rnd = random.Random(31)
+    for n in (3000, 70000, 300000):
+        ks = model.gen_scalars(n, n)
+        for i in range(n):
+            q = rnd.random()
+            if q < 0.5:
+                ks[i] = 0 if q < 0.2 else 1 if q < 0.4 else rnd.randrange(1 << 20)
+        pts, sc = ora.gen_points(n, n), model.scalars_to_bytes(ks)
+        exp = ora.msm(pts, sc, threads=8)
+        for c in (0, 16):
+            ctx.set_option("window_bits", c)
+            assert ctx.run(pts, sc) == exp, (n, c)
+        ctx.set_option("window_bits", 0)
+        ctx.set_option("signed_digits", 0)
+        assert ctx.run(pts, sc) == exp, (n, "unsigned")
+        ctx.set_option("signed_digits", 1)
+
+
 def test_random_configurations(pkg, ora):
     """differential run over seeded random combinations of size, window bits, digit form, segment length, schedule and
     host pieces -- every one must equal the oracle"""
