@@ -818,7 +818,7 @@ def test_trim_gives_device_memory_back(pkg, ora):
 
 
 def test_many_parts_per_bucket(ctx, ora):
-    """segment length 1 with few buckets: every bucket has thousands of parts, more 1024-part chunks than buckets
+    """segment length 1 with few buckets: every bucket has thousands of parts, more runs of the giant-bucket combine than buckets
     (found by tools/soak.py: the chunk list was sized by the bucket count)"""
     n = 158508
     pts, sc = ora.gen_points(5, n), ora.gen_scalars(5, n)

@@ -488,7 +488,7 @@ struct msm_launch {
   }
   int accumulate() { return bls() ? accumulate_t<14>() : accumulate_t<9>(); }
 
-  // sums of the buckets that were accumulated in several parts: buckets cut into 2..16 parts (quads) and the 1024-part runs
+  // sums of the buckets that were accumulated in several parts: buckets cut into 2..16 parts (quads) and the TE_GIANT_RUN-part runs
   // of giant buckets (blocks; the block that finishes a bucket's last run adds the runs up) in one launch
   template <int N> int combine_t() {
     if (p.nw <= 0) return 0;
