@@ -15,3 +15,11 @@ python3 tools/overlap_report.py gpurun_out/prof_pipe --alone gpurun_out/prof/tra
 bash tools/profile_trace.sh --no-pipeline --no-sizes --no-host-buffers --no-configs --steps 30 --log2n 16 --window-bits 0 > /dev/null 2>&1 || exit 1
 python3 tools/trace_one_msm.py gpurun_out/prof/trace k_digits > $F/single_msm_timeline_2_16.txt
 ls -la $F
+# the driver's line on the SAME box (roofline.kernel_ms there must agree with the one-MSM-at-a-time trace above)
+python3 bench.py --steps 20 --warmup 5 2> /dev/null | grep '^{' | tail -1 > $F/bench_default_line.json
+python3 - $F <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1] + "/bench_default_line.json"))
+print("bench line on this box: %.1f MSM/s, latency %.3f ms, k_accumulate alone %.4f ms (frac %.3f), traffic %s" % (
+    d["value"], d["latency_ms"], d["roofline"]["kernel_ms"], d["roofline"]["frac"], d["roofline"]["traffic"]))
+PY
