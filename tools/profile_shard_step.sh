@@ -32,8 +32,14 @@ for s, e, _ in sel:
 busy += cur_e - cur_s
 span = hi - lo
 n_seq = i1 - i0
-n_acc = sum(1 for r in sel if r[2] == "k_digits")          # one k_digits launch per MSM; a launch sequence may carry several (--batch)
-print("window %.2f ms, %d launch sequences (k_accumulate launches) carrying %d MSMs -> %.3f ms per MSM; GPU has at least one kernel running %.0f %% of the time" % (span / 1e6, n_seq, n_acc, span / 1e6 / max(n_acc, 1), 100.0 * busy / span))
+# MSMs per launch sequence: one k_digits launch covers every MSM of a batch since round 3, so the count comes from the bench line
+import json
+per_seq = 1
+for line in open(os.path.join(sys.argv[1], "trace.log")):
+    if line.startswith("{"):
+        per_seq = int(json.loads(line).get("roofline", {}).get("timed_region", {}).get("msms_per_launch", 1) or 1)
+n_acc = n_seq * per_seq
+print("window %.2f ms, %d launch sequences (k_accumulate launches) carrying %d MSMs -> %.4f ms per MSM; GPU has at least one kernel running %.0f %% of the time" % (span / 1e6, n_seq, n_acc, span / 1e6 / max(n_acc, 1), 100.0 * busy / span))
 print("sum of kernel durations per MSM: %.0f us (overlapped kernels counted separately)" % (sum(sum(v) for v in dur.values()) / max(n_acc, 1)))
 for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
     print("%-28s n=%4d mean %7.1f us  per MSM %7.1f us" % (k[:28], len(v), sum(v) / len(v), sum(v) / max(n_acc, 1)))
