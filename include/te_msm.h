@@ -208,9 +208,9 @@ int te_msm_finalize(te_ctx* ctx, const uint8_t* partials, int window_bits, int n
 /* The same tail without a context (pure host code, no device needed): used when the rows were produced
  * elsewhere, e.g. gathered from other ranks.  Does not know about scalar-range errors. */
 int te_msm_finalize_host(const uint8_t* partials, int window_bits, int num_windows, uint8_t out_xy_le[64]);
-/* Which form of the host tail's arithmetic this process uses (Twisted-Edwards curve): bit 0 = the mulx / adcx / adox field product
- * (BMI2 + ADX), bit 1 = the AVX-512 IFMA accumulator (the four coordinates of the running point in vector lanes: two vector products
- * per doubling; about half the time of the scalar form).  Both forms are checked against the portable one at te_msm_init; env
+/* Which form of the host tail's arithmetic this process uses: bit 0 = the mulx / adcx / adox field product (BMI2 + ADX; Twisted-Edwards
+ * curve), bit 1 = the AVX-512 IFMA accumulator of both curves (the four coordinates of the running point in vector lanes: two vector
+ * products per doubling; about half the time of the scalar form).  Both forms are checked against the portable one at te_msm_init; env
  * TE_MSM_HOST_TAIL=scalar turns bit 1 off, TE_MSM_HOST_MUL=c both (A/B measurements, tests). */
 int te_msm_host_tail_features(void);
 /* Same for either digit form: bucket_bits = window_bits - 1 (signed digits, what te_msm_finalize_host assumes) or

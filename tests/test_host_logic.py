@@ -208,7 +208,7 @@ def test_host_tail_forms_agree(fpcheck, pkg, model, ora, tmp_path):
     prog = ("import importlib, sys; sys.path.insert(0, %r); p = importlib.import_module('webgpu-msm-twisted-edwards_amd'); "
             "print(p.host_tail_features(), p.finalize_host(open(%r, 'rb').read(), %d, %d).hex())" % (ROOT, str(rows), c, W))
     seen = {pkg.host_tail_features()}
-    for env in ({"TE_MSM_HOST_TAIL": "scalar"}, {"TE_MSM_HOST_MUL": "c"}, {}):
+    for env in ({"TE_MSM_HOST_TAIL": "scalar"}, {"TE_MSM_HOST_MUL": "c", "TE_MSM_HOST_TAIL": "scalar"}, {"TE_MSM_HOST_MUL": "c"}, {}):
         r = subprocess.run([sys.executable, "-c", prog], env={**os.environ, **env}, capture_output=True, timeout=300)
         assert r.returncode == 0, r.stderr.decode()[-400:]
         feat, hexout = r.stdout.decode().split()

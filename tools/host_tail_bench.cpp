@@ -30,7 +30,7 @@ int main() {
     auto a1 = std::chrono::steady_clock::now();
     double ifma_us = -1;
 #if defined(__x86_64__)
-    if (ifma::available()) {
+    if (have_ifma()) {
       for (int i = 0; i < 2000; i++) horner_with<IfmaAcc>(pts, 16, 15, 16, o2);
       ifma_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a1).count() / 2000.0;
     }

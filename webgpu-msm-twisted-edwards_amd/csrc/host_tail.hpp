@@ -252,14 +252,27 @@ struct ScalarAcc {
   void to_affine(uint8_t out_xy_le[64]) const { affine_out(acc, out_xy_le); }
 };
 #if defined(__x86_64__)
+// 52-bit limbs of p, -p^-1 mod 2^52, 2 p, 4 p (re-derived in tests/test_host_logic.py::test_host_tail_forms_agree via the self-test)
+static const te_ifma::field52<5> TE_F52 = {
+  {0x1800000000001ULL, 0xfed00000010a1ULL, 0xc37b00159aa76ULL, 0xa55660b44d1e5ULL, 0x12ab655e9a2cULL}, 0x17fffffffffffULL,
+  {0x3000000000002ULL, 0xfda0000002142ULL, 0x86f6002b354edULL, 0x4aacc1689a3cbULL, 0x2556cabd3459ULL},
+  {0x6000000000004ULL, 0xfb40000004284ULL, 0xdec00566a9dbULL, 0x955982d134797ULL, 0x4aad957a68b2ULL}};
+static inline bool have_ifma() { return te_ifma::cpu_has_ifma(); }
+#define TE_IFMA_M __attribute__((target("avx512f,avx512ifma,avx512dq,avx512vl")))
 struct IfmaAcc {
-  ifma::V acc; Fe k2d;
-  __attribute__((target("avx512f,avx512ifma,avx512dq,avx512vl"))) IfmaAcc() : acc(ifma::videntity()), k2d(tail_k2d()) {}
-  __attribute__((target("avx512f,avx512ifma,avx512dq,avx512vl"))) void dbl_n(int k) { for (int i = 0; i < k; i++) acc = ifma::vdbl(acc); }
-  __attribute__((target("avx512f,avx512ifma,avx512dq,avx512vl"))) void add_point(const Pt& q) { acc = ifma::vaddp(acc, ifma::prepare(q, k2d)); }
-  __attribute__((target("avx512f,avx512ifma,avx512dq,avx512vl"))) void to_affine(uint8_t out_xy_le[64]) const {
-    Fe c[4]; ifma::to_fes(acc, c);
-    Pt r; r.x = c[0]; r.y = c[1]; r.z = c[2]; r.t = c[3];
+  te_ifma::V<5> acc; Fe k2d;
+  TE_IFMA_M IfmaAcc() : k2d(tail_k2d()) { const Fe zero = {{0, 0, 0, 0}}, one = {{1, 0, 0, 0}}; acc = te_ifma::from_words<5, 4>(zero.l, one.l, one.l, zero.l); }
+  TE_IFMA_M void dbl_n(int k) { for (int i = 0; i < k; i++) acc = te_ifma::vdbl<5>(acc, TE_F52); }
+  // the operand of an addition prepared on the scalar side: lanes [Y - X, Y + X, 2 Z, 2 d T] (the host's Montgomery form of 2 d
+  // applied with the host's product: the result carries T's own factor, like the other three)
+  TE_IFMA_M void add_point(const Pt& q) {
+    const Fe a = sub(q.y, q.x), b = add(q.y, q.x), c = add(q.z, q.z), d = mul(q.t, k2d);
+    acc = te_ifma::vaddp<5>(acc, te_ifma::from_words<5, 4>(a.l, b.l, c.l, d.l), TE_F52);
+  }
+  TE_IFMA_M void to_affine(uint8_t out_xy_le[64]) const {
+    uint64_t w[4][4]; te_ifma::to_words<5, 4>(acc, w);
+    Pt r; Fe* c[4] = {&r.x, &r.y, &r.z, &r.t};
+    for (int k = 0; k < 4; k++) { Fe v; memcpy(v.l, w[k], 32); *c[k] = reduce_once(v); }       // below 2 p in the lanes
     affine_out(r, out_xy_le);
   }
 };
@@ -286,7 +299,7 @@ template <typename Acc, typename F> static inline void horner_with(F&& points_of
 }
 template <typename F> static inline void horner_core(F&& points_of, int c, int bucket_bits, int W, uint8_t out_xy_le[64]) {
 #if defined(__x86_64__)
-  if (ifma::available()) { horner_with<IfmaAcc>(points_of, c, bucket_bits, W, out_xy_le); return; }
+  if (have_ifma()) { horner_with<IfmaAcc>(points_of, c, bucket_bits, W, out_xy_le); return; }
 #endif
   horner_with<ScalarAcc>(points_of, c, bucket_bits, W, out_xy_le);
 }
@@ -336,7 +349,7 @@ static inline bool tail_selftest_run() {
   const Fe top = {{MOD[0] - 1, MOD[1], MOD[2], MOD[3]}};           // p - 1: the widest operands
   { const Fe c = mul(top, top), d = mul_c(top, top); if (memcmp(c.l, d.l, 32) != 0) return false; }
 #if defined(__x86_64__)
-  if (ifma::available()) {
+  if (have_ifma()) {
     // the two accumulators over the same sequence of doublings and additions (the generator, its multiples as they come out of the
     // scalar form, the neutral element, a point with the widest coordinates): the affine results must be the same 64 bytes
     const Fe R2 = {{0x25d577bab861857bULL, 0xcc2c27b58860591fULL, 0xa7cc008fe5dc8593ULL, 0x011fdae7eff1c939ULL}};

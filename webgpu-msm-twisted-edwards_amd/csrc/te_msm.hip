@@ -1489,7 +1489,7 @@ int te_msm_finalize(te_ctx* ctx, const uint8_t* partials, int window_bits, int n
 int te_msm_host_tail_features(void) {
   int f = te_host::have_adx() ? 1 : 0;
 #if defined(__x86_64__)
-  if (te_host::ifma::available()) f |= 2;
+  if (te_host::have_ifma()) f |= 2;
 #endif
   return f;
 }
