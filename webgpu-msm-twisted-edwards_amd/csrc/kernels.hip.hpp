@@ -1381,17 +1381,35 @@ __global__ void __launch_bounds__(1024) k_reduce_tail(tail_params_t<N> prm) {
 // ------------------------------------------------------------------------------------------------
 // K1a for BLS12-377 G1: short-Weierstrass affine (x, y), 48-byte little-endian each -> projective twisted-Edwards record
 // (curve.hpp, pnt_from_sw377), one lane per point; loads and stores are 16 bytes per lane.
-__global__ void __launch_bounds__(256) k_prep_points377(batch_ptrs in, batch_slabs row_slab, rec_slot<14>* __restrict__ recs, uint32_t n) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n) return;
-  const uint4* __restrict__ pts = in.p[blockIdx.y];
-  recs += (size_t)row_slab.s[blockIdx.y] * n;
+__device__ __forceinline__ void prep_point377(uint32_t i, const uint4* __restrict__ pts, rec_slot<14>* __restrict__ recs) {
   uint4 u[6];
 #pragma unroll
   for (int j = 0; j < 6; j++) u[j] = pts[6 * (size_t)i + j];
   const uint32_t xw[12] = {u[0].x, u[0].y, u[0].z, u[0].w, u[1].x, u[1].y, u[1].z, u[1].w, u[2].x, u[2].y, u[2].z, u[2].w};
   const uint32_t yw[12] = {u[3].x, u[3].y, u[3].z, u[3].w, u[4].x, u[4].y, u[4].z, u[4].w, u[5].x, u[5].y, u[5].z, u[5].w};
   store_pnt<14>(recs + i, pnt_from_sw377(te377::fq_from_words32(xw), te377::fq_from_words32(yw)));
+}
+__global__ void __launch_bounds__(256) k_prep_points377(batch_ptrs in, batch_slabs row_slab, rec_slot<14>* __restrict__ recs, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  prep_point377(i, in.p[blockIdx.y], recs + (size_t)row_slab.s[blockIdx.y] * n);
+}
+// Level 1 of the sort and the BLS12-377 record conversion in one launch (k_part_scatter_prep for the other curve): the scatter is
+// bound by its LDS rounds and barriers, the conversion by its eight 14-limb products per point -- back to back they cost 46 + 130 us
+// of one MSM's critical path.  1-D grid, the two kinds of blocks interleaved evenly; a conversion block converts 512 points (one
+// per thread, no LDS).  Four waves per SIMD: the conversion needs ~100 VGPRs.
+__global__ void __launch_bounds__(512, 4) k_part_scatter_prep377(scatter_args a, uint32_t scatter_blocks, batch_ptrs in, batch_slabs row_slab,
+                                                                 rec_slot<14>* __restrict__ recs, uint32_t n, uint32_t prep_blocks_per_row, uint32_t prep_blocks) {
+  __shared__ uint32_t lds[TE_SCATTER_LDS_WORDS];
+  const uint64_t tot = (uint64_t)scatter_blocks + prep_blocks, b = blockIdx.x;
+  const uint32_t s_before = (uint32_t)(b * scatter_blocks / tot), s_after = (uint32_t)((b + 1u) * scatter_blocks / tot);
+  if (s_after > s_before) {                               // this block is scatter block number s_before
+    part_scatter_block(s_before % a.g.CH, s_before / a.g.CH, lds, a);
+  } else {
+    const uint32_t pb = (uint32_t)b - s_before, row = pb / prep_blocks_per_row, blk = pb - row * prep_blocks_per_row;
+    const uint32_t i = blk * 512u + threadIdx.x;
+    if (i < n) prep_point377(i, in.p[row], recs + (size_t)row_slab.s[row] * n);
+  }
 }
 
 }  // namespace te

@@ -339,7 +339,7 @@ struct msm_launch {
   void mark(int i) const { if (prof >= 2 || (prof == 1 && (i == ST_ACCUM || i == ST_ACCUM + 1))) (void)hipEventRecord(ws.ev[i], stream); }
 
   // device-resident inputs, no per-stage timing: the record conversion rides in the launch of the sort's first level
-  bool can_fuse_prep() const { return ctx->opt_fuse_prep && p.curve == TE_MSM_CURVE_TE_BLS12 && prof < 2 && p.nw > 0; }
+  bool can_fuse_prep() const { return ctx->opt_fuse_prep && prof < 2 && p.nw > 0; }
   int front() {
     if (can_fuse_prep()) return front_scalars(true);
     if (int rc = front_scalars()) return rc;
@@ -428,9 +428,16 @@ struct msm_launch {
       sa.part_count = ws.d_part_count; sa.seg_part_base = ws.d_seg_part_base; sa.seg_len = p.seg_len; sa.cap_w = cap_w; sa.nw = (uint32_t)p.nw; sa.g = sg;
       if (with_prep) {
         te::batch_ptrs tab; te::batch_slabs row_slab;
-        const uint32_t rows = (uint32_t)prep_rows(tab, row_slab), per_row = (n32 + 255u) / 256u, sblocks = p.CH * (uint32_t)p.nw;
-        hipLaunchKernelGGL(te::k_part_scatter_prep, dim3(sblocks + rows * per_row), dim3(512), 0, stream, sa, sblocks, tab, row_slab,
-                           reinterpret_cast<te::pnt_slot*>(ws.d_recs), n32, per_row, rows * per_row);
+        const uint32_t rows = (uint32_t)prep_rows(tab, row_slab), sblocks = p.CH * (uint32_t)p.nw;
+        if (bls()) {                                      // 512 points per conversion block, one per thread
+          const uint32_t per_row = (n32 + 511u) / 512u;
+          hipLaunchKernelGGL(te::k_part_scatter_prep377, dim3(sblocks + rows * per_row), dim3(512), 0, stream, sa, sblocks, tab, row_slab,
+                             reinterpret_cast<te::rec_slot<14>*>(ws.d_recs), n32, per_row, rows * per_row);
+        } else {
+          const uint32_t per_row = (n32 + 255u) / 256u;
+          hipLaunchKernelGGL(te::k_part_scatter_prep, dim3(sblocks + rows * per_row), dim3(512), 0, stream, sa, sblocks, tab, row_slab,
+                             reinterpret_cast<te::pnt_slot*>(ws.d_recs), n32, per_row, rows * per_row);
+        }
       } else {
         hipLaunchKernelGGL(te::k_part_scatter, dim3(p.CH, p.nw), dim3(512), 0, stream, sa);
       }
