@@ -16,6 +16,7 @@ bash tools/profile_trace.sh --no-pipeline --no-sizes --no-host-buffers --no-conf
 python3 tools/trace_one_msm.py gpurun_out/prof/trace k_digits > $F/single_msm_timeline_2_16.txt
 ls -la $F
 # the driver's line on the SAME box (roofline.kernel_ms there must agree with the one-MSM-at-a-time trace above)
+cp $F/pmc_traffic.json profiles/pmc_traffic.json      # (the line reads the traffic figure from there: this run's own, same sources)
 python3 bench.py --steps 20 --warmup 5 2> /dev/null | grep '^{' | tail -1 > $F/bench_default_line.json
 python3 - $F <<'PY'
 import json, sys
