@@ -195,16 +195,20 @@ int set_err(te_ctx* ctx, int code, const char* msg) { std::lock_guard<std::mutex
 uint32_t ilog2(uint32_t v) { uint32_t l = 0; while ((1u << l) < v) l++; return l; }
 
 int auto_window_bits(uint64_t n) {
-  // measured on MI355X (profiles/r01_window_sweep.txt, r03_n_sweep.txt): 16 bits from 3 * 2^17 points up, 15 bits for
-  // 2^14 .. below that (fewer buckets to reduce, and at that size the fixed stages weigh more than the additions; at n = 2^18
-  // 15 bits: 0.341 ms per MSM pipelined / 0.536 ms latency, 16 bits: 0.357 / 0.547; at 2^19 16 bits win the latency by 4 %);
-  // below 2^14 about log2(n) + 1 bits so that the W * 2^(c-1) buckets do not dwarf the n points.
+  // measured on MI355X (profiles/r01_window_sweep.txt, r04_n_sweep.txt, r04_n_sweep_small.txt): 16 bits from 3 * 2^17 points up,
+  // 15 bits from 2^16 (fewer buckets to reduce, and at that size the fixed stages weigh more than the additions; at n = 2^18
+  // 15 bits: 0.295 ms per MSM pipelined / 0.479 ms latency, 16 bits: 0.328 / 0.503; at 2^19 16 bits win the latency by 2 %, 15 bits
+  // the throughput by 3 %).  Below the harness sizes the bucket reduction is the whole cost: 13 bits for 2^14 .. 2^16 (2^15: 0.099
+  // ms per MSM / 0.235 ms latency against 0.112 / 0.247 with 15 bits), 11 bits for 2^11 .. 2^14 (2^13: 0.080 / 0.200 against
+  // 0.095 / 0.235 with 14), below that about log2(n) + 1 bits so that the W * 2^(c-1) buckets do not dwarf the n points.
   if (n >= (3ull << 17)) return 16;
-  if (n >= (1ull << 14)) return 15;
+  if (n >= (1ull << 16)) return 15;
+  if (n >= (1ull << 14)) return 13;
+  if (n >= (1ull << 11)) return 11;
   int lg = 0; while ((1ull << (lg + 1)) <= n) lg++;
   int c = lg + 1;
   if (c < 8) c = 8;
-  if (c > 15) c = 15;
+  if (c > 11) c = 11;
   return c;
 }
 
