@@ -45,6 +45,9 @@ CASES = [  # (name, seed, n, mode)
     ("random_n262144", 0x5EED0040002, 1 << 18, "random"),
     ("chain_n524288", 0x5EED0080000, 1 << 19, "chain"),
     ("fixed_n1048576", 0x5EED0100001, 1 << 20, "fixed"),
+    # SURVEY 8f rank 3, skewed scalars as a prover feeds them: a quarter zeros, a quarter ones, a quarter small values, the rest uniform
+    ("witness_n4096", 0x5EED1001, 4096, "witness"),
+    ("witness_n65536", 0x5EED0010003, 65536, "witness"),
 ]
 
 
@@ -53,6 +56,14 @@ def make_inputs(seed: int, n: int, mode: str):
     sc = oracle.gen_scalars(seed, n)
     if mode == "edge":
         sc = model.scalars_to_bytes(edge_scalars(seed, n))
+    if mode == "witness":
+        a = bytearray(sc)
+        for i in range(n):
+            r = i & 3
+            if r < 3:
+                v = 0 if r == 0 else 1 if r == 1 else (i * 2654435761 + seed) % (1 << 20)
+                a[32 * i:32 * i + 32] = v.to_bytes(32, "little")
+        sc = bytes(a)
     return pts, sc
 
 
