@@ -86,12 +86,17 @@ def isa_cycles(bls):
     return {"cycles": float(k["valu_issue_cycles"]), "note": k.get("note", ""), "stale": j.get("kernel_sources_sha") != kernel_sources_sha()}
 
 
-def algorithmic_bytes(n, W, B, bls=False):
-    """whole MSM, and the share of the dominant kernel (bucket accumulation)."""
+def algorithmic_bytes(n, W, B, bls=False, entries=None):
+    """whole MSM, and the share of the dominant kernel (bucket accumulation).
+    entries: the points the accumulation actually gathers = non-zero window digits, counted by the engine (option
+    "entries_accumulated"): a zero digit contributes nothing (smvp.template.wgsl:128) and is dropped by the sort.  SURVEY's
+    formula writes W * n for it -- exact to 2^-c for uniform scalars, but a prover's witness with half of its scalars 0 or 1
+    has 8.25 non-zero digits of 16: pricing W * n there put the kernel ABOVE its own instruction floor (round 4: frac 1.49)."""
+    e = W * n if entries is None else entries
     if bls:                                               # 48-B coordinates and scalar records, 144-B projective buckets
-        return 144 * n + W * n * (96 + 4) + 2 * W * B * 144 + 96, W * n * (96 + 4) + W * B * 144
-    whole = 96 * n + W * n * (64 + 4) + 2 * W * B * 128 + 64
-    accumulate = W * n * (64 + 4) + W * B * 128          # gather each point + its 4-B index once, write each bucket once
+        return 144 * n + e * (96 + 4) + 2 * W * B * 144 + 96, e * (96 + 4) + W * B * 144
+    whole = 96 * n + e * (64 + 4) + 2 * W * B * 128 + 64
+    accumulate = e * (64 + 4) + W * B * 128              # gather each point + its 4-B index once, write each bucket once
     return whole, accumulate
 
 
@@ -127,7 +132,7 @@ def alone_pass(ctx, step, reps):
     return {k: v / reps for k, v in acc.items()}
 
 
-def roofline_block(acc_bytes, alone, timed, bls, waves, traffic=None, traffic_info=None, msms_per_launch=1):
+def roofline_block(acc_bytes, alone, timed, bls, waves, traffic=None, traffic_info=None, msms_per_launch=1, entries=None):
     """roofline of the dominant kernel.  `achieved` = algorithmic bytes per launch / the kernel's mean duration with the GPU
     to itself (HIP events around the launch on the engine's stream, measured live in this run; agrees with the kernel trace
     of `bench.py --no-pipeline`): a per-launch cost that cannot exceed ms_per_step.  The duration seen in the timed region,
@@ -142,7 +147,7 @@ def roofline_block(acc_bytes, alone, timed, bls, waves, traffic=None, traffic_in
             "valu_issue_cycles_per_64_points": isa["cycles"], "isa_listing_stale": isa["stale"], "note": isa["note"]}
     out = {"bound": "hbm", "kernel": "k_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_info": traffic_info,
-           "algorithmic_bytes_per_launch": acc_bytes, "kernel_ms": alone_ms, "kernel_ms_device_clock": alone.get("accumulate_on_device"),
+           "algorithmic_bytes_per_launch": acc_bytes, "entries_accumulated_per_launch": entries, "kernel_ms": alone_ms, "kernel_ms_device_clock": alone.get("accumulate_on_device"),
            "msms_per_launch": msms_per_launch,
            "duration": "mean of the launches of an untimed pass inside this run with one MSM on the GPU (HIP events on the engine's stream)",
            "timed_region": timed, "binding_roofline": valu,
@@ -185,12 +190,13 @@ def side_config(pkg, dev, name, curve, digits, log2n, depth, threads, steps, exp
         cx.set_option("profile", 1)
         elapsed, result = pipelined_pass(cx, dp, ds, n, steps, depth)
         alone = alone_pass(cx, lambda: cx.run_device(dp, ds, n), 4)
-    whole, acc_bytes = algorithmic_bytes(n, W, B, bls)
+        entries = cx.get_option("entries_accumulated")     # non-zero window digits of that last MSM, counted on the device
+    whole, acc_bytes = algorithmic_bytes(n, W, B, bls, entries)
     traffic, traffic_info = measured_traffic(log2n, c, 1, False, name)
     out = {"workload": "n=2^%d %s MSM, %d-bit %s windows (%d windows x %d buckets)%s, inputs resident in HBM" % (
                log2n, "BLS12-377 G1" if bls else "TE-BLS12", c, digits, W, B, workload_note),
            "value": steps / elapsed, "unit": "MSM/s", "steps": steps, "ms_per_step": elapsed * 1e3 / steps, "latency_ms": min(lat),
-           "roofline": roofline_block(acc_bytes, alone, None, bls, W * n / 64.0, traffic, traffic_info),
+           "roofline": roofline_block(acc_bytes, alone, None, bls, entries / 64.0, traffic, traffic_info, entries=entries),
            "msm_algorithmic_bytes": whole}
     if expect is None:
         t0 = time.perf_counter()
@@ -493,9 +499,11 @@ def main():
              "note": "concurrency-stretched: %d launch sequences share the GPU" % (depth if pipelined else 1)}
     # full per-stage breakdown from a few extra, untimed steps with the GPU to itself (an event at every stage boundary)
     stage_ms = alone_pass(ctx, step, 6)
-    whole_bytes, acc_bytes = algorithmic_bytes(n, W, B, bls)
+    # the points this rank's accumulation gathers per MSM: non-zero digits of ITS windows, counted by the engine
+    entries_rank = ctx.get_option("entries_accumulated")
     div = rehearse or world
-    acc_bytes_rank = acc_bytes / div                      # windows are sharded
+    whole_bytes, _ = algorithmic_bytes(n, W, B, bls, entries_rank * div)       # (whole MSM: the ranks' windows are alike to 2^-c)
+    _, acc_bytes_rank = algorithmic_bytes(n, W / div, B, bls, entries_rank)    # windows are sharded
     traffic, traffic_info = (None, None) if bls else measured_traffic(
         args.log2n, c, world if not rehearse else rehearse,
         args.digits == "signed" and args.scalars == "uniform" and args.points == "random" and not args.segment_len)
@@ -527,7 +535,7 @@ def main():
                    "parallelism": "windows sharded over %d rank(s), one %s all-gather of %d B partial sums per launch sequence of %d MSM(s), %s point buffers"
                                   % (world, "RCCL" if (world > 1 and dist.get_backend() == "nccl") else "gloo (rehearsal: ranks share one GPU)", batch * W * 720, batch,
                                      "one shared" if len(base_copies) == 1 else "distinct") if world > 1 else "single GPU"},
-        "roofline": roofline_block(acc_bytes_rank, stage_ms, timed, bls, (W / div) * n / 64.0, traffic, traffic_info),
+        "roofline": roofline_block(acc_bytes_rank, stage_ms, timed, bls, entries_rank / 64.0, traffic, traffic_info, entries=entries_rank),
         "msm_algorithmic_bytes": whole_bytes,
         "msm_algorithmic_gbps": whole_bytes / (ms_per_step * 1e-3) / 1e9,
         "stage_ms_untimed_pass": {k: v for k, v in stage_ms.items() if not k.endswith("_ghz")},
@@ -633,6 +641,23 @@ def main():
                     mc.run(pts, sc)                               # buffers, staging areas, the per-device host threads
                     hb, r_host = host_buffer_ms(mc, pts, sc, reps=7)
                     cb, Wb = mc.plan((n + world - 1) // world)
+                    # the same boundary with MSMs in flight: whole-MSM tickets, one per device and upload thread
+                    # (te_msm_submit_async: what concurrent compute_msm promises map onto under the N-API addon)
+                    infl = 2 * world
+                    for t in [mc.submit_async(pts, sc) for _ in range(infl)]:          # every work set's buffers and staging area
+                        assert mc.collect(t) == r_host
+                    k_in = 6 * world
+                    t1 = time.perf_counter()
+                    tk = []
+                    for _ in range(k_in):
+                        tk.append(mc.submit_async(pts, sc))
+                        if len(tk) >= infl:
+                            assert mc.collect(tk.pop(0)) == r_host
+                    while tk:
+                        assert mc.collect(tk.pop(0)) == r_host
+                    out["host_buffers_in_flight_ms"] = (time.perf_counter() - t1) * 1e3 / k_in
+                    out["host_buffers_in_flight_note"] = ("%d te_msm_submit_async calls from pageable host buffers on the n_dev = %d context, %d in flight "
+                                                          "(two whole MSMs per device, one upload thread and PCIe link per device), per MSM" % (k_in, world, infl))
                 out["host_buffers_ms"] = hb
                 out["pcie_inclusive_ms_host_buffers"] = hb
                 out["host_buffers_ms_one_device"] = hb1
@@ -747,6 +772,10 @@ def main():
             if rank == 0:
                 print(json.dumps(out))
             raise SystemExit("window-sharded result differs from the single-GPU result")
+    # the driver's record keeps `config`, `roofline` and `cpu_baseline` of this line: the figures of the boundary go there too
+    for k in ("latency_ms", "host_buffers_ms", "host_buffers_in_flight_ms", "host_buffers_ms_one_device", "sizes"):
+        if out.get(k) is not None:
+            out["config"][k] = out[k]
     if rank == 0:
         print(json.dumps(out))
     if ctx is not None:

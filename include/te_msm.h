@@ -8,11 +8,12 @@
  *
  * Wire format (README.md:297-299; encoder reference/webgpu/utils.ts:90-99):
  *   points : n x (x[32 B little-endian] || y[32 B little-endian]), canonical affine, NOT Montgomery
- *   scalars: n x 32 B little-endian integers (< p; anything < 2^255 is accepted)
+ *   scalars: n x 32 B little-endian integers (< p < 2^253; signed digits accept anything below 2^254 - 2^240 at every
+ *            window size -- TE_MSM_ESCALAR above --, unsigned digits any 256-bit value)
  *   result : x[32 B LE] || y[32 B LE], canonical affine  ( == result.toAffine(), submission.ts:412 )
  *
  * All functions return 0 on success or a negative TE_MSM_E* code; te_msm_last_error() gives text.
- * A context is not thread-safe; use one context per host thread / device.
+ * A context is not thread-safe: serialise the calls on one context (the one exception is te_msm_ticket_wait).
  * There is NO CPU fallback: without a usable HIP device te_msm_init fails.
  */
 #ifndef TE_MSM_H
@@ -53,15 +54,21 @@ typedef struct te_ctx te_ctx;
 
 /* Replaces get_device() + per-call buffer/pipeline creation (implementation/cuzk/gpu.ts:14-25,
  * submission.ts:96-97).  The context is persistent: buffers and streams live across calls.
- * n_dev == 1: one GPU.  n_dev > 1: every MSM is sharded over the listed devices inside this process
- * (device ids may repeat) -- this is how a single-process host (the reference's JavaScript, README.md:551
- * "multi-device" future work) uses a node's GPUs:
+ * n_dev == 1: one GPU.  n_dev > 1: the listed devices (ids may repeat) work for this one context -- this is how a
+ * single-process host (the reference's JavaScript, README.md:551 "multi-device" future work) uses a node's GPUs.
+ * Two shapes:
+ *   MSMs in flight (te_msm_submit / te_msm_submit_async / te_msm_submit_device + te_msm_collect): one WHOLE MSM per
+ *     device, a ticket goes to the device with the fewest in flight -- D PCIe links, no replicated bucket reduction, no
+ *     row merge.  The throughput form for a caller with several MSMs to do (concurrent compute_msm promises).
+ *   the lone call (te_msm_run / te_msm_run_device): every device works on the one MSM:
  *   te_msm_run (host buffers): POINT shards.  Points and scalars are cut into n_dev contiguous slices; one
  *     host thread per device uploads its slice over that device's own PCIe link (the upload is most of a
  *     host-buffer call: 1.85 of 2.47 ms at n = 2^20 on one device) and runs all windows on it; the host tail
  *     folds the sum of the devices' rows.  Window bits follow the slice size.  Option "host_shard_min": fewer
  *     devices are used when a slice would hold fewer points than that (default 4096).
- *   te_msm_run_device (inputs resident on the first device): WINDOW shards, inputs copied peer-to-peer.
+ *   te_msm_run_device (inputs resident on the first device): WINDOW shards; the inputs travel as a scatter + all-gather
+ *     over the peer links (slice i to device i, then every device pulls the other slices from their holders:
+ *     2 (D - 1) / D of the input leaves the first device instead of D - 1 copies of it), enqueued by one host thread per device.
  * For one-process-per-GPU deployments use n_dev == 1 plus te_msm_set_window_shard / te_msm_partial_device /
  * te_msm_finalize and exchange the partial sums yourself (bench.py does it with an RCCL all-gather). */
 int te_msm_init(const int* device_ids, int n_dev, te_ctx** out);
@@ -77,7 +84,7 @@ int te_msm_run(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars_
 int te_msm_run_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_scalars_le, uint64_t n,
                       uint8_t out_xy_le[64]);
 
-/* Pipelined form of te_msm_run_device (single-device contexts): te_msm_submit_device enqueues every device stage plus
+/* Pipelined form of te_msm_run_device: te_msm_submit_device enqueues every device stage plus
  * the 11 KB read-back and returns at once with a ticket; te_msm_collect waits for that MSM, runs the host tail and
  * writes the result.  Up to TE_MSM_WORKSETS MSMs may be in flight, each on its own stream and device work set: the host
  * tail of MSM k overlaps the device work of MSM k+1, and on the GPU the launch gaps and the latency-bound reduction tail
@@ -85,6 +92,11 @@ int te_msm_run_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_sca
  * prover calling MSMs back to back does not have to).
  * Inputs must stay valid until the ticket is collected.  Tickets may be collected in any order (until round 4: in
  * submission order only).
+ * Contexts of several devices: the inputs may be resident on ANY device of the context (both buffers on the same one); the
+ * ticket goes to the device with the fewest MSMs in flight -- ties to the device that holds the inputs -- and a device that
+ * does not hold them pulls them over its peer link first (hipMemcpyPeerAsync on the work set's stream; option
+ * "stage_device_inputs" = 1 forces that copy even onto the holder: tests on a one-GPU box).  A ticket is a whole MSM there
+ * (the window shards of a multi-device context belong to te_msm_run_device).
  * A work set owned by an uncollected ticket is never reused underneath it: te_msm_run / te_msm_run_device move to a
  * free work set (TE_MSM_ESTATE when all TE_MSM_WORKSETS are owned), te_msm_partial_device on such a set returns
  * TE_MSM_ESTATE.  A ticket is consumed by te_msm_collect whether it ends in a result or in TE_MSM_ESCALAR. */
@@ -94,14 +106,26 @@ int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]);
  * (ui/Benchmark.tsx:32 awaits an async call; nothing stops a caller from having several in flight): uploads the buffers
  * (in pieces, like te_msm_run) into the staging area of a free work set, enqueues every device stage and returns a ticket
  * for te_msm_collect.  The call returns when the data has LEFT the caller's buffers (pageable copies are staged by the
- * calling thread), so points_xy_le / scalars_le may be released as soon as it returns; the upload of MSM k+1 overlaps the
- * device work of MSM k.  Single-device contexts. */
+ * calling thread; for pinned / hipHostRegister'ed buffers, whose copies are truly asynchronous, the call waits for the last
+ * upload), so points_xy_le / scalars_le may be released as soon as it returns; the upload of MSM k+1 overlaps the
+ * device work of MSM k.  Contexts of several devices: the ticket goes to the device with the fewest in flight (idle
+ * devices in turn); the uploads of consecutive calls still follow each other on the calling thread -- see te_msm_submit_async. */
 int te_msm_submit(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars_le, uint64_t n, uint64_t* ticket);
+/* The same with the upload itself in the background: the call picks device and work set, hands upload + enqueue to that
+ * device's host thread and returns AT ONCE.  D calls in a row put D uploads on D PCIe links at the same time -- what a
+ * single-threaded caller (the JavaScript event loop behind the N-API addon, a Python prover) needs to keep D devices busy
+ * from host buffers: from the builder's figures 8 x (1 / 2.2 ms) MSM/s against 1 / 0.69 ms for point slices of one call.
+ * The price: points_xy_le / scalars_le must stay valid and unchanged until te_msm_ticket_wait or te_msm_collect has
+ * returned for the ticket.  A failure of the upload or the enqueue (TE_MSM_EDEVICE) is reported by te_msm_collect, which
+ * frees the ticket.  Tickets of one device are worked off in submission order.  Works on single-device contexts too. */
+int te_msm_submit_async(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars_le, uint64_t n, uint64_t* ticket);
 /* Blocks until the MSM of `ticket` has left the device (its rows are in host memory); te_msm_collect then returns without
  * waiting.  This is the ONE entry point that may be called from another thread while the context is in use elsewhere -- it
  * only waits on the ticket's event -- so a multi-threaded host (libuv's pool under the N-API addon) serialises submit and
  * collect with a lock of its own and waits outside it. */
 int te_msm_ticket_wait(te_ctx* ctx, uint64_t ticket);
+/* Where a ticket in flight runs: index into the context's device list and the HIP device id there (either may be NULL). */
+int te_msm_ticket_device(te_ctx* ctx, uint64_t ticket, int* device_index, int* device_id);
 
 /* Options (the reference hard-codes these: chunk_size submission.ts:80, dispatch table :109-142).
  *   "window_bits"   c in [4,16]; 0 = choose from n (default)
@@ -124,11 +148,17 @@ int te_msm_ticket_wait(te_ctx* ctx, uint64_t ticket);
  *                   else 1), 1 = whole.  Twisted-Edwards: all scalars go first, in one copy (the link is the bottleneck);
  *                   BLS12-377: scalars piece by piece with their points (the device is).  The result does not depend on it.
  *   "host_shard_min" multi-device te_msm_run: smallest slice worth a device of its own (default 4096 points)
- *   "queue_probe"   1 (default) = the first te_msm_submit* measures the hardware queues of the work sets' streams (see
- *                   te_msm_workset_stream); 0 = never (env TE_MSM_QUEUE_PROBE=0).  te_msm_probe_queues does it on request.
+ *   "queue_probe"   1 (default) = the first te_msm_submit_device on a device measures the hardware queues of its work sets' streams
+ *                   (see te_msm_workset_stream); 0 = never (env TE_MSM_QUEUE_PROBE=0).  te_msm_probe_queues does it on request.
+ *                   te_msm_submit / te_msm_submit_async never trigger it: a host-buffer ticket is bound by its upload
+ *                   (until round 4 they did: 16 ms at the first submit).
  *   "workset"       which of the TE_MSM_WORKSETS device work sets te_msm_run* / te_msm_partial_device use (default 0)
- *   read-only:      "num_devices", "segment_len_used", "peer_copies" (hipMemcpyPeerAsync calls a multi-device context issued),
- *                   "in_flight" (tickets not collected), "streams_final" (te_msm_workset_stream's handles will not change any
+ *   "stage_device_inputs"  see te_msm_submit_device (default 0)
+ *   read-only:      "num_devices", "segment_len_used", "peer_copies" / "peer_bytes" (hipMemcpyPeerAsync calls a multi-device
+ *                   context issued, and the bytes they moved), "entries_accumulated" (non-zero window digits of the MSM whose
+ *                   result was fetched last, counted on the device: the points k_accumulate gathered -- all windows of this
+ *                   context's shard, all MSMs of a batch; bench.py prices its roofline with it),
+ *                   "in_flight" (tickets not collected, all devices), "streams_final" (te_msm_workset_stream's handles will not change any
  *                   more), "device_bytes" (device memory held in work-set buffers, see te_msm_trim)
  *   "prezero"       1 (default) = a work set's block of counters is cleared BEHIND an MSM's read-back, for its next MSM
  *                   (the next MSM starts with its first kernel instead of a fill); 0 = cleared in front of every MSM --
@@ -144,7 +174,9 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value);
 int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value);
 
 /* ---- window-sharded building blocks (multi-GPU: one process per GPU) --------------------------
- * This context computes windows w = first + k*step (k >= 0) of every MSM.  Default: first 0, step 1. */
+ * This context computes windows w = first + k*step (k >= 0) of every MSM.  Default: first 0, step 1.
+ * Number of windows W of a plan: ceil(255 / c) for signed digits (scalars below 2^254 - 2^240; 17 windows of 15 bits, 16 of
+ * 16), ceil(256 / c) for unsigned ones; te_msm_plan reports it. */
 int te_msm_set_window_shard(te_ctx* ctx, int first, int step);
 /* Geometry for n points under the current options: window bits c and total number of windows W. */
 int te_msm_plan(te_ctx* ctx, uint64_t n, int* window_bits, int* num_windows);

@@ -479,11 +479,19 @@ def test_multi_device_context_same_gpu(pkg, ora):
         # device-resident inputs live on the first device: the second "device" gets them through hipMemcpyPeerAsync -- the
         # copies are issued and ordered in front of its kernels also when both ids name one physical GPU (the only form a
         # one-GPU box can run: whether the path is right across two physical devices stays unmeasured)
+        # The inputs travel as a scatter + all-gather (SURVEY 8e "Inputs"): device i >= 1 pulls slice i from the source, then the
+        # other slices from their holders -- 2 (D - 1) D copies per call (points and scalars), every device but the first receives
+        # all n points once, and only 2 (D - 1) / D of the input leaves the first device's memory.
         for k in range(3):
             assert c.run_device(dp.data_ptr(), ds.data_ptr(), n) == exp
-            assert c.get_option("peer_copies") == 2 * (k + 1)
-    with pkg.MsmContext((0, 0, 0)) as c3:                               # 16 windows over three "devices": 6 + 5 + 5
-        assert c3.run_device(dp.data_ptr(), ds.data_ptr(), n) == exp and c3.get_option("peer_copies") == 4
+            assert c.get_option("peer_copies") == 4 * (k + 1) and c.get_option("peer_bytes") == n * 96 * (k + 1)
+    with pkg.MsmContext((0, 0, 0)) as c3:                               # 16 windows over three "devices": 6 + 5 + 5; ragged slices (6667 + 6667 + 6666)
+        assert c3.run_device(dp.data_ptr(), ds.data_ptr(), n) == exp
+        assert c3.get_option("peer_copies") == 12 and c3.get_option("peer_bytes") == 2 * n * 96
+    with pkg.MsmContext((0,) * 8) as c8:                                # two windows per device; tiny n: some slices are empty
+        assert c8.run_device(dp.data_ptr(), ds.data_ptr(), n) == exp
+        assert c8.get_option("peer_bytes") == 7 * n * 96
+        assert c8.run_device(dp.data_ptr(), ds.data_ptr(), 5) == ora.msm(pts[:64 * 5], sc[:32 * 5])
 
 
 @pytest.mark.parametrize("ids", [(0, 0), (0, 0, 0, 0), (0,) * 8])
@@ -513,7 +521,7 @@ def test_multi_device_host_point_shards(pkg, model, ora, wasm_golden, ids):
         n = 100003
         pts, sc = ora.gen_points(56, n), ora.gen_scalars(56, n)
         bad = bytearray(sc); bad[32 * (n - 3):32 * (n - 3) + 32] = b"\xff" * 32          # lands in the last device's slice
-        c.set_option("window_bits", 16)                                  # 16 x 16 bits: 2^256 - 1 leaves a final carry (18 x 15 would hold it)
+        c.set_option("window_bits", 16)                                  # 16 x 16 bits: 2^256 - 1 leaves a final carry
         with pytest.raises(pkg.MsmError) as e:
             c.run(pts, bytes(bad))
         assert e.value.code == -3

@@ -1,0 +1,227 @@
+"""GPU tests of whole-MSM TICKETS on contexts of several devices (te_msm_submit / te_msm_submit_async /
+te_msm_submit_device + te_msm_ticket_wait / te_msm_collect on n_dev = D): one whole MSM per device, a ticket goes to the
+device with the fewest in flight.  A one-GPU box names GPU 0 several times: D device records, D x TE_MSM_WORKSETS work
+sets, D host threads on the one card -- the scheduling, the threads and every copy run; two PHYSICAL devices stay
+unmeasured.  Reference side: the async call convention ui/Benchmark.tsx:32, multi-device as the
+README's future work (README.md:551), the entry point submission.ts:73-78.  Nothing here reads /root/reference."""
+import ctypes
+import os
+
+import pytest
+
+from oracle.gen_golden import make_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(buf: bytes):
+    import torch
+    return torch.frombuffer(bytearray(buf), dtype=torch.uint8).cuda()
+
+
+@pytest.mark.parametrize("ids", [(0, 0), (0, 0, 0, 0), (0,) * 8])
+def test_tickets_on_a_multi_device_context(pkg, model, ora, wasm_golden, ids):
+    """2 D tickets in flight (asynchronous and blocking submits mixed) against the oracle; every device gets two; collected
+    out of order; a scalar-range error belongs to its ticket; te_msm_trim and a lone te_msm_run beside tickets; capacity"""
+    D = len(ids)
+    cases = [(1200 + i, [70001, 1000, 30000, 65536, 5, 40000, 12345, 257][i % 8]) for i in range(2 * D)]
+    data = []
+    for seed, n in cases:
+        pts, sc = ora.gen_points(seed, n), ora.gen_scalars(seed, n)
+        data.append((pts, sc, ora.msm(pts, sc, threads=8)))
+    with pkg.MsmContext(ids) as c:
+        assert c.get_option("num_devices") == D
+        for signed in (1, 0):
+            c.set_option("signed_digits", signed)
+            ts = [(c.submit_async if i % 3 else c.submit)(data[i][0], data[i][1]) for i in range(2 * D)]
+            assert c.get_option("in_flight") == 2 * D
+            where = [c.ticket_device(t) for t in ts]
+            assert sorted(i for i, _ in where) == sorted(list(range(D)) * 2), where       # the least loaded device, idle ones in turn
+            assert all(dev == ids[i] for i, dev in where)
+            order = list(reversed(range(2 * D)))
+            order = order[1::2] + order[0::2]
+            for i in order:
+                if i % 2:
+                    c.ticket_wait(ts[i])
+                assert c.collect(ts[i]) == data[i][2], (signed, i)
+            assert c.get_option("in_flight") == 0
+            with pytest.raises(pkg.MsmError):
+                c.collect(ts[0])                                                           # a ticket is consumed once
+            with pytest.raises(pkg.MsmError):
+                c.ticket_device(ts[0])
+        c.set_option("signed_digits", 1)
+        # an error in one ticket only; a lone call (point slices over all devices) and a trim beside tickets in flight
+        n = 100003
+        pts, sc = ora.gen_points(1300, n), ora.gen_scalars(1300, n)
+        want = ora.msm(pts, sc, threads=8)
+        bad = bytearray(sc); bad[32 * (n - 2):32 * (n - 2) + 32] = b"\xff" * 32
+        c.set_option("window_bits", 16)                                                    # 16 x 16 bits: 2^256 - 1 leaves a final carry
+        t = [c.submit_async(pts, sc), c.submit_async(pts, bytes(bad)), c.submit(pts, sc), c.submit_async(pts, sc)]
+        assert c.run(pts, sc) == want                                                      # te_msm_run on the sets no ticket owns
+        full = c.get_option("device_bytes")
+        assert c.trim(0) >= 0 and c.get_option("device_bytes") <= full                     # owned sets are skipped, idle ones freed
+        assert c.collect(t[3]) == want
+        with pytest.raises(pkg.MsmError) as e:
+            c.collect(t[1])
+        assert e.value.code == -3
+        assert c.collect(t[0]) == want and c.collect(t[2]) == want
+        c.set_option("window_bits", 0)
+        # capacity: D x WORKSETS tickets, then TE_MSM_ESTATE until one is collected
+        small_p, small_s = data[1][0], data[1][1]
+        ts = [c.submit_async(small_p, small_s) for _ in range(D * pkg.WORKSETS)]
+        with pytest.raises(pkg.MsmError) as e:
+            c.submit_async(small_p, small_s)
+        assert e.value.code == -4
+        with pytest.raises(pkg.MsmError):
+            c.submit(small_p, small_s)
+        with pytest.raises(pkg.MsmError):
+            c.run(small_p, small_s)                                                        # no free work set for the slices either
+        assert c.collect(ts.pop(3)) == data[1][2]
+        ts.append(c.submit(small_p, small_s))                                              # takes the set that ticket left
+        assert all(c.collect(t) == data[1][2] for t in ts)
+        assert c.get_option("in_flight") == 0
+        assert c.run(pts, sc) == want
+
+
+@pytest.mark.parametrize("ids", [(0, 0), (0,) * 8])
+def test_tickets_against_the_reference_outputs(pkg, model, wasm_golden, ids):
+    """tickets on D devices against the points the reference's own CPU MSM (Aleo WASM) returned: every golden up to 2^16 in
+    flight together, then the headline size n = 2^20 on every device at once"""
+    D = len(ids)
+    with pkg.MsmContext(ids) as c:
+        small = [g for g in wasm_golden if g["n"] <= 65536]
+        assert small
+        while small:
+            batch, small = small[:2 * D], small[2 * D:]
+            ts = []
+            for g in batch:
+                pts, sc = make_inputs(g["seed"], g["n"], g["mode"])
+                ts.append(c.submit_async(pts, sc))
+            for g, t in reversed(list(zip(batch, ts))):
+                assert model.xy_from_bytes(c.collect(t)) == (int(g["x"]), int(g["y"])), g["name"]
+        big = [g for g in wasm_golden if g["n"] == 1 << 20]
+        assert big, "the reference-generated golden at the headline size is missing"
+        g = big[0]
+        pts, sc = make_inputs(g["seed"], g["n"], g["mode"])
+        ts = [c.submit_async(pts, sc) for _ in range(D)]
+        assert sorted(c.ticket_device(t)[0] for t in ts) == list(range(D))                 # one whole MSM per device
+        for t in ts:
+            assert model.xy_from_bytes(c.collect(t)) == (int(g["x"]), int(g["y"])), D
+
+
+def test_device_resident_tickets_on_a_multi_device_context(pkg, ora):
+    """te_msm_submit_device on n_dev = 4: the inputs live on one device of the context, a ticket that lands on another device
+    pulls them over its peer link first ("stage_device_inputs" forces the copy on a one-GPU box, where every device id names
+    the holder); bytes and copies are counted; mixed with host-buffer tickets; single-device contexts keep their window shard"""
+    import torch
+    n = 50000
+    pts, sc = ora.gen_points(1400, n), ora.gen_scalars(1400, n)
+    want = ora.msm(pts, sc, threads=8)
+    dp, ds = _dev(pts), _dev(sc)
+    torch.cuda.synchronize()
+    with pkg.MsmContext((0, 0, 0, 0)) as c:
+        ts = [c.submit_device(dp.data_ptr(), ds.data_ptr(), n) for _ in range(4)]
+        assert sorted(c.ticket_device(t)[0] for t in ts) == [0, 1, 2, 3]
+        assert c.get_option("peer_copies") == 0                                            # every "device" is the holder: no copy
+        assert all(c.collect(t) == want for t in ts)
+        c.set_option("stage_device_inputs", 1)
+        ts = [c.submit_device(dp.data_ptr(), ds.data_ptr(), n) for _ in range(6)] + [c.submit_async(pts, sc)]
+        assert c.get_option("peer_copies") == 12 and c.get_option("peer_bytes") == 6 * n * 96
+        for t in reversed(ts):
+            assert c.collect(t) == want
+        # the lone call on the same context: window shards, inputs as scatter + all-gather over the peer links
+        before = c.get_option("peer_copies"), c.get_option("peer_bytes")
+        assert c.run_device(dp.data_ptr(), ds.data_ptr(), n) == want
+        assert c.get_option("peer_copies") - before[0] == 2 * 3 * 4                        # 2 (D - 1) D
+        assert c.get_option("peer_bytes") - before[1] == 3 * n * 96                        # every other device ends up with all n points
+        with pytest.raises(pkg.MsmError):
+            c.submit_device(0, ds.data_ptr(), n)
+        host = torch.empty(64 * n, dtype=torch.uint8).pin_memory()
+        with pytest.raises(pkg.MsmError):
+            c.submit_device(host.data_ptr(), ds.data_ptr(), n)                             # not resident on a device of the context
+    with pkg.MsmContext((0,)) as c1:                                                       # one device: the ticket follows the window shard
+        c1.set_window_shard(1, 2)
+        t = c1.submit_device(dp.data_ptr(), ds.data_ptr(), n)
+        part1 = c1.collect(t)
+        c1.set_window_shard(0, 1)
+        assert part1 != want and c1.collect(c1.submit_device(dp.data_ptr(), ds.data_ptr(), n)) == want
+
+
+def test_pinned_host_buffers_are_released_at_return(pkg, ora):
+    """te_msm_submit / te_msm_run promise that the caller's buffers are free when the call returns.  Copies from PINNED memory
+    are truly asynchronous, so the call has to wait for its uploads: the buffers are overwritten right after it returns"""
+    import torch
+    n = 300000
+    pts, sc = ora.gen_points(1500, n), ora.gen_scalars(1500, n)
+    want = ora.msm(pts, sc, threads=8)
+    hp = torch.frombuffer(bytearray(pts), dtype=torch.uint8).pin_memory()
+    hs = torch.frombuffer(bytearray(sc), dtype=torch.uint8).pin_memory()
+    keep_p, keep_s = hp.clone(), hs.clone()
+    from importlib import import_module
+    L = import_module("webgpu-msm-twisted-edwards_amd.binding")._lib()
+    as_cp = lambda t: ctypes.cast(ctypes.c_void_p(t.data_ptr()), ctypes.c_char_p)
+    with pkg.MsmContext((0,)) as c:
+        for chunks in (0, 1, 3):
+            c.set_option("host_chunks", chunks)
+            hp.copy_(keep_p); hs.copy_(keep_s)
+            t = ctypes.c_uint64()
+            assert L.te_msm_submit(c._h, as_cp(hp), as_cp(hs), n, ctypes.byref(t)) == 0
+            hp.fill_(0xff); hs.fill_(0xff)                                                 # the call is over: the buffers are the caller's again
+            assert c.collect(t.value) == want, chunks
+        hp.copy_(keep_p); hs.copy_(keep_s)
+        out = ctypes.create_string_buffer(96)
+        assert L.te_msm_run(c._h, as_cp(hp), as_cp(hs), n, out) == 0 and out.raw[:64] == want
+
+
+def test_window_count_of_15_and_5_bit_plans(pkg, model, ora):
+    """signed digits run ceil(255 / c) windows (17 x 15 bits, 51 x 5): scalars of this boundary are below p < 2^253.  The
+    error rule stays exact: s + sum_w 2^(c w + c - 1) >= 2^(c W) is the reference's "final carry is 1" (utils.ts:80-83)"""
+    n = 64
+    pts = ora.gen_points(1600, n)
+    p = 8444461749428370424248824938781546531375899335154063827935233455917409239041
+    with pkg.MsmContext((0,)) as c:
+        for bits, W in ((15, 17), (5, 51), (16, 16), (13, 20), (8, 32)):
+            c.set_option("window_bits", bits)
+            assert c.plan(n) == (bits, W)
+            H = sum(1 << (bits * w + bits - 1) for w in range(W))
+            top = (1 << (bits * W)) - H                                                    # the first scalar that leaves a final carry
+            ok = [p - 1, p - 2, (1 << 253) - 1, min(top, 1 << 254) - 1, 0, 1] + [(p - 1) >> k for k in range(1, n - 5)]     # (the oracle's own 16-bit windows hold anything below 2^255 - 2^239)
+            sc = model.scalars_to_bytes(ok[:n])
+            assert c.run(pts, sc) == ora.msm(pts, sc, threads=4), bits
+            if top < (1 << 256):
+                with pytest.raises(pkg.MsmError) as e:
+                    c.run(pts, model.scalars_to_bytes([1, top] + [2] * (n - 2)))
+                assert e.value.code == -3, bits
+        c.set_option("signed_digits", 0)                                                   # unsigned digits: ceil(256 / c), any 256-bit scalar
+        c.set_option("window_bits", 15)
+        assert c.plan(n) == (15, 18)
+        sc = model.scalars_to_bytes([(1 << 256) - 1, p - 1] + [3] * (n - 2))
+        assert c.run(pts, sc) == ora.msm(pts, sc, threads=4)
+
+
+def test_node_eight_promises_on_four_devices(pkg, model, ora, tmp_path):
+    """From the reference's host language: eight compute_msm promises in flight on TE_MSM_DEVICES=0,0,0,0 become eight
+    tickets, two per device (te_msm_submit_async from the JavaScript thread, wait + collect on libuv's pool); a lone call
+    on the same device list runs as point slices; all equal the oracle"""
+    import json
+    import shutil
+    import subprocess
+    node = shutil.which("node")
+    if not node:
+        pytest.skip("node is not installed on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    js = os.path.join(root, "webgpu-msm-twisted-edwards_amd", "js")
+    if not os.path.exists(os.path.join(js, "te_msm_napi.node")):
+        subprocess.check_call(["make", "-C", js, "-s"])
+    n = 1 << 17
+    pts, sc = ora.gen_points(1700, n), ora.gen_scalars(1700, n)
+    (tmp_path / "p.bin").write_bytes(pts)
+    (tmp_path / "s.bin").write_bytes(sc)
+    exp = model.xy_from_bytes(ora.msm(pts, sc, threads=8))
+    for k, env in ((8, {"TE_MSM_DEVICES": "0,0,0,0"}), (8, {"TE_MSM_DEVICES": "0,0,0,0", "UV_THREADPOOL_SIZE": "2"}), (12, {"TE_MSM_DEVICES": "0"})):
+        r = subprocess.run([node, os.path.join(js, "run_concurrent.js"), str(tmp_path / "p.bin"), str(tmp_path / "s.bin"), str(k)],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=dict(os.environ, **env))
+        out = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        assert "x" in out, (out, r.stderr.decode()[-2000:])
+        assert (int(out["x"]), int(out["y"])) == exp and out["all_equal"], (k, env)
+        print("node %s: single %.3f ms, %d in flight %.3f ms" % (env, out["single_ms"], k, out["concurrent_ms"]))

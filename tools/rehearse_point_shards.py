@@ -47,3 +47,20 @@ for D in (2, 4, 8):
         assert c.run(pts, sc) == ref
         _, best, med = timed(lambda: c.run(pts, sc), 7)
         print("in-process te_msm_run, the one GPU named %d times (D uploads share one link): best %.3f ms, median %.3f ms" % (D, best, med))
+
+# ---- round 5: whole-MSM tickets on D "devices" (te_msm_submit_async: one upload thread per device; on this box they share one
+# link and one GPU: the code path and its host-side cost, not a speed-up), and every single time of the D = 8 lone call
+for D in (2, 4, 8):
+    with pkg.MsmContext((0,) * D) as c:
+        def go():
+            ts = [c.submit_async(pts, sc) for _ in range(2 * D)]
+            return [c.collect(t) for t in ts]
+        assert all(x == ref for x in go())
+        r, best, med = timed(go, 5)
+        print("tickets on the one GPU named %d times, %d whole MSMs in flight (te_msm_submit_async): best %.3f ms, median %.3f ms per MSM" % (D, 2 * D, best / (2 * D), med / (2 * D)))
+with pkg.MsmContext((0,) * 8) as c:
+    c.run(pts, sc)
+    ts = []
+    for _ in range(25):
+        t0 = time.perf_counter(); c.run(pts, sc); ts.append((time.perf_counter() - t0) * 1e3)
+    print("in-process te_msm_run, D = 8, 25 calls in order (ms):", " ".join("%.2f" % t for t in ts))

@@ -94,6 +94,10 @@ def _lib() -> ctypes.CDLL:
         L.te_msm_submit.restype = ci
         L.te_msm_ticket_wait.argtypes = [vp, u64]
         L.te_msm_ticket_wait.restype = ci
+        L.te_msm_submit_async.argtypes = [vp, cp, cp, u64, ctypes.POINTER(u64)]
+        L.te_msm_submit_async.restype = ci
+        L.te_msm_ticket_device.argtypes = [vp, u64, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+        L.te_msm_ticket_device.restype = ci
         L.te_msm_probe_queues.argtypes = [vp]
         L.te_msm_probe_queues.restype = ci
         L.te_msm_trim.argtypes = [vp, ci]
@@ -156,11 +160,13 @@ class MsmContext:
         self._L = L
         self._sizes = (64, 32, 64)          # point, scalar, result bytes of the selected curve
         self.curve = CURVE_TE_BLS12
+        self._held = {}                     # ticket -> the buffers of an asynchronous submit (alive until collected)
 
     def close(self):
         if getattr(self, "_h", None):
-            self._L.te_msm_destroy(self._h)
+            self._L.te_msm_destroy(self._h)        # (finishes the uploads of asynchronous tickets that were never collected)
             self._h = None
+            self._held.clear()
 
     __del__ = close
 
@@ -225,7 +231,10 @@ class MsmContext:
 
     def collect(self, ticket: int) -> bytes:
         out = ctypes.create_string_buffer(96)
-        self._check(self._L.te_msm_collect(self._h, ticket, out))
+        try:
+            self._check(self._L.te_msm_collect(self._h, ticket, out))
+        finally:
+            self._held.pop(ticket, None)
         return out.raw[:self._sizes[2]]
 
     def submit(self, points: bytes, scalars: bytes) -> int:
@@ -239,8 +248,28 @@ class MsmContext:
         self._check(self._L.te_msm_submit(self._h, bytes(points), bytes(scalars), n, ctypes.byref(t)))
         return t.value
 
+    def submit_async(self, points: bytes, scalars: bytes) -> int:
+        """te_msm_submit_async: returns at once, the upload runs on the chosen device's host thread (D calls in a row keep D
+        PCIe links busy on a context of D devices).  The buffers must stay alive and unchanged until the ticket is collected:
+        this object holds references to the two `bytes` objects until then."""
+        pb, sb, _ = self._sizes
+        n = len(scalars) // sb
+        if len(scalars) != sb * n or len(points) != pb * n:
+            raise MsmError(-1, f"points must be {pb}*n bytes and scalars {sb}*n bytes")
+        points, scalars = bytes(points), bytes(scalars)
+        t = ctypes.c_uint64()
+        self._check(self._L.te_msm_submit_async(self._h, points, scalars, n, ctypes.byref(t)))
+        self._held[t.value] = (points, scalars)
+        return t.value
+
     def ticket_wait(self, ticket: int):
         self._check(self._L.te_msm_ticket_wait(self._h, ticket))
+
+    def ticket_device(self, ticket: int):
+        """(index into the context's device list, HIP device id) a ticket in flight runs on"""
+        i, d = ctypes.c_int(-1), ctypes.c_int(-1)
+        self._check(self._L.te_msm_ticket_device(self._h, ticket, ctypes.byref(i), ctypes.byref(d)))
+        return i.value, d.value
 
     def probe_queues(self) -> int:
         """Measures the hardware queues of the work sets' streams now (te_msm_probe_queues); number of classes found."""

@@ -1,0 +1,109 @@
+// host_sched.hpp -- the parts of the engine's host side that involve more than one thread: the per-device host thread (a
+// FIFO of jobs) and the bookkeeping of MSMs in flight (tickets on work sets, which device the next one goes to).
+//
+// No HIP in here.  te_msm.hip builds the C-ABI's submit / ticket_wait / collect on these pieces, and
+// tests/csrc/sched_harness.cpp drives the SAME code under ThreadSanitizer with a stand-in for the device (SURVEY.md
+// section 5, "race detection / sanitizers"; the reference is single-threaded JavaScript and has no counterpart --
+// its async call convention is ui/Benchmark.tsx:32, multi-device its README's future work, README.md:551).
+#pragma once
+#include <stdint.h>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+
+namespace te_sched {
+
+// One unit of work for a device's host thread.  `done` / `rc` are guarded by the worker's mutex.
+struct job_t {
+  std::function<int()> fn;
+  int rc = 0;
+  bool done = false;
+};
+using job_ref = std::shared_ptr<job_t>;
+
+// One host thread per device of a context.  Pageable host-to-device copies block the thread that issues them while the data
+// is staged, so D uploads issued from one thread run one after another; D threads drive D PCIe links at once.  The thread is
+// persistent (a wake-up costs microseconds; creating a thread and its HIP thread state per call would cost more than a
+// small MSM) and works its jobs off in the order they were posted -- tickets that went to one device keep their order.
+class worker_t {
+ public:
+  worker_t() : th_([this] { loop(); }) {}
+  worker_t(const worker_t&) = delete;
+  worker_t& operator=(const worker_t&) = delete;
+  // finishes what was posted, then joins (the jobs refer to state of the context: the context drops its workers first)
+  ~worker_t() {
+    { std::lock_guard<std::mutex> lk(mu_); quit_ = true; }
+    cv_.notify_all();
+    if (th_.joinable()) th_.join();
+  }
+  job_ref post(std::function<int()> fn) {
+    job_ref j = std::make_shared<job_t>();
+    j->fn = std::move(fn);
+    { std::lock_guard<std::mutex> lk(mu_); q_.push_back(j); }
+    cv_.notify_all();
+    return j;
+  }
+  // blocks until the job has run; any thread, any number of times
+  int wait(const job_ref& j) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [&] { return j->done; });
+    return j->rc;
+  }
+  // blocks until nothing is queued or running
+  void drain() {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [&] { return q_.empty() && !running_; });
+  }
+
+ private:
+  void loop() {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      cv_.wait(lk, [&] { return !q_.empty() || quit_; });
+      if (q_.empty()) return;                    // quit, and nothing left to do
+      job_ref j = q_.front();
+      q_.pop_front();
+      running_ = true;
+      lk.unlock();
+      const int r = j->fn();
+      j->fn = nullptr;                           // drop what the closure holds before anybody is told
+      lk.lock();
+      j->rc = r; j->done = true; running_ = false;
+      cv_.notify_all();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<job_ref> q_;
+  bool quit_ = false, running_ = false;
+  std::thread th_;                               // last: the thread starts in the constructor and uses everything above
+};
+
+// Ticket state of one work set.  A ticket is published with release semantics AFTER everything a waiter needs (the job, the
+// plan) has been written, and looked up with acquire loads: te_msm_ticket_wait may run on any thread while another thread
+// submits or collects OTHER tickets.  One ticket is waited for / collected by one thread at a time (the caller's protocol).
+struct slot_t {
+  uint64_t ticket = 0;       // 0 = free
+  job_ref job;               // asynchronous submit: the enqueue running on the device's host thread (null: enqueued by the submitting thread)
+};
+inline void slot_publish(slot_t& s, uint64_t ticket) { __atomic_store_n(&s.ticket, ticket, __ATOMIC_RELEASE); }
+inline uint64_t slot_ticket(const slot_t& s) { return __atomic_load_n(&s.ticket, __ATOMIC_ACQUIRE); }
+inline void slot_release(slot_t& s) { s.job.reset(); __atomic_store_n(&s.ticket, (uint64_t)0, __ATOMIC_RELEASE); }
+
+// Which device does the next whole MSM go to?  The one with the fewest MSMs in flight among those that still have a free
+// work set; ties go to `prefer` (the device that already holds the inputs, or -1), then to the device after `last` in
+// round-robin order (so that D tickets on D idle devices spread over all of them).  -1: every work set of every device is taken.
+inline int pick_device(const int* in_flight, int n_dev, int sets_per_dev, int prefer, int last) {
+  int best = -1;
+  for (int k = 1; k <= n_dev; k++) {
+    const int i = (last + k) % n_dev;
+    if (in_flight[i] >= sets_per_dev) continue;
+    if (best < 0 || in_flight[i] < in_flight[best] || (in_flight[i] == in_flight[best] && i == prefer)) best = i;
+  }
+  return best;
+}
+
+}  // namespace te_sched

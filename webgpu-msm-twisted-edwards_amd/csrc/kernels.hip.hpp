@@ -305,6 +305,7 @@ __device__ __forceinline__ void unpack8(const uint4& v, uint32_t (&d)[8]) {
 struct scatter_args {
   const uint16_t* digits; const uint32_t* counts1; uint16_t* part_keys; uint32_t* part_idx;
   uint32_t *part_start, *part_count, *seg_part_base; uint32_t seg_len, cap_w, nw /* local windows of the launch sequence */; sort_geom g;
+  uint32_t* entries;     // += the non-zero digits of every window (one atomic per window): what k_accumulate will gather -- bench.py's roofline
 };
 // LDS of one level-1 block in words: one packed word per entry of the tile, four 512-entry tables, scan scratch.
 // Packed entry: source slot in the tile (12 bits) | partition << 12 (8 bits: P <= 256) | bucket low bits << 20 (8) | sign << 28 --
@@ -341,6 +342,7 @@ __device__ __forceinline__ void part_scatter_block(uint32_t ch, uint32_t k, uint
     const uint32_t start = block_excl_scan(tot, sm, bt);
     if (t < g.P) run_base[t] = start + pre;
     if (ch == 0) {
+      if (t == 0 && bt) atomicAdd(a.entries, bt);
       const uint32_t extra = block_excl_scan(tot / seg_len, sm, bt);
       if (t < g.P) {
         part_start[k * g.P + t] = start; part_count[k * g.P + t] = tot;

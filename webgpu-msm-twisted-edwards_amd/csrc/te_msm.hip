@@ -29,6 +29,7 @@
 #include "kernels.hip.hpp"
 #include "probe.hip.hpp"
 #include "host_tail377.hpp"
+#include "host_sched.hpp"
 
 namespace {
 
@@ -55,6 +56,7 @@ struct plan_t {
   int curve = 0;                      // TE_MSM_CURVE_*
   int c = 0, W = 0, nw = 0;           // window bits, total windows, windows of this launch sequence (shard windows x batch)
   int nw1 = 0, batch = 1;             // windows of this shard per MSM; MSMs that share the launch sequence (te_msm_partial_device_batch)
+  int w_first = 0, w_step = 1;        // the windows this launch sequence computes: w_first + k * w_step (the device's shard, or 0 / 1 = all: whole MSMs)
   uint32_t B = 0, logB = 0;           // buckets per window = 2^(c-1) (signed digits) or 2^c (unsigned)
   int signed_digits = 1;
   uint32_t dw[4] = {0, 0, 0, 0};      // bits of the four digits of a bucket index (dw[0] lowest)
@@ -81,7 +83,8 @@ struct workset_t {
   uint32_t *d_seg_base = nullptr, *d_seg_bucket = nullptr, *d_seg_lenv = nullptr, *d_order = nullptr;
   uint32_t *d_split_list = nullptr, *d_chunk_list = nullptr;
   uint8_t *d_seg_out = nullptr, *d_buckets = nullptr, *d_red[4] = {};   // accumulators of the plan's curve (te::ete_t<N>); d_red: ping/pong of the two fold chains
-  // ONE zeroed block per MSM (a single memset), words: [0] final-carry flag, [1] number of segments, [2..4] split / giant
+  // ONE zeroed block per MSM (a single memset), words: [0] final-carry flag, [1] non-zero window digits (= entries accumulated;
+  // both survive the pieces of a host-buffer MSM), [2] number of segments, [3..5] split / giant
   // bucket counters, [Z_ROWS..) the partial rows of the MSM (so that flag and rows come back in ONE device-to-host copy),
   // [Z_HIST..) segment-length histogram (TE_HIST_COPIES copies), [Z_CURSOR..) reservation cursors of the schedule, [Z_END..) the level-1 histogram
   // counts1[window][chunk][partition], then bucket_count[window][bucket].  d_err .. d_bucket_count point into d_zero.
@@ -99,7 +102,8 @@ struct workset_t {
   hipEvent_t ev_result = nullptr;     // flag + rows of its last MSM are in host memory (recorded before the clearing: what a caller waits for)
   hipEvent_t ev[ST_COUNT + 1] = {};
   plan_t plan; uint64_t n = 0; bool used = false;
-  uint64_t pending_ticket = 0;        // ticket of an MSM submitted on this set and not collected yet (0 = none)
+  te_sched::slot_t slot;              // ticket of an MSM submitted on this set and not collected yet (0 = none) + the host-thread job of an asynchronous submit
+  std::string job_err;                // why that job failed (written by the device's host thread before the job is marked done)
   int prof_level = 0;                 // profile level the events of the last enqueue were recorded at
   hipStream_t last_stream = nullptr;  // stream of the previous MSM on this set: a different one must wait for it (scratch reuse)
   uint64_t generation = 0;            // bumped whenever ensure() reallocates a buffer of this set
@@ -113,6 +117,7 @@ struct workset_t {
 constexpr int TE_MAX_WINDOWS = 64;    // window_bits >= 4
 // words [Z_CLOCK, Z_ROWS): k_accumulate's profiling words, 4 x TE_CLK_SLOTS 64-bit values (first wave in / last wave out on the
 // wall clock, core and wall ticks summed over the waves), see the kernel
+constexpr size_t Z_KEEP = 2;            // words [0, Z_KEEP) are kept from piece to piece of one host-buffer MSM (flag, entry count)
 constexpr size_t Z_CLOCK = 8;
 constexpr size_t Z_ROWS = Z_CLOCK + 4 * 2 * TE_CLK_SLOTS, Z_HIST = Z_ROWS + (size_t)TE_MAX_WINDOWS * TE_MAX_ROW_BYTES / 4, Z_CURSOR = Z_HIST + 1024 * TE_HIST_COPIES, Z_END = Z_CURSOR + 1024;
 
@@ -122,31 +127,9 @@ struct gpu_t {
   workset_t ws[TE_MSM_WORKSETS];
   int last_ws = 0;
   int wall_clock_khz = 0;                // rate of wall_clock64() on this device
-  uint64_t next_ticket = 1;              // tickets are handed out in order; a ticket lives on the work set whose pending_ticket it is
   int in_flight = 0;                     // submitted and not collected
   bool queues_probed = false;            // the hardware-queue measurement has run (spread_streams_over_queues)
   bool streams_final = false;            // ... and the work sets' streams will not be re-dealt any more
-};
-
-// One host thread per further device of a multi-device context (te_msm_run on n_dev > 1): pageable host-to-device copies
-// block the calling thread while the data is staged, so D uploads issued from one thread in turn run one after another --
-// D threads drive D PCIe links at once.  The threads are persistent (a wake-up costs microseconds; creating a thread and its
-// HIP thread state per call would cost more than a small MSM).
-struct worker_t {
-  std::thread th; std::mutex mu; std::condition_variable cv;
-  std::function<int()> job; bool has_job = false, done = false, quit = false; int rc = 0;
-  void loop() {
-    std::unique_lock<std::mutex> lk(mu);
-    for (;;) {
-      cv.wait(lk, [&] { return has_job || quit; });
-      if (quit) return;
-      lk.unlock(); const int r = job(); lk.lock();
-      rc = r; has_job = false; done = true; cv.notify_all();
-    }
-  }
-  void start(std::function<int()> f) { { std::lock_guard<std::mutex> lk(mu); job = std::move(f); has_job = true; done = false; } cv.notify_all(); }
-  int wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done; }); done = false; return rc; }
-  ~worker_t() { { std::lock_guard<std::mutex> lk(mu); quit = true; } cv.notify_all(); if (th.joinable()) th.join(); }
 };
 
 }  // namespace
@@ -155,7 +138,12 @@ struct te_ctx {
   std::vector<gpu_t> devs;
   std::string err;
   std::mutex err_mu;           // the per-device host threads of a multi-device te_msm_run report into the one string
-  std::vector<std::unique_ptr<worker_t>> workers;   // devs[i + 1]'s thread; created by the first multi-device host-buffer call
+  std::vector<std::unique_ptr<te_sched::worker_t>> workers;   // devs[i]'s host thread (host_sched.hpp); created by the first call that needs them
+  uint64_t next_ticket = 1;         // tickets are handed out in order, over all devices; a ticket lives on the work set whose slot holds it
+  int last_dev = -1;                // the device the previous ticket went to (te_sched::pick_device deals idle devices round-robin)
+  int opt_stage_device_inputs = 0;  // tickets for device-resident inputs: copy them to the chosen device even when it is the one that holds them (tests on a one-GPU box)
+  int64_t stat_peer_bytes = 0;      // bytes those copies moved (get_option "peer_bytes")
+  int64_t stat_entries = 0;         // non-zero window digits (= accumulated entries) of the MSM whose result was fetched last (get_option "entries_accumulated")
   std::vector<double> host_split;   // TE_MSM_HOST_SPLIT (relative piece weights of a host-buffer upload; experiments), read once
   int opt_host_shard_min = 4096;    // multi-device te_msm_run: points per device below which fewer devices are used
   int opt_queue_probe = 1;          // 1 = the first te_msm_submit* measures the hardware queues (lazily); 0 = never; te_msm_probe_queues does it now
@@ -212,14 +200,25 @@ int auto_window_bits(uint64_t n) {
   return c;
 }
 
-void make_plan(const te_ctx* ctx, const gpu_t& d, uint64_t n, plan_t& p, int force_c = 0, int batch = 1, uint32_t force_seg = 0) {
+// Windows of the decomposition.  Unsigned digits cover all 256 bits of a scalar record.  Signed digits: the scalars of this
+// boundary are below p < 2^253 (harness generator reference/webgpu/utils.ts:118-124), so the windows only have to reach bit 254
+// -- 255 bits: 17 windows of 15 bits where 256 bits take 18 (and 51 of 5 instead of 52; every other size gives the same count).
+// The 18th window of a 15-bit plan held bits 255..269 and never received a digit or a carry: 16 384 empty buckets folded and a
+// tail block run for nothing at n = 2^16 .. 2^18, where the reduction is ~40 % of the device span.  The error rule stays exact:
+// k_digits flags any bit of s + sum_w 2^(cw + c - 1) at or above c * W, the reference's "final carry is 1"
+// (miscellaneous/utils.ts:80-83) -- with c * W = 255 that is every scalar from 2^254 - 2^240 up (all of them >= 2 p).
+int num_windows_for(int c, int signed_digits) { return ((signed_digits ? 255 : 256) + c - 1) / c; }
+
+// whole: every window (a whole MSM: host buffers, tickets of a multi-device context) instead of the device's window shard
+void make_plan(const te_ctx* ctx, const gpu_t& d, uint64_t n, plan_t& p, int force_c = 0, int batch = 1, uint32_t force_seg = 0, bool whole = false) {
   p.curve = ctx->opt_curve;
   p.c = force_c ? force_c : ctx->opt_window_bits ? ctx->opt_window_bits : auto_window_bits(n);
-  p.W = (256 + p.c - 1) / p.c;
-  p.nw = 0;
-  for (int w = d.w_first; w < p.W; w += d.w_step) p.nw++;
-  p.nw1 = p.nw; p.batch = batch; p.nw *= batch;
   p.signed_digits = ctx->opt_signed;
+  p.W = num_windows_for(p.c, p.signed_digits);
+  p.w_first = whole ? 0 : d.w_first; p.w_step = whole ? 1 : d.w_step;
+  p.nw = 0;
+  for (int w = p.w_first; w < p.W; w += p.w_step) p.nw++;
+  p.nw1 = p.nw; p.batch = batch; p.nw *= batch;
   p.logB = (uint32_t)(p.signed_digits ? p.c - 1 : p.c); p.B = 1u << p.logB;
   for (int k = 0; k < 4; k++) p.dw[k] = (p.logB + 3u - (uint32_t)k) / 4u;       // 15 -> 4,4,4,3
 #ifndef TE_SCATTER_BLOCKS
@@ -283,7 +282,7 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, workset_t& ws, uint64_t n, const plan_
     const size_t c1 = (size_t)p.nw * p.CH * p.P;
     ws.zero_words = Z_END + c1 + wb + (size_t)p.nw * p.P;
     { const uint32_t* before = ws.d_zero; if ((rc = ensure(ctx, ws, ws.d_zero, ws.cap[3], ws.zero_words))) return rc; if (ws.d_zero != before) ws.zero_clean_words = 0; }
-    ws.d_err = ws.d_zero; ws.d_num_seg = ws.d_zero + 1; ws.d_size_hist = ws.d_zero + Z_HIST; ws.d_size_cursor = ws.d_zero + Z_CURSOR;
+    ws.d_err = ws.d_zero; ws.d_num_seg = ws.d_zero + Z_KEEP; ws.d_size_hist = ws.d_zero + Z_HIST; ws.d_size_cursor = ws.d_zero + Z_CURSOR;
     ws.d_partials = reinterpret_cast<uint8_t*>(ws.d_zero + Z_ROWS);
     ws.d_counts1 = ws.d_zero + Z_END; ws.d_bucket_count = ws.d_counts1 + c1; ws.d_part_ticket = ws.d_bucket_count + wb;
   }
@@ -332,7 +331,7 @@ struct msm_launch {
   // rewritten by every MSM).  Not with window shards (rows of foreign windows must read as zero: they come from the cleared
   // device block), not with captured graphs (fixed pointers), not with "prezero" = 0 (stage verifiers read the device rows).
   static bool rows_to_host(const te_ctx* ctx, const gpu_t& d, const plan_t& p, bool own_rows) {
-    return own_rows && p.nw > 0 && p.batch == 1 && d.w_first == 0 && d.w_step == 1 && ctx->opt_prezero && !ctx->opt_graph;
+    return own_rows && p.nw > 0 && p.batch == 1 && p.w_first == 0 && p.w_step == 1 && ctx->opt_prezero && !ctx->opt_graph;
   }
   uint32_t n32() const { return (uint32_t)n; }
   uint32_t total() const { return (uint32_t)p.nw * p.B; }
@@ -388,10 +387,10 @@ struct msm_launch {
   // conversion shares the launch of the sort's first level (k_part_scatter_prep)
   int front_scalars(bool with_prep = false) {
     const uint32_t n32 = this->n32();
-    // flags, counters, histograms, bucket counts (a later piece of the same MSM keeps word 0, the final-carry flag)
+    // flags, counters, histograms, bucket counts (a later piece of the same MSM keeps the final-carry flag and the entry count)
     // -- unless the block is still clean from the clearing that followed the set's previous MSM (finish_sequence)
     if (onto || ws.zero_clean_words < ws.zero_words)
-      HIP_TRY(ctx, hipMemsetAsync(ws.d_zero + (onto ? 1 : 0), 0, (ws.zero_words - (onto ? 1 : 0)) * sizeof(uint32_t), stream));
+      HIP_TRY(ctx, hipMemsetAsync(ws.d_zero + (onto ? Z_KEEP : 0), 0, (ws.zero_words - (onto ? Z_KEEP : 0)) * sizeof(uint32_t), stream));
     ws.zero_clean_words = 0;
     mark(ST_DIGITS);
     te::sort_geom sg;
@@ -401,7 +400,7 @@ struct msm_launch {
       if (p.signed_digits) for (int w = 0; w < p.W; w++) { const int bit = w * p.c + p.c - 1; if (bit < 320) prm.half[bit >> 5] |= 1u << (bit & 31); }
       prm.zero_digit = p.signed_digits ? 1u << (p.c - 1) : 0u;
       prm.sc_stride = (uint32_t)(sizes_of(p.curve).scalar_in / 16);
-      prm.n = n32; prm.nst = p.nst; prm.num_windows = p.W; prm.w_first = d.w_first; prm.w_step = d.w_step; prm.nw_local = p.nw1;
+      prm.n = n32; prm.nst = p.nst; prm.num_windows = p.W; prm.w_first = p.w_first; prm.w_step = p.w_step; prm.nw_local = p.nw1;
       prm.half_code = sg.half; prm.logS = p.logS; prm.P = p.P; prm.CH = p.CH; prm.chunk_len = p.chunk_len;
       // one launch over the MSMs of the sequence: MSM m (blockIdx.y) fills digit rows and level-1 counts [m * nw1, (m + 1) * nw1)
       te::batch_ptrs sc; memset(&sc, 0, sizeof sc);
@@ -429,7 +428,7 @@ struct msm_launch {
     if (p.nw > 0) {
       te::scatter_args sa;
       sa.digits = ws.d_digits; sa.counts1 = ws.d_counts1; sa.part_keys = ws.d_part_keys; sa.part_idx = ws.d_part_idx; sa.part_start = ws.d_part_start;
-      sa.part_count = ws.d_part_count; sa.seg_part_base = ws.d_seg_part_base; sa.seg_len = p.seg_len; sa.cap_w = cap_w; sa.nw = (uint32_t)p.nw; sa.g = sg;
+      sa.part_count = ws.d_part_count; sa.seg_part_base = ws.d_seg_part_base; sa.entries = ws.d_zero + 1; sa.seg_len = p.seg_len; sa.cap_w = cap_w; sa.nw = (uint32_t)p.nw; sa.g = sg;
       if (with_prep) {
         te::batch_ptrs tab; te::batch_slabs row_slab;
         const uint32_t rows = (uint32_t)prep_rows(tab, row_slab), sblocks = p.CH * (uint32_t)p.nw;
@@ -572,7 +571,7 @@ struct msm_launch {
       // host_rows: the rows (and the flag words in front of them) are written to the pinned host block by the kernel itself
       uint8_t* const rows_base = host_rows ? reinterpret_cast<uint8_t*>(ws.h_err_dev + Z_ROWS) : static_cast<uint8_t*>(d_partials_out);
       tp.flag_src = host_rows ? ws.d_zero : nullptr; tp.flag_dst = host_rows ? ws.h_err_dev : nullptr; tp.flag_words = (uint32_t)Z_ROWS;
-      tp.rows = reinterpret_cast<E*>(rows_base) + (size_t)d.w_first * 5; tp.row_stride = (uint32_t)d.w_step * 5u;
+      tp.rows = reinterpret_cast<E*>(rows_base) + (size_t)p.w_first * 5; tp.row_stride = (uint32_t)p.w_step * 5u;
       tp.win_per_msm = (uint32_t)p.nw1; tp.msm_stride = (uint32_t)p.W * 5u;          // batch: MSM m's W rows follow MSM m-1's
       const size_t lds_bytes = (size_t)(std::max(H, L) + 16u) * sizeof(E);
       hipLaunchKernelGGL(te::k_reduce_tail<N>, dim3(4, p.nw), dim3(1024), lds_bytes, stream, tp);
@@ -699,7 +698,7 @@ int create_workset_streams(gpu_t& d) {
 // disturb the host-timed pairs, the two passes disagree and the creation order stays.
 void spread_streams_over_queues(gpu_t& d) {
   d.queues_probed = true;
-  for (const workset_t& ws : d.ws) if (ws.pending_ticket) return;            // cannot happen on the first submit; be safe
+  for (const workset_t& ws : d.ws) if (te_sched::slot_ticket(ws.slot)) return;            // cannot happen on the first submit; be safe
   for (workset_t& ws : d.ws) {
     if (ws.used && ws.ev_done && hipEventSynchronize(ws.ev_done) != hipSuccess) { (void)hipGetLastError(); return; }
     if (hipStreamSynchronize(ws.stream) != hipSuccess) { (void)hipGetLastError(); return; }
@@ -730,15 +729,15 @@ int finish_sequence(te_ctx* ctx, workset_t& ws, hipStream_t stream);
 
 int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, const void* d_scalars, uint64_t n,
                     void* d_partials_out, hipStream_t stream, const std::function<int(hipStream_t)>* upload_points = nullptr, int force_c = 0,
-                    bool side_stream = false, int batch = 1) {
-  plan_t p; make_plan(ctx, d, n, p, force_c, batch);
+                    bool side_stream = false, int batch = 1, bool whole = false) {
+  plan_t p; make_plan(ctx, d, n, p, force_c, batch, 0, whole);
   if (batch > 1 && (uint64_t)p.nw * p.nst >= (1ull << 31)) return set_err(ctx, TE_MSM_EINVAL, "batch too large for this n: windows x points must stay below 2^31");
   HIP_TRY(ctx, hipSetDevice(d.device));
   if ((uint64_t)p.nw * p.B + (uint64_t)p.nw * (n / p.seg_len) + 1024u >= (1ull << 32))
     return set_err(ctx, TE_MSM_EINVAL, "segment_len is too small for this n: more than 2^32 segments");
   if (int rc = ensure_buffers(ctx, d, ws, n, p)) return rc;
   if (ws.used && ws.last_stream != stream) HIP_TRY(ctx, hipStreamWaitEvent(stream, ws.ev_done, 0));   // the set's buffers are still the previous MSM's
-  ws.plan = p; ws.n = n; ws.used = true; ws.last_stream = stream; d.last_ws = (int)(&ws - d.ws);
+  ws.plan = p; ws.n = n; ws.used = true; ws.last_stream = stream; __atomic_store_n(&d.last_ws, (int)(&ws - d.ws), __ATOMIC_RELAXED);
   ws.prof_level = ctx->opt_profile;
   const bool own_rows = d_partials_out == nullptr;
   if (own_rows) d_partials_out = ws.d_partials;
@@ -753,7 +752,7 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, 
     ws.zero_clean_words = 0;
     graph_key key; memset(&key, 0, sizeof key);          // padding bytes take part in the memcmp below
     key.pts = d_points; key.sc = d_scalars; key.out = d_partials_out; key.n = n; key.generation = ws.generation;
-    key.c = p.c; key.w_first = d.w_first; key.w_step = d.w_step; key.seg_len = (int)p.seg_len;
+    key.c = p.c; key.w_first = p.w_first; key.w_step = p.w_step; key.seg_len = (int)p.seg_len;
     key.sort = ctx->opt_sort | (ctx->opt_signed << 1) | (ctx->opt_curve << 2) | (ctx->opt_packed << 4) | (ctx->opt_fold_pairs << 5);
     if (!ws.g_front || !ws.g_back || memcmp(&key, &ws.g_key, sizeof key) != 0) {
       if (ws.g_front || ws.g_back) HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));   // a previous replay may still be running
@@ -824,7 +823,7 @@ int finish_sequence(te_ctx* ctx, workset_t& ws, hipStream_t stream) {
 
 // Stage times of the MSM that last ran on `ws`, read from the events recorded at ITS profile level (the option may have
 // changed since).  Never fatal: a failed read leaves "no stage times" instead of losing the MSM's result.
-int collect_stage_ms(te_ctx* ctx, workset_t& ws) {
+int collect_stage_ms(te_ctx* ctx, const gpu_t& d, workset_t& ws) {
   if (!ws.prof_level) return 0;
   bool ok = true;
   for (int i = 0; i < ST_COUNT; i++) {
@@ -841,7 +840,7 @@ int collect_stage_ms(te_ctx* ctx, workset_t& ws) {
       c[0] = std::max(c[0], raw[i]); c[1] = std::max(c[1], raw[TE_CLK_SLOTS + i]);
       c[2] += raw[2 * TE_CLK_SLOTS + i]; c[3] += raw[3 * TE_CLK_SLOTS + i];
     }
-    const int khz = ctx->devs[0].wall_clock_khz;      // stage times are a single-device feature
+    const int khz = d.wall_clock_khz;
     const bool have = c[0] && c[1] && khz > 0 && c[1] > ~c[0];
     const double ms = have ? (double)(c[1] - ~c[0]) / khz : -1.0;
     ctx->stage_ms[ST_COUNT] = (float)ms;
@@ -902,6 +901,15 @@ int ensure_staging(te_ctx* ctx, workset_t& ws, size_t bytes_points, size_t bytes
   return 0;
 }
 
+// Is this host address pinned (hipHostMalloc) or registered (hipHostRegister) memory?  A copy from such memory does not
+// stage: hipMemcpyAsync returns before the data has left it.  Ordinary (pageable) memory is unknown to the runtime: the query
+// fails with hipErrorInvalidValue or reports hipMemoryTypeUnregistered, depending on the ROCm version.
+bool host_memory_is_pinned(const void* p) {
+  hipPointerAttribute_t at; memset(&at, 0, sizeof at);
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return at.type == hipMemoryTypeHost;
+}
+
 const char* const kFinalCarry = "final carry is 1: a scalar does not fit the signed window decomposition";
 
 // pieces a host buffer of n points is uploaded and processed in on ONE device (option "host_chunks", else from n).
@@ -917,9 +925,14 @@ int host_pieces(const te_ctx* ctx, uint64_t n) {
 // pieces -- while piece i is on the GPU, piece i+1 crosses PCIe -- whose additions land on the SAME buckets, one reduction at
 // the end, flag + rows on their way to the set's pinned block when the call returns.  Window bits are forced to c (the slices
 // of a point-sharded MSM must agree on the geometry of their rows).  Does not wait: the caller synchronises ws.ev_result.
-int enqueue_host_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* src_points, const uint8_t* src_scalars, uint64_t n, int c, int K) {
+// All windows, whatever the device's window shard says (host buffers always are whole MSMs or point slices of one).
+// wait_for_pinned: the caller promises its buffers only until this call returns (te_msm_run, te_msm_submit).  Copies from
+// PAGEABLE memory have left the caller's buffer when hipMemcpyAsync returns (the runtime stages them); from pinned or
+// registered memory they are truly asynchronous -- then the call waits for the last piece's upload before it returns.
+int enqueue_host_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* src_points, const uint8_t* src_scalars, uint64_t n, int c, int K,
+                       bool wait_for_pinned = true) {
   HIP_TRY(ctx, hipSetDevice(d.device));
-  plan_t pf; make_plan(ctx, d, n, pf, c);
+  plan_t pf; make_plan(ctx, d, n, pf, c, 1, 0, true);
   const curve_sizes sz = sizes_of(pf.curve);
   if (int rc = ensure_staging(ctx, ws, n * sz.point_in, n * sz.scalar_in)) return rc;
   uint8_t* dpts = static_cast<uint8_t*>(ws.d_in_points);
@@ -947,7 +960,7 @@ int enqueue_host_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* src_
   for (int i = 0; i < K; i++) m_max = std::max(m_max, piece_lo(i + 1) - piece_lo(i));
   uint32_t seg_all = 0;
   {
-    plan_t pm; make_plan(ctx, d, m_max, pm, pf.c);
+    plan_t pm; make_plan(ctx, d, m_max, pm, pf.c, 1, 0, true);
     seg_all = pm.seg_len;
     if (int rc = ensure_buffers(ctx, d, ws, m_max, pm)) return rc;        // every buffer at its final size before the first piece
   }
@@ -957,7 +970,13 @@ int enqueue_host_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* src_
   HIP_TRY(ctx, hipStreamWaitEvent(ws.copy_stream, ws.ev_start, 0));
   const bool tr = getenv("TE_MSM_TRACE_HOST") != nullptr;
   const auto t00 = std::chrono::steady_clock::now();
-  auto stamp = [&](const char* what, int i) { if (tr) fprintf(stderr, "[te_msm_run dev %d] %8.1f us  %s %d\n", d.device, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t00).count(), what, i); };
+  // (index of the device in the context's list / its HIP id; the absolute time tells the threads of one call apart from the next call's)
+  auto stamp = [&](const char* what, int i) {
+    if (!tr) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[te_msm_run dev %d/%d] %8.1f us  %s %d   (t = %.1f us)\n", (int)(&d - ctx->devs.data()), d.device,
+            std::chrono::duration<double, std::micro>(now - t00).count(), what, i, std::chrono::duration<double, std::micro>(now.time_since_epoch()).count());
+  };
   std::vector<hipEvent_t>& evs = ws.piece_events;
   while ((int)evs.size() < K + 1) { hipEvent_t e; HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); evs.push_back(e); }
   plan_t p;
@@ -979,7 +998,7 @@ int enqueue_host_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* src_
   for (int i = 0; i < K; i++) {
     const uint64_t lo = piece_lo(i), hi = piece_lo(i + 1), m = hi - lo;
     if (m == 0) continue;
-    make_plan(ctx, d, m, p, pf.c, 1, seg_all);
+    make_plan(ctx, d, m, p, pf.c, 1, seg_all, true);
     if (int rc = ensure_buffers(ctx, d, ws, m, p)) return rc;              // no reallocation: only the pointers into the zeroed block move
     msm_launch L{ctx, d, ws, p, dpts + lo * sz.point_in, dscs + lo * sz.scalar_in, m, ws.d_partials, 0, ws.stream, true, !first};
     L.host_rows = msm_launch::rows_to_host(ctx, d, p, true);
@@ -1002,19 +1021,46 @@ int enqueue_host_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* src_
     if (i == last_piece) { if (int rc = L.reduce()) return rc; }
     stamp("piece enqueued", i);
   }
-  ws.plan = p; ws.n = piece_lo(last_piece + 1) - piece_lo(last_piece); ws.used = true; ws.last_stream = ws.stream; ws.prof_level = 0; d.last_ws = (int)(&ws - d.ws);
+  ws.plan = p; ws.n = piece_lo(last_piece + 1) - piece_lo(last_piece); ws.used = true; ws.last_stream = ws.stream; ws.prof_level = 0;
+  __atomic_store_n(&d.last_ws, (int)(&ws - d.ws), __ATOMIC_RELAXED);      // (the device's host thread may be the writer: asynchronous submits)
   if (int rc = fetch_rows(ctx, ws, ws.stream)) return rc;
   HIP_TRY(ctx, hipGetLastError());
+  if (wait_for_pinned && (host_memory_is_pinned(src_points) || host_memory_is_pinned(src_scalars))) {
+    // everything on the copy stream is ordered: the last recorded upload event covers the scalars and every piece
+    HIP_TRY(ctx, hipEventSynchronize(evs[(size_t)last_piece]));
+    stamp("pinned source: uploads awaited", -1);
+  }
   return 0;
 }
 
-// te_msm_run for a large MSM on one device: enqueue_host_slice on work set 0, wait, host tail
+// the host thread of device i of the context (host_sched.hpp), created on first use
+te_sched::worker_t& worker_of(te_ctx* ctx, size_t i) {
+  if (ctx->workers.size() < ctx->devs.size()) ctx->workers.resize(ctx->devs.size());
+  if (!ctx->workers[i]) ctx->workers[i].reset(new te_sched::worker_t());
+  return *ctx->workers[i];
+}
+// every job posted to the context's host threads has run (asynchronous submits touch work sets, options and the error
+// string: calls that change or read those beside them wait first)
+void drain_workers(te_ctx* ctx) { for (auto& w : ctx->workers) if (w) w->drain(); }
+
+// the lowest-numbered work set of a device that no ticket owns (-1: none)
+int free_workset_index(const gpu_t& d) {
+  for (int i = 0; i < TE_MSM_WORKSETS; i++) if (!te_sched::slot_ticket(d.ws[i].slot)) return i;
+  return -1;
+}
+const char* const kAllSetsOwned = "every work set holds a submitted MSM that has not been collected: te_msm_collect one first";
+
+// the non-zero window digits the device counted for the MSM whose flag words are in the set's pinned block (word 1)
+void note_entries(te_ctx* ctx, const workset_t& ws) { ctx->stat_entries = (int64_t)ws.h_err[1]; }
+
+// te_msm_run for a large MSM on one device: enqueue_host_slice on a free work set, wait, host tail
 int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_scalars, uint64_t n, int K, uint8_t out[64]) {
   gpu_t& d = ctx->devs[0];
   workset_t& ws = d.ws[0];
-  plan_t pf; make_plan(ctx, d, n, pf);
+  plan_t pf; make_plan(ctx, d, n, pf, 0, 1, 0, true);
   if (int rc = enqueue_host_slice(ctx, d, ws, src_points, src_scalars, n, pf.c, K)) return rc;
   HIP_TRY(ctx, hipEventSynchronize(ws.ev_result));
+  note_entries(ctx, ws);
   if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, kFinalCarry);
   if (pf.curve == TE_MSM_CURVE_BLS12_377_G1) te377_host::horner_to_affine(ws.h_partials, pf.c, (int)pf.logB, pf.W, out);
   else te_host::horner_to_affine(ws.h_partials, pf.c, (int)pf.logB, pf.W, out);
@@ -1029,42 +1075,43 @@ int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_
 // the WINDOWS instead -- but on this boundary the cost is the link: 1.85 of 2.47 ms at n = 2^20 on one device.  The window size
 // follows the slice (all slices share it).  Reference: compute_msm uploads inside the call (cuzk/gpu.ts:33-46,
 // submission.ts:73-78); multi-device is its README's future work (README.md:551).
+// This is the form for the LONE call.  A caller with several MSMs to do keeps whole MSMs in flight instead, one per device
+// (te_msm_submit / te_msm_submit_async below): no replicated bucket reduction, no row merge.
 int run_host_sharded(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_scalars, uint64_t n, uint8_t* out) {
   const size_t nd = ctx->devs.size();
   uint64_t per_min = ctx->opt_host_shard_min > 0 ? (uint64_t)ctx->opt_host_shard_min : 1;
   size_t D = (size_t)std::min<uint64_t>(nd, std::max<uint64_t>(1, n / per_min));
   const uint64_t per = (n + D - 1) / D;
-  plan_t p0; make_plan(ctx, ctx->devs[0], per, p0);          // geometry of every slice's rows (window bits from the slice size)
+  plan_t p0; make_plan(ctx, ctx->devs[0], per, p0, 0, 1, 0, true);     // geometry of every slice's rows (window bits from the slice size)
   const curve_sizes sz = sizes_of(p0.curve);
   const int K = host_pieces(ctx, per);
-  while (ctx->workers.size() + 1 < D) {
-    ctx->workers.emplace_back(new worker_t());
-    worker_t* w = ctx->workers.back().get();
-    w->th = std::thread([w] { w->loop(); });
-  }
-  struct saved_t { int first, step; };
-  std::vector<saved_t> saved(nd);
-  for (size_t i = 0; i < nd; i++) { saved[i] = {ctx->devs[i].w_first, ctx->devs[i].w_step}; ctx->devs[i].w_first = 0; ctx->devs[i].w_step = 1; }
+  // a work set per device that no ticket owns (tickets and lone calls may be mixed)
+  std::vector<int> wsel(D, 0);
+  for (size_t i = 0; i < D; i++) { wsel[i] = free_workset_index(ctx->devs[i]); if (wsel[i] < 0) return set_err(ctx, TE_MSM_ESTATE, kAllSetsOwned); }
   auto slice = [&](size_t i) -> int {
     const uint64_t lo = std::min<uint64_t>(n, per * i), hi = std::min<uint64_t>(n, lo + per);
     gpu_t& d = ctx->devs[i];
     if (hi == lo) return 0;
-    if (int rc = enqueue_host_slice(ctx, d, d.ws[0], src_points + lo * sz.point_in, src_scalars + lo * sz.scalar_in, hi - lo, p0.c, K)) return rc;
-    HIP_TRY(ctx, hipEventSynchronize(d.ws[0].ev_result));
+    workset_t& ws = d.ws[wsel[i]];
+    if (int rc = enqueue_host_slice(ctx, d, ws, src_points + lo * sz.point_in, src_scalars + lo * sz.scalar_in, hi - lo, p0.c, K)) return rc;
+    HIP_TRY(ctx, hipEventSynchronize(ws.ev_result));
     return 0;
   };
-  for (size_t i = 1; i < D; i++) ctx->workers[i - 1]->start([&slice, i] { return slice(i); });
+  std::vector<te_sched::job_ref> jobs(D);
+  for (size_t i = 1; i < D; i++) jobs[i] = worker_of(ctx, i).post([&slice, i] { return slice(i); });
   int rc = slice(0);
-  for (size_t i = 1; i < D; i++) { const int r = ctx->workers[i - 1]->wait(); if (!rc) rc = r; }
-  for (size_t i = 0; i < nd; i++) { ctx->devs[i].w_first = saved[i].first; ctx->devs[i].w_step = saved[i].step; }
+  for (size_t i = 1; i < D; i++) { const int r = worker_of(ctx, i).wait(jobs[i]); if (!rc) rc = r; }
   if (rc) return rc;
   std::vector<const uint8_t*> sets;
+  int64_t entries = 0;
   for (size_t i = 0; i < D; i++) {
     if (per * i >= n) break;
-    workset_t& ws = ctx->devs[i].ws[0];
+    workset_t& ws = ctx->devs[i].ws[wsel[i]];
     if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, kFinalCarry);
+    entries += (int64_t)ws.h_err[1];
     sets.push_back(ws.h_partials);
   }
+  ctx->stat_entries = entries;
   const int ns = (int)sets.size();
   if (ns <= 2) {                                            // one or two sets: summed on the fly inside the fold
     if (p0.curve == TE_MSM_CURVE_BLS12_377_G1) te377_host::horner_to_affine_multi(sets.data(), ns, p0.c, (int)p0.logB, p0.W, out);
@@ -1073,7 +1120,7 @@ int run_host_sharded(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_
   }
   // more: the sets' rows are summed window by window by the devices' host threads (5 x (sets - 1) additions per window,
   // ~0.2 us each: summed on the fly by the one thread that folds, eight sets cost ~100 us of a 0.7 ms call), then one fold
-  // over the merged points
+  // over the merged points.  Thread t merges windows t, t + D, ...: distinct elements of merged[] and present[].
   const bool bls = p0.curve == TE_MSM_CURVE_BLS12_377_G1;
   std::vector<te_host::Pt> m9(bls ? 0 : (size_t)p0.W * 5);
   std::vector<te377_host::Pt> m14(bls ? (size_t)p0.W * 5 : 0);
@@ -1085,11 +1132,99 @@ int run_host_sharded(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_
     }
     return 0;
   };
-  for (size_t i = 1; i < D; i++) ctx->workers[i - 1]->start([&merge, i] { return merge(i); });
+  for (size_t i = 1; i < D; i++) jobs[i] = worker_of(ctx, i).post([&merge, i] { return merge(i); });
   (void)merge(0);
-  for (size_t i = 1; i < D; i++) (void)ctx->workers[i - 1]->wait();
+  for (size_t i = 1; i < D; i++) (void)worker_of(ctx, i).wait(jobs[i]);
   if (bls) te377_host::horner_to_affine_points(m14.data(), present.data(), p0.c, (int)p0.logB, p0.W, out);
   else te_host::horner_to_affine_points(m9.data(), present.data(), p0.c, (int)p0.logB, p0.W, out);
+  return 0;
+}
+
+// te_msm_run_device on a context of D > 1 devices: WINDOW shards (device i computes windows i, i + D, ...), inputs resident
+// on the first device.  Every device needs all n points and scalars; they travel as a scatter + all-gather over the
+// point-to-point xGMI links instead of D - 1 full copies out of the first device's memory (SURVEY.md 8e "Inputs"):
+//   phase 1  device i >= 1 pulls slice i (n / D points and their scalars) from the source           -- issued here, in turn: cheap,
+//            and the "slice i has arrived" events must exist before any other device waits for them
+//   phase 2  device i pulls slice 0 from the source and slice j from device j's staging area (j != i, j >= 1), behind the
+//            event of phase 1 -- D - 1 different links into every device, 2 (D - 1) / D of the input out of the first
+//            device instead of D - 1 times all of it
+// Phase 2, the ~30 launches of the device's share and its read-back are enqueued by the device's own host thread: D enqueue
+// sequences side by side instead of one after the other on the calling thread (0.35 ms of host time each).
+// (One physical GPU named several times -- the only form a one-GPU box can run -- makes every copy a device-to-device copy.)
+int run_device_window_shards(te_ctx* ctx, const void* src_points, const void* src_scalars, uint64_t n, uint8_t* out) {
+  const size_t nd = ctx->devs.size();
+  plan_t p0; make_plan(ctx, ctx->devs[0], n, p0);
+  const curve_sizes sz = sizes_of(p0.curve);
+  std::vector<int> wsel(nd, 0);
+  for (size_t i = 0; i < nd; i++) { wsel[i] = free_workset_index(ctx->devs[i]); if (wsel[i] < 0) return set_err(ctx, TE_MSM_ESTATE, kAllSetsOwned); }
+  const int src_dev = ctx->devs[0].device;
+  const uint64_t per = (n + nd - 1) / nd;
+  auto lo_of = [&](size_t j) { return std::min<uint64_t>(n, per * j); };
+  const uint8_t* sp = static_cast<const uint8_t*>(src_points); const uint8_t* ss = static_cast<const uint8_t*>(src_scalars);
+  // phase 1 (calling thread)
+  for (size_t i = 1; i < nd; i++) {
+    gpu_t& d = ctx->devs[i]; workset_t& ws = d.ws[wsel[i]];
+    HIP_TRY(ctx, hipSetDevice(d.device));
+    if (int rc = ensure_staging(ctx, ws, n * sz.point_in, n * sz.scalar_in)) return rc;
+    if (ws.used && ws.ev_done) HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ws.ev_done, 0));      // the staging area may still be read by the set's previous MSM
+    const uint64_t lo = lo_of(i), m = lo_of(i + 1) - lo;
+    if (m) {
+      HIP_TRY(ctx, hipMemcpyPeerAsync(static_cast<uint8_t*>(ws.d_in_points) + lo * sz.point_in, d.device, sp + lo * sz.point_in, src_dev, m * sz.point_in, ws.stream));
+      HIP_TRY(ctx, hipMemcpyPeerAsync(static_cast<uint8_t*>(ws.d_in_scalars) + lo * sz.scalar_in, d.device, ss + lo * sz.scalar_in, src_dev, m * sz.scalar_in, ws.stream));
+      ctx->stat_peer_copies += 2; ctx->stat_peer_bytes += (int64_t)(m * (sz.point_in + sz.scalar_in));
+    }
+    HIP_TRY(ctx, hipEventRecord(ws.ev_copy, ws.stream));
+  }
+  // phase 2 + the device's share, one host thread per device
+  std::vector<int64_t> copies(nd, 0), bytes(nd, 0);
+  auto share = [&](size_t i) -> int {
+    gpu_t& d = ctx->devs[i]; workset_t& ws = d.ws[wsel[i]];
+    HIP_TRY(ctx, hipSetDevice(d.device));
+    const void *dp = src_points, *ds = src_scalars;
+    if (i > 0) {
+      for (size_t j = 0; j < nd; j++) {
+        if (j == i) continue;
+        const uint64_t lo = lo_of(j), m = lo_of(j + 1) - lo;
+        if (!m) continue;
+        const gpu_t& o = ctx->devs[j]; const workset_t& ows = o.ws[wsel[j]];
+        const uint8_t* fp = j == 0 ? sp : static_cast<const uint8_t*>(ows.d_in_points);
+        const uint8_t* fs = j == 0 ? ss : static_cast<const uint8_t*>(ows.d_in_scalars);
+        if (j > 0) HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ows.ev_copy, 0));
+        HIP_TRY(ctx, hipMemcpyPeerAsync(static_cast<uint8_t*>(ws.d_in_points) + lo * sz.point_in, d.device, fp + lo * sz.point_in, o.device, m * sz.point_in, ws.stream));
+        HIP_TRY(ctx, hipMemcpyPeerAsync(static_cast<uint8_t*>(ws.d_in_scalars) + lo * sz.scalar_in, d.device, fs + lo * sz.scalar_in, o.device, m * sz.scalar_in, ws.stream));
+        copies[i] += 2; bytes[i] += (int64_t)(m * (sz.point_in + sz.scalar_in));
+      }
+      dp = ws.d_in_points; ds = ws.d_in_scalars;
+    }
+    if (int rc = enqueue_partial(ctx, d, ws, dp, ds, n, nullptr, ws.stream)) return rc;
+    return fetch_rows(ctx, ws, ws.stream);
+  };
+  std::vector<te_sched::job_ref> jobs(nd);
+  for (size_t i = 1; i < nd; i++) jobs[i] = worker_of(ctx, i).post([&share, i] { return share(i); });
+  int rc = share(0);
+  for (size_t i = 1; i < nd; i++) { const int r = worker_of(ctx, i).wait(jobs[i]); if (!rc) rc = r; }
+  // a device whose staging area other devices read must not reuse it before they are done: every set's next MSM waits for
+  // its own ev_done only, so the call ends with all of them complete (below) -- the copies are over by then
+  for (size_t i = 0; i < nd; i++) { ctx->stat_peer_copies += copies[i]; ctx->stat_peer_bytes += bytes[i]; }
+  std::vector<uint8_t> merged((size_t)p0.W * sz.row, 0);
+  int64_t entries = 0; bool carry = false;
+  for (size_t i = 0; i < nd; i++) {
+    gpu_t& d = ctx->devs[i];
+    workset_t& ws = d.ws[wsel[i]];
+    if (rc) { (void)hipSetDevice(d.device); (void)hipStreamSynchronize(ws.stream); continue; }      // leave nothing of a failed call in flight
+    HIP_TRY(ctx, hipSetDevice(d.device));
+    HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));
+    carry = carry || *ws.h_err != 0;
+    entries += (int64_t)ws.h_err[1];
+    for (int w = d.w_first; w < p0.W; w += d.w_step)
+      memcpy(&merged[(size_t)w * sz.row], ws.h_partials + (size_t)w * sz.row, sz.row);
+  }
+  if (rc) return rc;
+  ctx->stat_entries = entries;
+  if (carry) return set_err(ctx, TE_MSM_ESCALAR, kFinalCarry);
+  (void)collect_stage_ms(ctx, ctx->devs[0], ctx->devs[0].ws[wsel[0]]);
+  if (p0.curve == TE_MSM_CURVE_BLS12_377_G1) te377_host::horner_to_affine(merged.data(), p0.c, (int)p0.logB, p0.W, out);
+  else te_host::horner_to_affine(merged.data(), p0.c, (int)p0.logB, p0.W, out);
   return 0;
 }
 
@@ -1103,65 +1238,50 @@ int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, boo
   }
   if (!src_points || !src_scalars) return set_err(ctx, TE_MSM_EINVAL, "null input buffer");
   const size_t nd = ctx->devs.size();
-  // host buffers on several devices: slices of the points, one upload thread per device (device-resident inputs: window shards, below)
-  if (src_is_host && nd > 1) return run_host_sharded(ctx, static_cast<const uint8_t*>(src_points), static_cast<const uint8_t*>(src_scalars), n, out);
-  if (src_is_host && nd == 1 && !ctx->opt_profile && ctx->opt_workset == 0 &&
-      ctx->devs[0].w_step == 1 && ctx->devs[0].in_flight == 0) {
+  // several devices: host buffers -> slices of the points, one upload thread per device; device-resident inputs -> window shards
+  if (nd > 1) {
+    if (src_is_host) return run_host_sharded(ctx, static_cast<const uint8_t*>(src_points), static_cast<const uint8_t*>(src_scalars), n, out);
+    return run_device_window_shards(ctx, src_points, src_scalars, n, out);
+  }
+  gpu_t& d = ctx->devs[0];
+  if (src_is_host && !ctx->opt_profile && ctx->opt_workset == 0 && d.w_step == 1 && d.in_flight == 0) {
     // no tickets in flight, no stage timing requested: every work set is free for the pieces
     const int K = host_pieces(ctx, n);
     if (K > 1) return run_host_chunked(ctx, static_cast<const uint8_t*>(src_points), static_cast<const uint8_t*>(src_scalars), n, K, out);
   }
-  // the work set this call runs on: the selected one, unless a submitted MSM still owns it (tickets exist on
-  // single-device contexts only) -- then any free one; with every set owned by a ticket the call is refused
+  // the work set this call runs on: the selected one, unless a submitted MSM still owns it -- then any free one; with every
+  // set owned by a ticket the call is refused
   int wsel = ctx->opt_workset;
-  if (ctx->devs[0].ws[wsel].pending_ticket) {
-    wsel = -1;
-    for (int i = 0; i < TE_MSM_WORKSETS && wsel < 0; i++) if (!ctx->devs[0].ws[i].pending_ticket) wsel = i;
-    if (wsel < 0) return set_err(ctx, TE_MSM_ESTATE, "every work set holds a submitted MSM that has not been collected: te_msm_collect one first");
+  if (te_sched::slot_ticket(d.ws[wsel].slot)) {
+    wsel = free_workset_index(d);
+    if (wsel < 0) return set_err(ctx, TE_MSM_ESTATE, kAllSetsOwned);
   }
-  plan_t p0; make_plan(ctx, ctx->devs[0], n, p0);
+  plan_t p0; make_plan(ctx, d, n, p0);
   const curve_sizes sz = sizes_of(p0.curve);
-  // stage inputs on every device
-  for (size_t i = 0; i < nd; i++) {
-    gpu_t& d = ctx->devs[i];
-    workset_t& ws = d.ws[wsel];
-    HIP_TRY(ctx, hipSetDevice(d.device));
-    const void *dp = src_points, *ds = src_scalars;
-    if (src_is_host || i > 0) {
-      if (int rc = ensure_staging(ctx, ws, n * sz.point_in, n * sz.scalar_in)) return rc;
-      if (src_is_host) {
-        // scalars first; the points follow from inside enqueue_partial (pageable copies return when the data has left
-        // the caller's buffer, so the scalar-only stages enqueued in between run while the points are still in flight)
-        HIP_TRY(ctx, hipMemcpyAsync(ws.d_in_scalars, src_scalars, n * sz.scalar_in, hipMemcpyHostToDevice, ws.stream));
-      } else {
-        // inputs live on device 0's memory: wait for nothing (caller's data is ready), copy peer-to-peer
-        HIP_TRY(ctx, hipMemcpyPeerAsync(ws.d_in_points, d.device, src_points, ctx->devs[0].device, n * sz.point_in, ws.stream));
-        HIP_TRY(ctx, hipMemcpyPeerAsync(ws.d_in_scalars, d.device, src_scalars, ctx->devs[0].device, n * sz.scalar_in, ws.stream));
-        ctx->stat_peer_copies += 2;
-      }
-      dp = ws.d_in_points; ds = ws.d_in_scalars;
-    }
-    const std::function<int(hipStream_t)> upload_points = [&](hipStream_t side) -> int {
-      // on the side stream, beside the scalar-only kernels on ws.stream; the conversion to records follows it there
-      HIP_TRY(ctx, hipMemcpyAsync(ws.d_in_points, src_points, n * sz.point_in, hipMemcpyHostToDevice, side));
-      return 0;
-    };
-    if (int rc = enqueue_partial(ctx, d, ws, dp, ds, n, nullptr, ws.stream, src_is_host ? &upload_points : nullptr)) return rc;
-    if (int rc = fetch_rows(ctx, ws, ws.stream)) return rc;
+  workset_t& ws = d.ws[wsel];
+  HIP_TRY(ctx, hipSetDevice(d.device));
+  const void *dp = src_points, *ds = src_scalars;
+  if (src_is_host) {
+    if (int rc = ensure_staging(ctx, ws, n * sz.point_in, n * sz.scalar_in)) return rc;
+    // scalars first; the points follow from inside enqueue_partial (pageable copies return when the data has left
+    // the caller's buffer, so the scalar-only stages enqueued in between run while the points are still in flight)
+    HIP_TRY(ctx, hipMemcpyAsync(ws.d_in_scalars, src_scalars, n * sz.scalar_in, hipMemcpyHostToDevice, ws.stream));
+    dp = ws.d_in_points; ds = ws.d_in_scalars;
   }
-  std::vector<uint8_t> merged((size_t)p0.W * sz.row, 0);
-  for (size_t i = 0; i < nd; i++) {
-    gpu_t& d = ctx->devs[i];
-    workset_t& ws = d.ws[wsel];
-    HIP_TRY(ctx, hipSetDevice(d.device));
-    HIP_TRY(ctx, hipEventSynchronize(ws.ev_result));
-    if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, kFinalCarry);
-    for (int w = d.w_first; w < p0.W; w += d.w_step)
-      memcpy(&merged[(size_t)w * sz.row], ws.h_partials + (size_t)w * sz.row, sz.row);
-  }
-  (void)collect_stage_ms(ctx, ctx->devs[0].ws[wsel]);
-  if (p0.curve == TE_MSM_CURVE_BLS12_377_G1) te377_host::horner_to_affine(merged.data(), p0.c, (int)p0.logB, p0.W, out);
-  else te_host::horner_to_affine(merged.data(), p0.c, (int)p0.logB, p0.W, out);
+  const std::function<int(hipStream_t)> upload_points = [&](hipStream_t side) -> int {
+    // on the side stream, beside the scalar-only kernels on ws.stream; the conversion to records follows it there
+    HIP_TRY(ctx, hipMemcpyAsync(ws.d_in_points, src_points, n * sz.point_in, hipMemcpyHostToDevice, side));
+    return 0;
+  };
+  if (int rc = enqueue_partial(ctx, d, ws, dp, ds, n, nullptr, ws.stream, src_is_host ? &upload_points : nullptr)) return rc;
+  if (int rc = fetch_rows(ctx, ws, ws.stream)) return rc;
+  HIP_TRY(ctx, hipEventSynchronize(ws.ev_result));          // (pinned sources included: the call ends after its uploads)
+  note_entries(ctx, ws);
+  if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, kFinalCarry);
+  (void)collect_stage_ms(ctx, d, ws);
+  // a window-sharded single-device context (te_msm_set_window_shard) folds its own rows only: the others read as zero
+  if (p0.curve == TE_MSM_CURVE_BLS12_377_G1) te377_host::horner_to_affine(ws.h_partials, p0.c, (int)p0.logB, p0.W, out);
+  else te_host::horner_to_affine(ws.h_partials, p0.c, (int)p0.logB, p0.W, out);
   return 0;
 }
 
@@ -1249,79 +1369,177 @@ int te_msm_run_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_sca
 }
 
 namespace {
-// the lowest-numbered free work set (each has its own stream: the MSMs overlap on the device).  Not ticket % sets: with
-// fewer MSMs in flight than sets only as many sets as needed are ever touched -- no buffer allocation in the middle
+// Tickets.  A ticket is a whole MSM in flight on ONE work set of ONE device of the context; its number is context-wide.
+//   single-device context   the MSMs overlap on the device (own stream and buffers per work set)
+//   D devices               a ticket goes to the device with the fewest in flight (ties: the device that holds the inputs, then
+//                           round-robin): one whole MSM per device -- D PCIe links for host buffers, no replicated bucket
+//                           reduction, no row merge -- the throughput form for a prover with several MSMs to do
+//                           (ui/Benchmark.tsx:32 awaits an async call; nothing stops a caller from having several in flight;
+//                           multi-device is the reference README's future work, README.md:551).  te_msm_run* stay the forms
+//                           for the lone call (point slices / window shards over all devices).
+
+// the lowest-numbered free work set of the device (each has its own stream: the MSMs overlap on the device).  Not ticket % sets:
+// with fewer MSMs in flight than sets only as many sets as needed are ever touched -- no buffer allocation in the middle
 // of a run, and a smaller footprint in the Infinity Cache.
-int take_free_workset(te_ctx* ctx, gpu_t& d) {
+// probe: the lazy hardware-queue measurement (16 ms, once per device) -- device-resident tickets only: a host-buffer ticket is bound
+// by its upload, not by how the work sets' streams share the hardware queues
+int take_free_workset(te_ctx* ctx, gpu_t& d, bool probe) {
   if (d.in_flight >= TE_MSM_WORKSETS) return set_err(ctx, TE_MSM_ESTATE, "every work set has an MSM in flight: collect one first");
-  if (!d.queues_probed && ctx->opt_queue_probe) spread_streams_over_queues(d);      // once per context, with nothing of it in flight
+  if (probe && !d.queues_probed && ctx->opt_queue_probe && d.in_flight == 0) spread_streams_over_queues(d);      // once per device, with nothing of it in flight
   d.streams_final = true;
-  int wi = 0;
-  while (wi < TE_MSM_WORKSETS && d.ws[wi].pending_ticket) wi++;
-  if (wi == TE_MSM_WORKSETS) return set_err(ctx, TE_MSM_ESTATE, "every work set has an MSM in flight: collect one first");
+  const int wi = free_workset_index(d);
+  if (wi < 0) return set_err(ctx, TE_MSM_ESTATE, "every work set has an MSM in flight: collect one first");
   return wi;
 }
-void hand_out_ticket(gpu_t& d, workset_t& ws, uint64_t* ticket) {
-  *ticket = d.next_ticket++;
-  __atomic_store_n(&ws.pending_ticket, *ticket, __ATOMIC_RELEASE); d.in_flight++;      // te_msm_ticket_wait reads it from other threads
+// the device the next ticket goes to (index into ctx->devs); prefer: the device that holds the inputs, or -1
+int pick_device(te_ctx* ctx, int prefer) {
+  const int nd = (int)ctx->devs.size();
+  if (nd == 1) return ctx->devs[0].in_flight < TE_MSM_WORKSETS ? 0 : -1;
+  int fl[64];
+  for (int i = 0; i < nd; i++) fl[i] = ctx->devs[i].in_flight;
+  return te_sched::pick_device(fl, nd, TE_MSM_WORKSETS, prefer, ctx->last_dev);
 }
-workset_t* workset_of_ticket(gpu_t& d, uint64_t ticket) {
+void hand_out_ticket(te_ctx* ctx, int di, workset_t& ws, uint64_t* ticket, te_sched::job_ref job = nullptr) {
+  *ticket = ctx->next_ticket++;
+  ws.slot.job = std::move(job);
+  te_sched::slot_publish(ws.slot, *ticket);          // te_msm_ticket_wait looks it up from other threads
+  ctx->devs[(size_t)di].in_flight++; ctx->last_dev = di;
+}
+workset_t* workset_of_ticket(te_ctx* ctx, uint64_t ticket, gpu_t** dev = nullptr) {
   if (!ticket) return nullptr;
-  for (workset_t& ws : d.ws) if (__atomic_load_n(&ws.pending_ticket, __ATOMIC_ACQUIRE) == ticket) return &ws;
+  for (gpu_t& d : ctx->devs)
+    for (workset_t& ws : d.ws) if (te_sched::slot_ticket(ws.slot) == ticket) { if (dev) *dev = &d; return &ws; }
   return nullptr;
 }
+// index into ctx->devs of the device whose memory holds p (device-resident inputs of a ticket), -1 if none of the context's
+int device_index_of_pointer(te_ctx* ctx, const void* p) {
+  hipPointerAttribute_t at; memset(&at, 0, sizeof at);
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  if (at.type != hipMemoryTypeDevice) return -1;
+  for (size_t i = 0; i < ctx->devs.size(); i++) if (ctx->devs[i].device == at.device) return (int)i;
+  return -1;
+}
+const char* const kNoTicket = "no such ticket in flight (already collected, or never handed out)";
 }  // namespace
 
 int te_msm_submit_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_scalars_le, uint64_t n, uint64_t* ticket) {
   if (!ctx || !ticket) return TE_MSM_EINVAL;
-  if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_submit_device needs a single-device context");
   if (!d_points_xy_le || !d_scalars_le || n == 0 || n >= (1ull << 31)) return set_err(ctx, TE_MSM_EINVAL, "bad arguments");
-  gpu_t& d = ctx->devs[0];
+  const bool multi = ctx->devs.size() > 1;
+  // several devices: the inputs may live on any of them; the ticket goes to the least loaded one and pulls them over xGMI
+  const int owner = multi ? device_index_of_pointer(ctx, d_points_xy_le) : 0;
+  if (multi && (owner < 0 || device_index_of_pointer(ctx, d_scalars_le) != owner))
+    return set_err(ctx, TE_MSM_EINVAL, "te_msm_submit_device: points and scalars must be resident on one device of the context");
+  const int di = pick_device(ctx, owner);
+  if (di < 0) return set_err(ctx, TE_MSM_ESTATE, "every work set has an MSM in flight: collect one first");
+  gpu_t& d = ctx->devs[(size_t)di];
   HIP_TRY(ctx, hipSetDevice(d.device));
-  const int wi = take_free_workset(ctx, d);
+  const int wi = take_free_workset(ctx, d, true);
   if (wi < 0) return wi;
   workset_t& ws = d.ws[wi];
-  if (int rc = enqueue_partial(ctx, d, ws, d_points_xy_le, d_scalars_le, n, nullptr, ws.stream)) return rc;
+  const void *dp = d_points_xy_le, *ds = d_scalars_le;
+  if (multi && (d.device != ctx->devs[(size_t)owner].device || ctx->opt_stage_device_inputs)) {
+    const curve_sizes sz = sizes_of(ctx->opt_curve);
+    if (int rc = ensure_staging(ctx, ws, n * sz.point_in, n * sz.scalar_in)) return rc;
+    if (ws.used) HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ws.ev_done, 0));
+    const int src_dev = ctx->devs[(size_t)owner].device;
+    HIP_TRY(ctx, hipMemcpyPeerAsync(ws.d_in_scalars, d.device, d_scalars_le, src_dev, n * sz.scalar_in, ws.stream));
+    HIP_TRY(ctx, hipMemcpyPeerAsync(ws.d_in_points, d.device, d_points_xy_le, src_dev, n * sz.point_in, ws.stream));
+    ctx->stat_peer_copies += 2; ctx->stat_peer_bytes += (int64_t)(n * (sz.point_in + sz.scalar_in));
+    dp = ws.d_in_points; ds = ws.d_in_scalars;
+  }
+  // a single-device context keeps its window shard (te_msm_set_window_shard); on several devices a ticket is a whole MSM
+  if (int rc = enqueue_partial(ctx, d, ws, dp, ds, n, nullptr, ws.stream, nullptr, 0, false, 1, multi)) return rc;
   if (int rc = fetch_rows(ctx, ws, ws.stream)) return rc;
-  hand_out_ticket(d, ws, ticket);
+  hand_out_ticket(ctx, di, ws, ticket);
   return 0;
 }
 
-int te_msm_submit(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars_le, uint64_t n, uint64_t* ticket) {
+namespace {
+int submit_host(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars_le, uint64_t n, uint64_t* ticket, bool async) {
   if (!ctx || !ticket) return TE_MSM_EINVAL;
-  if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_submit needs a single-device context");
   if (!points_xy_le || !scalars_le || n == 0 || n >= (1ull << 31)) return set_err(ctx, TE_MSM_EINVAL, "bad arguments");
-  gpu_t& d = ctx->devs[0];
-  if (d.w_step != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_submit computes whole MSMs: reset the window shard first");
+  if (ctx->devs.size() == 1 && ctx->devs[0].w_step != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_submit computes whole MSMs: reset the window shard first");
+  const int di = pick_device(ctx, -1);
+  if (di < 0) return set_err(ctx, TE_MSM_ESTATE, "every work set has an MSM in flight: collect one first");
+  gpu_t& d = ctx->devs[(size_t)di];
   HIP_TRY(ctx, hipSetDevice(d.device));
-  const int wi = take_free_workset(ctx, d);
+  const int wi = take_free_workset(ctx, d, false);
   if (wi < 0) return wi;
   workset_t& ws = d.ws[wi];
-  plan_t pf; make_plan(ctx, d, n, pf);
-  if (int rc = enqueue_host_slice(ctx, d, ws, points_xy_le, scalars_le, n, pf.c, host_pieces(ctx, n))) return rc;
-  hand_out_ticket(d, ws, ticket);
+  plan_t pf; make_plan(ctx, d, n, pf, 0, 1, 0, true);
+  const int c = pf.c, K = host_pieces(ctx, n);
+  if (!async) {
+    if (int rc = enqueue_host_slice(ctx, d, ws, points_xy_le, scalars_le, n, c, K, true)) return rc;
+    hand_out_ticket(ctx, di, ws, ticket);
+    return 0;
+  }
+  // the upload and the enqueue run on the device's host thread: this call returns at once, D of them keep D links busy.
+  // The job reads the context's options as they are NOW only by accident of timing -- so te_msm_set_option waits for the host
+  // threads first (drain_workers); the plan's window bits and pieces are fixed here.
+  ws.job_err.clear();
+  workset_t* wsp = &ws; gpu_t* dp = &d;
+  te_sched::job_ref job = worker_of(ctx, (size_t)di).post([ctx, dp, wsp, points_xy_le, scalars_le, n, c, K]() -> int {
+    const int rc = enqueue_host_slice(ctx, *dp, *wsp, points_xy_le, scalars_le, n, c, K, false);
+    if (rc) { std::lock_guard<std::mutex> lk(ctx->err_mu); wsp->job_err = ctx->err; }
+    return rc;
+  });
+  hand_out_ticket(ctx, di, ws, ticket, std::move(job));
   return 0;
+}
+// the enqueue of an asynchronous ticket has run (any thread); its status
+int await_job(te_ctx* ctx, gpu_t& d, workset_t& ws) {
+  const te_sched::job_ref job = ws.slot.job;
+  if (!job) return 0;
+  return ctx->workers[(size_t)(&d - ctx->devs.data())]->wait(job);
+}
+}  // namespace
+
+int te_msm_submit(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars_le, uint64_t n, uint64_t* ticket) {
+  return submit_host(ctx, points_xy_le, scalars_le, n, ticket, false);
+}
+
+int te_msm_submit_async(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars_le, uint64_t n, uint64_t* ticket) {
+  return submit_host(ctx, points_xy_le, scalars_le, n, ticket, true);
 }
 
 int te_msm_ticket_wait(te_ctx* ctx, uint64_t ticket) {
   if (!ctx) return TE_MSM_EINVAL;
-  if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "tickets exist on single-device contexts");
-  workset_t* ws = workset_of_ticket(ctx->devs[0], ticket);
-  if (!ws) return set_err(ctx, TE_MSM_ESTATE, "no such ticket in flight");
+  gpu_t* d = nullptr;
+  workset_t* ws = workset_of_ticket(ctx, ticket, &d);
+  if (!ws) return set_err(ctx, TE_MSM_ESTATE, kNoTicket);
+  if (const int rc = await_job(ctx, *d, *ws)) return rc;      // te_msm_collect reports it (and frees the ticket)
   HIP_TRY(ctx, hipEventSynchronize(ws->ev_result));
+  return 0;
+}
+
+int te_msm_ticket_device(te_ctx* ctx, uint64_t ticket, int* device_index, int* device_id) {
+  if (!ctx) return TE_MSM_EINVAL;
+  gpu_t* d = nullptr;
+  if (!workset_of_ticket(ctx, ticket, &d)) return set_err(ctx, TE_MSM_ESTATE, kNoTicket);
+  if (device_index) *device_index = (int)(d - ctx->devs.data());
+  if (device_id) *device_id = d->device;
   return 0;
 }
 
 int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]) {
   if (!ctx || !out_xy_le) return TE_MSM_EINVAL;
-  if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_collect needs a single-device context");
-  gpu_t& d = ctx->devs[0];
-  workset_t* wsp = workset_of_ticket(d, ticket);
-  if (!wsp) return set_err(ctx, TE_MSM_ESTATE, "no such ticket in flight (already collected, or never handed out)");
-  workset_t& ws = *wsp;
+  gpu_t* dp = nullptr;
+  workset_t* wsp = workset_of_ticket(ctx, ticket, &dp);
+  if (!wsp) return set_err(ctx, TE_MSM_ESTATE, kNoTicket);
+  workset_t& ws = *wsp; gpu_t& d = *dp;
+  if (const int jrc = await_job(ctx, d, ws)) {
+    // the upload / enqueue failed on the device's host thread: the ticket is over, the set must not keep half an MSM
+    (void)hipSetDevice(d.device);
+    (void)hipStreamSynchronize(ws.stream); if (ws.copy_stream) (void)hipStreamSynchronize(ws.copy_stream);
+    ws.zero_clean_words = 0;
+    d.in_flight--; te_sched::slot_release(ws.slot);
+    return set_err(ctx, jrc, ws.job_err.empty() ? "the asynchronous submit failed" : ws.job_err.c_str());
+  }
   HIP_TRY(ctx, hipEventSynchronize(ws.ev_result));   // on failure the ticket stays collectable
-  (void)collect_stage_ms(ctx, ws);
-  d.in_flight--; __atomic_store_n(&ws.pending_ticket, (uint64_t)0, __ATOMIC_RELEASE);   // the MSM is over, with a result or with a scalar-range error
+  (void)collect_stage_ms(ctx, d, ws);
+  note_entries(ctx, ws);
+  d.in_flight--; te_sched::slot_release(ws.slot);    // the MSM is over, with a result or with a scalar-range error
   if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, kFinalCarry);
   if (ws.plan.curve == TE_MSM_CURVE_BLS12_377_G1) te377_host::horner_to_affine(ws.h_partials, ws.plan.c, (int)ws.plan.logB, ws.plan.W, out_xy_le);
   else te_host::horner_to_affine(ws.h_partials, ws.plan.c, (int)ws.plan.logB, ws.plan.W, out_xy_le);
@@ -1330,6 +1548,7 @@ int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]) {
 
 int te_msm_probe_queues(te_ctx* ctx) {
   if (!ctx) return TE_MSM_EINVAL;
+  drain_workers(ctx);
   int classes = 0;
   for (gpu_t& d : ctx->devs) {
     if (d.in_flight) return set_err(ctx, TE_MSM_ESTATE, "te_msm_probe_queues: collect the MSMs in flight first");
@@ -1344,12 +1563,13 @@ int te_msm_probe_queues(te_ctx* ctx) {
 
 int te_msm_trim(te_ctx* ctx, int keep_worksets) {
   if (!ctx || keep_worksets < 0) return TE_MSM_EINVAL;
+  drain_workers(ctx);
   int freed = 0;
   for (gpu_t& d : ctx->devs) {
     HIP_TRY(ctx, hipSetDevice(d.device));
     for (int i = keep_worksets; i < TE_MSM_WORKSETS; i++) {
       workset_t& ws = d.ws[i];
-      if (ws.pending_ticket || !(ws.d_recs || ws.d_in_points || ws.d_zero)) continue;       // owned by a ticket, or nothing to free
+      if (te_sched::slot_ticket(ws.slot) || !(ws.d_recs || ws.d_in_points || ws.d_zero)) continue;       // owned by a ticket, or nothing to free
       if (ws.used) HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));
       if (ws.copy_stream) HIP_TRY(ctx, hipStreamSynchronize(ws.copy_stream));
       free_workset_buffers(ws);
@@ -1361,6 +1581,7 @@ int te_msm_trim(te_ctx* ctx, int keep_worksets) {
 
 int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   if (!ctx || !key) return TE_MSM_EINVAL;
+  drain_workers(ctx);               // asynchronous submits read the options on the devices' host threads
   if (!strcmp(key, "window_bits")) { if (value != 0 && (value < 4 || value > 16)) return set_err(ctx, TE_MSM_EINVAL, "window_bits must be 0 or in [4,16]"); ctx->opt_window_bits = (int)value; return 0; }
   if (!strcmp(key, "sort_buckets")) { ctx->opt_sort = value ? 1 : 0; return 0; }
   if (!strcmp(key, "signed_digits")) { ctx->opt_signed = value ? 1 : 0; return 0; }
@@ -1379,6 +1600,7 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   if (!strcmp(key, "queue_probe")) { ctx->opt_queue_probe = value ? 1 : 0; return 0; }
   if (!strcmp(key, "packed_sort")) { ctx->opt_packed = value ? 1 : 0; return 0; }
   if (!strcmp(key, "fold_pairs")) { ctx->opt_fold_pairs = value ? 1 : 0; return 0; }
+  if (!strcmp(key, "stage_device_inputs")) { ctx->opt_stage_device_inputs = value ? 1 : 0; return 0; }
   return set_err(ctx, TE_MSM_EINVAL, "unknown option");
 }
 
@@ -1391,8 +1613,11 @@ int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value) {
   if (!strcmp(key, "profile")) { *value = ctx->opt_profile; return 0; }
   if (!strcmp(key, "num_devices")) { *value = (int64_t)ctx->devs.size(); return 0; }
   if (!strcmp(key, "peer_copies")) { *value = ctx->stat_peer_copies; return 0; }
+  if (!strcmp(key, "peer_bytes")) { *value = ctx->stat_peer_bytes; return 0; }
+  if (!strcmp(key, "entries_accumulated")) { *value = ctx->stat_entries; return 0; }
+  if (!strcmp(key, "stage_device_inputs")) { *value = ctx->opt_stage_device_inputs; return 0; }
   if (!strcmp(key, "segment_len")) { *value = ctx->opt_seg_len; return 0; }
-  if (!strcmp(key, "segment_len_used")) { const gpu_t& d0 = ctx->devs[0]; *value = d0.ws[d0.last_ws].used ? (int64_t)d0.ws[d0.last_ws].plan.seg_len : 0; return 0; }
+  if (!strcmp(key, "segment_len_used")) { drain_workers(ctx); const gpu_t& d0 = ctx->devs[0]; *value = d0.ws[d0.last_ws].used ? (int64_t)d0.ws[d0.last_ws].plan.seg_len : 0; return 0; }
   if (!strcmp(key, "workset")) { *value = ctx->opt_workset; return 0; }
   if (!strcmp(key, "graph")) { *value = ctx->opt_graph; return 0; }
   if (!strcmp(key, "prezero")) { *value = ctx->opt_prezero; return 0; }
@@ -1403,8 +1628,8 @@ int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value) {
   if (!strcmp(key, "packed_sort")) { *value = ctx->opt_packed; return 0; }
   if (!strcmp(key, "fold_pairs")) { *value = ctx->opt_fold_pairs; return 0; }
   if (!strcmp(key, "streams_final")) { *value = ctx->devs[0].streams_final ? 1 : 0; return 0; }
-  if (!strcmp(key, "in_flight")) { *value = ctx->devs[0].in_flight; return 0; }
-  if (!strcmp(key, "device_bytes")) {      // device memory this context holds in work-set buffers (te_msm_trim gives it back)
+  if (!strcmp(key, "in_flight")) { int64_t t = 0; for (const gpu_t& d : ctx->devs) t += d.in_flight; *value = t; return 0; }
+  if (!strcmp(key, "device_bytes")) {      drain_workers(ctx);      // device memory this context holds in work-set buffers (te_msm_trim gives it back)
     int64_t tot = 0;
     for (const gpu_t& d : ctx->devs) for (const workset_t& ws : d.ws) { for (size_t cb : ws.cap) tot += (int64_t)cb; tot += (int64_t)(ws.cap_in_points + ws.cap_in_scalars); }
     *value = tot; return 0;
@@ -1434,7 +1659,7 @@ int te_msm_partial_device(te_ctx* ctx, const void* d_points_xy_le, const void* d
   if (!d_points_xy_le || !d_scalars_le || !d_partials || n == 0 || n >= (1ull << 31)) return set_err(ctx, TE_MSM_EINVAL, "bad arguments");
   gpu_t& d = ctx->devs[0];
   workset_t& ws = d.ws[ctx->opt_workset];
-  if (ws.pending_ticket) return set_err(ctx, TE_MSM_ESTATE, "the selected work set holds a submitted MSM that has not been collected");
+  if (te_sched::slot_ticket(ws.slot)) return set_err(ctx, TE_MSM_ESTATE, "the selected work set holds a submitted MSM that has not been collected");
   HIP_TRY(ctx, hipSetDevice(d.device));
   return enqueue_partial(ctx, d, ws, d_points_xy_le, d_scalars_le, n, d_partials, stream == TE_MSM_OWN_STREAM ? ws.stream : (hipStream_t)stream);
 }
@@ -1448,7 +1673,7 @@ int te_msm_partial_device_batch(te_ctx* ctx, const void* const* d_points_xy_le, 
   for (int m = 0; m < count; m++) if (!d_points_xy_le[m] || !d_scalars_le[m]) return set_err(ctx, TE_MSM_EINVAL, "bad arguments");
   gpu_t& d = ctx->devs[0];
   workset_t& ws = d.ws[ctx->opt_workset];
-  if (ws.pending_ticket) return set_err(ctx, TE_MSM_ESTATE, "the selected work set holds a submitted MSM that has not been collected");
+  if (te_sched::slot_ticket(ws.slot)) return set_err(ctx, TE_MSM_ESTATE, "the selected work set holds a submitted MSM that has not been collected");
   HIP_TRY(ctx, hipSetDevice(d.device));
   hipStream_t st = stream == TE_MSM_OWN_STREAM ? ws.stream : (hipStream_t)stream;
   if (count == 1) return enqueue_partial(ctx, d, ws, d_points_xy_le[0], d_scalars_le[0], n, d_partials, st);
@@ -1468,10 +1693,12 @@ int te_msm_workset_stream(te_ctx* ctx, int workset, void** stream, int* hw_queue
 int te_msm_partial_wait(te_ctx* ctx, int workset) {
   if (!ctx || workset < 0 || workset >= TE_MSM_WORKSETS) return TE_MSM_EINVAL;
   if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_partial_wait needs a single-device context");
+  drain_workers(ctx);
   workset_t& ws = ctx->devs[0].ws[workset];
   if (!ws.used) return 0;
   HIP_TRY(ctx, hipEventSynchronize(ws.ev_result));
-  (void)collect_stage_ms(ctx, ws);                   // stage times of that launch sequence, when it was profiled (te_msm_stage_ms)
+  (void)collect_stage_ms(ctx, ctx->devs[0], ws);     // stage times of that launch sequence, when it was profiled (te_msm_stage_ms)
+  note_entries(ctx, ws);
   if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
   return 0;
 }
@@ -1484,7 +1711,8 @@ int te_msm_finalize(te_ctx* ctx, const uint8_t* partials, int window_bits, int n
   if (ws.used) {
     HIP_TRY(ctx, hipEventSynchronize(ws.ev_result));
     if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, "final carry is 1: a scalar does not fit the signed window decomposition");
-    (void)collect_stage_ms(ctx, ws);
+    (void)collect_stage_ms(ctx, d, ws);
+    note_entries(ctx, ws);
     // the rows were produced under ws.plan: its digit form decides, not an option changed since
     if (window_bits != ws.plan.c || num_windows != ws.plan.W)
       return set_err(ctx, TE_MSM_ESTATE, "te_msm_finalize: window_bits / num_windows differ from the plan of the last te_msm_partial_device call (use te_msm_finalize_host_ex for rows produced elsewhere)");
@@ -1605,6 +1833,7 @@ int te_msm_synth_inputs_bls12_377(uint64_t seed, uint64_t n, uint8_t* points_xy_
 
 int64_t te_msm_debug_read(te_ctx* ctx, const char* stage, void* dst, uint64_t cap) {
   if (!ctx || !stage || !dst) return TE_MSM_EINVAL;
+  drain_workers(ctx);
   gpu_t& d = ctx->devs[0];
   workset_t& ws = d.ws[d.last_ws];
   if (!ws.used) return set_err(ctx, TE_MSM_ESTATE, "no run yet");

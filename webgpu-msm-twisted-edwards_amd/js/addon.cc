@@ -7,14 +7,17 @@
 // JS event loop is not blocked -- the reference's call is async for the same reason (ui/Benchmark.tsx:32).
 // Errors reject the promise, as the reference's `throw`s do (implementation/cuzk/gpu.ts:19-22).
 //
-// Devices: TE_MSM_DEVICES="0,1,2,3" (or setDevices([0,1,2,3])) shards every call over several GPUs of the node --
-// te_msm_run on an n_dev > 1 context: point slices, one upload thread and PCIe link per device (include/te_msm.h).
-// Default: device 0.
-// Concurrency: promises in flight at the same time (a prover that does not await each call) are mapped onto the
-// engine's work sets -- te_msm_submit under the lock, te_msm_ticket_wait outside it, te_msm_collect under it again --
-// so the upload of one MSM overlaps the device work of the previous ones; as many as libuv has pool threads (4 unless
-// UV_THREADPOOL_SIZE says otherwise, at most TE_MSM_WORKSETS) are in flight.  Multi-device contexts run one call at a
-// time (each call already uses every device).
+// Devices: TE_MSM_DEVICES="0,1,2,3" (or setDevices([0,1,2,3])) puts several GPUs of the node behind the one entry point
+// (a context of n_dev > 1 devices, include/te_msm.h).  Default: device 0.
+// Concurrency: promises in flight at the same time (a prover that does not await each call) become TICKETS of the engine --
+// te_msm_submit_async under the lock (it returns at once: the upload runs on the chosen device's host thread),
+// te_msm_ticket_wait outside it on a libuv pool thread, te_msm_collect under it again.  On one device the upload of one
+// MSM overlaps the device work of the previous ones; on D devices every ticket is a whole MSM on the device with the fewest
+// in flight -- D uploads on D PCIe links at once.  Calls made while others are pending are submitted right from the
+// JavaScript thread, so the number in flight is not bounded by libuv's pool (4 threads unless UV_THREADPOOL_SIZE says
+// otherwise) but by the engine's work sets (TE_MSM_WORKSETS per device); beyond that, calls queue inside their pool thread.
+// The LONE call on several devices -- nothing else pending when it starts -- uses all of them for its one MSM
+// (te_msm_run: point slices, one upload thread per device): the latency form.
 #include <node_api.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -32,14 +35,15 @@ std::mutex g_mu;            // guards the context (it is not thread-safe) and th
 std::condition_variable g_cv;   // a work set became free / the context went idle
 te_ctx* g_ctx = nullptr;
 std::vector<int> g_devices;     // empty: TE_MSM_DEVICES, else device 0
-int g_busy = 0;                 // Execute() calls that are using g_ctx right now (resetContext / setDevices wait for 0)
+int g_pending = 0;              // msmNative calls whose promise is not settled yet (resetContext / setDevices wait for 0)
 
 struct Job {
   napi_async_work work = nullptr;
   napi_deferred deferred = nullptr;
-  napi_ref points_ref = nullptr, scalars_ref = nullptr;   // keep the JS Buffers alive until completion
+  napi_ref points_ref = nullptr, scalars_ref = nullptr;   // keep the JS Buffers alive until completion (asynchronous uploads read them)
   const uint8_t* points = nullptr; const uint8_t* scalars = nullptr;
   uint64_t n = 0;
+  uint64_t ticket = 0; bool submitted = false;            // te_msm_submit_async went through (on the JavaScript thread or in Execute)
   int rc = 0; std::string err;
   uint8_t out[64];
 };
@@ -61,45 +65,45 @@ int ensure_context(std::string& err) {
   const std::vector<int> ids = g_devices.empty() ? devices_from_env() : g_devices;
   const int rc = te_msm_init(ids.data(), (int)ids.size(), &g_ctx);
   if (rc) { err = te_msm_last_error(nullptr); g_ctx = nullptr; return rc; }
-  // the lazy hardware-queue measurement (16 ms at the first submit) only pays off for many small device-resident MSMs in flight;
-  // a host-buffer caller is bound by its uploads.  TE_MSM_QUEUE_PROBE=1 asks for it.
-  const char* qp = getenv("TE_MSM_QUEUE_PROBE");
-  if (!(qp && qp[0] == '1')) te_msm_set_option(g_ctx, "queue_probe", 0);
   return 0;
+}
+
+// with g_mu held: one attempt to turn the job into a ticket.  true = settled (submitted, or failed for good: j->rc);
+// false = every work set is taken (the caller waits for a collect and tries again)
+bool try_submit(Job* j) {
+  j->rc = te_msm_submit_async(g_ctx, j->points, j->scalars, j->n, &j->ticket);
+  if (j->rc == 0) { j->submitted = true; return true; }
+  int64_t fl = 0; te_msm_get_option(g_ctx, "in_flight", &fl);
+  if (j->rc == TE_MSM_ESTATE && fl > 0) return false;                  // capacity
+  j->err = te_msm_last_error(g_ctx);
+  return true;
 }
 
 void Execute(napi_env, void* data) {
   Job* j = static_cast<Job*>(data);
   std::unique_lock<std::mutex> lk(g_mu);
-  if ((j->rc = ensure_context(j->err))) return;
-  te_ctx* const ctx = g_ctx;
-  g_busy++;
-  int64_t ndev = 1;
-  te_msm_get_option(ctx, "num_devices", &ndev);
-  if (ndev > 1 || j->n == 0) {
-    j->rc = te_msm_run(ctx, j->points, j->scalars, j->n, j->out);       // every device works on this one call
-    if (j->rc) j->err = te_msm_last_error(ctx);
-  } else {
-    uint64_t ticket = 0;
-    for (;;) {
-      j->rc = te_msm_submit(ctx, j->points, j->scalars, j->n, &ticket);
-      if (j->rc != TE_MSM_ESTATE) break;
-      int64_t fl = 0; te_msm_get_option(ctx, "in_flight", &fl);
-      if (fl == 0) break;                                                // not a capacity problem
-      g_cv.wait(lk);                                                     // every work set is taken: wait for a collect
-    }
-    if (j->rc) {
-      j->err = te_msm_last_error(ctx);
-    } else {
-      lk.unlock();
-      const int wrc = te_msm_ticket_wait(ctx, ticket);                   // the one call that may run beside others
-      lk.lock();
-      j->rc = te_msm_collect(ctx, ticket, j->out);
-      if (j->rc) j->err = te_msm_last_error(ctx);
-      else if (wrc) { j->rc = wrc; j->err = "te_msm_ticket_wait failed"; }
+  if (!j->submitted) {
+    if ((j->rc = ensure_context(j->err)) == 0) {
+      int64_t ndev = 1;
+      te_msm_get_option(g_ctx, "num_devices", &ndev);
+      if (j->n == 0 || (ndev > 1 && g_pending == 1)) {
+        j->rc = te_msm_run(g_ctx, j->points, j->scalars, j->n, j->out);     // the lone call: every device works on this one MSM
+        if (j->rc) j->err = te_msm_last_error(g_ctx);
+      } else {
+        while (!try_submit(j)) g_cv.wait(lk);                               // every work set is taken: wait for a collect
+      }
     }
   }
-  g_busy--;
+  if (j->submitted) {
+    te_ctx* const ctx = g_ctx;                                              // (cannot change: resetContext waits for g_pending == 0)
+    lk.unlock();
+    const int wrc = te_msm_ticket_wait(ctx, j->ticket);                     // the one call that may run beside others
+    lk.lock();
+    j->rc = te_msm_collect(ctx, j->ticket, j->out);
+    if (j->rc) j->err = te_msm_last_error(ctx);
+    else if (wrc) { j->rc = wrc; j->err = "te_msm_ticket_wait failed"; }
+  }
+  g_pending--;
   g_cv.notify_all();
 }
 
@@ -143,13 +147,22 @@ napi_value MsmNative(napi_env env, napi_callback_info info) {
   napi_create_promise(env, &j->deferred, &promise);
   napi_create_string_utf8(env, "te_msm_run", NAPI_AUTO_LENGTH, &name);
   napi_create_async_work(env, nullptr, name, Execute, Complete, j, &j->work);
+  {
+    // other calls are pending and the context exists: this one becomes a ticket right here (microseconds: device and work set
+    // are picked, the upload is handed to the device's host thread) -- its pool thread will only wait and collect.  The first
+    // call of a burst is left to its pool thread, which by then sees whether it is alone (te_msm_run over all devices) or not.
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_pending++;
+    if (g_ctx && j->n > 0 && g_pending > 1) (void)try_submit(j);            // a failure or a full house is dealt with in Execute
+    j->rc = 0; j->err.clear();
+  }
   napi_queue_async_work(env, j->work);
   return promise;
 }
 
-// with g_mu held by lk: waits until no Execute() uses the context, then drops it
+// with g_mu held by lk: waits until no call is pending, then drops the context
 void drop_context(std::unique_lock<std::mutex>& lk) {
-  g_cv.wait(lk, [] { return g_busy == 0; });
+  g_cv.wait(lk, [] { return g_pending == 0; });
   if (g_ctx) { te_msm_destroy(g_ctx); g_ctx = nullptr; }
 }
 
