@@ -196,7 +196,7 @@ def test_window_count_of_15_and_5_bit_plans(pkg, model, ora):
         c.set_option("window_bits", 15)
         assert c.plan(n) == (15, 18)
         sc = model.scalars_to_bytes([(1 << 256) - 1, p - 1] + [3] * (n - 2))
-        assert c.run(pts, sc) == ora.msm(pts, sc, threads=4)
+        assert c.run(pts, sc) == ora.msm_naive(pts, sc)                                    # (the pipeline oracle has signed windows only)
 
 
 def test_node_eight_promises_on_four_devices(pkg, model, ora, tmp_path):

@@ -13,6 +13,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <utility>
 
 namespace te_sched {
 
@@ -105,5 +106,60 @@ inline int pick_device(const int* in_flight, int n_dev, int sets_per_dev, int pr
   }
   return best;
 }
+
+// ---- the bookkeeping of tickets, written once for anything shaped like the engine's context:
+//   ctx.devs[i]            devices (random access), each with  int in_flight  and work sets  ws[0 .. sets)  holding a  slot_t slot
+//   ctx.next_ticket        uint64_t, tickets are handed out in order over all devices
+//   ctx.last_dev           int, the device the previous ticket went to
+//   ctx.workers[i]         std::unique_ptr<worker_t>, device i's host thread
+// te_msm.hip instantiates these with te_ctx / gpu_t / workset_t, tests/csrc/sched_harness.cpp with a stand-in device.
+// Except for find_ticket and await_job -- which only read, with acquire loads, and may run on any thread -- everything here
+// runs under the caller's serialisation of the context.
+
+// the lowest-numbered work set of a device that no ticket owns (-1: none)
+template <class Dev> int free_set_index(const Dev& d, int sets) {
+  for (int i = 0; i < sets; i++) if (!slot_ticket(d.ws[i].slot)) return i;
+  return -1;
+}
+// the device the next ticket goes to (index into ctx.devs; -1: everything is taken); prefer: the device that holds the inputs, or -1
+template <class Ctx> int pick_device_of(const Ctx& ctx, int sets, int prefer) {
+  const int nd = (int)ctx.devs.size();
+  if (nd == 1) return ctx.devs[0].in_flight < sets ? 0 : -1;
+  int fl[64];
+  for (int i = 0; i < nd && i < 64; i++) fl[i] = ctx.devs[(size_t)i].in_flight;
+  return pick_device(fl, nd < 64 ? nd : 64, sets, prefer, ctx.last_dev);
+}
+// the ticket exists from here on: job first, then the number (release), then the counters
+template <class Ctx, class Set> void hand_out(Ctx& ctx, int di, Set& ws, uint64_t* ticket, job_ref job = nullptr) {
+  *ticket = ctx.next_ticket++;
+  ws.slot.job = std::move(job);
+  slot_publish(ws.slot, *ticket);
+  ctx.devs[(size_t)di].in_flight++; ctx.last_dev = di;
+}
+// the work set that holds a ticket, or nullptr (any thread)
+template <class Ctx> auto find_ticket(Ctx& ctx, uint64_t ticket, int* dev_index = nullptr) -> decltype(&ctx.devs[0].ws[0]) {
+  if (!ticket) return nullptr;
+  for (size_t i = 0; i < ctx.devs.size(); i++)
+    for (auto& ws : ctx.devs[i].ws) if (slot_ticket(ws.slot) == ticket) { if (dev_index) *dev_index = (int)i; return &ws; }
+  return nullptr;
+}
+// the enqueue of an asynchronous ticket has run on its device's host thread (any thread); its status
+template <class Ctx, class Set> int await_job(Ctx& ctx, int dev_index, Set& ws) {
+  const job_ref job = ws.slot.job;
+  if (!job) return 0;
+  return ctx.workers[(size_t)dev_index]->wait(job);
+}
+// the ticket is over (collected, with a result or with an error)
+template <class Ctx, class Set> void retire(Ctx& ctx, int dev_index, Set& ws) {
+  ctx.devs[(size_t)dev_index].in_flight--;
+  slot_release(ws.slot);
+}
+// device i's host thread, created on first use
+template <class Ctx> worker_t& worker_of(Ctx& ctx, size_t i) {
+  if (ctx.workers.size() < ctx.devs.size()) ctx.workers.resize(ctx.devs.size());
+  if (!ctx.workers[i]) ctx.workers[i].reset(new worker_t());
+  return *ctx.workers[i];
+}
+template <class Ctx> void drain_workers(Ctx& ctx) { for (auto& w : ctx.workers) if (w) w->drain(); }
 
 }  // namespace te_sched

@@ -1034,20 +1034,13 @@ int enqueue_host_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* src_
 }
 
 // the host thread of device i of the context (host_sched.hpp), created on first use
-te_sched::worker_t& worker_of(te_ctx* ctx, size_t i) {
-  if (ctx->workers.size() < ctx->devs.size()) ctx->workers.resize(ctx->devs.size());
-  if (!ctx->workers[i]) ctx->workers[i].reset(new te_sched::worker_t());
-  return *ctx->workers[i];
-}
+te_sched::worker_t& worker_of(te_ctx* ctx, size_t i) { return te_sched::worker_of(*ctx, i); }
 // every job posted to the context's host threads has run (asynchronous submits touch work sets, options and the error
 // string: calls that change or read those beside them wait first)
-void drain_workers(te_ctx* ctx) { for (auto& w : ctx->workers) if (w) w->drain(); }
+void drain_workers(te_ctx* ctx) { te_sched::drain_workers(*ctx); }
 
 // the lowest-numbered work set of a device that no ticket owns (-1: none)
-int free_workset_index(const gpu_t& d) {
-  for (int i = 0; i < TE_MSM_WORKSETS; i++) if (!te_sched::slot_ticket(d.ws[i].slot)) return i;
-  return -1;
-}
+int free_workset_index(const gpu_t& d) { return te_sched::free_set_index(d, TE_MSM_WORKSETS); }
 const char* const kAllSetsOwned = "every work set holds a submitted MSM that has not been collected: te_msm_collect one first";
 
 // the non-zero window digits the device counted for the MSM whose flag words are in the set's pinned block (word 1)
@@ -1392,24 +1385,16 @@ int take_free_workset(te_ctx* ctx, gpu_t& d, bool probe) {
   return wi;
 }
 // the device the next ticket goes to (index into ctx->devs); prefer: the device that holds the inputs, or -1
-int pick_device(te_ctx* ctx, int prefer) {
-  const int nd = (int)ctx->devs.size();
-  if (nd == 1) return ctx->devs[0].in_flight < TE_MSM_WORKSETS ? 0 : -1;
-  int fl[64];
-  for (int i = 0; i < nd; i++) fl[i] = ctx->devs[i].in_flight;
-  return te_sched::pick_device(fl, nd, TE_MSM_WORKSETS, prefer, ctx->last_dev);
-}
+// (the bookkeeping itself is host_sched.hpp's: the same code runs under ThreadSanitizer in tests/csrc/sched_harness.cpp)
+int pick_device(te_ctx* ctx, int prefer) { return te_sched::pick_device_of(*ctx, TE_MSM_WORKSETS, prefer); }
 void hand_out_ticket(te_ctx* ctx, int di, workset_t& ws, uint64_t* ticket, te_sched::job_ref job = nullptr) {
-  *ticket = ctx->next_ticket++;
-  ws.slot.job = std::move(job);
-  te_sched::slot_publish(ws.slot, *ticket);          // te_msm_ticket_wait looks it up from other threads
-  ctx->devs[(size_t)di].in_flight++; ctx->last_dev = di;
+  te_sched::hand_out(*ctx, di, ws, ticket, std::move(job));          // te_msm_ticket_wait looks the ticket up from other threads
 }
 workset_t* workset_of_ticket(te_ctx* ctx, uint64_t ticket, gpu_t** dev = nullptr) {
-  if (!ticket) return nullptr;
-  for (gpu_t& d : ctx->devs)
-    for (workset_t& ws : d.ws) if (te_sched::slot_ticket(ws.slot) == ticket) { if (dev) *dev = &d; return &ws; }
-  return nullptr;
+  int di = -1;
+  workset_t* ws = te_sched::find_ticket(*ctx, ticket, &di);
+  if (ws && dev) *dev = &ctx->devs[(size_t)di];
+  return ws;
 }
 // index into ctx->devs of the device whose memory holds p (device-resident inputs of a ticket), -1 if none of the context's
 int device_index_of_pointer(te_ctx* ctx, const void* p) {
@@ -1488,11 +1473,8 @@ int submit_host(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars
   return 0;
 }
 // the enqueue of an asynchronous ticket has run (any thread); its status
-int await_job(te_ctx* ctx, gpu_t& d, workset_t& ws) {
-  const te_sched::job_ref job = ws.slot.job;
-  if (!job) return 0;
-  return ctx->workers[(size_t)(&d - ctx->devs.data())]->wait(job);
-}
+int await_job(te_ctx* ctx, gpu_t& d, workset_t& ws) { return te_sched::await_job(*ctx, (int)(&d - ctx->devs.data()), ws); }
+void retire_ticket(te_ctx* ctx, gpu_t& d, workset_t& ws) { te_sched::retire(*ctx, (int)(&d - ctx->devs.data()), ws); }
 }  // namespace
 
 int te_msm_submit(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars_le, uint64_t n, uint64_t* ticket) {
@@ -1533,13 +1515,13 @@ int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]) {
     (void)hipSetDevice(d.device);
     (void)hipStreamSynchronize(ws.stream); if (ws.copy_stream) (void)hipStreamSynchronize(ws.copy_stream);
     ws.zero_clean_words = 0;
-    d.in_flight--; te_sched::slot_release(ws.slot);
+    retire_ticket(ctx, d, ws);
     return set_err(ctx, jrc, ws.job_err.empty() ? "the asynchronous submit failed" : ws.job_err.c_str());
   }
   HIP_TRY(ctx, hipEventSynchronize(ws.ev_result));   // on failure the ticket stays collectable
   (void)collect_stage_ms(ctx, d, ws);
   note_entries(ctx, ws);
-  d.in_flight--; te_sched::slot_release(ws.slot);    // the MSM is over, with a result or with a scalar-range error
+  retire_ticket(ctx, d, ws);                         // the MSM is over, with a result or with a scalar-range error
   if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, kFinalCarry);
   if (ws.plan.curve == TE_MSM_CURVE_BLS12_377_G1) te377_host::horner_to_affine(ws.h_partials, ws.plan.c, (int)ws.plan.logB, ws.plan.W, out_xy_le);
   else te_host::horner_to_affine(ws.h_partials, ws.plan.c, (int)ws.plan.logB, ws.plan.W, out_xy_le);
