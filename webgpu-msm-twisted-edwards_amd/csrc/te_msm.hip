@@ -1351,7 +1351,14 @@ void te_msm_destroy(te_ctx* ctx) {
   delete ctx;
 }
 
-const char* te_msm_last_error(const te_ctx* ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
+// (a device's host thread may be writing ctx->err this very moment -- an asynchronous submit that fails: a copy taken under
+// the lock, per calling thread; valid until that thread asks again)
+const char* te_msm_last_error(const te_ctx* ctx) {
+  if (!ctx) return g_init_error.c_str();
+  thread_local std::string copy;
+  { std::lock_guard<std::mutex> lk(const_cast<te_ctx*>(ctx)->err_mu); copy = ctx->err; }
+  return copy.c_str();
+}
 
 int te_msm_run(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars_le, uint64_t n, uint8_t out_xy_le[64]) {
   return run_common(ctx, points_xy_le, scalars_le, true, n, out_xy_le);

@@ -22,100 +22,58 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
-#include <condition_variable>
-#include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/te_msm.h"
+#include "promise_protocol.hpp"
 
 namespace {
 
-std::mutex g_mu;            // guards the context (it is not thread-safe) and the fields below
-std::condition_variable g_cv;   // a work set became free / the context went idle
-te_ctx* g_ctx = nullptr;
-std::vector<int> g_devices;     // empty: TE_MSM_DEVICES, else device 0
-int g_pending = 0;              // msmNative calls whose promise is not settled yet (resetContext / setDevices wait for 0)
+// the engine behind te_promise::protocol (js/promise_protocol.hpp holds the lock protocol itself)
+struct EngineApi {
+  using ctx_t = te_ctx;
+  static constexpr int ESTATE = TE_MSM_ESTATE;
+  static std::vector<int> default_devices() {        // TE_MSM_DEVICES="0,1,..", else device 0
+    std::vector<int> ids;
+    const char* e = getenv("TE_MSM_DEVICES");
+    if (e && *e) {
+      const char* q = e;
+      while (*q) { char* end = nullptr; const long v = strtol(q, &end, 10); if (end == q) break; ids.push_back((int)v); q = *end == ',' ? end + 1 : end; }
+    }
+    if (ids.empty()) ids.push_back(0);
+    return ids;
+  }
+  static int init(const int* ids, int n, te_ctx** out) { return te_msm_init(ids, n, out); }
+  static void destroy(te_ctx* c) { te_msm_destroy(c); }
+  static const char* last_error(te_ctx* c) { return te_msm_last_error(c); }
+  static int run(te_ctx* c, const uint8_t* p, const uint8_t* s, uint64_t n, uint8_t* out) { return te_msm_run(c, p, s, n, out); }
+  static int submit_async(te_ctx* c, const uint8_t* p, const uint8_t* s, uint64_t n, uint64_t* t) { return te_msm_submit_async(c, p, s, n, t); }
+  static int ticket_wait(te_ctx* c, uint64_t t) { return te_msm_ticket_wait(c, t); }
+  static int collect(te_ctx* c, uint64_t t, uint8_t* out) { return te_msm_collect(c, t, out); }
+  static int64_t in_flight(te_ctx* c) { int64_t v = 0; te_msm_get_option(c, "in_flight", &v); return v; }
+  static int64_t num_devices(te_ctx* c) { int64_t v = 1; te_msm_get_option(c, "num_devices", &v); return v; }
+};
+te_promise::protocol<EngineApi> g_proto;
 
 struct Job {
   napi_async_work work = nullptr;
   napi_deferred deferred = nullptr;
   napi_ref points_ref = nullptr, scalars_ref = nullptr;   // keep the JS Buffers alive until completion (asynchronous uploads read them)
-  const uint8_t* points = nullptr; const uint8_t* scalars = nullptr;
-  uint64_t n = 0;
-  uint64_t ticket = 0; bool submitted = false;            // te_msm_submit_async went through (on the JavaScript thread or in Execute)
-  int rc = 0; std::string err;
-  uint8_t out[64];
+  te_promise::job_t j;
 };
 
-std::vector<int> devices_from_env() {
-  std::vector<int> ids;
-  const char* e = getenv("TE_MSM_DEVICES");
-  if (e && *e) {
-    const char* q = e;
-    while (*q) { char* end = nullptr; const long v = strtol(q, &end, 10); if (end == q) break; ids.push_back((int)v); q = *end == ',' ? end + 1 : end; }
-  }
-  if (ids.empty()) ids.push_back(0);
-  return ids;
-}
-
-// with g_mu held
-int ensure_context(std::string& err) {
-  if (g_ctx) return 0;
-  const std::vector<int> ids = g_devices.empty() ? devices_from_env() : g_devices;
-  const int rc = te_msm_init(ids.data(), (int)ids.size(), &g_ctx);
-  if (rc) { err = te_msm_last_error(nullptr); g_ctx = nullptr; return rc; }
-  return 0;
-}
-
-// with g_mu held: one attempt to turn the job into a ticket.  true = settled (submitted, or failed for good: j->rc);
-// false = every work set is taken (the caller waits for a collect and tries again)
-bool try_submit(Job* j) {
-  j->rc = te_msm_submit_async(g_ctx, j->points, j->scalars, j->n, &j->ticket);
-  if (j->rc == 0) { j->submitted = true; return true; }
-  int64_t fl = 0; te_msm_get_option(g_ctx, "in_flight", &fl);
-  if (j->rc == TE_MSM_ESTATE && fl > 0) return false;                  // capacity
-  j->err = te_msm_last_error(g_ctx);
-  return true;
-}
-
-void Execute(napi_env, void* data) {
-  Job* j = static_cast<Job*>(data);
-  std::unique_lock<std::mutex> lk(g_mu);
-  if (!j->submitted) {
-    if ((j->rc = ensure_context(j->err)) == 0) {
-      int64_t ndev = 1;
-      te_msm_get_option(g_ctx, "num_devices", &ndev);
-      if (j->n == 0 || (ndev > 1 && g_pending == 1)) {
-        j->rc = te_msm_run(g_ctx, j->points, j->scalars, j->n, j->out);     // the lone call: every device works on this one MSM
-        if (j->rc) j->err = te_msm_last_error(g_ctx);
-      } else {
-        while (!try_submit(j)) g_cv.wait(lk);                               // every work set is taken: wait for a collect
-      }
-    }
-  }
-  if (j->submitted) {
-    te_ctx* const ctx = g_ctx;                                              // (cannot change: resetContext waits for g_pending == 0)
-    lk.unlock();
-    const int wrc = te_msm_ticket_wait(ctx, j->ticket);                     // the one call that may run beside others
-    lk.lock();
-    j->rc = te_msm_collect(ctx, j->ticket, j->out);
-    if (j->rc) j->err = te_msm_last_error(ctx);
-    else if (wrc) { j->rc = wrc; j->err = "te_msm_ticket_wait failed"; }
-  }
-  g_pending--;
-  g_cv.notify_all();
-}
+void Execute(napi_env, void* data) { g_proto.execute(&static_cast<Job*>(data)->j); }
 
 void Complete(napi_env env, napi_status, void* data) {
   Job* j = static_cast<Job*>(data);
-  if (j->rc == 0) {
+  if (j->j.rc == 0) {
     napi_value buf; void* dst = nullptr;
-    napi_create_buffer_copy(env, 64, j->out, &dst, &buf);
+    napi_create_buffer_copy(env, 64, j->j.out, &dst, &buf);
     napi_resolve_deferred(env, j->deferred, buf);
   } else {
     napi_value msg, errv;
-    std::string m = "te_msm error " + std::to_string(j->rc) + ": " + j->err;
+    std::string m = "te_msm error " + std::to_string(j->j.rc) + ": " + j->j.err;
     napi_create_string_utf8(env, m.c_str(), m.size(), &msg);
     napi_create_error(env, nullptr, msg, &errv);
     napi_reject_deferred(env, j->deferred, errv);
@@ -140,36 +98,23 @@ napi_value MsmNative(napi_env env, napi_callback_info info) {
     return nullptr;
   }
   Job* j = new Job();
-  j->points = static_cast<const uint8_t*>(p); j->scalars = static_cast<const uint8_t*>(s); j->n = sl / 32;
+  j->j.points = static_cast<const uint8_t*>(p); j->j.scalars = static_cast<const uint8_t*>(s); j->j.n = sl / 32;
   napi_create_reference(env, argv[0], 1, &j->points_ref);
   napi_create_reference(env, argv[1], 1, &j->scalars_ref);
   napi_value promise, name;
   napi_create_promise(env, &j->deferred, &promise);
   napi_create_string_utf8(env, "te_msm_run", NAPI_AUTO_LENGTH, &name);
   napi_create_async_work(env, nullptr, name, Execute, Complete, j, &j->work);
-  {
-    // other calls are pending and the context exists: this one becomes a ticket right here (microseconds: device and work set
-    // are picked, the upload is handed to the device's host thread) -- its pool thread will only wait and collect.  The first
-    // call of a burst is left to its pool thread, which by then sees whether it is alone (te_msm_run over all devices) or not.
-    std::lock_guard<std::mutex> lk(g_mu);
-    g_pending++;
-    if (g_ctx && j->n > 0 && g_pending > 1) (void)try_submit(j);            // a failure or a full house is dealt with in Execute
-    j->rc = 0; j->err.clear();
-  }
+  // other calls pending and the context exists: this one becomes a ticket right here (microseconds) and its pool thread will
+  // only wait and collect; the first call of a burst is left to its pool thread (te_promise::protocol::enter)
+  g_proto.enter(&j->j);
   napi_queue_async_work(env, j->work);
   return promise;
 }
 
-// with g_mu held by lk: waits until no call is pending, then drops the context
-void drop_context(std::unique_lock<std::mutex>& lk) {
-  g_cv.wait(lk, [] { return g_pending == 0; });
-  if (g_ctx) { te_msm_destroy(g_ctx); g_ctx = nullptr; }
-}
-
-// resetContext(): drops the cached engine context (compute_msm's force_recompile)
+// resetContext(): drops the cached engine context (compute_msm's force_recompile) once no promise is pending
 napi_value ResetContext(napi_env env, napi_callback_info) {
-  std::unique_lock<std::mutex> lk(g_mu);
-  drop_context(lk);
+  g_proto.reset();
   napi_value u; napi_get_undefined(env, &u); return u;
 }
 
@@ -189,16 +134,13 @@ napi_value SetDevices(napi_env env, napi_callback_info info) {
     if (napi_get_value_int32(env, v, &id) != napi_ok || id < 0) { napi_throw_type_error(env, nullptr, "setDevices: device ids are non-negative integers"); return nullptr; }
     ids.push_back(id);
   }
-  std::unique_lock<std::mutex> lk(g_mu);
-  drop_context(lk);
-  g_devices = ids;
+  g_proto.set_devices(ids);
   napi_value u; napi_get_undefined(env, &u); return u;
 }
 
 // getDevices(): the device list the next context is (or the current one was) created with
 napi_value GetDevices(napi_env env, napi_callback_info) {
-  std::vector<int> ids;
-  { std::lock_guard<std::mutex> lk(g_mu); ids = g_devices.empty() ? devices_from_env() : g_devices; }
+  const std::vector<int> ids = g_proto.devices();
   napi_value arr; napi_create_array_with_length(env, ids.size(), &arr);
   for (size_t i = 0; i < ids.size(); i++) { napi_value v; napi_create_int32(env, ids[i], &v); napi_set_element(env, arr, (uint32_t)i, v); }
   return arr;
