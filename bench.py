@@ -247,6 +247,10 @@ def main():
     ap.add_argument("--bases", choices=("shared", "distinct"), default="shared",
                     help="window-sharded batches: every MSM of a batch names the SAME point buffer (a prover's batch over one SRS: the "
                          "engine converts it once per launch sequence) or each its own copy")
+    ap.add_argument("--inputs", choices=("resident", "host"), default="resident",
+                    help="window-sharded runs: resident = every rank synthesises the full inputs on its GPU (untimed); host = the inputs are "
+                         "distributed first -- rank r uploads its n/D slice, one all-gather per buffer over RCCL assembles the whole on every GPU "
+                         "(ShardedPipeline.load_host) -- timed separately as input_distribution_ms; the timed steps then run on those buffers")
     ap.add_argument("--no-pipeline", action="store_true", help="N=1: await every MSM before submitting the next (latency mode)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--repeats", type=int, default=3, help="timed passes of --steps steps each; value = the median pass")
@@ -370,6 +374,19 @@ def main():
         if batch > 1 and not args.inflight:
             depth = 4
     pipe = pkg.ShardedPipeline(ctx, n, dist, depth=depth, batch=batch) if (sharded and pipelined) else None
+    distribution_ms = None
+    if pipe is not None and args.inputs == "host" and not bls:
+        # SURVEY 8e "Inputs": the full inputs reach every GPU once -- each rank's own PCIe link carries n / D points, xGMI the rest
+        ts = []
+        for _ in range(3):
+            dist.barrier(); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            d_pts, d_sc = pipe.load_host(pts, sc)
+            torch.cuda.synchronize()
+            tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda" if dist.get_backend() != "gloo" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ts.append(float(tt.item()) * 1e3)
+        distribution_ms = min(ts)
     # the point buffers the MSMs of one batch name: one shared buffer, or a copy per MSM (same bytes, distinct addresses)
     base_copies = [d_pts] + ([d_pts.clone() for _ in range(batch - 1)] if (args.bases == "distinct" and batch > 1) else [])
 
@@ -541,6 +558,11 @@ def main():
         "stage_ms_untimed_pass": {k: v for k, v in stage_ms.items() if not k.endswith("_ghz")},
         "result_x": str(int.from_bytes(result[:32], "little")),
     }
+    if distribution_ms is not None:
+        out["input_distribution_ms"] = distribution_ms
+        out["input_distribution_note"] = ("ShardedPipeline.load_host, best of 3, max over ranks: each rank uploads %d of the %d points (+ scalars) from pageable host "
+                                          "memory and two all-gathers (points, scalars) assemble the %d MB on every GPU; not part of the timed steps" % (
+                                              (n + world - 1) // world, n, (len(pts) + len(sc)) >> 20))
     if sharded:
         out["rccl_ranks"] = dist.get_world_size()
         out["backend"] = dist.get_backend()

@@ -148,6 +148,13 @@ int te_msm_ticket_device(te_ctx* ctx, uint64_t ticket, int* device_index, int* d
  *                   else 1), 1 = whole.  Twisted-Edwards: all scalars go first, in one copy (the link is the bottleneck);
  *                   BLS12-377: scalars piece by piece with their points (the device is).  The result does not depend on it.
  *   "host_shard_min" multi-device te_msm_run: smallest slice worth a device of its own (default 4096 points)
+ *   "host_staging"  0 (default) = host buffers are copied straight from the caller's memory: the fastest form while the caller
+ *                   REUSES its buffers (the runtime keeps pages it has copied from registered: 2.35 ms per 2^20-point call), but
+ *                   the first call on a buffer costs 4.7-5.0 ms and a caller that allocates fresh buffers for every call pays
+ *                   4.4-27 ms per call (profiles/r05_host_buffers_first_touch.txt).  1 = the engine copies the buffers, 2 MB at a
+ *                   time, with a crew of eight host threads into a pinned ring of the work set (32 MB, allocated on first use)
+ *                   and uploads from there: the same cost whatever the history of the caller's memory (env TE_MSM_HOST_STAGING).
+ *                   A caller that can register its arena once (hipHostRegister) should do that instead and keep 0.
  *   "queue_probe"   1 (default) = the first te_msm_submit_device on a device measures the hardware queues of its work sets' streams
  *                   (see te_msm_workset_stream); 0 = never (env TE_MSM_QUEUE_PROBE=0).  te_msm_probe_queues does it on request.
  *                   te_msm_submit / te_msm_submit_async never trigger it: a host-buffer ticket is bound by its upload

@@ -58,3 +58,26 @@ def test_isa_listing_figures():
     assert 5000 < te["cycles"] < 8000 and 12000 < bls["cycles"] < 20000
     j = json.load(open(bench.ISA_JSON))
     assert j["k_accumulate<9>"]["mads"] == 7 * 153     # seven field products of 153 multiply-accumulates per accumulated point
+
+
+def test_roofline_follows_the_accumulated_entries_not_w_times_n():
+    """A prover's witness (a quarter zeros, a quarter ones, the rest uniform) has ~8.25 non-zero digits of 16 per scalar: the
+    roofline is priced with the entries the engine counted (option "entries_accumulated"), so neither fraction can exceed what
+    the kernel did.  Round 4 charged W * n and reported the kernel at 1.49 of its own instruction floor."""
+    n, W, B = 1 << 20, 16, 1 << 15
+    entries = int(n * (0.25 * 0 + 0.25 * 1 + 0.5 * 16 * (1 - 2.0 ** -16)))        # 8 650 k of the 16 777 k of a uniform set
+    whole_u, acc_u = bench.algorithmic_bytes(n, W, B)
+    whole_w, acc_w = bench.algorithmic_bytes(n, W, B, entries=entries)
+    assert acc_w == entries * 68 + W * B * 128 and whole_w == 96 * n + entries * 68 + 2 * W * B * 128 + 64
+    assert 0.5 < acc_w / acc_u < 0.56
+    # the driver's round-4 figures for this config: the kernel alone 0.440 ms at 2.0 GHz
+    alone = {"accumulate": 0.440, "accumulate_core_clock_ghz": 2.0}
+    r = bench.roofline_block(acc_w, alone, None, False, entries / 64.0, entries=entries)
+    assert r["entries_accumulated_per_launch"] == entries and r["algorithmic_bytes_per_launch"] == acc_w
+    assert 0.15 < r["frac"] < 0.22                                                  # HBM: ~0.19, not 0.34
+    v = r["binding_roofline"]
+    assert v["frac"] < 1.0 and 0.8 < v["frac_at_measured_clock"] < 1.0             # VALU issue: ~0.9, not 1.49 / 1.79
+    wrong = bench.roofline_block(acc_u, alone, None, False, W * n / 64.0)
+    assert wrong["binding_roofline"]["frac_at_measured_clock"] > 1.5               # what charging W * n gives
+    # a uniform set: the count changes nothing beyond 2^-16
+    assert abs(bench.algorithmic_bytes(n, W, B, entries=int(W * n * (1 - 2.0 ** -16)))[1] / acc_u - 1) < 1e-4

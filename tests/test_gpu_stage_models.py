@@ -218,6 +218,11 @@ def test_sharded_pipeline_over_rccl(pkg, model, ora, nccl_world1):
             assert bp.collect_batch(t0) + bp.collect_batch(t1) == [e for _, _, e in cases]
             t2 = bp.submit(cases[2][0], cases[2][1])
             assert bp.collect(t2) == cases[2][2]
+            # host buffers: the rank uploads its slice, one all-gather per buffer over RCCL assembles the whole (load_host)
+            pts_h, sc_h = ora.gen_points(301, n), ora.gen_scalars(301, n)
+            dp_h, ds_h = pipe.load_host(pts_h, sc_h)
+            assert dp_h.is_cuda and bytes(dp_h.cpu().numpy()) == pts_h and bytes(ds_h.cpu().numpy()) == sc_h
+            assert pipe.collect(pipe.submit()) == cases[0][2]
             # the synchronous form over the same backend
             part = torch.zeros(pipe.W * pkg.PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
             assert pkg.compute_msm_sharded(ctx, cases[0][0], cases[0][1], n, part, dist) == cases[0][2]

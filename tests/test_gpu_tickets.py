@@ -173,6 +173,44 @@ def test_pinned_host_buffers_are_released_at_return(pkg, ora):
         assert L.te_msm_run(c._h, as_cp(hp), as_cp(hs), n, out) == 0 and out.raw[:64] == want
 
 
+def test_host_staging_option(pkg, model, ora):
+    """option "host_staging" = 1: host buffers travel through the work set's own pinned ring, filled 2 MB at a time by the
+    engine's crew of host threads (independent of what the runtime remembers about the caller's pages).  Same results; the
+    caller's buffers are free when a blocking call returns; pieces, tickets, several devices, both curves' record sizes"""
+    import torch
+    n = 300007                                                  # 18.3 MB of points: ten chunks, the last one short
+    pts, sc = ora.gen_points(1800, n), ora.gen_scalars(1800, n)
+    want = ora.msm(pts, sc, threads=8)
+    small = (ora.gen_points(1801, 1000), ora.gen_scalars(1801, 1000))      # below the staging threshold: direct copies
+    with pkg.MsmContext((0,)) as c:
+        c.set_option("host_staging", 1)
+        assert c.get_option("host_staging") == 1
+        for chunks in (0, 1, 3):
+            c.set_option("host_chunks", chunks)
+            assert c.run(pts, sc) == want, chunks
+            bp, bs = bytearray(pts), bytearray(sc)
+            hp = torch.frombuffer(bp, dtype=torch.uint8); hs = torch.frombuffer(bs, dtype=torch.uint8)
+            L = __import__("importlib").import_module("webgpu-msm-twisted-edwards_amd.binding")._lib()
+            as_cp = lambda t: ctypes.cast(ctypes.c_void_p(t.data_ptr()), ctypes.c_char_p)
+            tk = ctypes.c_uint64()
+            assert L.te_msm_submit(c._h, as_cp(hp), as_cp(hs), n, ctypes.byref(tk)) == 0
+            hp.fill_(0xff); hs.fill_(0xff)                      # the call is over: the buffers are the caller's again
+            t2 = c.submit_async(pts, sc)
+            assert c.collect(tk.value) == want and c.collect(t2) == want, chunks
+        c.set_option("host_chunks", 0)
+        assert c.run(*small) == ora.msm(*small)
+        ts = [c.submit(pts, sc) for _ in range(pkg.WORKSETS)]   # every work set gets a ring
+        assert all(c.collect(t) == want for t in ts)
+        assert c.trim(0) == pkg.WORKSETS and c.run(pts, sc) == want            # rings are freed with the sets and come back
+        c.set_option("host_staging", 0)
+        assert c.run(pts, sc) == want
+    with pkg.MsmContext((0, 0, 0, 0)) as c:
+        c.set_option("host_staging", 1)
+        assert c.run(pts, sc) == want                           # point slices: four device threads post to the one crew
+        ts = [c.submit_async(pts, sc) for _ in range(8)]
+        assert all(c.collect(t) == want for t in ts)
+
+
 def test_window_count_of_15_and_5_bit_plans(pkg, model, ora):
     """signed digits run ceil(255 / c) windows (17 x 15 bits, 51 x 5): scalars of this boundary are below p < 2^253.  The
     error rule stays exact: s + sum_w 2^(c w + c - 1) >= 2^(c W) is the reference's "final carry is 1" (utils.ts:80-83)"""

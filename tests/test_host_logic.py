@@ -415,6 +415,16 @@ dist.all_gather_into_tensor(gathered, torch.frombuffer(mine, dtype=torch.uint8))
 for m, (p_, s_) in enumerate(ins):
     rows = pkg.rows_of_batched_msm(gathered, world, batch, m)
     assert pkg.finalize_gathered(rows.data_ptr(), world, c, W) == o.msm(p_, s_), "rank %d, MSM %d of the batch" % (rank, m)
+# inputs for the window-sharded form arrive once (SURVEY 8e "Inputs"): every rank contributes its slice of the host buffers,
+# one all-gather per buffer assembles the whole on every rank -- ragged n (the last slice is padded), and the MSM over the
+# assembled buffers is the oracle's
+for n2 in (301, 2, 1):
+    p2, s2 = o.gen_points(91, n2), o.gen_scalars(92, n2)
+    dp, ds, got_n = pkg.distribute_inputs(p2, s2, dist, device="cpu")
+    assert got_n == n2 and dp.numpy().tobytes() == p2 and ds.numpy().tobytes() == s2, "rank %d: assembled inputs differ (n = %d)" % (rank, n2)
+    assert L.fpc_partial_rows(dp.numpy().tobytes(), ds.numpy().tobytes(), n2, c, first, step, buf) == 0
+    t2 = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
+    assert pkg.finalize_host(pkg.exchange_partials(t2, W, dist), c, W) == o.msm(p2, s2), "rank %d: MSM over distributed inputs" % rank
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """

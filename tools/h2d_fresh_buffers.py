@@ -22,24 +22,31 @@ def series(name, call, pick, k=24):
     print("%-64s best %.3f median %.3f worst %.3f | %s" % (name, srt[0], srt[len(srt) // 2], srt[-1], " ".join("%.2f" % t for t in ts)))
 
 
-for ids in ((0,), (0,) * 8):
+import os
+for ids, staging in (((0,), 0), ((0,), 1), ((0,) * 8, 0), ((0,) * 8, 1)):
+    if os.environ.get("TE_H2D_ONLY_STAGED") and not staging:
+        continue
     with pkg.MsmContext(ids) as c:
+        c.set_option("host_staging", staging)
         ref = c.run(pts, sc)
-        tag = "D = %d te_msm_run" % len(ids)
+        tag = "D = %d te_msm_run%s" % (len(ids), ", host_staging" if staging else "")
         series(tag + ", same buffers", c.run, lambda i: (pts, sc))
         series(tag + ", rotation of 8 copies (first round = first touch)", c.run, lambda i: rot[i % 8])
         series(tag + ", rotation of 8 copies again", c.run, lambda i: rot[i % 8])
         series(tag + ", a fresh copy per call", c.run, lambda i: (bytes(bytearray(pts)), bytes(bytearray(sc))), 12)
         series(tag + ", same buffers again", c.run, lambda i: (pts, sc), 8)
-with pkg.MsmContext((0,) * 8) as c:
+for staging in (0, 1):
+  with pkg.MsmContext((0,) * 8) as c:
+    c.set_option("host_staging", staging)
+    print("-- tickets, host_staging = %d" % staging)
     for name, pick in (("same buffers", lambda i: (pts, sc)), ("rotation of 8 copies", lambda i: rot[i % 8])):
-        for rep in range(3):
-            t0 = time.perf_counter()
-            tk = []
-            for i in range(48):
-                tk.append(c.submit_async(*pick(i)))
-                if len(tk) >= 16:
-                    assert c.collect(tk.pop(0)) == ref
-            while tk:
-                assert c.collect(tk.pop(0)) == ref
-            print("D = 8 tickets (te_msm_submit_async, 16 in flight), %s: %.3f ms per MSM" % (name, (time.perf_counter() - t0) * 1e3 / 48))
+          for rep in range(3):
+              t0 = time.perf_counter()
+              tk = []
+              for i in range(48):
+                  tk.append(c.submit_async(*pick(i)))
+                  if len(tk) >= 16:
+                      assert c.collect(tk.pop(0)) == ref
+              while tk:
+                  assert c.collect(tk.pop(0)) == ref
+              print("D = 8 tickets (te_msm_submit_async, 16 in flight), %s: %.3f ms per MSM" % (name, (time.perf_counter() - t0) * 1e3 / 48))

@@ -30,4 +30,4 @@ from .binding import (  # noqa: F401
     WORKSETS,
     MAX_BATCH,
 )
-from .sharding import ShardedPipeline, compute_msm_sharded, exchange_partials, merge_partials, rows_of_batched_msm, window_shard_for_rank  # noqa: F401
+from .sharding import ShardedPipeline, compute_msm_sharded, distribute_inputs, exchange_partials, merge_partials, rows_of_batched_msm, window_shard_for_rank  # noqa: F401

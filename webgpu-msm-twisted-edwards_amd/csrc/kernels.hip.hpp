@@ -223,6 +223,35 @@ __device__ __forceinline__ void wait_own_accesses() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);
 }
+// The arrival itself, by ONE thread of the block, behind a block barrier that follows wait_own_accesses() in every wave;
+// returns the number of arrivals before this one.  Two builds:
+//   default             a relaxed device-scope atomic.  This stands OUTSIDE the HIP / LLVM memory model: it relies on gfx950
+//                       performing device-scope (sc1) atomic accesses at the memory side and on s_waitcnt covering them.
+//                       Correct on ROCm 7.2 / MI355X by test and soak.
+//   -DTE_HANDOFF_FENCED the memory model's own form (libtemsm_fenced.so, `make fenced`): the arriving thread releases at agent
+//                       scope before the atomic and acquires after it; the other waves of the block are ordered through the
+//                       block barriers on either side (workgroup-scope synchronisation, cumulative into the agent-scope
+//                       release).  The fences write back / invalidate the XCD's L2: measured cost in
+//                       profiles/r05_handoff_fenced_twin.txt.  A runtime or compiler update that changes cache policy is
+//                       A/B-ed against this build through TE_MSM_LIB.
+// The two hand-offs of the engine and the tests that reach them (tests/test_gpu_handoffs.py runs them against BOTH builds):
+//   k_l2_local         pieces of a partition with more than TE_L2_CAP entries: bucket_count by global atomics, part_ticket
+//                      counts the pieces, the last one plans the partition -- every canonical scalar set has such partitions in
+//                      its top window (test_full_size_2_20, test_wasm_golden_cases); skew makes more: test_witness_like_scalars,
+//                      test_giant_buckets (all scalars equal: ONE partition holds every entry of a window)
+//   k_seg_combine_all  runs of a giant bucket (more than TE_COMBINE_SMALL parts): store_coord_agent, bucket_cursor counts the runs,
+//                      the last one sums them with block_sum_points<COHERENT> -- test_giant_buckets, test_many_parts_per_bucket,
+//                      test_witness_like_scalars (bucket 0 of window 0: n / 4 entries)
+__device__ __forceinline__ uint32_t handoff_arrive(uint32_t* counter) {
+#if defined(TE_HANDOFF_FENCED)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  const uint32_t v = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return v;
+#else
+  return atomicAdd(counter, 1u);
+#endif
+}
 
 // block-wide exclusive scan of one value per thread (blockDim.x <= 1024, multiple of 64 or < 64)
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds /*>= 17 words*/, uint32_t& block_total) {
@@ -653,7 +682,7 @@ __global__ void __launch_bounds__(256, 3) k_l2_local(l2_args a) {
     if (c0) atomicAdd(&a.bucket_count[gb], c0);
     wait_own_accesses();                                // the atomic adds have been performed before the piece is counted as done
     __syncthreads();
-    if (t == 0) pj[2] = (atomicAdd(&a.part_ticket[k * g.P + p], 1u) + 1u == (cntp + TE_L2_CAP - 1u) / TE_L2_CAP) ? 1u : 0u;
+    if (t == 0) pj[2] = (handoff_arrive(&a.part_ticket[k * g.P + p]) + 1u == (cntp + TE_L2_CAP - 1u) / TE_L2_CAP) ? 1u : 0u;
     __syncthreads();
     if (pj[2]) (void)seg_plan_block(p, k, t < g.S ? ld_agent(a.bucket_count + gb) : 0u, g, a.pa, PL, pb, cntp, sbp);      // uniform
     return;
@@ -1233,7 +1262,7 @@ __global__ void __launch_bounds__(256) k_seg_combine_all(const uint32_t* __restr
     if ((threadIdx.x >> 2) == 0) store_coord_agent<N>(words<N>(base) + wq, r);      // past the L2: another XCD's block may add the runs up
     wait_own_accesses();                                   // ... and performed before the arrival is counted
     __syncthreads();
-    if (threadIdx.x == 0) arrived = atomicAdd(&bucket_cursor[g], 1u) - (bucket_start[g] + bucket_count[g]);
+    if (threadIdx.x == 0) arrived = handoff_arrive(&bucket_cursor[g]) - (bucket_start[g] + bucket_count[g]);
     __syncthreads();
     if (arrived + 1u == nchunks) {                         // uniform: this block finished the bucket's last run
       const fel<N> t = block_sum_points<N, true>(seg_out + seg_base[g], run, nchunks, lds);

@@ -15,6 +15,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <deque>
 #include <algorithm>
 #include <functional>
 #include <chrono>
@@ -112,6 +113,8 @@ struct workset_t {
   // call, and the "piece i has arrived" events of an upload in pieces
   void *d_in_points = nullptr, *d_in_scalars = nullptr; size_t cap_in_points = 0, cap_in_scalars = 0;
   std::vector<hipEvent_t> piece_events;
+  // option "host_staging": the set's own pinned ring for host-buffer uploads (allocated on first use; te_msm_trim / destroy free it)
+  uint8_t* h_ring = nullptr; std::vector<hipEvent_t> ring_ev; size_t ring_next = 0;
   uint64_t idle_calls = 0;            // te_msm_trim: context-level calls since the set was last used
 };
 constexpr int TE_MAX_WINDOWS = 64;    // window_bits >= 4
@@ -141,6 +144,8 @@ struct te_ctx {
   std::vector<std::unique_ptr<te_sched::worker_t>> workers;   // devs[i]'s host thread (host_sched.hpp); created by the first call that needs them
   uint64_t next_ticket = 1;         // tickets are handed out in order, over all devices; a ticket lives on the work set whose slot holds it
   int last_dev = -1;                // the device the previous ticket went to (te_sched::pick_device deals idle devices round-robin)
+  int opt_host_staging = 0;         // host-buffer uploads through the work sets' own pinned rings (staged_copy) instead of straight from the caller's memory
+  std::vector<std::unique_ptr<te_sched::worker_t>> stagers;   // the threads that fill those rings (created on first use)
   int opt_stage_device_inputs = 0;  // tickets for device-resident inputs: copy them to the chosen device even when it is the one that holds them (tests on a one-GPU box)
   int64_t stat_peer_bytes = 0;      // bytes those copies moved (get_option "peer_bytes")
   int64_t stat_entries = 0;         // non-zero window digits (= accumulated entries) of the MSM whose result was fetched last (get_option "entries_accumulated")
@@ -859,6 +864,7 @@ void free_workset_buffers(workset_t& ws) {      // the big device buffers of a w
                    (void**)&ws.d_chunk_list, (void**)&ws.d_seg_out, (void**)&ws.d_buckets, (void**)&ws.d_red[0], (void**)&ws.d_red[1],
                    (void**)&ws.d_red[2], (void**)&ws.d_red[3], &ws.d_in_points, &ws.d_in_scalars};
   for (void** q : ptrs) if (*q) { (void)hipFree(*q); *q = nullptr; }
+  if (ws.h_ring) { (void)hipHostFree(ws.h_ring); ws.h_ring = nullptr; }       // the pinned ring of option "host_staging" (its events stay)
   memset(ws.cap, 0, sizeof ws.cap); ws.cap_in_points = ws.cap_in_scalars = 0;
   ws.zero_words = ws.zero_clean_words = 0;
   ws.d_err = ws.d_num_seg = ws.d_size_hist = ws.d_size_cursor = ws.d_counts1 = ws.d_bucket_count = ws.d_part_ticket = nullptr; ws.d_partials = nullptr;
@@ -872,6 +878,7 @@ void free_dev(gpu_t& d) {
   for (workset_t& ws : d.ws) {
     free_workset_buffers(ws);
     if (ws.h_err) (void)hipHostFree(ws.h_err);
+    for (hipEvent_t e : ws.ring_ev) if (e) (void)hipEventDestroy(e);
     if (ws.ev_done) (void)hipEventDestroy(ws.ev_done);
     if (ws.ev_result) (void)hipEventDestroy(ws.ev_result);
     for (auto& ev : ws.ev) if (ev) (void)hipEventDestroy(ev);
@@ -908,6 +915,68 @@ bool host_memory_is_pinned(const void* p) {
   hipPointerAttribute_t at; memset(&at, 0, sizeof at);
   if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
   return at.type == hipMemoryTypeHost;
+}
+
+// ---- option "host_staging" ------------------------------------------------------------------------------------------------
+// A copy from pageable memory is fast only while the runtime still holds the caller's pages registered from an earlier copy
+// of the SAME range: te_msm_run of 2^20 points takes 2.35 ms from buffers it has seen, 4.7-5.0 ms at the first touch of a
+// buffer, and 4.4-27 ms when every call brings freshly allocated buffers (registration and the release of the previous
+// buffers' registration sit on the call's critical path; eight threads touching new ranges at once serialise in it: round
+// 4's "9.5 ms median" of the eight-device call -- profiles/r05_host_buffers_first_touch.txt, r05_point_shard_stamps_D8.txt).
+// A prover that allocates its buffers per call never sees the fast case.  With "host_staging" = 1 the engine does not depend
+// on the history of the caller's memory: the buffers are copied, 2 MB at a time, by a small crew of host threads into a pinned
+// ring of the work set and travel from there; the call returns when the last chunk has left the caller's buffer.
+constexpr size_t TE_RING_SLOT = 2u << 20;      // bytes per slot: 48 DMA calls per 96 MB, ~0.2 ms of enqueue cost
+constexpr int TE_RING_SLOTS = 16;              // 32 MB pinned per work set that stages
+constexpr int TE_STAGERS = 8;                  // crew size: 8 x ~10 GB/s of memcpy against a 52 GB/s link
+int ensure_ring(te_ctx* ctx, workset_t& ws) {
+  if (ws.h_ring) return 0;
+  HIP_TRY(ctx, hipHostMalloc((void**)&ws.h_ring, TE_RING_SLOT * TE_RING_SLOTS, hipHostMallocDefault));
+  if (ws.ring_ev.empty()) {
+    ws.ring_ev.resize(TE_RING_SLOTS, nullptr);
+    for (auto& e : ws.ring_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  ws.ring_next = 0;
+  return 0;
+}
+// the crew is shared by everything of the context that stages (its threads only ever run memcpy jobs); created under the
+// context's error lock: the devices' host threads may get here together
+int ensure_stagers(te_ctx* ctx) {
+  std::lock_guard<std::mutex> lk(ctx->err_mu);
+  while ((int)ctx->stagers.size() < TE_STAGERS) ctx->stagers.emplace_back(new te_sched::worker_t());
+  return 0;
+}
+// dst (device) <- src (host), `bytes`, on `stream`, through the set's ring; returns when src has been read completely
+int staged_copy(te_ctx* ctx, workset_t& ws, void* dst, const uint8_t* src, size_t bytes, hipStream_t stream) {
+  if (int rc = ensure_ring(ctx, ws)) return rc;
+  if (int rc = ensure_stagers(ctx)) return rc;
+  struct pending_t { te_sched::job_ref job; te_sched::worker_t* who; int slot; size_t off, len; };
+  std::deque<pending_t> fifo;
+  auto flush_one = [&]() -> int {
+    pending_t p = fifo.front(); fifo.pop_front();
+    (void)p.who->wait(p.job);
+    HIP_TRY(ctx, hipMemcpyAsync(static_cast<uint8_t*>(dst) + p.off, ws.h_ring + (size_t)p.slot * TE_RING_SLOT, p.len, hipMemcpyHostToDevice, stream));
+    HIP_TRY(ctx, hipEventRecord(ws.ring_ev[(size_t)p.slot], stream));
+    return 0;
+  };
+  for (size_t off = 0; off < bytes; off += TE_RING_SLOT) {
+    const size_t len = std::min(TE_RING_SLOT, bytes - off);
+    const size_t turn = ws.ring_next++;
+    const int slot = (int)(turn % TE_RING_SLOTS);
+    if ((int)fifo.size() >= TE_RING_SLOTS / 2) { if (int rc = flush_one()) return rc; }        // at most half of the ring filling, the other half draining
+    if (turn >= (size_t)TE_RING_SLOTS) HIP_TRY(ctx, hipEventSynchronize(ws.ring_ev[(size_t)slot]));   // the slot's previous chunk has left it
+    uint8_t* to = ws.h_ring + (size_t)slot * TE_RING_SLOT; const uint8_t* from = src + off;
+    te_sched::worker_t* who = ctx->stagers[turn % TE_STAGERS].get();
+    fifo.push_back({who->post([to, from, len] { memcpy(to, from, len); return 0; }), who, slot, off, len});
+  }
+  while (!fifo.empty()) { if (int rc = flush_one()) return rc; }
+  return 0;
+}
+// every host-to-device copy of a caller's buffer goes through here
+int upload(te_ctx* ctx, workset_t& ws, void* dst, const uint8_t* src, size_t bytes, hipStream_t stream) {
+  if (ctx->opt_host_staging && bytes >= (256u << 10)) return staged_copy(ctx, ws, dst, src, bytes, stream);
+  HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+  return 0;
 }
 
 const char* const kFinalCarry = "final carry is 1: a scalar does not fit the signed window decomposition";
@@ -990,7 +1059,7 @@ int enqueue_host_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* src_
   // bound by the device, which must not sit idle while 48 MB of scalar records arrive: piece by piece, 4.1 against 4.7 ms.)
   const bool scalars_first = pf.curve == TE_MSM_CURVE_TE_BLS12;
   if (scalars_first) {
-    HIP_TRY(ctx, hipMemcpyAsync(dscs, src_scalars, n * sz.scalar_in, hipMemcpyHostToDevice, ws.copy_stream));
+    if (int rc = upload(ctx, ws, dscs, src_scalars, n * sz.scalar_in, ws.copy_stream)) return rc;
     HIP_TRY(ctx, hipEventRecord(evs[K], ws.copy_stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, evs[K], 0));
     stamp("scalars staged", -1);
@@ -1005,13 +1074,13 @@ int enqueue_host_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* src_
     ws.rows_on_host = L.host_rows;
     first = false;
     if (!scalars_first) {
-      HIP_TRY(ctx, hipMemcpyAsync(dscs + lo * sz.scalar_in, src_scalars + lo * sz.scalar_in, m * sz.scalar_in, hipMemcpyHostToDevice, ws.copy_stream));
+      if (int rc = upload(ctx, ws, dscs + lo * sz.scalar_in, src_scalars + lo * sz.scalar_in, m * sz.scalar_in, ws.copy_stream)) return rc;
       HIP_TRY(ctx, hipEventRecord(evs[K], ws.copy_stream));
       HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, evs[K], 0));
       stamp("scalars staged", i);
     }
     if (int rc = L.front_scalars()) return rc;                             // digits, sort and schedule run while the piece's points cross PCIe
-    HIP_TRY(ctx, hipMemcpyAsync(dpts + lo * sz.point_in, src_points + lo * sz.point_in, m * sz.point_in, hipMemcpyHostToDevice, ws.copy_stream));
+    if (int rc = upload(ctx, ws, dpts + lo * sz.point_in, src_points + lo * sz.point_in, m * sz.point_in, ws.copy_stream)) return rc;
     stamp("points staged", i);
     HIP_TRY(ctx, hipEventRecord(evs[i], ws.copy_stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, evs[i], 0));
@@ -1025,7 +1094,7 @@ int enqueue_host_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* src_
   __atomic_store_n(&d.last_ws, (int)(&ws - d.ws), __ATOMIC_RELAXED);      // (the device's host thread may be the writer: asynchronous submits)
   if (int rc = fetch_rows(ctx, ws, ws.stream)) return rc;
   HIP_TRY(ctx, hipGetLastError());
-  if (wait_for_pinned && (host_memory_is_pinned(src_points) || host_memory_is_pinned(src_scalars))) {
+  if (wait_for_pinned && !ctx->opt_host_staging && (host_memory_is_pinned(src_points) || host_memory_is_pinned(src_scalars))) {
     // everything on the copy stream is ordered: the last recorded upload event covers the scalars and every piece
     HIP_TRY(ctx, hipEventSynchronize(evs[(size_t)last_piece]));
     stamp("pinned source: uploads awaited", -1);
@@ -1258,13 +1327,12 @@ int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, boo
     if (int rc = ensure_staging(ctx, ws, n * sz.point_in, n * sz.scalar_in)) return rc;
     // scalars first; the points follow from inside enqueue_partial (pageable copies return when the data has left
     // the caller's buffer, so the scalar-only stages enqueued in between run while the points are still in flight)
-    HIP_TRY(ctx, hipMemcpyAsync(ws.d_in_scalars, src_scalars, n * sz.scalar_in, hipMemcpyHostToDevice, ws.stream));
+    if (int rc = upload(ctx, ws, ws.d_in_scalars, static_cast<const uint8_t*>(src_scalars), n * sz.scalar_in, ws.stream)) return rc;
     dp = ws.d_in_points; ds = ws.d_in_scalars;
   }
   const std::function<int(hipStream_t)> upload_points = [&](hipStream_t side) -> int {
     // on the side stream, beside the scalar-only kernels on ws.stream; the conversion to records follows it there
-    HIP_TRY(ctx, hipMemcpyAsync(ws.d_in_points, src_points, n * sz.point_in, hipMemcpyHostToDevice, side));
-    return 0;
+    return upload(ctx, ws, ws.d_in_points, static_cast<const uint8_t*>(src_points), n * sz.point_in, side);
   };
   if (int rc = enqueue_partial(ctx, d, ws, dp, ds, n, nullptr, ws.stream, src_is_host ? &upload_points : nullptr)) return rc;
   if (int rc = fetch_rows(ctx, ws, ws.stream)) return rc;
@@ -1297,6 +1365,7 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
   if (const char* e = getenv("TE_MSM_FUSE_PREP")) ctx->opt_fuse_prep = e[0] != '0';      // A/B measurements; option "fuse_prep"
   if (const char* e = getenv("TE_MSM_QUEUE_PROBE")) ctx->opt_queue_probe = e[0] != '0';  // option "queue_probe"
   if (const char* e = getenv("TE_MSM_PACKED")) ctx->opt_packed = e[0] != '0';            // option "packed_sort"
+  if (const char* e = getenv("TE_MSM_HOST_STAGING")) ctx->opt_host_staging = e[0] != '0'; // option "host_staging"
   if (const char* e = getenv("TE_MSM_FOLD_PAIRS")) ctx->opt_fold_pairs = e[0] != '0';    // option "fold_pairs"
   if (const char* e = getenv("TE_MSM_HOST_SPLIT")) {                                     // relative piece weights "w0,w1,..." (experiments)
     const char* q = e;
@@ -1339,6 +1408,7 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
 void te_msm_destroy(te_ctx* ctx) {
   if (!ctx) return;
   ctx->workers.clear();                 // joins the per-device host threads (idle between calls)
+  ctx->stagers.clear();
   for (auto& d : ctx->devs) {
     (void)hipSetDevice(d.device);
     for (workset_t& ws : d.ws) {        // this context's streams only: other work of the process is none of its business
@@ -1590,6 +1660,7 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   if (!strcmp(key, "packed_sort")) { ctx->opt_packed = value ? 1 : 0; return 0; }
   if (!strcmp(key, "fold_pairs")) { ctx->opt_fold_pairs = value ? 1 : 0; return 0; }
   if (!strcmp(key, "stage_device_inputs")) { ctx->opt_stage_device_inputs = value ? 1 : 0; return 0; }
+  if (!strcmp(key, "host_staging")) { ctx->opt_host_staging = value ? 1 : 0; return 0; }
   return set_err(ctx, TE_MSM_EINVAL, "unknown option");
 }
 
@@ -1605,6 +1676,7 @@ int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value) {
   if (!strcmp(key, "peer_bytes")) { *value = ctx->stat_peer_bytes; return 0; }
   if (!strcmp(key, "entries_accumulated")) { *value = ctx->stat_entries; return 0; }
   if (!strcmp(key, "stage_device_inputs")) { *value = ctx->opt_stage_device_inputs; return 0; }
+  if (!strcmp(key, "host_staging")) { *value = ctx->opt_host_staging; return 0; }
   if (!strcmp(key, "segment_len")) { *value = ctx->opt_seg_len; return 0; }
   if (!strcmp(key, "segment_len_used")) { drain_workers(ctx); const gpu_t& d0 = ctx->devs[0]; *value = d0.ws[d0.last_ws].used ? (int64_t)d0.ws[d0.last_ws].plan.seg_len : 0; return 0; }
   if (!strcmp(key, "workset")) { *value = ctx->opt_workset; return 0; }

@@ -68,6 +68,49 @@ def compute_msm_sharded(ctx, d_points, d_scalars, n: int, partials, dist=None, g
     return ctx.finalize(merged, c, W)
 
 
+def distribute_inputs(points, scalars, dist=None, group=None, device="cuda", point_bytes: int = 64, scalar_bytes: int = 32):
+    """Inputs for the window-sharded form arrive ONCE (SURVEY.md 8e "Inputs"; the reference uploads inside the call,
+    cuzk/gpu.ts:33-46): every rank needs all n points and scalars, but rank r uploads only ITS n/D slice over its own PCIe
+    link and one all-gather per buffer assembles the whole on every GPU -- RCCL over xGMI for CUDA tensors (12 MB per rank at
+    n = 2^20, D = 8: each GPU receives 84 MB from seven peers), gloo for CPU tensors (tests, rehearsals).
+
+    points / scalars   the full host buffers (bytes-like) as this rank's process holds them; only the rank's own slice
+                       [rank * ceil(n / D), (rank + 1) * ceil(n / D)) of them is read and uploaded
+    Returns (d_points, d_scalars, n): uint8 tensors on `device` holding the n points / scalars in order."""
+    import warnings
+    import torch
+
+    n = len(scalars) // scalar_bytes
+    assert len(scalars) == n * scalar_bytes and len(points) == n * point_bytes
+    grouped = dist is not None and dist.is_initialized()         # (a group of one rank still runs the collective: the RCCL leg of the tests)
+    world = dist.get_world_size(group) if grouped else 1
+    rank = dist.get_rank(group) if grouped else 0
+    per = (n + world - 1) // world                               # equal contributions: the last slice is padded
+    lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
+    gloo = grouped and dist.get_backend(group) == "gloo"
+    stage = "cpu" if gloo else device
+
+    def mine(buf, unit):
+        t = torch.zeros(per * unit, dtype=torch.uint8, device=stage)
+        if hi > lo:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")              # (a read-only buffer: it is only read)
+                src = torch.frombuffer(memoryview(buf)[lo * unit:hi * unit], dtype=torch.uint8)
+            t[:(hi - lo) * unit].copy_(src, non_blocking=True)
+        return t
+
+    mp, ms = mine(points, point_bytes), mine(scalars, scalar_bytes)
+    if not grouped:
+        return mp[:n * point_bytes].to(device), ms[:n * scalar_bytes].to(device), n
+    fp = torch.empty(world * per * point_bytes, dtype=torch.uint8, device=stage)
+    fs = torch.empty(world * per * scalar_bytes, dtype=torch.uint8, device=stage)
+    dist.all_gather_into_tensor(fp, mp, group=group)
+    dist.all_gather_into_tensor(fs, ms, group=group)
+    if fp.is_cuda:
+        torch.cuda.current_stream().synchronize()
+    return fp[:n * point_bytes].to(device), fs[:n * scalar_bytes].to(device), n
+
+
 def rows_of_batched_msm(gathered, world: int, batch: int, m: int):
     """gathered: the all-gathered rows of a launch sequence that carried `batch` MSMs, a 1-D uint8 CPU tensor laid out
     [rank][MSM][W rows].  Returns MSM m's rows as a contiguous [rank][W rows] tensor -- the layout finalize_gathered takes."""
@@ -115,7 +158,18 @@ class ShardedPipeline:
         self.count = [0] * depth
         self.next_ticket = self.next_collect = 0
 
-    def submit(self, d_points, d_scalars) -> int:
+    def load_host(self, points, scalars):
+        """Distributes HOST buffers to the ranks' GPUs (distribute_inputs: rank r uploads its n / D slice, one all-gather per
+        buffer over RCCL assembles the whole on every GPU) and keeps the result: (d_points, d_scalars) for submit()."""
+        pb, sb = (96, 48) if self.curve == 1 else (64, 32)
+        dp, ds, n = distribute_inputs(points, scalars, self.dist, self.group, "cuda", pb, sb)
+        assert n == self.n, "the pipeline was planned for n = %d points" % self.n
+        self.inputs = (dp, ds)
+        return self.inputs
+
+    def submit(self, d_points=None, d_scalars=None) -> int:
+        if d_points is None:
+            d_points, d_scalars = self.inputs                   # what load_host left on this rank's GPU
         return self.submit_batch([(d_points, d_scalars)])
 
     def submit_batch(self, inputs) -> int:
