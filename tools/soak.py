@@ -30,11 +30,12 @@ while time.time() < t_end:
     for k, v in (("window_bits", rnd.choice([0, 0, 4, 7, 10, 13, 15, 16])), ("signed_digits", rnd.choice([1, 1, 0])),
                  ("segment_len", rnd.choice([0, 0, 64, 1, 7, 500])), ("sort_buckets", rnd.choice([1, 1, 0])), ("host_chunks", rnd.choice([0, 1, 3, 5])),
                  ("graph", rnd.choice([0, 0, 1])), ("profile", rnd.choice([0, 0, 1, 2])), ("prezero", rnd.choice([1, 1, 0])),
-                 ("fuse_prep", rnd.choice([1, 1, 0])), ("packed_sort", rnd.choice([1, 1, 0])), ("fold_pairs", rnd.choice([1, 1, 0]))):
+                 ("fuse_prep", rnd.choice([1, 1, 0])), ("packed_sort", rnd.choice([1, 1, 0])), ("fold_pairs", rnd.choice([1, 1, 0])),
+                 ("host_staging", rnd.choice([0, 0, 1]))):
         ctx.set_option(k, v)
         opts[k] = v
-    mode = rnd.choice(["run", "run", "tickets", "tickets", "shards", "batch", "host_tickets", "host_tickets", "multi"])
-    if mode == "multi":
+    mode = rnd.choice(["run", "run", "tickets", "tickets", "shards", "batch", "host_tickets", "host_tickets", "multi", "multi_tickets", "multi_tickets"])
+    if mode in ("multi", "multi_tickets"):
         ctx = multi_bls if ctx is bls else multi[rnd.choice([2, 3, 4])]
         for k, v in opts.items():
             ctx.set_option(k, v)
@@ -68,6 +69,33 @@ while time.time() < t_end:
         tickets = [ctx.submit(p, s) if n else None for p, s, n in batch]
         got = [None] * len(batch)
         for i in rnd.sample(range(len(batch)), len(batch)):
+            got[i] = ctx.collect(tickets[i]) if tickets[i] is not None else ctx.run(batch[i][0], batch[i][1])
+        if rnd.random() < 0.3:
+            ctx.trim(rnd.choice([0, 1, 4]))
+    elif mode == "multi_tickets":
+        # round 5: whole-MSM tickets on a context of several "devices" -- blocking, asynchronous and device-resident submits mixed,
+        # collected in random order, now and then beside a lone call (point slices / window shards over all devices) and a trim
+        ctx.set_option("graph", 0)
+        ctx.set_option("stage_device_inputs", rnd.choice([0, 1]))
+        keep, tickets = [], []
+        for p, s, n in batch:
+            if not n:
+                tickets.append(None)
+                continue
+            kind = rnd.choice(["submit", "async", "async", "device"])
+            if kind == "device":
+                a = torch.frombuffer(bytearray(p), dtype=torch.uint8).cuda(); b = torch.frombuffer(bytearray(s), dtype=torch.uint8).cuda()
+                torch.cuda.synchronize()
+                keep.append((a, b))
+                tickets.append(ctx.submit_device(a.data_ptr(), b.data_ptr(), n))
+            else:
+                tickets.append((ctx.submit if kind == "submit" else ctx.submit_async)(p, s))
+        got = [None] * len(batch)
+        if rnd.random() < 0.3 and len(batch) < pkg.WORKSETS:
+            assert ctx.run(batch[0][0], batch[0][1]) == exp[0]
+        for i in rnd.sample(range(len(batch)), len(batch)):
+            if tickets[i] is not None and rnd.random() < 0.5:
+                ctx.ticket_wait(tickets[i])
             got[i] = ctx.collect(tickets[i]) if tickets[i] is not None else ctx.run(batch[i][0], batch[i][1])
         if rnd.random() < 0.3:
             ctx.trim(rnd.choice([0, 1, 4]))

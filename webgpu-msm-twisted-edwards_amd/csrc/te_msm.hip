@@ -23,6 +23,9 @@
 #include <mutex>
 #include <condition_variable>
 #include <memory>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include "../../include/te_msm.h"
 #include "host_tail.hpp"
@@ -929,6 +932,30 @@ bool host_memory_is_pinned(const void* p) {
 constexpr size_t TE_RING_SLOT = 2u << 20;      // bytes per slot: 48 DMA calls per 96 MB, ~0.2 ms of enqueue cost
 constexpr int TE_RING_SLOTS = 16;              // 32 MB pinned per work set that stages
 constexpr int TE_STAGERS = 8;                  // crew size: 8 x ~10 GB/s of memcpy against a 52 GB/s link
+// chunk copy of the crew: the destination (a ring slot) is read next by the DMA engine, never by a core -- streaming stores keep it
+// out of the caches and skip the read-for-ownership of every destination line (env TE_MSM_STAGING_COPY=memcpy: plain memcpy, A/B)
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) void copy_streaming_avx2(uint8_t* to, const uint8_t* from, size_t len) {
+  size_t i = 0;
+  if ((reinterpret_cast<uintptr_t>(to) & 31u) == 0) {
+    for (; i + 128 <= len; i += 128) {
+      const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(from + i)), b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(from + i + 32));
+      const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(from + i + 64)), d = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(from + i + 96));
+      _mm256_stream_si256(reinterpret_cast<__m256i*>(to + i), a); _mm256_stream_si256(reinterpret_cast<__m256i*>(to + i + 32), b);
+      _mm256_stream_si256(reinterpret_cast<__m256i*>(to + i + 64), c); _mm256_stream_si256(reinterpret_cast<__m256i*>(to + i + 96), d);
+    }
+    _mm_sfence();
+  }
+  if (i < len) memcpy(to + i, from + i, len - i);
+}
+#endif
+void staging_chunk_copy(uint8_t* to, const uint8_t* from, size_t len) {
+#if defined(__x86_64__)
+  static const bool streaming = [] { const char* e = getenv("TE_MSM_STAGING_COPY"); return !(e && e[0] == 'm') && __builtin_cpu_supports("avx2"); }();
+  if (streaming) { copy_streaming_avx2(to, from, len); return; }
+#endif
+  memcpy(to, from, len);
+}
 int ensure_ring(te_ctx* ctx, workset_t& ws) {
   if (ws.h_ring) return 0;
   HIP_TRY(ctx, hipHostMalloc((void**)&ws.h_ring, TE_RING_SLOT * TE_RING_SLOTS, hipHostMallocDefault));
@@ -967,7 +994,7 @@ int staged_copy(te_ctx* ctx, workset_t& ws, void* dst, const uint8_t* src, size_
     if (turn >= (size_t)TE_RING_SLOTS) HIP_TRY(ctx, hipEventSynchronize(ws.ring_ev[(size_t)slot]));   // the slot's previous chunk has left it
     uint8_t* to = ws.h_ring + (size_t)slot * TE_RING_SLOT; const uint8_t* from = src + off;
     te_sched::worker_t* who = ctx->stagers[turn % TE_STAGERS].get();
-    fifo.push_back({who->post([to, from, len] { memcpy(to, from, len); return 0; }), who, slot, off, len});
+    fifo.push_back({who->post([to, from, len] { staging_chunk_copy(to, from, len); return 0; }), who, slot, off, len});
   }
   while (!fifo.empty()) { if (int rc = flush_one()) return rc; }
   return 0;
