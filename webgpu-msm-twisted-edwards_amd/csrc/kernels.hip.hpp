@@ -213,9 +213,10 @@ __device__ __forceinline__ bool digit_bucket(uint32_t stored, uint32_t half, uin
 
 // Hand-offs between blocks of ONE launch ("the block that finishes last does the next step").  The L2 caches of the eight XCDs
 // are not coherent with each other: a device-scope fence (__threadfence) writes back and invalidates the issuing XCD's whole
-// L2 -- measured at ~60 us per fence inside a streaming kernel (a fused count + plan kernel built that way took 663 us instead
-// of 20).  So the handed-over DATA travels through device-scope atomic accesses (performed at the memory side, past the L2s),
-// the producer only waits for its own accesses to be acknowledged (s_waitcnt), and no cache is flushed.
+// L2 -- measured at ~60 us per fence when every thread of a streaming kernel issues one (a fused count + plan kernel built that
+// way took 663 us instead of 20).  So the handed-over DATA travels through device-scope atomic accesses, every wave only waits
+// for its own accesses to be acknowledged (s_waitcnt), and the fences of the memory model are issued by the ONE thread that
+// counts the block's arrival (handoff_arrive below).
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // every memory access this wave has issued is complete (acknowledged by the memory side for device-scope accesses)
@@ -225,15 +226,19 @@ __device__ __forceinline__ void wait_own_accesses() {
 }
 // The arrival itself, by ONE thread of the block, behind a block barrier that follows wait_own_accesses() in every wave;
 // returns the number of arrivals before this one.  Two builds:
-//   default             a relaxed device-scope atomic.  This stands OUTSIDE the HIP / LLVM memory model: it relies on gfx950
-//                       performing device-scope (sc1) atomic accesses at the memory side and on s_waitcnt covering them.
-//                       Correct on ROCm 7.2 / MI355X by test and soak.
-//   -DTE_HANDOFF_FENCED the memory model's own form (libtemsm_fenced.so, `make fenced`): the arriving thread releases at agent
-//                       scope before the atomic and acquires after it; the other waves of the block are ordered through the
-//                       block barriers on either side (workgroup-scope synchronisation, cumulative into the agent-scope
-//                       release).  The fences write back / invalidate the XCD's L2: measured cost in
-//                       profiles/r05_handoff_fenced_twin.txt.  A runtime or compiler update that changes cache policy is
-//                       A/B-ed against this build through TE_MSM_LIB.
+//   default (round 5)    the memory model's own form: the arriving thread RELEASES at agent scope before the atomic and ACQUIRES
+//                        after it; the other waves of the block are ordered through the block barriers on either side
+//                        (workgroup-scope synchronisation, cumulative into the agent-scope release).  The fences write back /
+//                        invalidate the XCD's L2 (buffer_wbl2 sc1 / buffer_inv sc1) -- but only ONE wave of a block that hands
+//                        over issues them, a few hundred times per MSM: k_l2_local 58.0 against 56.6 us at n = 2^20, the
+//                        pipelined headline 1 037-1 050 against 1 039-1 044 MSM/s on one box, three rounds back to back
+//                        (profiles/r05_handoff_fenced_twin.txt, r05_handoff_fenced_pipelined_ab.txt).  Rounds 1-4 feared
+//                        60 us per fence: that was EVERY block of a streaming kernel fencing (__threadfence in each thread).
+//   -DTE_HANDOFF_RELAXED the form of rounds 3-4 (libtemsm_relaxed.so, `make relaxed`): a relaxed device-scope atomic and nothing
+//                        else.  It stands OUTSIDE the HIP / LLVM memory model -- it relies on gfx950 performing device-scope
+//                        atomic accesses at the memory side and on s_waitcnt covering them -- and was correct on ROCm 7.2 /
+//                        MI355X by test and soak only.  Kept as the A/B twin (TE_MSM_LIB): only the pathological
+//                        many-parts case tells the two apart (its combine 1.10 against 1.49 ms).
 // The two hand-offs of the engine and the tests that reach them (tests/test_gpu_handoffs.py runs them against BOTH builds):
 //   k_l2_local         pieces of a partition with more than TE_L2_CAP entries: bucket_count by global atomics, part_ticket
 //                      counts the pieces, the last one plans the partition -- every canonical scalar set has such partitions in
@@ -243,13 +248,13 @@ __device__ __forceinline__ void wait_own_accesses() {
 //                      the last one sums them with block_sum_points<COHERENT> -- test_giant_buckets, test_many_parts_per_bucket,
 //                      test_witness_like_scalars (bucket 0 of window 0: n / 4 entries)
 __device__ __forceinline__ uint32_t handoff_arrive(uint32_t* counter) {
-#if defined(TE_HANDOFF_FENCED)
+#if defined(TE_HANDOFF_RELAXED)
+  return atomicAdd(counter, 1u);
+#else
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   const uint32_t v = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   return v;
-#else
-  return atomicAdd(counter, 1u);
 #endif
 }
 
