@@ -180,7 +180,9 @@ __global__ void __launch_bounds__(TE_DIG_THREADS) k_digits(batch_ptrs in, uint16
       if (w >= prm.num_windows) { bad |= ((v[0] | v[1]) != 0u); continue; }
       if (w == next) {
         if (k < prm.nw_local) {
+#if !defined(TE_EXP_NO_DIGIT_STORE)      // (timing experiment only, profiles/r05_sort_bytes_experiment.txt: what the digit rows cost k_digits)
           out[(size_t)k * half_stride + pair] = v[0] | (v[1] << 16);
+#endif
 #pragma unroll
           for (int t = 0; t < 2; t++) {
             uint32_t b, neg;
