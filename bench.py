@@ -695,8 +695,8 @@ def main():
                                             "one host thread + PCIe link per device, rows summed in the host tail" % (world, world, (n + world - 1) // world, cb))
                 out["host_buffers_parity"] = "identical to the window-sharded result" if (r_host == result and r1 == result) else "MISMATCH"
                 out["host_buffers_devices"] = list(host_ids)
-            except pkg.MsmError as e:
-                out["host_buffers_error"] = str(e)
+            except Exception as e:                                   # this leg is a side figure: it must never cost the line
+                out["host_buffers_error"] = "%s: %s" % (type(e).__name__, e)
         if cpu_group is not None:
             dist.barrier(group=cpu_group)                         # ranks 1.. wait here, on the host
         elif share:
