@@ -26,6 +26,8 @@ import os
 for ids, staging in (((0,), 0), ((0,), 1), ((0,) * 8, 0), ((0,) * 8, 1)):
     if os.environ.get("TE_H2D_ONLY_STAGED") and not staging:
         continue
+    if os.environ.get("TE_H2D_D1_ONLY") and len(ids) > 1:
+        continue
     with pkg.MsmContext(ids) as c:
         c.set_option("host_staging", staging)
         ref = c.run(pts, sc)
@@ -35,7 +37,7 @@ for ids, staging in (((0,), 0), ((0,), 1), ((0,) * 8, 0), ((0,) * 8, 1)):
         series(tag + ", rotation of 8 copies again", c.run, lambda i: rot[i % 8])
         series(tag + ", a fresh copy per call", c.run, lambda i: (bytes(bytearray(pts)), bytes(bytearray(sc))), 12)
         series(tag + ", same buffers again", c.run, lambda i: (pts, sc), 8)
-for staging in (0, 1):
+for staging in (() if os.environ.get("TE_H2D_D1_ONLY") else (0, 1)):
   with pkg.MsmContext((0,) * 8) as c:
     c.set_option("host_staging", staging)
     print("-- tickets, host_staging = %d" % staging)

@@ -931,7 +931,13 @@ bool host_memory_is_pinned(const void* p) {
 // ring of the work set and travel from there; the call returns when the last chunk has left the caller's buffer.
 constexpr size_t TE_RING_SLOT = 2u << 20;      // bytes per slot: 48 DMA calls per 96 MB, ~0.2 ms of enqueue cost
 constexpr int TE_RING_SLOTS = 16;              // 32 MB pinned per work set that stages
-constexpr int TE_STAGERS = 8;                  // crew size: 8 x ~10 GB/s of memcpy against a 52 GB/s link
+constexpr int TE_STAGERS_MAX = 32;
+// crew size: each thread copies ~5 GB/s into the ring while the DMA engine reads behind it (env TE_MSM_STAGERS, measurements:
+// profiles/r05_host_staging_copy_ab.txt)
+int stager_count() {
+  static const int n = [] { const char* e = getenv("TE_MSM_STAGERS"); int v = e ? atoi(e) : 8; return v < 1 ? 1 : v > TE_STAGERS_MAX ? TE_STAGERS_MAX : v; }();
+  return n;
+}
 // chunk copy of the crew: the destination (a ring slot) is read next by the DMA engine, never by a core -- streaming stores keep it
 // out of the caches and skip the read-for-ownership of every destination line (env TE_MSM_STAGING_COPY=memcpy: plain memcpy, A/B)
 #if defined(__x86_64__)
@@ -970,7 +976,7 @@ int ensure_ring(te_ctx* ctx, workset_t& ws) {
 // context's error lock: the devices' host threads may get here together
 int ensure_stagers(te_ctx* ctx) {
   std::lock_guard<std::mutex> lk(ctx->err_mu);
-  while ((int)ctx->stagers.size() < TE_STAGERS) ctx->stagers.emplace_back(new te_sched::worker_t());
+  while ((int)ctx->stagers.size() < stager_count()) ctx->stagers.emplace_back(new te_sched::worker_t());
   return 0;
 }
 // dst (device) <- src (host), `bytes`, on `stream`, through the set's ring; returns when src has been read completely
@@ -990,10 +996,10 @@ int staged_copy(te_ctx* ctx, workset_t& ws, void* dst, const uint8_t* src, size_
     const size_t len = std::min(TE_RING_SLOT, bytes - off);
     const size_t turn = ws.ring_next++;
     const int slot = (int)(turn % TE_RING_SLOTS);
-    if ((int)fifo.size() >= TE_RING_SLOTS / 2) { if (int rc = flush_one()) return rc; }        // at most half of the ring filling, the other half draining
+    if ((int)fifo.size() >= std::min(stager_count(), TE_RING_SLOTS - 4)) { if (int rc = flush_one()) return rc; }   // one chunk per crew thread filling, the rest of the ring draining
     if (turn >= (size_t)TE_RING_SLOTS) HIP_TRY(ctx, hipEventSynchronize(ws.ring_ev[(size_t)slot]));   // the slot's previous chunk has left it
     uint8_t* to = ws.h_ring + (size_t)slot * TE_RING_SLOT; const uint8_t* from = src + off;
-    te_sched::worker_t* who = ctx->stagers[turn % TE_STAGERS].get();
+    te_sched::worker_t* who = ctx->stagers[turn % (size_t)stager_count()].get();
     fifo.push_back({who->post([to, from, len] { staging_chunk_copy(to, from, len); return 0; }), who, slot, off, len});
   }
   while (!fifo.empty()) { if (int rc = flush_one()) return rc; }
