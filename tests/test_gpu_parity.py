@@ -984,6 +984,14 @@ def test_work_set_streams_are_spread_over_the_hardware_queues(pkg, ora):
         tickets = [c.submit_device(dp.data_ptr(), ds.data_ptr(), n) for _ in range(4)]
         assert all(c.collect(t) == exp for t in tickets)
         assert [c.workset_stream(i) for i in range(pkg.WORKSETS)] == before and all(k == -1 for _, k in before)
+    with pkg.MsmContext((0,)) as c:                                       # round 5: host-buffer tickets never trigger the measurement
+        before = [c.workset_stream(i) for i in range(pkg.WORKSETS)]
+        for t in [c.submit(pts, sc), c.submit_async(pts, sc)]:
+            assert c.collect(t) == exp
+        assert [c.workset_stream(i) for i in range(pkg.WORKSETS)] == before and all(k == -1 for _, k in before)
+        assert c.get_option("streams_final") == 0                         # a later te_msm_submit_device may still re-deal them
+        assert c.collect(c.submit_device(dp.data_ptr(), ds.data_ptr(), n)) == exp
+        assert c.get_option("streams_final") == 1
     del extra
     if accepted == 0:
         pytest.skip("the hardware-queue measurement was not accepted in any of three contexts (its passes disagreed): the spreading property itself was not checked")

@@ -992,6 +992,8 @@ int staged_copy(te_ctx* ctx, workset_t& ws, void* dst, const uint8_t* src, size_
     HIP_TRY(ctx, hipEventRecord(ws.ring_ev[(size_t)p.slot], stream));
     return 0;
   };
+  // whatever happens, no crew thread may still be reading the caller's buffer when this function returns
+  struct drain_t { std::deque<pending_t>& f; ~drain_t() { for (auto& p : f) (void)p.who->wait(p.job); } } drain_on_exit{fifo};
   for (size_t off = 0; off < bytes; off += TE_RING_SLOT) {
     const size_t len = std::min(TE_RING_SLOT, bytes - off);
     const size_t turn = ws.ring_next++;
@@ -1489,7 +1491,8 @@ namespace {
 int take_free_workset(te_ctx* ctx, gpu_t& d, bool probe) {
   if (d.in_flight >= TE_MSM_WORKSETS) return set_err(ctx, TE_MSM_ESTATE, "every work set has an MSM in flight: collect one first");
   if (probe && !d.queues_probed && ctx->opt_queue_probe && d.in_flight == 0) spread_streams_over_queues(d);      // once per device, with nothing of it in flight
-  d.streams_final = true;
+  // the work sets' streams can still be re-dealt by a later te_msm_submit_device as long as the measurement is on and has not run
+  d.streams_final = d.queues_probed || !ctx->opt_queue_probe;
   const int wi = free_workset_index(d);
   if (wi < 0) return set_err(ctx, TE_MSM_ESTATE, "every work set has an MSM in flight: collect one first");
   return wi;
