@@ -715,6 +715,7 @@ def main():
                 out["host_buffers_devices"] = list(host_ids)
             except Exception as e:                                   # this leg is a side figure: it must never cost the line
                 out["host_buffers_error"] = "%s: %s" % (type(e).__name__, e)
+            torch.cuda.set_device(dev)                                # (the C-ABI restores the caller's device itself since round 5; belt and braces)
         if cpu_group is not None:
             dist.barrier(group=cpu_group)                         # ranks 1.. wait here, on the host
         elif share:

@@ -14,6 +14,8 @@
  *
  * All functions return 0 on success or a negative TE_MSM_E* code; te_msm_last_error() gives text.
  * A context is not thread-safe: serialise the calls on one context (the one exception is te_msm_ticket_wait).
+ * Every entry point leaves the calling thread's current HIP device as it found it (hipSetDevice is per-thread state that a
+ * multi-device context has to change while it works).
  * There is NO CPU fallback: without a usable HIP device te_msm_init fails.
  */
 #ifndef TE_MSM_H

@@ -188,6 +188,18 @@ namespace {
 
 int set_err(te_ctx* ctx, int code, const char* msg) { std::lock_guard<std::mutex> lk(ctx->err_mu); ctx->err = msg; return code; }
 
+// The engine selects devices with hipSetDevice, which is state of the CALLING thread: every entry point that may do so puts the
+// caller's device back when it returns.  (A host that shares the thread with another HIP user -- PyTorch in bench.py's rank 0,
+// which opens all N devices in its own process -- would otherwise find its "current device" moved to wherever the last ticket
+// went: tensors on the wrong GPU, collectives on the wrong communicator.)
+struct device_guard {
+  int prev = -1;
+  device_guard() { if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; } }
+  ~device_guard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  device_guard(const device_guard&) = delete;
+  device_guard& operator=(const device_guard&) = delete;
+};
+
 uint32_t ilog2(uint32_t v) { uint32_t l = 0; while ((1u << l) < v) l++; return l; }
 
 int auto_window_bits(uint64_t n) {
@@ -1387,6 +1399,7 @@ int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, boo
 extern "C" {
 
 int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
+  device_guard restore_callers_device;
   if (!out || n_dev < 1 || n_dev > 64) { g_init_error = "te_msm_init: bad arguments"; return TE_MSM_EINVAL; }
   *out = nullptr;
   if (!te_host::tail_selftest() || !te377_host::tail_selftest()) { g_init_error = "te_msm_init: host tail constants self-test failed"; return TE_MSM_ESTATE; }
@@ -1441,6 +1454,7 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
 }
 
 void te_msm_destroy(te_ctx* ctx) {
+  device_guard restore_callers_device;
   if (!ctx) return;
   ctx->workers.clear();                 // joins the per-device host threads (idle between calls)
   ctx->stagers.clear();
@@ -1466,10 +1480,12 @@ const char* te_msm_last_error(const te_ctx* ctx) {
 }
 
 int te_msm_run(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars_le, uint64_t n, uint8_t out_xy_le[64]) {
+  device_guard restore_callers_device;
   return run_common(ctx, points_xy_le, scalars_le, true, n, out_xy_le);
 }
 
 int te_msm_run_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_scalars_le, uint64_t n, uint8_t out_xy_le[64]) {
+  device_guard restore_callers_device;
   return run_common(ctx, d_points_xy_le, d_scalars_le, false, n, out_xy_le);
 }
 
@@ -1521,6 +1537,7 @@ const char* const kNoTicket = "no such ticket in flight (already collected, or n
 }  // namespace
 
 int te_msm_submit_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_scalars_le, uint64_t n, uint64_t* ticket) {
+  device_guard restore_callers_device;
   if (!ctx || !ticket) return TE_MSM_EINVAL;
   if (!d_points_xy_le || !d_scalars_le || n == 0 || n >= (1ull << 31)) return set_err(ctx, TE_MSM_EINVAL, "bad arguments");
   const bool multi = ctx->devs.size() > 1;
@@ -1591,14 +1608,17 @@ void retire_ticket(te_ctx* ctx, gpu_t& d, workset_t& ws) { te_sched::retire(*ctx
 }  // namespace
 
 int te_msm_submit(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars_le, uint64_t n, uint64_t* ticket) {
+  device_guard restore_callers_device;
   return submit_host(ctx, points_xy_le, scalars_le, n, ticket, false);
 }
 
 int te_msm_submit_async(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars_le, uint64_t n, uint64_t* ticket) {
+  device_guard restore_callers_device;
   return submit_host(ctx, points_xy_le, scalars_le, n, ticket, true);
 }
 
 int te_msm_ticket_wait(te_ctx* ctx, uint64_t ticket) {
+  device_guard restore_callers_device;
   if (!ctx) return TE_MSM_EINVAL;
   gpu_t* d = nullptr;
   workset_t* ws = workset_of_ticket(ctx, ticket, &d);
@@ -1618,6 +1638,7 @@ int te_msm_ticket_device(te_ctx* ctx, uint64_t ticket, int* device_index, int* d
 }
 
 int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]) {
+  device_guard restore_callers_device;
   if (!ctx || !out_xy_le) return TE_MSM_EINVAL;
   gpu_t* dp = nullptr;
   workset_t* wsp = workset_of_ticket(ctx, ticket, &dp);
@@ -1642,6 +1663,7 @@ int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]) {
 }
 
 int te_msm_probe_queues(te_ctx* ctx) {
+  device_guard restore_callers_device;
   if (!ctx) return TE_MSM_EINVAL;
   drain_workers(ctx);
   int classes = 0;
@@ -1657,6 +1679,7 @@ int te_msm_probe_queues(te_ctx* ctx) {
 }
 
 int te_msm_trim(te_ctx* ctx, int keep_worksets) {
+  device_guard restore_callers_device;
   if (!ctx || keep_worksets < 0) return TE_MSM_EINVAL;
   drain_workers(ctx);
   int freed = 0;
@@ -1751,6 +1774,7 @@ int te_msm_plan(te_ctx* ctx, uint64_t n, int* window_bits, int* num_windows) {
 }
 
 int te_msm_partial_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_scalars_le, uint64_t n, void* d_partials, void* stream) {
+  device_guard restore_callers_device;
   if (!ctx) return TE_MSM_EINVAL;
   if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_partial_device needs a single-device context");
   if (!d_points_xy_le || !d_scalars_le || !d_partials || n == 0 || n >= (1ull << 31)) return set_err(ctx, TE_MSM_EINVAL, "bad arguments");
@@ -1763,6 +1787,7 @@ int te_msm_partial_device(te_ctx* ctx, const void* d_points_xy_le, const void* d
 
 int te_msm_partial_device_batch(te_ctx* ctx, const void* const* d_points_xy_le, const void* const* d_scalars_le, uint64_t n, int count,
                                 void* d_partials, void* stream) {
+  device_guard restore_callers_device;
   if (!ctx) return TE_MSM_EINVAL;
   if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_partial_device_batch needs a single-device context");
   if (!d_points_xy_le || !d_scalars_le || !d_partials || n == 0 || n >= (1ull << 31) || count < 1 || count > TE_MSM_MAX_BATCH)
@@ -1788,6 +1813,7 @@ int te_msm_workset_stream(te_ctx* ctx, int workset, void** stream, int* hw_queue
 }
 
 int te_msm_partial_wait(te_ctx* ctx, int workset) {
+  device_guard restore_callers_device;
   if (!ctx || workset < 0 || workset >= TE_MSM_WORKSETS) return TE_MSM_EINVAL;
   if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_partial_wait needs a single-device context");
   drain_workers(ctx);
@@ -1801,6 +1827,7 @@ int te_msm_partial_wait(te_ctx* ctx, int workset) {
 }
 
 int te_msm_finalize(te_ctx* ctx, const uint8_t* partials, int window_bits, int num_windows, uint8_t out_xy_le[64]) {
+  device_guard restore_callers_device;
   if (!ctx || !partials || !out_xy_le || window_bits < 2 || window_bits > 16 || num_windows < 1 || num_windows > 128) return TE_MSM_EINVAL;
   gpu_t& d = ctx->devs[0];
   workset_t& ws = d.ws[d.last_ws];
@@ -1929,6 +1956,7 @@ int te_msm_synth_inputs_bls12_377(uint64_t seed, uint64_t n, uint8_t* points_xy_
 }
 
 int64_t te_msm_debug_read(te_ctx* ctx, const char* stage, void* dst, uint64_t cap) {
+  device_guard restore_callers_device;
   if (!ctx || !stage || !dst) return TE_MSM_EINVAL;
   drain_workers(ctx);
   gpu_t& d = ctx->devs[0];
