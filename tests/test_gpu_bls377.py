@@ -272,3 +272,21 @@ def test_full_size_2_20(bls):
     bls.set_option("window_bits", 16)
     assert bls.run(pts, sc) == o.msm(pts, sc, c=16, threads=16)
     bls.set_option("window_bits", 0)
+
+
+def test_tickets_on_a_multi_device_context_bls12_377(pkg):
+    """round 5: whole-MSM tickets of the second curve on four "devices" (96-byte points, 48-byte scalar records, 1 120-byte rows):
+    blocking, asynchronous and staged submits, any collect order, the lone call beside them"""
+    cases = []
+    for seed, n in ((601, 30000), (602, 70001), (603, 257), (604, 9000)):
+        pts, sc = o.gen_points(seed, n), o.gen_scalars(seed, n)
+        cases.append((pts, sc, o.msm(pts, sc, threads=8)))
+    with pkg.MsmContext((0, 0, 0, 0)) as c:
+        c.set_option("curve", pkg.CURVE_BLS12_377_G1)
+        for staging in (0, 1):
+            c.set_option("host_staging", staging)
+            ts = [(c.submit_async if i % 2 else c.submit)(p, s) for i, (p, s, _) in enumerate(cases * 2)]
+            assert sorted(c.ticket_device(t)[0] for t in ts) == [0, 0, 1, 1, 2, 2, 3, 3]
+            assert c.run(cases[1][0], cases[1][1]) == cases[1][2]
+            for i in (5, 0, 7, 2, 1, 6, 3, 4):
+                assert c.collect(ts[i]) == cases[i % 4][2], (staging, i)
