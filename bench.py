@@ -621,18 +621,20 @@ def main():
         # the same boundary with several calls in flight (te_msm_submit: what concurrent compute_msm promises map onto): the upload
         # of MSM k+1 overlaps the device work of MSM k -- bound by the one PCIe link
         ctx.set_option("profile", 0)
-        for t in [ctx.submit(pts, sc) for _ in range(depth)]:
+        infl = pkg.WORKSETS
+        for t in [ctx.submit_async(pts, sc) for _ in range(infl)]:
             assert ctx.collect(t) == result
         t1 = time.perf_counter()
         tk = []
-        for _ in range(12):
-            tk.append(ctx.submit(pts, sc))
-            if len(tk) >= depth:
+        for _ in range(32):
+            tk.append(ctx.submit_async(pts, sc))
+            if len(tk) >= infl:
                 assert ctx.collect(tk.pop(0)) == result
         while tk:
             assert ctx.collect(tk.pop(0)) == result
-        out["host_buffers_in_flight_ms"] = (time.perf_counter() - t1) * 1e3 / 12
-        out["host_buffers_in_flight_note"] = "12 te_msm_submit calls from pageable host buffers, %d in flight, per MSM" % depth
+        out["host_buffers_in_flight_ms"] = (time.perf_counter() - t1) * 1e3 / 32
+        out["host_buffers_in_flight_note"] = ("32 te_msm_submit_async calls from pageable host buffers (what the N-API addon turns concurrent compute_msm promises "
+                                              "into), %d in flight, %d upload threads, per MSM" % (infl, ctx.get_option("upload_threads")))
         ctx.set_option("profile", 1)
         out["sizes"] = {str(args.log2n): {"ms_per_step": ms_per_step, "latency_ms": min(lat), "host_buffers_ms": hb, "window_bits": c,
                                           "core_clock_ghz": stage_ms.get("accumulate_core_clock_ghz")}}

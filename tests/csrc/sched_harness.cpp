@@ -21,6 +21,7 @@
 
 namespace {
 
+constexpr int LANES = 2;         // upload lanes per fake device (the engine: option "upload_threads", 4)
 constexpr int SETS = 3;          // work sets per fake device (the engine has TE_MSM_WORKSETS = 8; fewer here so that capacity waits happen)
 constexpr int WBITS = 4;         // window bits of every fake MSM (64 windows of 8 buckets: the arithmetic runs under the sanitizer; 4 x 64 = 256 bits, so an all-ones scalar leaves a final carry)
 constexpr int NWIN = (256 + WBITS - 1) / WBITS;
@@ -48,6 +49,7 @@ struct fake_ctx {
   std::vector<fake_dev> devs;
   uint64_t next_ticket = 1; int last_dev = -1;
   std::vector<std::unique_ptr<te_sched::worker_t>> workers;
+  std::vector<std::unique_ptr<te_sched::worker_t>> lanes; uint64_t next_lane = 0;     // upload lanes of asynchronous tickets
   std::string err; std::mutex err_mu;
   std::atomic<int> fail_next_upload{0};                          // test hook: the next asynchronous upload fails with FK_EDEVICE
 };
@@ -80,7 +82,8 @@ int fk_init(const int* ids, int n, fake_ctx** out) {
   return 0;
 }
 void fk_destroy(fake_ctx* c) {
-  c->workers.clear();                                            // finishes the uploads that were never collected
+  c->lanes.clear();                                              // finishes the uploads that were never collected
+  c->workers.clear();
   for (auto& d : c->devs) d.stream.reset();                      // ... and the device work behind them
   delete c;
 }
@@ -99,7 +102,7 @@ int fk_submit(fake_ctx* c, const uint8_t* points, const uint8_t* scalars, uint64
   }
   ws.job_err.clear();
   fake_set* wsp = &ws; fake_dev* dp = &d;
-  te_sched::job_ref job = te_sched::worker_of(*c, (size_t)di).post([c, dp, wsp, points, scalars, n]() -> int {
+  te_sched::job_ref job = te_sched::next_lane_of(*c, (size_t)di, LANES).post([c, dp, wsp, points, scalars, n]() -> int {
     const int rc = enqueue_host(c, *dp, *wsp, points, scalars, n);
     if (rc) { std::lock_guard<std::mutex> lk(c->err_mu); wsp->job_err = c->err; }
     return rc;
@@ -111,7 +114,7 @@ int fk_ticket_wait(fake_ctx* c, uint64_t ticket) {
   int di = -1;
   fake_set* ws = te_sched::find_ticket(*c, ticket, &di);
   if (!ws) return set_err(c, FK_ESTATE, "no such ticket in flight");
-  if (const int rc = te_sched::await_job(*c, di, *ws)) return rc;
+  if (const int rc = te_sched::await_job(*ws)) return rc;
   ws->ev_result->wait();
   return 0;
 }
@@ -120,7 +123,7 @@ int fk_collect(fake_ctx* c, uint64_t ticket, uint8_t out[64]) {
   fake_set* wsp = te_sched::find_ticket(*c, ticket, &di);
   if (!wsp) return set_err(c, FK_ESTATE, "no such ticket in flight");
   fake_set& ws = *wsp;
-  if (const int jrc = te_sched::await_job(*c, di, ws)) {
+  if (const int jrc = te_sched::await_job(ws)) {
     te_sched::retire(*c, di, ws);
     return set_err(c, jrc, ws.job_err.empty() ? "the asynchronous submit failed" : ws.job_err.c_str());
   }

@@ -41,6 +41,43 @@ with pkg.MsmContext((0,)) as c:
         r, best, med = timed(go, 7)
         assert all(x == ref for x in r)
         print("  %d te_msm_submit ticket(s) in flight: best %.3f ms, median %.3f ms per MSM" % (k, best / k, med / k))
+    # the same with the upload on the device's host thread (te_msm_submit_async: what the N-API addon uses since round 5)
+    for k in (2, 4, 8):
+        def go_async():
+            ts = [c.submit_async(pts, sc) for _ in range(k)]
+            return [c.collect(t) for t in ts]
+        go_async()
+        r, best, med = timed(go_async, 7)
+        assert all(x == ref for x in r)
+        print("  %d te_msm_submit_async ticket(s) in flight: best %.3f ms, median %.3f ms per MSM" % (k, best / k, med / k))
+    for lanes in (1, 2, 4, 8):
+        c.set_option("upload_threads", lanes)
+        def go_lanes():
+            tk, out = [], []
+            for _ in range(32):
+                tk.append(c.submit_async(pts, sc))
+                if len(tk) >= 8:
+                    out.append(c.collect(tk.pop(0)))
+            while tk:
+                out.append(c.collect(tk.pop(0)))
+            return out
+        go_lanes()
+        r, best, med = timed(go_lanes, 5)
+        assert all(x == ref for x in r)
+        print("  upload_threads = %d: 32 te_msm_submit_async tickets, 8 in flight: best %.3f ms, median %.3f ms per MSM" % (lanes, best / 32, med / 32))
+    c.set_option("upload_threads", 4)
+    def stream_async(total=24, depth=4):
+        tk, out = [], []
+        for _ in range(total):
+            tk.append(c.submit_async(pts, sc))
+            if len(tk) >= depth:
+                out.append(c.collect(tk.pop(0)))
+        while tk:
+            out.append(c.collect(tk.pop(0)))
+        return out
+    r, best, med = timed(stream_async, 5)
+    assert all(x == ref for x in r)
+    print("  24 te_msm_submit_async tickets, 4 in flight, collected as they come: best %.3f ms, median %.3f ms per MSM" % (best / 24, med / 24))
 
 for D in (2, 4, 8):
     with pkg.MsmContext((0,) * D) as c:

@@ -17,9 +17,11 @@
 
 namespace te_sched {
 
-// One unit of work for a device's host thread.  `done` / `rc` are guarded by the worker's mutex.
+// One unit of work for a device's host thread.  `done` / `rc` are guarded by the mutex of the worker that runs it (`owner`).
+class worker_t;
 struct job_t {
   std::function<int()> fn;
+  worker_t* owner = nullptr;     // set by post(): whoever holds the job can wait for it without knowing which thread took it
   int rc = 0;
   bool done = false;
 };
@@ -43,6 +45,7 @@ class worker_t {
   job_ref post(std::function<int()> fn) {
     job_ref j = std::make_shared<job_t>();
     j->fn = std::move(fn);
+    j->owner = this;
     { std::lock_guard<std::mutex> lk(mu_); q_.push_back(j); }
     cv_.notify_all();
     return j;
@@ -111,7 +114,8 @@ inline int pick_device(const int* in_flight, int n_dev, int sets_per_dev, int pr
 //   ctx.devs[i]            devices (random access), each with  int in_flight  and work sets  ws[0 .. sets)  holding a  slot_t slot
 //   ctx.next_ticket        uint64_t, tickets are handed out in order over all devices
 //   ctx.last_dev           int, the device the previous ticket went to
-//   ctx.workers[i]         std::unique_ptr<worker_t>, device i's host thread
+//   ctx.workers[i]         std::unique_ptr<worker_t>, device i's host thread (the lone call's slices and shares)
+//   ctx.lanes, ctx.next_lane   the upload lanes of asynchronous tickets, see next_lane_of
 // te_msm.hip instantiates these with te_ctx / gpu_t / workset_t, tests/csrc/sched_harness.cpp with a stand-in device.
 // Except for find_ticket and await_job -- which only read, with acquire loads, and may run on any thread -- everything here
 // runs under the caller's serialisation of the context.
@@ -143,11 +147,11 @@ template <class Ctx> auto find_ticket(Ctx& ctx, uint64_t ticket, int* dev_index 
     for (auto& ws : ctx.devs[i].ws) if (slot_ticket(ws.slot) == ticket) { if (dev_index) *dev_index = (int)i; return &ws; }
   return nullptr;
 }
-// the enqueue of an asynchronous ticket has run on its device's host thread (any thread); its status
-template <class Ctx, class Set> int await_job(Ctx& ctx, int dev_index, Set& ws) {
+// the enqueue of an asynchronous ticket has run on the host thread that took it (any thread may ask); its status
+template <class Set> int await_job(Set& ws) {
   const job_ref job = ws.slot.job;
   if (!job) return 0;
-  return ctx.workers[(size_t)dev_index]->wait(job);
+  return job->owner->wait(job);
 }
 // the ticket is over (collected, with a result or with an error)
 template <class Ctx, class Set> void retire(Ctx& ctx, int dev_index, Set& ws) {
@@ -160,6 +164,22 @@ template <class Ctx> worker_t& worker_of(Ctx& ctx, size_t i) {
   if (!ctx.workers[i]) ctx.workers[i].reset(new worker_t());
   return *ctx.workers[i];
 }
-template <class Ctx> void drain_workers(Ctx& ctx) { for (auto& w : ctx.workers) if (w) w->drain(); }
+// Upload lanes: the host threads that take ASYNCHRONOUS tickets (upload + enqueue of one whole MSM each), `lanes` per device.
+// One pageable upload keeps its thread inside the runtime while the data is staged; a second thread preparing the next
+// ticket's copy meanwhile keeps the link busy -- on ONE device 2.10 ms per 2^20-point MSM with one upload thread, 1.9-1.8 with
+// four to eight (profiles/r05_upload_lanes.txt).  Tickets of one device may therefore finish their uploads out of submission
+// order; each owns its work set, so nothing depends on the order.   ctx.lanes: std::vector<std::unique_ptr<worker_t>>,
+// ctx.next_lane: a counter.
+template <class Ctx> worker_t& next_lane_of(Ctx& ctx, size_t dev_index, int lanes) {
+  const size_t need = ctx.devs.size() * (size_t)lanes;
+  if (ctx.lanes.size() < need) ctx.lanes.resize(need);
+  const size_t i = dev_index * (size_t)lanes + (size_t)(ctx.next_lane++ % (uint64_t)lanes);
+  if (!ctx.lanes[i]) ctx.lanes[i].reset(new worker_t());
+  return *ctx.lanes[i];
+}
+template <class Ctx> void drain_workers(Ctx& ctx) {
+  for (auto& w : ctx.workers) if (w) w->drain();
+  for (auto& w : ctx.lanes) if (w) w->drain();
+}
 
 }  // namespace te_sched

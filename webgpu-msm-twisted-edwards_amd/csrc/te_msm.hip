@@ -145,6 +145,9 @@ struct te_ctx {
   std::string err;
   std::mutex err_mu;           // the per-device host threads of a multi-device te_msm_run report into the one string
   std::vector<std::unique_ptr<te_sched::worker_t>> workers;   // devs[i]'s host thread (host_sched.hpp); created by the first call that needs them
+  std::vector<std::unique_ptr<te_sched::worker_t>> lanes;     // the upload lanes of asynchronous tickets: opt_upload_threads per device (host_sched.hpp)
+  uint64_t next_lane = 0;
+  int opt_upload_threads = 4;       // option "upload_threads" (env TE_MSM_UPLOAD_THREADS)
   uint64_t next_ticket = 1;         // tickets are handed out in order, over all devices; a ticket lives on the work set whose slot holds it
   int last_dev = -1;                // the device the previous ticket went to (te_sched::pick_device deals idle devices round-robin)
   int opt_host_staging = 0;         // host-buffer uploads through the work sets' own pinned rings (staged_copy) instead of straight from the caller's memory
@@ -1414,6 +1417,7 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
   if (const char* e = getenv("TE_MSM_QUEUE_PROBE")) ctx->opt_queue_probe = e[0] != '0';  // option "queue_probe"
   if (const char* e = getenv("TE_MSM_PACKED")) ctx->opt_packed = e[0] != '0';            // option "packed_sort"
   if (const char* e = getenv("TE_MSM_HOST_STAGING")) ctx->opt_host_staging = e[0] != '0'; // option "host_staging"
+  if (const char* e = getenv("TE_MSM_UPLOAD_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 16) ctx->opt_upload_threads = v; }   // option "upload_threads"
   if (const char* e = getenv("TE_MSM_FOLD_PAIRS")) ctx->opt_fold_pairs = e[0] != '0';    // option "fold_pairs"
   if (const char* e = getenv("TE_MSM_HOST_SPLIT")) {                                     // relative piece weights "w0,w1,..." (experiments)
     const char* q = e;
@@ -1456,6 +1460,7 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
 void te_msm_destroy(te_ctx* ctx) {
   device_guard restore_callers_device;
   if (!ctx) return;
+  ctx->lanes.clear();                   // finishes the uploads of tickets that were never collected, joins the threads
   ctx->workers.clear();                 // joins the per-device host threads (idle between calls)
   ctx->stagers.clear();
   for (auto& d : ctx->devs) {
@@ -1594,7 +1599,7 @@ int submit_host(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars
   // threads first (drain_workers); the plan's window bits and pieces are fixed here.
   ws.job_err.clear();
   workset_t* wsp = &ws; gpu_t* dp = &d;
-  te_sched::job_ref job = worker_of(ctx, (size_t)di).post([ctx, dp, wsp, points_xy_le, scalars_le, n, c, K]() -> int {
+  te_sched::job_ref job = te_sched::next_lane_of(*ctx, (size_t)di, ctx->opt_upload_threads).post([ctx, dp, wsp, points_xy_le, scalars_le, n, c, K]() -> int {
     const int rc = enqueue_host_slice(ctx, *dp, *wsp, points_xy_le, scalars_le, n, c, K, false);
     if (rc) { std::lock_guard<std::mutex> lk(ctx->err_mu); wsp->job_err = ctx->err; }
     return rc;
@@ -1603,7 +1608,7 @@ int submit_host(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars
   return 0;
 }
 // the enqueue of an asynchronous ticket has run (any thread); its status
-int await_job(te_ctx* ctx, gpu_t& d, workset_t& ws) { return te_sched::await_job(*ctx, (int)(&d - ctx->devs.data()), ws); }
+int await_job(te_ctx*, gpu_t&, workset_t& ws) { return te_sched::await_job(ws); }
 void retire_ticket(te_ctx* ctx, gpu_t& d, workset_t& ws) { te_sched::retire(*ctx, (int)(&d - ctx->devs.data()), ws); }
 }  // namespace
 
@@ -1720,6 +1725,7 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   if (!strcmp(key, "fold_pairs")) { ctx->opt_fold_pairs = value ? 1 : 0; return 0; }
   if (!strcmp(key, "stage_device_inputs")) { ctx->opt_stage_device_inputs = value ? 1 : 0; return 0; }
   if (!strcmp(key, "host_staging")) { ctx->opt_host_staging = value ? 1 : 0; return 0; }
+  if (!strcmp(key, "upload_threads")) { if (value < 1 || value > 16) return set_err(ctx, TE_MSM_EINVAL, "upload_threads must be in [1, 16]"); ctx->opt_upload_threads = (int)value; return 0; }
   return set_err(ctx, TE_MSM_EINVAL, "unknown option");
 }
 
@@ -1736,6 +1742,7 @@ int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value) {
   if (!strcmp(key, "entries_accumulated")) { *value = ctx->stat_entries; return 0; }
   if (!strcmp(key, "stage_device_inputs")) { *value = ctx->opt_stage_device_inputs; return 0; }
   if (!strcmp(key, "host_staging")) { *value = ctx->opt_host_staging; return 0; }
+  if (!strcmp(key, "upload_threads")) { *value = ctx->opt_upload_threads; return 0; }
   if (!strcmp(key, "segment_len")) { *value = ctx->opt_seg_len; return 0; }
   if (!strcmp(key, "segment_len_used")) { drain_workers(ctx); const gpu_t& d0 = ctx->devs[0]; *value = d0.ws[d0.last_ws].used ? (int64_t)d0.ws[d0.last_ws].plan.seg_len : 0; return 0; }
   if (!strcmp(key, "workset")) { *value = ctx->opt_workset; return 0; }
