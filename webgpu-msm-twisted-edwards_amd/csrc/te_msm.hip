@@ -1557,20 +1557,30 @@ int te_msm_submit_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_
   const int wi = take_free_workset(ctx, d, true);
   if (wi < 0) return wi;
   workset_t& ws = d.ws[wi];
-  const void *dp = d_points_xy_le, *ds = d_scalars_le;
-  if (multi && (d.device != ctx->devs[(size_t)owner].device || ctx->opt_stage_device_inputs)) {
-    const curve_sizes sz = sizes_of(ctx->opt_curve);
-    if (int rc = ensure_staging(ctx, ws, n * sz.point_in, n * sz.scalar_in)) return rc;
-    if (ws.used) HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ws.ev_done, 0));
-    const int src_dev = ctx->devs[(size_t)owner].device;
-    HIP_TRY(ctx, hipMemcpyPeerAsync(ws.d_in_scalars, d.device, d_scalars_le, src_dev, n * sz.scalar_in, ws.stream));
-    HIP_TRY(ctx, hipMemcpyPeerAsync(ws.d_in_points, d.device, d_points_xy_le, src_dev, n * sz.point_in, ws.stream));
-    ctx->stat_peer_copies += 2; ctx->stat_peer_bytes += (int64_t)(n * (sz.point_in + sz.scalar_in));
-    dp = ws.d_in_points; ds = ws.d_in_scalars;
-  }
-  // a single-device context keeps its window shard (te_msm_set_window_shard); on several devices a ticket is a whole MSM
-  if (int rc = enqueue_partial(ctx, d, ws, dp, ds, n, nullptr, ws.stream, nullptr, 0, false, 1, multi)) return rc;
-  if (int rc = fetch_rows(ctx, ws, ws.stream)) return rc;
+  const bool stage = multi && (d.device != ctx->devs[(size_t)owner].device || ctx->opt_stage_device_inputs);
+  const int src_dev = ctx->devs[(size_t)owner].device;
+  if (stage) { const curve_sizes sz = sizes_of(ctx->opt_curve); ctx->stat_peer_copies += 2; ctx->stat_peer_bytes += (int64_t)(n * (sz.point_in + sz.scalar_in)); }
+  workset_t* wsp = &ws; gpu_t* dvp = &d;
+  // the peer copies (if any), the ~10 launches of the MSM and its read-back
+  auto work = [ctx, dvp, wsp, d_points_xy_le, d_scalars_le, n, stage, src_dev, multi]() -> int {
+    gpu_t& d = *dvp; workset_t& ws = *wsp;
+    HIP_TRY(ctx, hipSetDevice(d.device));
+    const void *dp = d_points_xy_le, *ds = d_scalars_le;
+    if (stage) {
+      const curve_sizes sz = sizes_of(ctx->opt_curve);
+      if (int rc = ensure_staging(ctx, ws, n * sz.point_in, n * sz.scalar_in)) return rc;
+      if (ws.used) HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ws.ev_done, 0));
+      HIP_TRY(ctx, hipMemcpyPeerAsync(ws.d_in_scalars, d.device, d_scalars_le, src_dev, n * sz.scalar_in, ws.stream));
+      HIP_TRY(ctx, hipMemcpyPeerAsync(ws.d_in_points, d.device, d_points_xy_le, src_dev, n * sz.point_in, ws.stream));
+      dp = ws.d_in_points; ds = ws.d_in_scalars;
+    }
+    // a single-device context keeps its window shard (te_msm_set_window_shard); on several devices a ticket is a whole MSM
+    if (int rc = enqueue_partial(ctx, d, ws, dp, ds, n, nullptr, ws.stream, nullptr, 0, false, 1, multi)) return rc;
+    return fetch_rows(ctx, ws, ws.stream);
+  };
+  // (Handing this to a host thread, as te_msm_submit_async does with uploads, was measured: no gain at n = 2^16 .. 2^18, 3-7 %
+  // slower at 2^19 / 2^20 -- the submitting thread is not what bounds small MSMs in flight; profiles/r05_enqueue_async_experiment.txt.)
+  if (int rc = work()) return rc;
   hand_out_ticket(ctx, di, ws, ticket);
   return 0;
 }
@@ -1768,6 +1778,7 @@ int te_msm_set_window_shard(te_ctx* ctx, int first, int step) {
   if (!ctx) return TE_MSM_EINVAL;
   if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "window shards are set automatically for multi-device contexts");
   if (first < 0 || step < 1) return set_err(ctx, TE_MSM_EINVAL, "need first >= 0 and step >= 1");
+  drain_workers(ctx);               // asynchronous enqueues read the shard on the device's host threads
   ctx->devs[0].w_first = first; ctx->devs[0].w_step = step;
   return 0;
 }
