@@ -268,6 +268,14 @@ void test_tickets(const std::vector<msm_case>& cs, int D) {
   std::vector<uint8_t> bad(cs[2].sc); memset(&bad[32 * 3], 0xff, 32);
   CHECK(fk_submit(c, cs[2].pts.data(), bad.data(), cs[2].n, &t1, true) == 0 && fk_submit(c, cs[2].pts.data(), cs[2].sc.data(), cs[2].n, &t2, false) == 0, "submit");
   CHECK(fk_collect(c, t2, out) == 0 && memcmp(out, cs[2].want, 64) == 0 && fk_collect(c, t1, out) == FK_ESCALAR, "error in one ticket only");
+  // a lone call (point slices on the devices' host threads, work sets no ticket owns) beside asynchronous tickets whose uploads
+  // are still running on the lanes
+  {
+    uint64_t tk[4]; uint8_t o2[64];
+    for (int i = 0; i < 4; i++) CHECK(fk_submit(c, cs[(size_t)i].pts.data(), cs[(size_t)i].sc.data(), cs[(size_t)i].n, &tk[i], true) == 0 || D * SETS < 4, "submit beside a lone call");
+    if (D * SETS > 4) CHECK(fk_run(c, cs[4].pts.data(), cs[4].sc.data(), cs[4].n, o2) == 0 && memcmp(o2, cs[4].want, 64) == 0, "lone call beside tickets");
+    for (int i = 0; i < 4; i++) if (te_sched::find_ticket(*c, tk[i])) CHECK(fk_collect(c, tk[i], o2) == 0 && memcmp(o2, cs[(size_t)i].want, 64) == 0, "ticket beside a lone call");
+  }
   // tickets never collected: destroy finishes their uploads first
   CHECK(fk_submit(c, cs[4].pts.data(), cs[4].sc.data(), cs[4].n, &t1, true) == 0, "submit");
   fk_destroy(c);
