@@ -367,7 +367,7 @@ def main():
     # sort are latency-bound), so D MSMs share one (their windows are sorted, accumulated and reduced together)
     batch = 1
     if sharded and pipelined:
-        own = len(range(rank if not rehearse else 0, W, rehearse or world))
+        own = -(-W // (rehearse or world))              # windows of the busiest rank: every rank must arrive at the SAME batch size
         batch = args.batch or max(1, min(pkg.MAX_BATCH, W // max(own, 1)))
         if not args.batch and batch < 4:               # measured (profiles/r02_rehearsal_per_rank_step.txt): pays from D = 4 on
             batch = 1
@@ -433,15 +433,15 @@ def main():
 
     last = 1                                           # MSMs in the last launch sequence (window-sharded batches)
 
-    def sharded_pass(inputs_of):
-        """args.steps window-sharded MSMs, `depth` launch sequences of up to `batch` MSMs in flight: all-gather, read-back and
+    def sharded_pass(inputs_of, pipe=pipe, batch=batch, steps=args.steps):
+        """`steps` window-sharded MSMs, `depth` launch sequences of up to `batch` MSMs in flight: all-gather, read-back and
         host tail of one sequence overlap the device work of the next; returns (seconds, MSMs in the last sequence, result)"""
         res, k = None, 1
         sync()
         t0 = time.perf_counter()
         tickets, sent = [], 0
-        while sent < args.steps:
-            k = min(batch, args.steps - sent)
+        while sent < steps:
+            k = min(batch, steps - sent)
             tickets.append(pipe.submit_batch(inputs_of(k)))
             sent += k
             if len(tickets) >= depth:
@@ -667,6 +667,33 @@ def main():
                                          "core_clock_ghz": sx.stage_ms().get("accumulate_core_clock_ghz")}
             sx.set_option("window_bits", args.window_bits)
             sx.set_option("profile", 1)
+    if pipe is not None and not rehearse and not bls and world > 1 and not args.no_sizes and args.log2n == 20:
+        # the other harness sizes on N GPUs (the north star asks for n = 2^16 .. 2^20 at every GPU count; full_benchmarks.ts:13-15
+        # runs 16..20): short passes, window size chosen by the engine, same sharding and batching rule, every rank's result
+        # compared with the oracle-checked single-GPU engine on that rank's own GPU
+        out["sizes"] = {str(args.log2n): {"ms_per_step": ms_per_step, "window_bits": c, "batch": batch}}
+        ctx.set_option("window_bits", 0)
+        for lg in (16, 17, 18, 19):
+            m = 1 << lg
+            p2, s2 = make_inputs(lg)
+            dp2 = torch.frombuffer(bytearray(p2), dtype=torch.uint8).cuda()
+            ds2 = torch.frombuffer(bytearray(s2), dtype=torch.uint8).cuda()
+            torch.cuda.synchronize()
+            c2, W2 = ctx.plan(m)
+            own2 = -(-W2 // world)                      # (17 windows over 4 ranks: 5 + 4 + 4 + 4 -- the busiest rank decides, for all)
+            b2 = args.batch or max(1, min(pkg.MAX_BATCH, W2 // max(own2, 1)))
+            if not args.batch and b2 < 4:
+                b2 = 1
+            p2pipe = pkg.ShardedPipeline(ctx, m, dist, depth=depth, batch=b2)
+            one = lambda k: [(dp2, ds2)] * k
+            for t in [p2pipe.submit_batch(one(b2)) for _ in range(depth)]:
+                p2pipe.collect_batch(t)
+            el2, _, r2 = sharded_pass(one, p2pipe, b2, 64)
+            with pkg.MsmContext((dev,)) as solo:
+                same2 = solo.run_device(dp2.data_ptr(), ds2.data_ptr(), m) == r2
+            out["sizes"][str(lg)] = {"ms_per_step": el2 * 1e3 / 64, "window_bits": c2, "batch": b2, "parity_this_rank": "identical to the single-GPU result" if same2 else "MISMATCH"}
+            del p2pipe, dp2, ds2
+        ctx.set_option("window_bits", args.window_bits)
     if world > 1 and not rehearse and not bls and not args.no_host_buffers and (share or cpu_group is not None):
         # compute_msm(Buffer, Buffer) on all N GPUs from ONE process: rank 0 opens an n_dev = N context (te_msm_run: point
         # slices, one upload thread and PCIe link per device) while the other ranks wait -- the reference's boundary (host buffers,
