@@ -1130,6 +1130,7 @@ int enqueue_host_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* src_
       stamp("scalars staged", i);
     }
     if (int rc = L.front_scalars()) return rc;                             // digits, sort and schedule run while the piece's points cross PCIe
+    stamp("scalar stages enqueued", i);
     if (int rc = upload(ctx, ws, dpts + lo * sz.point_in, src_points + lo * sz.point_in, m * sz.point_in, ws.copy_stream)) return rc;
     stamp("points staged", i);
     HIP_TRY(ctx, hipEventRecord(evs[i], ws.copy_stream));
@@ -1586,6 +1587,53 @@ int te_msm_submit_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_
 }
 
 namespace {
+// The first times SEVERAL host threads copy to one device at the same moment, the ROCm runtime brings further copy (SDMA)
+// engines online -- each time a pause of ~7 ms for every thread that is copying to that device (they are released together;
+// profiles/r05_point_shard_rehearsal.txt, r05_point_shard_sdma_experiment.txt: ~5 such pauses for eight threads, one for four,
+// once per process).  With upload lanes that would fall into the first few asynchronous tickets of a process; instead the lanes
+// of a device copy 2 MB each in lockstep, twice, before they take their first ticket (15-30 ms the first time in a process,
+// ~1 ms for a later context).  env TE_MSM_WARM_UPLOADS=0 turns it off.
+void warm_upload_lanes(te_ctx* ctx, size_t di) {
+  static std::mutex mu; static uint64_t warmed = 0;           // per process and HIP device (ids < 64)
+  const int dev = ctx->devs[di].device, L = ctx->opt_upload_threads;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev < 64 && ((warmed >> dev) & 1u)) return;
+    if (dev < 64) warmed |= 1ull << dev;
+  }
+  if (const char* e = getenv("TE_MSM_WARM_UPLOADS")) if (e[0] == '0') return;
+  if (L < 2) return;
+  struct gate_t { std::mutex m; std::condition_variable cv; int waiting = 0, round = 0, parties = 0; } gate;
+  gate.parties = L;
+  auto arrive = [&gate]() {
+    std::unique_lock<std::mutex> lk(gate.m);
+    const int r = gate.round;
+    if (++gate.waiting == gate.parties) { gate.waiting = 0; gate.round++; gate.cv.notify_all(); }
+    else gate.cv.wait(lk, [&] { return gate.round != r; });
+  };
+  constexpr size_t SZ = 2u << 20;
+  std::vector<te_sched::job_ref> jobs;
+  std::vector<te_sched::worker_t*> who;
+  for (int l = 0; l < L; l++) {
+    te_sched::worker_t& w = te_sched::next_lane_of(*ctx, di, L);
+    who.push_back(&w);
+    jobs.push_back(w.post([dev, &arrive]() -> int {
+      hipStream_t st = nullptr; void* dbuf = nullptr;
+      std::vector<uint8_t> h(SZ, 1);
+      const bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipMalloc(&dbuf, SZ) == hipSuccess;
+      for (int r = 0; r < 2; r++) {
+        arrive();                                             // every lane reaches the gate, whatever happened to its allocations
+        if (ok) { (void)hipMemcpyAsync(dbuf, h.data(), SZ, hipMemcpyHostToDevice, st); (void)hipStreamSynchronize(st); }
+      }
+      if (dbuf) (void)hipFree(dbuf);
+      if (st) (void)hipStreamDestroy(st);
+      (void)hipGetLastError();
+      return 0;
+    }));
+  }
+  for (size_t i = 0; i < jobs.size(); i++) (void)who[i]->wait(jobs[i]);
+}
+
 int submit_host(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars_le, uint64_t n, uint64_t* ticket, bool async) {
   if (!ctx || !ticket) return TE_MSM_EINVAL;
   if (!points_xy_le || !scalars_le || n == 0 || n >= (1ull << 31)) return set_err(ctx, TE_MSM_EINVAL, "bad arguments");
@@ -1609,6 +1657,7 @@ int submit_host(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars
   // threads first (drain_workers); the plan's window bits and pieces are fixed here.
   ws.job_err.clear();
   workset_t* wsp = &ws; gpu_t* dp = &d;
+  warm_upload_lanes(ctx, (size_t)di);                // (once per process and device)
   te_sched::job_ref job = te_sched::next_lane_of(*ctx, (size_t)di, ctx->opt_upload_threads).post([ctx, dp, wsp, points_xy_le, scalars_le, n, c, K]() -> int {
     const int rc = enqueue_host_slice(ctx, *dp, *wsp, points_xy_le, scalars_le, n, c, K, false);
     if (rc) { std::lock_guard<std::mutex> lk(ctx->err_mu); wsp->job_err = ctx->err; }
