@@ -1591,20 +1591,25 @@ namespace {
 // engines online -- each time a pause of ~7 ms for every thread that is copying to that device (they are released together;
 // profiles/r05_point_shard_rehearsal.txt, r05_point_shard_sdma_experiment.txt: ~5 such pauses for eight threads, one for four,
 // once per process).  With upload lanes that would fall into the first few asynchronous tickets of a process; instead the lanes
-// of a device copy 2 MB each in lockstep, twice, before they take their first ticket (15-30 ms the first time in a process,
-// ~1 ms for a later context).  env TE_MSM_WARM_UPLOADS=0 turns it off.
-void warm_upload_lanes(te_ctx* ctx, size_t di) {
+// of every device of the context copy 2 MB each in lockstep, twice, before the first asynchronous ticket is taken (15-30 ms the
+// first time in a process, ~1 ms for a later context).  env TE_MSM_WARM_UPLOADS=0 turns it off.
+void warm_upload_lanes(te_ctx* ctx) {
   static std::mutex mu; static uint64_t warmed = 0;           // per process and HIP device (ids < 64)
-  const int dev = ctx->devs[di].device, L = ctx->opt_upload_threads;
+  const int L = ctx->opt_upload_threads;
+  std::vector<size_t> todo;                                   // the context's devices whose lanes have not copied in lockstep yet: all of them at once
   {
     std::lock_guard<std::mutex> lk(mu);
-    if (dev < 64 && ((warmed >> dev) & 1u)) return;
-    if (dev < 64) warmed |= 1ull << dev;
+    for (size_t di = 0; di < ctx->devs.size(); di++) {
+      const int dev = ctx->devs[di].device;
+      if (dev < 64 && ((warmed >> dev) & 1u)) continue;
+      if (dev < 64) warmed |= 1ull << dev;
+      todo.push_back(di);
+    }
   }
   if (const char* e = getenv("TE_MSM_WARM_UPLOADS")) if (e[0] == '0') return;
-  if (L < 2) return;
+  if (L < 2 || todo.empty()) return;
   struct gate_t { std::mutex m; std::condition_variable cv; int waiting = 0, round = 0, parties = 0; } gate;
-  gate.parties = L;
+  gate.parties = L * (int)todo.size();
   auto arrive = [&gate]() {
     std::unique_lock<std::mutex> lk(gate.m);
     const int r = gate.round;
@@ -1614,22 +1619,25 @@ void warm_upload_lanes(te_ctx* ctx, size_t di) {
   constexpr size_t SZ = 2u << 20;
   std::vector<te_sched::job_ref> jobs;
   std::vector<te_sched::worker_t*> who;
-  for (int l = 0; l < L; l++) {
-    te_sched::worker_t& w = te_sched::next_lane_of(*ctx, di, L);
-    who.push_back(&w);
-    jobs.push_back(w.post([dev, &arrive]() -> int {
-      hipStream_t st = nullptr; void* dbuf = nullptr;
-      std::vector<uint8_t> h(SZ, 1);
-      const bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipMalloc(&dbuf, SZ) == hipSuccess;
-      for (int r = 0; r < 2; r++) {
-        arrive();                                             // every lane reaches the gate, whatever happened to its allocations
-        if (ok) { (void)hipMemcpyAsync(dbuf, h.data(), SZ, hipMemcpyHostToDevice, st); (void)hipStreamSynchronize(st); }
-      }
-      if (dbuf) (void)hipFree(dbuf);
-      if (st) (void)hipStreamDestroy(st);
-      (void)hipGetLastError();
-      return 0;
-    }));
+  for (size_t di : todo) {
+    const int dev = ctx->devs[di].device;
+    for (int l = 0; l < L; l++) {
+      te_sched::worker_t& w = te_sched::next_lane_of(*ctx, di, L);
+      who.push_back(&w);
+      jobs.push_back(w.post([dev, &arrive]() -> int {
+        hipStream_t st = nullptr; void* dbuf = nullptr;
+        std::vector<uint8_t> h(SZ, 1);
+        const bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipMalloc(&dbuf, SZ) == hipSuccess;
+        for (int r = 0; r < 2; r++) {
+          arrive();                                           // every lane reaches the gate, whatever happened to its allocations
+          if (ok) { (void)hipMemcpyAsync(dbuf, h.data(), SZ, hipMemcpyHostToDevice, st); (void)hipStreamSynchronize(st); }
+        }
+        if (dbuf) (void)hipFree(dbuf);
+        if (st) (void)hipStreamDestroy(st);
+        (void)hipGetLastError();
+        return 0;
+      }));
+    }
   }
   for (size_t i = 0; i < jobs.size(); i++) (void)who[i]->wait(jobs[i]);
 }
@@ -1657,7 +1665,7 @@ int submit_host(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars
   // threads first (drain_workers); the plan's window bits and pieces are fixed here.
   ws.job_err.clear();
   workset_t* wsp = &ws; gpu_t* dp = &d;
-  warm_upload_lanes(ctx, (size_t)di);                // (once per process and device)
+  warm_upload_lanes(ctx);                            // (once per process and device: all of the context's devices together)
   te_sched::job_ref job = te_sched::next_lane_of(*ctx, (size_t)di, ctx->opt_upload_threads).post([ctx, dp, wsp, points_xy_le, scalars_le, n, c, K]() -> int {
     const int rc = enqueue_host_slice(ctx, *dp, *wsp, points_xy_le, scalars_le, n, c, K, false);
     if (rc) { std::lock_guard<std::mutex> lk(ctx->err_mu); wsp->job_err = ctx->err; }
