@@ -624,17 +624,21 @@ def main():
         infl = pkg.WORKSETS
         for t in [ctx.submit_async(pts, sc) for _ in range(infl)]:
             assert ctx.collect(t) == result
-        t1 = time.perf_counter()
-        tk = []
-        for _ in range(32):
-            tk.append(ctx.submit_async(pts, sc))
-            if len(tk) >= infl:
+        in_flight_passes = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            tk = []
+            for _ in range(32):
+                tk.append(ctx.submit_async(pts, sc))
+                if len(tk) >= infl:
+                    assert ctx.collect(tk.pop(0)) == result
+            while tk:
                 assert ctx.collect(tk.pop(0)) == result
-        while tk:
-            assert ctx.collect(tk.pop(0)) == result
-        out["host_buffers_in_flight_ms"] = (time.perf_counter() - t1) * 1e3 / 32
-        out["host_buffers_in_flight_note"] = ("32 te_msm_submit_async calls from pageable host buffers (what the N-API addon turns concurrent compute_msm promises "
-                                              "into), %d in flight, %d upload threads, per MSM" % (infl, ctx.get_option("upload_threads")))
+            in_flight_passes.append((time.perf_counter() - t1) * 1e3 / 32)
+        out["host_buffers_in_flight_ms"] = min(in_flight_passes)
+        out["host_buffers_in_flight_note"] = ("best of 3 passes of 32 te_msm_submit_async calls from pageable host buffers (what the N-API addon turns concurrent "
+                                              "compute_msm promises into), %d in flight, %d upload threads, per MSM; passes: %s" % (
+                                                  infl, ctx.get_option("upload_threads"), " ".join("%.3f" % x for x in in_flight_passes)))
         ctx.set_option("profile", 1)
         out["sizes"] = {str(args.log2n): {"ms_per_step": ms_per_step, "latency_ms": min(lat), "host_buffers_ms": hb, "window_bits": c,
                                           "core_clock_ghz": stage_ms.get("accumulate_core_clock_ghz")}}
