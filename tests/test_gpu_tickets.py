@@ -83,7 +83,7 @@ def test_tickets_on_a_multi_device_context(pkg, model, ora, wasm_golden, ids):
         assert c.run(pts, sc) == want
 
 
-@pytest.mark.parametrize("ids", [(0, 0), (0,) * 8])
+@pytest.mark.parametrize("ids", [(0, 0), (0, 0, 0, 0), (0,) * 8])
 def test_tickets_against_the_reference_outputs(pkg, model, wasm_golden, ids):
     """tickets on D devices against the points the reference's own CPU MSM (Aleo WASM) returned: every golden up to 2^16 in
     flight together, then the headline size n = 2^20 on every device at once"""
