@@ -161,6 +161,14 @@ def test_wasm_golden_cases(ctx, wasm_golden, model):
             ctx.set_option("signed_digits", 1)
             ctx.set_option("window_bits", 0)
             del dp, ds
+        elif g["n"] <= 4096:
+            # round 5: the two plans whose window count changed (17 x 15 bits, 51 x 5 bits: ceil(255 / c) for signed digits) against
+            # the reference's own outputs, edge scalars (0, 1, p - 1, ...) included
+            for c in (15, 5):
+                ctx.set_option("window_bits", c)
+                assert ctx.plan(g["n"]) == (c, -(-255 // c))
+                assert model.xy_from_bytes(ctx.run(pts, sc)) == want, (g["name"], c)
+            ctx.set_option("window_bits", 0)
 
 
 @pytest.mark.parametrize("c", [4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
