@@ -48,6 +48,10 @@ CASES = [  # (name, seed, n, mode)
     # SURVEY 8f rank 3, skewed scalars as a prover feeds them: a quarter zeros, a quarter ones, a quarter small values, the rest uniform
     ("witness_n4096", 0x5EED1001, 4096, "witness"),
     ("witness_n65536", 0x5EED0010003, 65536, "witness"),
+    # round 5: edge scalars (0, 1, p - 1, l, l - 1, 2^k boundaries, then uniform ones) at a size the engine runs with its 15-bit plan --
+    # 17 windows since round 5 (scalars below p < 2^253 need no 18th)
+    ("edge_n4096", 0x5EED1002, 4096, "edge"),
+    ("edge_n65536", 0x5EED0010004, 65536, "edge"),
 ]
 
 
