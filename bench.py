@@ -593,6 +593,12 @@ def main():
         dist.all_gather(kms, km)
         out["per_rank_kernel_ms"] = [float(x.item()) for x in kms]
 
+    def size_rate(entry, m, cbits, Wn):
+        """MSM/s and the whole MSM's algorithmic bytes (SURVEY 8d, W * n gathered points) over 8 TB/s for a `sizes` entry"""
+        whole_m, _ = algorithmic_bytes(m, Wn, 1 << (cbits - 1 if args.digits == "signed" else cbits), bls)
+        entry["msm_per_s"] = 1e3 / entry["ms_per_step"]
+        entry["msm_algorithmic_hbm_frac"] = whole_m / (entry["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+
     def host_buffer_ms(cx, p, s, reps=3, all_times=None):
         """one te_msm_run from pageable host buffers, default options (profile 0: the chunked-upload path of te_msm_run)"""
         prof = cx.get_option("profile")
@@ -642,6 +648,7 @@ def main():
         ctx.set_option("profile", 1)
         out["sizes"] = {str(args.log2n): {"ms_per_step": ms_per_step, "latency_ms": min(lat), "host_buffers_ms": hb, "window_bits": c,
                                           "core_clock_ghz": stage_ms.get("accumulate_core_clock_ghz")}}
+        size_rate(out["sizes"][str(args.log2n)], n, c, W)
         if not args.no_sizes and not bls and args.log2n == 20:
             # the other harness sizes (full_benchmarks.ts:13-15), short runs, window size chosen by the engine, on the same
             # context (its work sets own the buffers already)
@@ -669,6 +676,7 @@ def main():
                 assert sx.run_device(dp2.data_ptr(), ds2.data_ptr(), m) == ref
                 out["sizes"][str(lg)] = {"ms_per_step": el * 1e3 / 40, "latency_ms": min(l2), "host_buffers_ms": hb2, "window_bits": sx.plan(m)[0],
                                          "core_clock_ghz": sx.stage_ms().get("accumulate_core_clock_ghz")}
+                size_rate(out["sizes"][str(lg)], m, *sx.plan(m))
             sx.set_option("window_bits", args.window_bits)
             sx.set_option("profile", 1)
     if pipe is not None and not rehearse and not bls and world > 1 and not args.no_sizes and args.log2n == 20:
@@ -676,6 +684,7 @@ def main():
         # runs 16..20): short passes, window size chosen by the engine, same sharding and batching rule, every rank's result
         # compared with the oracle-checked single-GPU engine on that rank's own GPU
         out["sizes"] = {str(args.log2n): {"ms_per_step": ms_per_step, "window_bits": c, "batch": batch}}
+        size_rate(out["sizes"][str(args.log2n)], n, c, W)
         ctx.set_option("window_bits", 0)
         for lg in (16, 17, 18, 19):
             m = 1 << lg
@@ -696,6 +705,7 @@ def main():
             with pkg.MsmContext((dev,)) as solo:
                 same2 = solo.run_device(dp2.data_ptr(), ds2.data_ptr(), m) == r2
             out["sizes"][str(lg)] = {"ms_per_step": el2 * 1e3 / 64, "window_bits": c2, "batch": b2, "parity_this_rank": "identical to the single-GPU result" if same2 else "MISMATCH"}
+            size_rate(out["sizes"][str(lg)], m, c2, W2)
             del p2pipe, dp2, ds2
         ctx.set_option("window_bits", args.window_bits)
     if world > 1 and not rehearse and not bls and not args.no_host_buffers and (share or cpu_group is not None):
