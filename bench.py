@@ -8,8 +8,9 @@ or, from four ranks on, as many MSMs as there are ranks (te_msm_partial_device_b
 host tail ("scaling": "strong").
 
     python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus N --steps K --warmup W          # no launcher: bench.py starts its N ranks itself (launch_ranks below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W            # under a launcher: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env
 
 One JSON line on rank 0.  `value` / `ms_per_step` = pipelined throughput with inputs resident in HBM; `latency_ms` =
 one synchronous MSM from resident inputs; `host_buffers_ms` = one te_msm_run from pageable host buffers (what the
@@ -23,7 +24,11 @@ import re
 import importlib
 import json
 import os
+import signal
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -218,6 +223,76 @@ def side_config(pkg, dev, name, curve, digits, log2n, depth, threads, steps, exp
     return out, expect == result
 
 
+def launch_ranks(n, cmd, timeout=None, env=None):
+    """`python bench.py --gpus N` WITHOUT a launcher: starts N fresh child processes of `cmd` (one rank per GPU) with RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set -- plain subprocess.Popen from a process that has not imported
+    torch nor touched HIP (never an exec of a process that has) --, relays rank 0's stdout (the JSON line) to ours and the other
+    ranks' output to stderr, and returns the exit code: 0 when every rank returned 0, else the first non-zero code, after the
+    remaining ranks have been terminated (a rank that died would otherwise leave the others in a collective until their own
+    timeout).  Every child is its own process group: what it started goes with it."""
+    timeout = float(os.environ.get("TE_BENCH_LAUNCH_TIMEOUT", "3000")) if timeout is None else timeout
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:          # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs, pumps = [], []
+    for r in range(n):
+        e = dict(os.environ if env is None else env)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                  "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": e.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        p = subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE, stderr=None, start_new_session=True, text=True, bufsize=1)
+        procs.append(p)
+
+        def pump(p=p, r=r):
+            for line in p.stdout:
+                if r == 0:
+                    sys.stdout.write(line); sys.stdout.flush()
+                else:
+                    sys.stderr.write("[rank %d] %s" % (r, line)); sys.stderr.flush()
+        t = threading.Thread(target=pump, daemon=True)
+        t.start()
+        pumps.append(t)
+
+    def stop_all():
+        for q in procs:
+            if q.poll() is None:
+                try:
+                    os.killpg(q.pid, signal.SIGTERM)
+                except OSError:
+                    pass
+        t_end = time.time() + 5.0
+        for q in procs:
+            while q.poll() is None and time.time() < t_end:
+                time.sleep(0.05)
+            if q.poll() is None:
+                try:
+                    os.killpg(q.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                q.wait()
+
+    rc, t0 = 0, time.time()
+    try:
+        while True:
+            codes = [q.poll() for q in procs]
+            failed = [(i, c) for i, c in enumerate(codes) if c not in (None, 0)]
+            if failed:
+                rc = failed[0][1] if failed[0][1] > 0 else 128 - failed[0][1]         # a signal -N reads as 128 + N
+                sys.stderr.write("bench.py: rank %d exited with %d: stopping the other ranks\n" % failed[0])
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() - t0 > timeout:
+                rc = 124
+                sys.stderr.write("bench.py: the ranks did not finish within %.0f s: stopping them\n" % timeout)
+                break
+            time.sleep(0.05)
+    finally:
+        stop_all()
+        for t in pumps:
+            t.join(timeout=2.0)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -247,14 +322,19 @@ def main():
     ap.add_argument("--bases", choices=("shared", "distinct"), default="shared",
                     help="window-sharded batches: every MSM of a batch names the SAME point buffer (a prover's batch over one SRS: the "
                          "engine converts it once per launch sequence) or each its own copy")
-    ap.add_argument("--inputs", choices=("resident", "host"), default="resident",
-                    help="window-sharded runs: resident = every rank synthesises the full inputs on its GPU (untimed); host = the inputs are "
-                         "distributed first -- rank r uploads its n/D slice, one all-gather per buffer over RCCL assembles the whole on every GPU "
-                         "(ShardedPipeline.load_host) -- timed separately as input_distribution_ms; the timed steps then run on those buffers")
+    ap.add_argument("--inputs", choices=("resident", "host"), default=None,
+                    help="window-sharded runs: host (the default there) = the inputs are distributed first -- rank r uploads its n/D slice, one "
+                         "all-gather per buffer over RCCL assembles the whole on every GPU (ShardedPipeline.load_host) -- timed separately as "
+                         "input_distribution_ms; the timed steps then run on those buffers (should the distribution fail, the run falls back to "
+                         "resident inputs and says so: input_distribution_error); resident = every rank synthesises the full inputs on its GPU (untimed)")
     ap.add_argument("--no-pipeline", action="store_true", help="N=1: await every MSM before submitting the next (latency mode)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--repeats", type=int, default=3, help="timed passes of --steps steps each; value = the median pass")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("TE_BENCH_FORCE_DIST") != "1":
+        # no launcher: start the N ranks ourselves -- BEFORE torch is imported or HIP is touched in this process
+        raise SystemExit(launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -375,18 +455,38 @@ def main():
             depth = 4
     pipe = pkg.ShardedPipeline(ctx, n, dist, depth=depth, batch=batch) if (sharded and pipelined) else None
     distribution_ms = None
-    if pipe is not None and args.inputs == "host" and not bls:
-        # SURVEY 8e "Inputs": the full inputs reach every GPU once -- each rank's own PCIe link carries n / D points, xGMI the rest
+    distribution_error = None
+    inputs_mode = args.inputs or ("host" if (world > 1 and not rehearse) else "resident")
+    if pipe is not None and inputs_mode == "host" and not bls:
+        # SURVEY 8e "Inputs": the full inputs reach every GPU once -- each rank's own PCIe link carries n / D points, xGMI the rest.
+        # The default of an N > 1 run; guarded: should the distribution fail on any rank, EVERY rank falls back to the inputs it
+        # synthesised itself (the timed steps do not depend on it) and the line says so
+        got = None
         ts = []
-        for _ in range(3):
-            dist.barrier(); torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            d_pts, d_sc = pipe.load_host(pts, sc)
-            torch.cuda.synchronize()
-            tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda" if dist.get_backend() != "gloo" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            ts.append(float(tt.item()) * 1e3)
-        distribution_ms = min(ts)
+        try:
+            for _ in range(3):
+                dist.barrier(); torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                got = pipe.load_host(pts, sc)
+                torch.cuda.synchronize()
+                tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda" if dist.get_backend() != "gloo" else "cpu")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                ts.append(float(tt.item()) * 1e3)
+            ok_here = bool(torch.equal(got[0], d_pts) and torch.equal(got[1], d_sc))
+            if not ok_here:
+                distribution_error = "the assembled buffers differ from the inputs"
+        except Exception as e:
+            ok_here = False
+            distribution_error = "%s: %s" % (type(e).__name__, e)
+        flag = torch.tensor([1 if ok_here else 0], dtype=torch.int32, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            d_pts, d_sc = got
+            distribution_ms = min(ts)
+        else:
+            distribution_error = distribution_error or "the distribution failed on another rank"
+            inputs_mode = "resident (fallback)"
+        del got
     # the point buffers the MSMs of one batch name: one shared buffer, or a copy per MSM (same bytes, distinct addresses)
     base_copies = [d_pts] + ([d_pts.clone() for _ in range(batch - 1)] if (args.bases == "distinct" and batch > 1) else [])
 
@@ -558,7 +658,10 @@ def main():
         "stage_ms_untimed_pass": {k: v for k, v in stage_ms.items() if not k.endswith("_ghz")},
         "result_x": str(int.from_bytes(result[:32], "little")),
     }
-    if pipe is not None and distribution_ms is None and not bls and world > 1:
+    if distribution_error:
+        out["input_distribution_error"] = distribution_error
+    out["inputs"] = inputs_mode
+    if pipe is not None and distribution_ms is None and not distribution_error and not bls and world > 1:
         # resident inputs (the default): the distribution is still measured, as a side figure behind the timed region -- guarded,
         # it must never cost the line -- and its result compared with the buffers the steps ran on
         try:

@@ -132,6 +132,44 @@ int te_msm_ticket_wait(te_ctx* ctx, uint64_t ticket);
 /* Where a ticket in flight runs: index into the context's device list and the HIP device id there (either may be NULL). */
 int te_msm_ticket_device(te_ctx* ctx, uint64_t ticket, int* device_index, int* device_id);
 
+/* ---- resident bases: points bound once, scalars per call ------------------------------------------------------------------
+ * The reference's harness hands the SAME bufferPoints to compute_msm for every run of a size (ui/AllBenchmarks.tsx:213-222,
+ * submission/miscellaneous/full_benchmarks.ts:63-68,100-105: one buffer, six calls), and a prover runs every MSM over one
+ * SRS; te_msm_run re-uploads 64 of its 96 bytes per point and converts the points again on every call.  A bound point set
+ * pays that once: te_msm_bind_points uploads the points, converts them to records ON EVERY DEVICE of the context and keeps
+ * only the records (128 bytes per point; BLS12-377: 168 bytes, see below); the MSMs over it take scalars alone -- 32 of 96
+ * bytes over PCIe, no conversion.  compute_msm's signature (submission.ts:73-78) is untouched: the N-API addon offers
+ * setBases(buffer) as an opt-in, after which compute_msm(thatBuffer, scalars) takes this path.
+ *   The curve is the one selected at bind time (option "curve"); the MSMs must run under the same curve (TE_MSM_EINVAL
+ *   otherwise).  Window bits, digit form, segment length follow the options at the time of each MSM, as for te_msm_run.
+ *   BLS12-377 G1: because the conversion is paid once, the bound records are AFFINE -- one inversion per point at bind time
+ *   (Montgomery's trick, a fixed Fermat chain per eight points) -- 168-byte records and 7 field products per accumulated
+ *   point instead of 224 bytes and 8 (option "bind_affine" = 0 keeps the projective records: A/B measurements).  Results are
+ *   identical either way.
+ *   A bound set holds device memory until te_msm_release_points or te_msm_destroy (option "bases_bytes" reports it); it may be
+ *   released only when no ticket that uses it is in flight (TE_MSM_ESTATE).  The caller's point buffer is not retained.
+ * te_msm_bind_points_device: the same from points already resident on a device of the context. */
+typedef struct te_bases te_bases;
+int te_msm_bind_points(te_ctx* ctx, const uint8_t* points_xy_le, uint64_t n, te_bases** out);
+int te_msm_bind_points_device(te_ctx* ctx, const void* d_points_xy_le, uint64_t n, te_bases** out);
+int te_msm_release_points(te_ctx* ctx, te_bases* bases);
+/* number of points of a bound set (0 for NULL) */
+uint64_t te_msm_bases_count(const te_bases* bases);
+/* compute_msm over a bound set: scalars_le holds te_msm_bases_count(bases) scalars (host memory, the wire format of te_msm_run).
+ * One device: the scalars are uploaded and processed in pieces (option "host_chunks"; piece i + 1 crosses PCIe while piece i
+ * is sorted and accumulated onto the same buckets).  Several devices: every device takes a slice of the scalars over its own
+ * link and the matching slice of its copy of the records (the point shards of te_msm_run without the points). */
+int te_msm_run_scalars(te_ctx* ctx, te_bases* bases, const uint8_t* scalars_le, uint8_t out_xy_le[64]);
+/* the same with the scalars resident on a device of the context (te_msm_run_device without the points) */
+int te_msm_run_scalars_device(te_ctx* ctx, te_bases* bases, const void* d_scalars_le, uint8_t out_xy_le[64]);
+/* Tickets over a bound set (te_msm_ticket_wait / te_msm_collect as for every ticket; the ticket goes to the device with the
+ * fewest in flight, every device holds the records).  te_msm_submit_scalars is ASYNCHRONOUS like te_msm_submit_async: it
+ * returns at once, the upload runs on one of the device's upload lanes, and scalars_le must stay valid and unchanged until
+ * te_msm_ticket_wait or te_msm_collect has returned for the ticket.  With MSMs in flight the 32 bytes per point of one MSM cross
+ * PCIe (0.6 ms at n = 2^20) under the device work of the others (1.0 ms): the boundary stops being the link. */
+int te_msm_submit_scalars(te_ctx* ctx, te_bases* bases, const uint8_t* scalars_le, uint64_t* ticket);
+int te_msm_submit_scalars_device(te_ctx* ctx, te_bases* bases, const void* d_scalars_le, uint64_t* ticket);
+
 /* Options (the reference hard-codes these: chunk_size submission.ts:80, dispatch table :109-142).
  *   "window_bits"   c in [4,16]; 0 = choose from n (default)
  *   "signed_digits" 1 = signed window digits, 2^(c-1) buckets per window (default; the reference's shipped behaviour,
@@ -167,10 +205,15 @@ int te_msm_ticket_device(te_ctx* ctx, uint64_t ticket, int* device_index, int* d
  *                   (until round 4 they did: 16 ms at the first submit).
  *   "workset"       which of the TE_MSM_WORKSETS device work sets te_msm_run* / te_msm_partial_device use (default 0)
  *   "stage_device_inputs"  see te_msm_submit_device (default 0)
+ *   "bind_affine"   1 (default) = te_msm_bind_points converts BLS12-377 points to AFFINE records (one inversion per point, once);
+ *                   0 = keeps the projective records of the per-call conversion (A/B measurements).  Read at bind time.
+ *   "scalar_chunks" te_msm_run_scalars / te_msm_submit_scalars: pieces the scalars of a bound point set are uploaded and processed
+ *                   in; 0 = from n (default), 1 = whole.  The result does not depend on it.
  *   read-only:      "num_devices", "segment_len_used", "peer_copies" / "peer_bytes" (hipMemcpyPeerAsync calls a multi-device
  *                   context issued, and the bytes they moved), "entries_accumulated" (non-zero window digits of the MSM whose
  *                   result was fetched last, counted on the device: the points k_accumulate gathered -- all windows of this
  *                   context's shard, all MSMs of a batch; bench.py prices its roofline with it),
+ *                   "bases_bytes" (device memory held by bound point sets, all devices), "bases_bound" (how many sets),
  *                   "in_flight" (tickets not collected, all devices), "streams_final" (te_msm_workset_stream's handles will not change any
  *                   more), "device_bytes" (device memory held in work-set buffers, see te_msm_trim)
  *   "prezero"       1 (default) = a work set's block of counters is cleared BEHIND an MSM's read-back, for its next MSM
@@ -224,6 +267,14 @@ int te_msm_partial_device_batch(te_ctx* ctx, const void* const* d_points_xy_le, 
 int te_msm_partial_wait(te_ctx* ctx, int workset);
 /* The private stream of a work set (what TE_MSM_OWN_STREAM selects) as a hipStream_t, for callers that order their own work
  * -- a collective, a copy -- behind te_msm_partial_device without a host round trip (PyTorch: torch.cuda.ExternalStream).
+ * LIFETIME: a handle returned here stays a VALID hipStream_t until the process exits.  te_msm_destroy synchronises the streams
+ * of a context whose handles were handed out and parks them (the next context on the same device takes them over) instead of
+ * destroying them, because callers remember such handles where the engine cannot see them: PyTorch's pinned-memory allocator
+ * records an event on every stream a pinned block was used on when the block is released -- for a tensor that outlives the
+ * context, after te_msm_destroy or at interpreter exit -- and hipEventRecord on a destroyed stream aborts the process (round 5:
+ * tools/exp_batch_small.py; profiles/r06_batch_small_abort.txt, tests/test_gpu_stream_export.py).  What the caller still owes:
+ * work it enqueues on the handle AFTER te_msm_destroy is ordered with whatever the next owner of the stream runs there -- finish
+ * (synchronise) your own work on the handle before the context goes away.
  * The FIRST te_msm_submit* of a context (not te_msm_init: one-shot callers never pay the ~16 ms) measures which of
  * its streams the runtime put on the same hardware queue (kernels of one queue run in order; see csrc/te_msm.hip,
  * spread_streams_over_queues), twice, and -- when both measurements agree -- re-deals them so that work sets 0..3, and 4..7,
@@ -308,6 +359,13 @@ int te_msm_stage_ms(te_ctx* ctx, float* ms, const char** names, int max_stages);
  * "buckets" (nw x B x 144 B), "partials" (W x 720 B).  Returns bytes copied
  * (<= cap) or a negative error. */
 int64_t te_msm_debug_read(te_ctx* ctx, const char* stage, void* dst, uint64_t cap);
+/* Copies records [first, first + count) of a bound point set from the memory of device `device_index` of the context to dst
+ * (stage verification of te_msm_bind_points).  Record layouts, little-endian u32 limb words of 29 bits, Montgomery form:
+ * Twisted-Edwards BLS12: 128-byte slots, hm | hp | dt of 9 words each; BLS12-377: 168 bytes, hm | hp | dt of 14 words (affine,
+ * option "bind_affine" = 1) or 224 bytes, hm | hp | dt | z (projective).  *record_bytes (optional) receives the slot size.
+ * Returns bytes copied (<= cap) or a negative error. */
+int64_t te_msm_bases_read(te_ctx* ctx, const te_bases* bases, int device_index, uint64_t first, uint64_t count, void* dst, uint64_t cap,
+                          int* record_bytes);
 
 #ifdef __cplusplus
 }

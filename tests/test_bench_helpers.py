@@ -81,3 +81,71 @@ def test_roofline_follows_the_accumulated_entries_not_w_times_n():
     assert wrong["binding_roofline"]["frac_at_measured_clock"] > 1.5               # what charging W * n gives
     # a uniform set: the count changes nothing beyond 2^-16
     assert abs(bench.algorithmic_bytes(n, W, B, entries=int(W * n * (1 - 2.0 ** -16)))[1] / acc_u - 1) < 1e-4
+
+
+# ------------------------------------------------------------------ `python bench.py --gpus N` without a launcher
+_STUB = r'''
+import os, sys, time
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == str(rank) and os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+mode = sys.argv[1]
+if mode == "ok":
+    time.sleep(0.2 * rank)
+    print('{"rank": %d, "world": %d}' % (rank, world), flush=True)
+elif mode == "fail1":
+    if rank == 1:
+        time.sleep(0.3)
+        sys.exit(7)
+    print("rank %d waits in its collective" % rank, flush=True)
+    time.sleep(600)                      # the other ranks would sit in a collective until their own timeout
+elif mode == "hang":
+    time.sleep(600)
+'''
+
+
+def _stub(tmp_path):
+    p = tmp_path / "rank_stub.py"
+    p.write_text(_STUB)
+    return str(p)
+
+
+def test_launch_ranks_relays_rank0_and_returns_zero(tmp_path, capfd):
+    import time
+    t0 = time.time()
+    assert bench.launch_ranks(3, [sys.executable, _stub(tmp_path), "ok"], timeout=60) == 0
+    out, err = capfd.readouterr()
+    assert out.strip() == '{"rank": 0, "world": 3}'                  # ONE line on stdout: rank 0's
+    assert '[rank 1] {"rank": 1, "world": 3}' in err and '[rank 2] {"rank": 2, "world": 3}' in err
+    assert time.time() - t0 < 30
+
+
+def test_launch_ranks_stops_everybody_when_one_rank_fails(tmp_path, capfd):
+    """a rank that exits non-zero ends the job with its code within seconds; the ranks left in their 'collective' are killed"""
+    import time
+    t0 = time.time()
+    rc = bench.launch_ranks(2, [sys.executable, _stub(tmp_path), "fail1"], timeout=120)
+    took = time.time() - t0
+    assert rc == 7 and took < 30, (rc, took)
+    out, err = capfd.readouterr()
+    assert "rank 1 exited with 7" in err and "rank 0 waits" in out
+
+
+def test_launch_ranks_times_out(tmp_path):
+    import time
+    t0 = time.time()
+    assert bench.launch_ranks(2, [sys.executable, _stub(tmp_path), "hang"], timeout=1.5) == 124
+    assert time.time() - t0 < 30
+
+
+def test_bench_without_a_launcher_starts_its_ranks_before_torch(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the parent never imports torch (it would touch HIP on a GPU box) -- checked by
+    making `import torch` fatal in the PARENT only; the children fail at once on this box (no GPU) and the parent reports it"""
+    import subprocess
+    site = tmp_path / "site"
+    site.mkdir()
+    (site / "torch.py").write_text("import os, sys\nif 'WORLD_SIZE' not in os.environ:\n    sys.exit(99)\nraise SystemExit(5)\n")
+    env = dict(os.environ, PYTHONPATH=str(site) + os.pathsep + os.environ.get("PYTHONPATH", ""), TE_BENCH_LAUNCH_TIMEOUT="60")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 5, (r.returncode, r.stderr[-800:])       # the children's code, not the parent's 99
+    assert "stopping the other ranks" in r.stderr

@@ -11,9 +11,11 @@ There is no CPU fallback anywhere in this package: without libtemsm.so and a HIP
 point raises.
 """
 from .binding import (  # noqa: F401
+    Bases,
     MsmContext,
     MsmError,
     compute_msm,
+    set_bases,
     finalize_host,
     host_tail_features,
     finalize_gathered,

@@ -98,6 +98,24 @@ def _lib() -> ctypes.CDLL:
         L.te_msm_submit_async.restype = ci
         L.te_msm_ticket_device.argtypes = [vp, u64, ctypes.POINTER(ci), ctypes.POINTER(ci)]
         L.te_msm_ticket_device.restype = ci
+        L.te_msm_bind_points.argtypes = [vp, cp, u64, ctypes.POINTER(vp)]
+        L.te_msm_bind_points.restype = ci
+        L.te_msm_bind_points_device.argtypes = [vp, vp, u64, ctypes.POINTER(vp)]
+        L.te_msm_bind_points_device.restype = ci
+        L.te_msm_release_points.argtypes = [vp, vp]
+        L.te_msm_release_points.restype = ci
+        L.te_msm_bases_count.argtypes = [vp]
+        L.te_msm_bases_count.restype = u64
+        L.te_msm_run_scalars.argtypes = [vp, vp, cp, cp]
+        L.te_msm_run_scalars.restype = ci
+        L.te_msm_run_scalars_device.argtypes = [vp, vp, vp, cp]
+        L.te_msm_run_scalars_device.restype = ci
+        L.te_msm_submit_scalars.argtypes = [vp, vp, cp, ctypes.POINTER(u64)]
+        L.te_msm_submit_scalars.restype = ci
+        L.te_msm_submit_scalars_device.argtypes = [vp, vp, vp, ctypes.POINTER(u64)]
+        L.te_msm_submit_scalars_device.restype = ci
+        L.te_msm_bases_read.argtypes = [vp, vp, ci, u64, u64, vp, u64, ctypes.POINTER(ci)]
+        L.te_msm_bases_read.restype = ctypes.c_int64
         L.te_msm_probe_queues.argtypes = [vp]
         L.te_msm_probe_queues.restype = ci
         L.te_msm_trim.argtypes = [vp, ci]
@@ -265,6 +283,68 @@ class MsmContext:
     def ticket_wait(self, ticket: int):
         self._check(self._L.te_msm_ticket_wait(self._h, ticket))
 
+    # ---- resident bases: points bound once, scalars per call (te_msm_bind_points ...)
+    def bind_points(self, points: bytes) -> "Bases":
+        """Uploads the points once, converts them to records on every device of the context and keeps only the records
+        (te_msm_bind_points).  The harness hands the same point buffer to compute_msm for every run of a size
+        (submission/miscellaneous/full_benchmarks.ts:63-68,100-105)."""
+        pb = self._sizes[0]
+        n = len(points) // pb
+        if len(points) != pb * n:
+            raise MsmError(-1, f"points must be {pb}*n bytes")
+        h = ctypes.c_void_p()
+        self._check(self._L.te_msm_bind_points(self._h, bytes(points), n, ctypes.byref(h)))
+        return Bases(self, h, n, self.curve)
+
+    def bind_points_device(self, d_points: int, n: int) -> "Bases":
+        h = ctypes.c_void_p()
+        self._check(self._L.te_msm_bind_points_device(self._h, d_points, n, ctypes.byref(h)))
+        return Bases(self, h, n, self.curve)
+
+    def bases_read(self, bases: "Bases", first: int, count: int, device_index: int = 0):
+        """(record bytes, raw records [first, first + count) of the bound set on one device) -- te_msm_bases_read"""
+        rb = ctypes.c_int(0)
+        buf = ctypes.create_string_buffer(max(1, count * 224))
+        got = self._check(self._L.te_msm_bases_read(self._h, bases._h, device_index, first, count, buf, count * 224, ctypes.byref(rb)))
+        return rb.value, buf.raw[:got]
+
+    def release_points(self, bases: "Bases"):
+        self._check(self._L.te_msm_release_points(self._h, bases._h))
+        bases._h = None
+
+    def _scalars_of(self, bases: "Bases", scalars: bytes) -> bytes:
+        if bases._h is None or bases._ctx is not self:
+            raise MsmError(-1, "not a bound point set of this context")
+        sb = self._sizes[1]
+        if len(scalars) != sb * bases.n:
+            raise MsmError(-1, f"scalars must be {sb}*{bases.n} bytes for this point set")
+        return bytes(scalars)
+
+    def run_scalars(self, bases: "Bases", scalars: bytes) -> bytes:
+        """compute_msm over a bound point set: only the scalars cross PCIe (te_msm_run_scalars)."""
+        out = ctypes.create_string_buffer(96)
+        self._check(self._L.te_msm_run_scalars(self._h, bases._h, self._scalars_of(bases, scalars), out))
+        return out.raw[:self._sizes[2]]
+
+    def run_scalars_device(self, bases: "Bases", d_scalars: int) -> bytes:
+        out = ctypes.create_string_buffer(96)
+        self._check(self._L.te_msm_run_scalars_device(self._h, bases._h, d_scalars, out))
+        return out.raw[:self._sizes[2]]
+
+    def submit_scalars(self, bases: "Bases", scalars: bytes) -> int:
+        """te_msm_submit_scalars: asynchronous ticket over a bound point set (this object holds the scalars until the ticket
+        is collected)."""
+        scalars = self._scalars_of(bases, scalars)
+        t = ctypes.c_uint64()
+        self._check(self._L.te_msm_submit_scalars(self._h, bases._h, scalars, ctypes.byref(t)))
+        self._held[t.value] = (scalars,)
+        return t.value
+
+    def submit_scalars_device(self, bases: "Bases", d_scalars: int) -> int:
+        t = ctypes.c_uint64()
+        self._check(self._L.te_msm_submit_scalars_device(self._h, bases._h, d_scalars, ctypes.byref(t)))
+        return t.value
+
     def ticket_device(self, ticket: int):
         """(index into the context's device list, HIP device id) a ticket in flight runs on"""
         i, d = ctypes.c_int(-1), ctypes.c_int(-1)
@@ -296,7 +376,10 @@ class MsmContext:
 
     def workset_stream(self, workset: int):
         """(hipStream_t handle as int, measured hardware-queue class or -1) of a work set's private stream
-        (te_msm_workset_stream); wrap the handle with torch.cuda.ExternalStream to order torch work behind it."""
+        (te_msm_workset_stream); wrap the handle with torch.cuda.ExternalStream to order torch work behind it.
+        The handle stays a valid stream until the process exits (close() parks exported streams instead of destroying them:
+        torch's pinned-memory allocator records an event on every stream a pinned block was used on when the block is
+        released, which may be after close()); synchronise your own work on it before close()."""
         st, cls = ctypes.c_void_p(), ctypes.c_int(-1)
         self._check(self._L.te_msm_workset_stream(self._h, workset, ctypes.byref(st), ctypes.byref(cls)))
         return int(st.value or 0), int(cls.value)
@@ -321,6 +404,18 @@ class MsmContext:
         buf = ctypes.create_string_buffer(max(nbytes, 1))
         got = self._check(self._L.te_msm_debug_read(self._h, stage.encode(), buf, nbytes))
         return buf.raw[:got]
+
+
+class Bases:
+    """A bound point set of one MsmContext (te_bases): n points as records on every device of the context."""
+
+    def __init__(self, ctx: MsmContext, handle, n: int, curve: int):
+        self._ctx, self._h, self.n, self.curve = ctx, handle, n, curve
+
+    def release(self):
+        if self._h is not None and getattr(self._ctx, "_h", None):
+            self._ctx.release_points(self)
+        self._h = None
 
 
 def partial_bytes(curve: int = CURVE_TE_BLS12) -> int:
@@ -383,6 +478,7 @@ def synth_inputs(seed: int, n: int, fixed_point=False, points: bool = True, scal
 
 
 _DEFAULT_CTX = None
+_DEFAULT_BASES = None           # (the caller's buffer object, Bases) after set_bases()
 
 
 def devices_from_env(default=(0,)):
@@ -404,14 +500,37 @@ def compute_msm(bufferPoints, bufferScalars, log_result: bool = True, force_reco
     Returns {"x": int, "y": int} (the reference resolves to {x: bigint, y: bigint}).  `force_recompile`
     only exists to defeat WGSL pipeline caching (shader_manager.ts:85-92); here it drops the cached context.
     """
-    global _DEFAULT_CTX
+    global _DEFAULT_CTX, _DEFAULT_BASES
     if force_recompile and _DEFAULT_CTX is not None:
         _DEFAULT_CTX.close()
         _DEFAULT_CTX = None
+        if _DEFAULT_BASES is not None:          # the records went with the context: bind again on the new one
+            buf = _DEFAULT_BASES[0]
+            _DEFAULT_BASES = None
+            set_bases(buf)
     if _DEFAULT_CTX is None:
         _DEFAULT_CTX = MsmContext(devices_from_env())
-    out = _DEFAULT_CTX.run(bytes(bufferPoints), bytes(bufferScalars))
+    if _DEFAULT_BASES is not None and bufferPoints is _DEFAULT_BASES[0] and len(bufferScalars) == 32 * _DEFAULT_BASES[1].n:
+        out = _DEFAULT_CTX.run_scalars(_DEFAULT_BASES[1], bytes(bufferScalars))      # the bound buffer itself: scalars only
+    else:
+        out = _DEFAULT_CTX.run(bytes(bufferPoints), bytes(bufferScalars))
     res = {"x": int.from_bytes(out[:32], "little"), "y": int.from_bytes(out[32:], "little")}
     if log_result:
         print(res)
     return res
+
+
+def set_bases(bufferPoints):
+    """Opt-in beside compute_msm (not part of the reference's interface): binds this point buffer (te_msm_bind_points); later
+    compute_msm(bufferPoints, scalars) calls that pass THE SAME buffer object -- identity and length are checked, its contents
+    must not change -- upload and decompose the scalars only.  set_bases(None) unbinds.  The reference's harness passes one
+    point buffer to six calls per size (submission/miscellaneous/full_benchmarks.ts:63-68,100-105)."""
+    global _DEFAULT_CTX, _DEFAULT_BASES
+    if _DEFAULT_BASES is not None:
+        _DEFAULT_BASES[1].release()
+        _DEFAULT_BASES = None
+    if bufferPoints is None:
+        return
+    if _DEFAULT_CTX is None:
+        _DEFAULT_CTX = MsmContext(devices_from_env())
+    _DEFAULT_BASES = (bufferPoints, _DEFAULT_CTX.bind_points(bytes(bufferPoints)))

@@ -940,6 +940,43 @@ template <int N> __device__ __forceinline__ ete_t<N> load_ete(const ete_t<N>* sr
   return a;
 }
 
+// Affine BLS12-377 record of a bound point set (curve.hpp, pnt_aff377): 42 limb words = 168 bytes, slots back to back (8-byte
+// aligned: ten 16-byte loads at 8-byte alignment -- gfx950 takes global_load_dwordx4 at any 4-byte alignment -- and one 8-byte load)
+struct __attribute__((aligned(8))) rec_aff377 { uint32_t w[42]; };
+struct __attribute__((aligned(8))) u4a8 { uint32_t v[4]; };
+struct __attribute__((aligned(8))) u2a8 { uint32_t v[2]; };
+static_assert(sizeof(rec_aff377) == 168, "affine record slot");
+__device__ __forceinline__ pnt_aff377 load_pnt_aff377(const rec_aff377* __restrict__ recs, uint32_t entry) {
+  const uint32_t* base = recs[entry & 0x7fffffffu].w;
+  u4a8 u[10];
+#pragma unroll
+  for (int j = 0; j < 10; j++) u[j] = reinterpret_cast<const u4a8*>(base)[j];
+  const u2a8 t = *reinterpret_cast<const u2a8*>(base + 40);
+  uint32_t w[42];
+#pragma unroll
+  for (int j = 0; j < 10; j++) { w[4 * j] = u[j].v[0]; w[4 * j + 1] = u[j].v[1]; w[4 * j + 2] = u[j].v[2]; w[4 * j + 3] = u[j].v[3]; }
+  w[40] = t.v[0]; w[41] = t.v[1];
+  pnt_aff377 r;
+#pragma unroll
+  for (int j = 0; j < 14; j++) { r.hm.v[j] = w[j]; r.hp.v[j] = w[14 + j]; r.dt.v[j] = w[28 + j]; }
+  return r;
+}
+__device__ __forceinline__ void store_pnt_aff377(rec_aff377* dst, const pnt_aff377& r) {
+#pragma unroll
+  for (int j = 0; j < 14; j++) { dst->w[j] = r.hm.v[j]; dst->w[14 + j] = r.hp.v[j]; dst->w[28 + j] = r.dt.v[j]; }
+}
+// The record a launch of k_accumulate gathers: RK = 0 the curve's own (converted per call: rec_slot<N>), RK = 1 the affine
+// BLS12-377 record of a bound point set (N = 14 only)
+template <int N, int RK> struct rec_kind;
+template <int N> struct rec_kind<N, 0> {
+  using slot = rec_slot<N>; using pnt = pnt_t<N>;
+  static __device__ __forceinline__ pnt load(const slot* __restrict__ recs, uint32_t e) { return load_pnt<N>(recs, e); }
+};
+template <> struct rec_kind<14, 1> {
+  using slot = rec_aff377; using pnt = pnt_aff377;
+  static __device__ __forceinline__ pnt load(const slot* __restrict__ recs, uint32_t e) { return load_pnt_aff377(recs, e); }
+};
+
 struct __attribute__((aligned(4))) idx4 { uint32_t v[4]; };      // 16 bytes at 4-byte alignment: one global_load_dwordx4
 #define TE_CLK_SLOTS 64u       // copies of k_accumulate's four profiling words (64-bit each), see the kernel
 #define TE_IDX_STRIP 16u       // sorted indices a lane fetches at a time (k_accumulate); d_sorted is padded by as many words
@@ -948,8 +985,8 @@ struct __attribute__((aligned(4))) idx4 { uint32_t v[4]; };      // 16 bytes at 
 // and boxes whose clock sags under this kernel sustain a higher one with fewer waves in flight -- 2.11-2.19 GHz against 2.00-2.07,
 // the kernel alone 0.77-0.79 ms against 0.82-0.85, +2-4 % MSM/s there, nothing lost on boxes that hold 2.15 GHz anyway
 // (profiles/r04_accumulate_occupancy_experiment.txt).  N = 14 holds 56 + 2 x 56 words of points alone: two waves
-template <int N>
-__global__ void __launch_bounds__(256, N == 9 ? 3 : 2) k_accumulate(const rec_slot<N>* __restrict__ recs, const uint32_t* __restrict__ sorted,
+template <int N, int RK = 0>
+__global__ void __launch_bounds__(256, N == 9 ? 3 : 2) k_accumulate(const typename rec_kind<N, RK>::slot* __restrict__ recs, const uint32_t* __restrict__ sorted,
                                                     const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ bucket_count,
                                                     const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ seg_bucket,
                                                     const uint32_t* __restrict__ seg_lenv, const uint32_t* __restrict__ order,
@@ -957,6 +994,7 @@ __global__ void __launch_bounds__(256, N == 9 ? 3 : 2) k_accumulate(const rec_sl
                                                     ete_t<N>* __restrict__ seg_out, uint32_t n, uint32_t logB, uint32_t seg_len, uint32_t ids, uint32_t onto,
                                                     uint32_t win_per_msm, batch_slabs slabs, unsigned long long* __restrict__ clk) {
   __shared__ uint32_t idx_strip[256 * TE_IDX_STRIP];
+  using RT = rec_kind<N, RK>; using P = typename RT::pnt;
 #if defined(TE_ACC_TWO_WAVES)
   // A/B builds only: naming a high register makes the kernel's VGPR allocation 176, i.e. two waves per SIMD without touching LDS
   if constexpr (N == 9) asm volatile("" ::: "v175");
@@ -991,12 +1029,12 @@ __global__ void __launch_bounds__(256, N == 9 ? 3 : 2) k_accumulate(const rec_sl
     const uint32_t last = cnt - 1u;
     uint32_t j0 = 0;
     uint32_t e = lst[0], e_n = lst[min(1u, last)];
-    pnt_t<N> cur = load_pnt<N>(recs, e);
+    P cur = RT::load(recs, e);
     if (!(onto && part == 0u)) {
       // first entry: neutral element + P needs 3 (4) products, not 7 (8) -- except where the segment continues a bucket
-      const pnt_t<N> first = pnt_cneg(cur, (e >> 31) != 0u);
+      const P first = pnt_cneg(cur, (e >> 31) != 0u);
       e = e_n; e_n = lst[min(2u, last)];
-      cur = load_pnt<N>(recs, e);
+      cur = RT::load(recs, e);
       acc = ete_from_pnt(first);
       j0 = 1;
     }
@@ -1018,11 +1056,11 @@ __global__ void __launch_bounds__(256, N == 9 ? 3 : 2) k_accumulate(const rec_sl
     if (((j0 + 2u) & (TE_IDX_STRIP - 1u)) != 0u) refill((j0 + 2u) & ~(TE_IDX_STRIP - 1u));
     for (uint32_t j = j0; j < cnt; j++) {
       const uint32_t e_cur = e;
-      pnt_t<N> nxt = cur;
+      P nxt = cur;
       const uint32_t pn = j + 2u;
       if ((pn & (TE_IDX_STRIP - 1u)) == 0u) refill(pn);
       const uint32_t e_nn = strip[pn & (TE_IDX_STRIP - 1u)];
-      if (j + 1 < cnt) { e = e_n; nxt = load_pnt<N>(recs, e); }
+      if (j + 1 < cnt) { e = e_n; nxt = RT::load(recs, e); }
       acc = ete_madd(acc, pnt_cneg(cur, (e_cur >> 31) != 0u));
       cur = nxt; e_n = e_nn;
     }
@@ -1447,6 +1485,71 @@ __global__ void __launch_bounds__(512, 4) k_part_scatter_prep377(scatter_args a,
     const uint32_t pb = (uint32_t)b - s_before, row = pb / prep_blocks_per_row, blk = pb - row * prep_blocks_per_row;
     const uint32_t i = blk * 512u + threadIdx.x;
     if (i < n) prep_point377(i, in.p[row], recs + (size_t)row_slab.s[row] * n);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// te_msm_bind_points, BLS12-377: projective records (k_prep_points377) -> AFFINE records, once per bound point set.  Every
+// thread takes TE_AFF_GROUP consecutive points: prefix products of their z (kept in the output slots, which are written last),
+// ONE inversion of the group's product by Fermat's exponent q - 2 (a fixed square-and-multiply chain: 376 squarings and 188
+// products, the same instruction stream in every lane), then z_j^-1 = inv * prefix_{j-1} backwards and three products per
+// point.  About 0.6 k products per thread -- a fraction of one MSM's accumulation, paid once for every MSM over the set.
+// A point whose z is 0 modulo q (y = 0 or the points of order 4: never in G1) keeps the factor 1 in the chain and gets an
+// all-zero record, so that it cannot spoil its neighbours' inverses (its own bucket is undefined either way: include/te_msm.h).
+#define TE_AFF_GROUP 8u
+__device__ __forceinline__ bool fq_is_zero_mod_q(const fel<14>& a) {      // a: product output (class N, value < 2q): 0 or q
+  const fel<14> t = fe_norm(fe_mul(a, fe_one<14>()));                     // a * R / R: below q + a little, limbs normalised
+  const fel<14> qq = te377::fq_Q();
+  uint32_t or0 = 0u, dq = 0u;
+#pragma unroll
+  for (int i = 0; i < 14; i++) { or0 |= t.v[i]; dq |= t.v[i] ^ qq.v[i]; }
+  return or0 == 0u || dq == 0u;
+}
+__global__ void __launch_bounds__(256) k_affine377(const rec_slot<14>* __restrict__ proj, rec_aff377* __restrict__ out, uint32_t n) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x, lo = t * TE_AFF_GROUP;
+  if (lo >= n) return;
+  const uint32_t cnt = min(TE_AFF_GROUP, n - lo);
+  const fel<14> one = fe_one<14>();
+  // forward: prefix products (prefix_j = z_0 ... z_j with zeros skipped) into the first 14 words of output slot j
+  fel<14> run = one;
+  for (uint32_t j = 0; j < cnt; j++) {
+    const pnt_t<14> r = load_pnt<14>(proj, lo + j);
+    if (!fq_is_zero_mod_q(r.z)) run = fe_mul(run, r.z);
+#pragma unroll
+    for (int i = 0; i < 14; i++) out[lo + j].w[i] = run.v[i];
+  }
+  // inv = run^(q - 2): square-and-multiply from the top bit (bit 376 of q - 2 is set)
+  // q - 2 in 32-bit words: q = 1 (mod 2^32), so the lowest word becomes ffffffff and the next one loses the borrow
+  const uint32_t ex[12] = {0xffffffffu, te377::Q_W32[1] - 1u, te377::Q_W32[2], te377::Q_W32[3], te377::Q_W32[4], te377::Q_W32[5],
+                           te377::Q_W32[6], te377::Q_W32[7], te377::Q_W32[8], te377::Q_W32[9], te377::Q_W32[10], te377::Q_W32[11]};
+  fel<14> inv = run;
+  for (int w = 11; w >= 0; w--) {
+    const uint32_t word = ex[w];                          // (w is a loop counter the compiler unrolls over: no indexed register array)
+    for (int b = (w == 11 ? 23 : 31); b >= 0; b--) {      // the top word holds bits 352 .. 376; bit 376 is `run` itself
+      inv = fe_mul(inv, inv);
+      if ((word >> b) & 1u) inv = fe_mul(inv, run);
+    }
+  }
+  // backwards: z_j^-1 = inv * prefix_{j-1}; inv *= z_j
+  for (uint32_t jj = cnt; jj-- > 0u;) {
+    const pnt_t<14> r = load_pnt<14>(proj, lo + jj);
+    pnt_aff377 a;
+    if (fq_is_zero_mod_q(r.z)) {
+      a.hm = a.hp = a.dt = fe_zero<14>();
+    } else {
+      fel<14> pre = one;
+      if (jj > 0u) {
+#pragma unroll
+        for (int i = 0; i < 14; i++) pre.v[i] = out[lo + jj - 1u].w[i];
+      }
+      const fel<14> zi = fe_mul(inv, pre);
+      inv = fe_mul(inv, r.z);
+      const fel<14> l[3] = {r.hm, r.hp, r.dt}, rr[3] = {zi, zi, zi};
+      fel<14> o[3];
+      fe_mul_x<3>(l, rr, o);
+      a.hm = o[0]; a.hp = o[1]; a.dt = o[2];
+    }
+    store_pnt_aff377(out + lo + jj, a);
   }
 }
 

@@ -53,6 +53,8 @@ inline curve_sizes sizes_of(int curve) {
   return curve == TE_MSM_CURVE_BLS12_377_G1 ? curve_sizes{96, 48, sizeof(te::ete_t<14>), sizeof(te::rec_slot<14>), TE377_TAIL_ROW_BYTES, 96}
                                             : curve_sizes{TE_MSM_POINT_BYTES, TE_MSM_SCALAR_BYTES, sizeof(te::ete), sizeof(te::rec_slot<9>), TE_MSM_PARTIAL_BYTES, 64};
 }
+// bytes of one record: the curve's own (converted per call), or -- rec_kind 1 -- the affine BLS12-377 record of a bound point set
+inline size_t rec_bytes_of(int curve, int rec_kind) { return (curve == TE_MSM_CURVE_BLS12_377_G1 && rec_kind == 1) ? sizeof(te::rec_aff377) : sizes_of(curve).rec; }
 static_assert(TE377_TAIL_ROW_BYTES == TE_MSM_PARTIAL_BYTES_BLS12_377 && sizeof(te::ete_t<14>) * 5 == TE377_TAIL_ROW_BYTES, "row layout");
 constexpr size_t TE_MAX_ROW_BYTES = TE377_TAIL_ROW_BYTES;
 
@@ -68,6 +70,7 @@ struct plan_t {
   uint32_t seg_len = 64;
   uint32_t S = 0, logS = 0, P = 0;   // level-1 partition: S buckets each, P = B/S partitions per window
   uint32_t packed = 0;               // level-1 entries as one 32-bit word (index | key << 23 | sign << 31): n <= 2^23
+  int rec_kind = 0;                  // records k_accumulate gathers: 0 = the curve's own, 1 = affine BLS12-377 (bound point sets)
 };
 
 struct graph_key { const void *pts, *sc, *out; uint64_t n, generation; int c, w_first, w_step, seg_len, sort; };
@@ -119,6 +122,7 @@ struct workset_t {
   // option "host_staging": the set's own pinned ring for host-buffer uploads (allocated on first use; te_msm_trim / destroy free it)
   uint8_t* h_ring = nullptr; std::vector<hipEvent_t> ring_ev; size_t ring_next = 0;
   uint64_t idle_calls = 0;            // te_msm_trim: context-level calls since the set was last used
+  te_bases* bound = nullptr;          // the bound point set the set's ticket in flight gathers from (te_msm_submit_scalars*): released only after the collect
 };
 constexpr int TE_MAX_WINDOWS = 64;    // window_bits >= 4
 // words [Z_CLOCK, Z_ROWS): k_accumulate's profiling words, 4 x TE_CLK_SLOTS 64-bit values (first wave in / last wave out on the
@@ -135,6 +139,7 @@ struct gpu_t {
   int wall_clock_khz = 0;                // rate of wall_clock64() on this device
   int in_flight = 0;                     // submitted and not collected
   bool queues_probed = false;            // the hardware-queue measurement has run (spread_streams_over_queues)
+  bool streams_exported = false;         // te_msm_workset_stream handed a handle out: te_msm_destroy parks the streams instead of destroying them
   bool streams_final = false;            // ... and the work sets' streams will not be re-dealt any more
 };
 
@@ -174,6 +179,20 @@ struct te_ctx {
   float stage_ms[ST_COUNT + 2] = {};
   bool have_stage_ms = false;
   int64_t stat_peer_copies = 0;  // hipMemcpyPeerAsync calls issued so far (multi-device contexts fed from device 0's memory; get_option "peer_copies")
+  std::vector<te_bases*> bases;  // the bound point sets of the context (te_msm_bind_points), freed by te_msm_release_points / te_msm_destroy
+  int opt_bind_affine = 1;       // te_msm_bind_points, BLS12-377: affine records (one inversion per point, once) instead of the projective ones of the per-call conversion
+  int opt_scalar_chunks = 0;     // te_msm_run_scalars / te_msm_submit_scalars: pieces the scalars of a bound set are uploaded and processed in (0 = from n)
+};
+
+// A bound point set (include/te_msm.h, "resident bases"): the records of n points on EVERY device of its context, converted
+// once.  The reference hands the same point buffer to compute_msm for every run of a size (full_benchmarks.ts:63-68,100-105).
+struct te_bases {
+  te_ctx* ctx = nullptr;
+  uint64_t n = 0;
+  int curve = TE_MSM_CURVE_TE_BLS12, rec_kind = 0;
+  size_t rec_bytes = 0;
+  std::vector<uint8_t*> recs;    // recs[i]: n records in the memory of ctx->devs[i]
+  int in_flight = 0;             // tickets not collected that gather from it (the set cannot be released under them)
 };
 
 namespace {
@@ -293,12 +312,13 @@ template <typename T> int ensure(te_ctx* ctx, workset_t& ws, T*& ptr, size_t& ca
   return 0;
 }
 
-int ensure_buffers(te_ctx* ctx, gpu_t& d, workset_t& ws, uint64_t n, const plan_t& p) {
+// need_recs = false: the launch sequence gathers from a bound point set, the work set needs no record slab of its own
+int ensure_buffers(te_ctx* ctx, gpu_t& d, workset_t& ws, uint64_t n, const plan_t& p, bool need_recs = true) {
   HIP_TRY(ctx, hipSetDevice(d.device));
   // + 64: k_accumulate fetches its sorted indices TE_IDX_STRIP at a time and may read that far past the end of a list
   const size_t nd = (size_t)p.nw * p.nst + 64, wb = (size_t)p.nw * p.B, ab = sizes_of(p.curve).acc;
   int rc = 0;
-  if ((rc = ensure(ctx, ws, ws.d_recs, ws.cap[0], (size_t)n * sizes_of(p.curve).rec * (size_t)p.batch))) return rc;
+  if (need_recs && (rc = ensure(ctx, ws, ws.d_recs, ws.cap[0], (size_t)n * sizes_of(p.curve).rec * (size_t)p.batch))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_digits, ws.cap[1], nd))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_sorted, ws.cap[2], nd))) return rc;
   {
@@ -350,6 +370,8 @@ struct msm_launch {
   bool own_rows = false;          // rows go to ws.d_partials: the caller fetches flag + rows with one copy
   bool onto = false;              // a later piece of a host-buffer MSM: keep the final-carry flag, add onto the buckets
   bool host_rows = false;         // own rows go straight to the work set's pinned host block, written by k_reduce_tail (no copy at all)
+  const uint8_t* bound = nullptr; // records of a bound point set (te_msm_bind_points), already offset to this launch's first point: no conversion,
+                                  // k_accumulate gathers from here instead of ws.d_recs (p.rec_kind tells which record form)
   // Own rows of a context that computes ALL windows can be written to host memory by the tail kernel (every row slot is
   // rewritten by every MSM).  Not with window shards (rows of foreign windows must read as zero: they come from the cleared
   // device block), not with captured graphs (fixed pointers), not with "prezero" = 0 (stage verifiers read the device rows).
@@ -506,12 +528,13 @@ struct msm_launch {
   bool bls() const { return p.curve == TE_MSM_CURVE_BLS12_377_G1; }
 
   // K3: one thread per segment (at most seg_len entries of one bucket): 7-product mixed additions (8 for BLS12-377)
-  template <int N> int accumulate_t() {
+  template <int N, int RK> int accumulate_t() {
     mark(ST_ACCUM);
     if (p.nw > 0) {
       const uint32_t n32 = this->n32(), smax = this->smax();
       const uint32_t* order = ctx->opt_sort ? ws.d_order : nullptr;
-      hipLaunchKernelGGL(te::k_accumulate<N>, dim3((smax + 255) / 256), dim3(256), 0, stream, reinterpret_cast<const te::rec_slot<N>*>(ws.d_recs), ws.d_sorted,
+      using slot_t = typename te::rec_kind<N, RK>::slot;
+      hipLaunchKernelGGL((te::k_accumulate<N, RK>), dim3((smax + 255) / 256), dim3(256), 0, stream, reinterpret_cast<const slot_t*>(bound ? bound : ws.d_recs), ws.d_sorted,
                          ws.d_bucket_start, ws.d_bucket_count, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv, order, ws.d_num_seg,
                          reinterpret_cast<te::ete_t<N>*>(ws.d_buckets), reinterpret_cast<te::ete_t<N>*>(ws.d_seg_out), n32, p.logB, p.seg_len, smax, onto ? 1u : 0u,
                          (uint32_t)p.nw1, slabs(),
@@ -519,7 +542,7 @@ struct msm_launch {
     }
     return 0;
   }
-  int accumulate() { return bls() ? accumulate_t<14>() : accumulate_t<9>(); }
+  int accumulate() { return bls() ? (p.rec_kind == 1 ? accumulate_t<14, 1>() : accumulate_t<14, 0>()) : accumulate_t<9, 0>(); }
 
   // sums of the buckets that were accumulated in several parts: buckets cut into 2..16 parts (quads) and the TE_GIANT_RUN-part runs
   // of giant buckets (blocks; the block that finishes a bucket's last run adds the runs up) in one launch
@@ -702,11 +725,38 @@ void deal_over_classes(const int* cls, int n, int ncls, int* order) {
   }
 }
 
-// te_msm_init: one compute stream per work set, in creation order (no measurement)
+// EXPORTED STREAMS ARE NEVER DESTROYED.  te_msm_workset_stream hands a work set's stream out as a raw hipStream_t so that a
+// caller can order its own work behind an MSM (PyTorch: torch.cuda.ExternalStream).  Such callers REMEMBER the handle in places
+// the engine cannot see: PyTorch's pinned-memory allocator keeps, for every pinned block, the streams it was used on and records
+// an event on each of them when the block is released -- for a tensor that outlives the context that is after te_msm_destroy,
+// possibly at interpreter exit; hipEventRecord on a destroyed stream fails, the error is raised inside a deleter, and the
+// process aborts (round 5: tools/exp_batch_small.py "dumped core" after its last result line; profiles/r06_batch_small_abort.txt).
+// So the streams of a device whose handles were exported are PARKED by te_msm_destroy -- synchronised, kept alive, and taken
+// over by the next context on that device -- and stay valid hipStream_t values until the process exits.  A context that never
+// exported a handle destroys its streams as before.  (env TE_MSM_PARK_STREAMS=0: the old behaviour, for the diagnosis only.)
+struct parked_streams_t { std::mutex mu; std::vector<std::pair<int, hipStream_t>> v; };
+parked_streams_t& parked_streams() { static parked_streams_t* p = new parked_streams_t(); return *p; }     // (leaked on purpose: no destructor at exit)
+bool park_exported_streams() { static const bool on = [] { const char* e = getenv("TE_MSM_PARK_STREAMS"); return !(e && e[0] == '0'); }(); return on; }
+hipStream_t take_parked_stream(int device) {
+  parked_streams_t& ps = parked_streams();
+  std::lock_guard<std::mutex> lk(ps.mu);
+  for (size_t i = 0; i < ps.v.size(); i++)
+    if (ps.v[i].first == device) { hipStream_t s = ps.v[i].second; ps.v.erase(ps.v.begin() + (long)i); return s; }
+  return nullptr;
+}
+void park_stream(int device, hipStream_t s) {
+  parked_streams_t& ps = parked_streams();
+  std::lock_guard<std::mutex> lk(ps.mu);
+  ps.v.emplace_back(device, s);
+}
+
+// te_msm_init: one compute stream per work set, in creation order (no measurement); parked streams of the device first
 int create_workset_streams(gpu_t& d) {
   for (int i = 0; i < TE_MSM_WORKSETS; i++) {
-    if (hipStreamCreateWithFlags(&d.ws[i].stream, hipStreamNonBlocking) != hipSuccess) {
-      for (int j = 0; j < i; j++) { (void)hipStreamDestroy(d.ws[j].stream); d.ws[j].stream = nullptr; }
+    d.ws[i].stream = take_parked_stream(d.device);
+    if (d.ws[i].stream) d.streams_exported = true;      // somebody may still hold this handle: it goes back to the pool, never to hipStreamDestroy
+    if (!d.ws[i].stream && hipStreamCreateWithFlags(&d.ws[i].stream, hipStreamNonBlocking) != hipSuccess) {
+      for (int j = 0; j < i; j++) { if (d.streams_exported) park_stream(d.device, d.ws[j].stream); else (void)hipStreamDestroy(d.ws[j].stream); d.ws[j].stream = nullptr; }
       d.ws[i].stream = nullptr;
       return -1;
     }
@@ -750,15 +800,17 @@ void spread_streams_over_queues(gpu_t& d) {
 
 int finish_sequence(te_ctx* ctx, workset_t& ws, hipStream_t stream);
 
+// bases: the launch sequence gathers from a bound point set (d_points is not read: no conversion); batch must be 1
 int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, const void* d_scalars, uint64_t n,
                     void* d_partials_out, hipStream_t stream, const std::function<int(hipStream_t)>* upload_points = nullptr, int force_c = 0,
-                    bool side_stream = false, int batch = 1, bool whole = false) {
+                    bool side_stream = false, int batch = 1, bool whole = false, const te_bases* bases = nullptr) {
   plan_t p; make_plan(ctx, d, n, p, force_c, batch, 0, whole);
+  if (bases) p.rec_kind = bases->rec_kind;
   if (batch > 1 && (uint64_t)p.nw * p.nst >= (1ull << 31)) return set_err(ctx, TE_MSM_EINVAL, "batch too large for this n: windows x points must stay below 2^31");
   HIP_TRY(ctx, hipSetDevice(d.device));
   if ((uint64_t)p.nw * p.B + (uint64_t)p.nw * (n / p.seg_len) + 1024u >= (1ull << 32))
     return set_err(ctx, TE_MSM_EINVAL, "segment_len is too small for this n: more than 2^32 segments");
-  if (int rc = ensure_buffers(ctx, d, ws, n, p)) return rc;
+  if (int rc = ensure_buffers(ctx, d, ws, n, p, bases == nullptr)) return rc;
   if (ws.used && ws.last_stream != stream) HIP_TRY(ctx, hipStreamWaitEvent(stream, ws.ev_done, 0));   // the set's buffers are still the previous MSM's
   ws.plan = p; ws.n = n; ws.used = true; ws.last_stream = stream; __atomic_store_n(&d.last_ws, (int)(&ws - d.ws), __ATOMIC_RELAXED);
   ws.prof_level = ctx->opt_profile;
@@ -769,7 +821,16 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, 
   msm_launch L{ctx, d, ws, p, d_points, d_scalars, n, d_partials_out, ctx->opt_profile, stream, own_rows};
   L.host_rows = msm_launch::rows_to_host(ctx, d, p, own_rows);
   ws.rows_on_host = L.host_rows;
-  if (ctx->opt_graph && ctx->opt_profile < 2 && !upload_points && batch == 1) {
+  if (bases) {
+    // resident bases: the scalar-only stages, then the accumulation straight from the bound records (never captured: option "graph"
+    // holds the pointers of device-resident point buffers)
+    L.bound = bases->recs[(size_t)(&d - ctx->devs.data())];
+    if (int rc = L.front_scalars()) return rc;
+    L.mark(ST_PREP);
+    if (int rc = L.accumulate()) return rc;
+    L.mark(ST_TREE);
+    if (int rc = L.back()) return rc;
+  } else if (ctx->opt_graph && ctx->opt_profile < 2 && !upload_points && batch == 1) {
     // the graphs hold pointers and geometry: re-captured when any of them changes (including a buffer reallocation);
     // the captured front always clears the zeroed block itself
     ws.zero_clean_words = 0;
@@ -904,7 +965,9 @@ void free_dev(gpu_t& d) {
     if (ws.ev_start) (void)hipEventDestroy(ws.ev_start);
     for (hipEvent_t e : ws.piece_events) (void)hipEventDestroy(e);
     if (ws.copy_stream) (void)hipStreamDestroy(ws.copy_stream);
-    if (ws.stream) (void)hipStreamDestroy(ws.stream);
+    // a stream whose handle left the library stays alive (see "EXPORTED STREAMS ARE NEVER DESTROYED"); te_msm_destroy has synchronised it
+    if (ws.stream) { if (d.streams_exported && park_exported_streams()) park_stream(d.device, ws.stream); else (void)hipStreamDestroy(ws.stream); }
+    ws.stream = nullptr; ws.copy_stream = nullptr;
   }
 }
 
@@ -1153,6 +1216,75 @@ int enqueue_host_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* src_
   return 0;
 }
 
+// pieces the scalars of a bound point set are uploaded and processed in on ONE device (option "scalar_chunks", else from n)
+int scalar_pieces(const te_ctx* ctx, uint64_t n) {
+  int K = ctx->opt_scalar_chunks ? ctx->opt_scalar_chunks : (n >= (3ull << 18) ? 3 : n >= (1ull << 18) ? 2 : 1);
+  if ((uint64_t)K > n) K = (int)n;
+  return K < 1 ? 1 : K;
+}
+
+// An MSM over a BOUND point set from host scalars (or one device's slice of it) on work set `ws` of device `d`: enqueue_host_slice
+// without the points.  `recs` are the records of the slice's first point on this device (rec_kind: their form).  The scalars
+// travel in K pieces on the set's copy stream -- piece i + 1 crosses PCIe while piece i is decomposed, sorted and accumulated
+// ONTO THE SAME BUCKETS on the main stream (its records are at recs + lo * record bytes) --, one bucket reduction at the end,
+// flag + rows on their way to the set's pinned block when the call returns.  Does not wait: the caller synchronises ws.ev_result.
+// All windows, window bits forced to c.  wait_for_pinned: as enqueue_host_slice.
+int enqueue_scalar_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* recs, int rec_kind, const uint8_t* src_scalars, uint64_t n, int c, int K,
+                         bool wait_for_pinned = true) {
+  HIP_TRY(ctx, hipSetDevice(d.device));
+  plan_t pf; make_plan(ctx, d, n, pf, c, 1, 0, true);
+  pf.rec_kind = rec_kind;
+  const curve_sizes sz = sizes_of(pf.curve);
+  const size_t rec_bytes = rec_bytes_of(pf.curve, rec_kind);
+  if (int rc = ensure_staging(ctx, ws, 0, n * sz.scalar_in)) return rc;
+  uint8_t* dscs = static_cast<uint8_t*>(ws.d_in_scalars);
+  if (K < 1) K = 1;
+  if ((uint64_t)K > n) K = (int)n;
+  auto piece_lo = [&](int i) -> uint64_t { return i >= K ? n : (uint64_t)(((unsigned __int128)n * (unsigned)i) / (unsigned)K); };
+  uint64_t m_max = 0;
+  for (int i = 0; i < K; i++) m_max = std::max(m_max, piece_lo(i + 1) - piece_lo(i));
+  uint32_t seg_all = 0;
+  {
+    plan_t pm; make_plan(ctx, d, m_max, pm, pf.c, 1, 0, true);
+    pm.rec_kind = rec_kind;
+    seg_all = pm.seg_len;
+    if (int rc = ensure_buffers(ctx, d, ws, m_max, pm, false)) return rc;      // every buffer at its final size before the first piece
+  }
+  if (ws.used && ws.last_stream != ws.stream) HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ws.ev_done, 0));
+  HIP_TRY(ctx, hipEventRecord(ws.ev_start, ws.stream));
+  if (int rc = need_copy_stream(ctx, ws)) return rc;
+  HIP_TRY(ctx, hipStreamWaitEvent(ws.copy_stream, ws.ev_start, 0));            // the staging area may still be read by the set's previous MSM
+  std::vector<hipEvent_t>& evs = ws.piece_events;
+  while ((int)evs.size() < K + 1) { hipEvent_t e; HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); evs.push_back(e); }
+  plan_t p;
+  bool first = true;
+  for (int i = 0; i < K; i++) {
+    const uint64_t lo = piece_lo(i), m = piece_lo(i + 1) - lo;
+    if (m == 0) continue;
+    if (int rc = upload(ctx, ws, dscs + lo * sz.scalar_in, src_scalars + lo * sz.scalar_in, m * sz.scalar_in, ws.copy_stream)) return rc;
+    HIP_TRY(ctx, hipEventRecord(evs[(size_t)i], ws.copy_stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, evs[(size_t)i], 0));
+    make_plan(ctx, d, m, p, pf.c, 1, seg_all, true);
+    p.rec_kind = rec_kind;
+    if (int rc = ensure_buffers(ctx, d, ws, m, p, false)) return rc;           // no reallocation: only the pointers into the zeroed block move
+    msm_launch L{ctx, d, ws, p, nullptr, dscs + lo * sz.scalar_in, m, ws.d_partials, 0, ws.stream, true, !first};
+    L.host_rows = msm_launch::rows_to_host(ctx, d, p, true);
+    L.bound = recs + lo * rec_bytes;
+    ws.rows_on_host = L.host_rows;
+    first = false;
+    if (int rc = L.front_scalars()) return rc;
+    if (int rc = L.accumulate()) return rc;
+    if (int rc = L.combine()) return rc;
+    if (i == K - 1) { if (int rc = L.reduce()) return rc; }
+  }
+  ws.plan = p; ws.n = piece_lo(K) - piece_lo(K - 1); ws.used = true; ws.last_stream = ws.stream; ws.prof_level = 0;
+  __atomic_store_n(&d.last_ws, (int)(&ws - d.ws), __ATOMIC_RELAXED);
+  if (int rc = fetch_rows(ctx, ws, ws.stream)) return rc;
+  HIP_TRY(ctx, hipGetLastError());
+  if (wait_for_pinned && !ctx->opt_host_staging && host_memory_is_pinned(src_scalars)) HIP_TRY(ctx, hipEventSynchronize(evs[(size_t)K - 1]));
+  return 0;
+}
+
 // the host thread of device i of the context (host_sched.hpp), created on first use
 te_sched::worker_t& worker_of(te_ctx* ctx, size_t i) { return te_sched::worker_of(*ctx, i); }
 // every job posted to the context's host threads has run (asynchronous submits touch work sets, options and the error
@@ -1190,14 +1322,16 @@ int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_
 // submission.ts:73-78); multi-device is its README's future work (README.md:551).
 // This is the form for the LONE call.  A caller with several MSMs to do keeps whole MSMs in flight instead, one per device
 // (te_msm_submit / te_msm_submit_async below): no replicated bucket reduction, no row merge.
-int run_host_sharded(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_scalars, uint64_t n, uint8_t* out) {
+// bases: the MSM runs over a bound point set -- every device holds all records, so device i takes slice i of the SCALARS over its
+// link and gathers from its own copy of the records at the slice's offset (src_points is not read).
+int run_host_sharded(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_scalars, uint64_t n, uint8_t* out, const te_bases* bases = nullptr) {
   const size_t nd = ctx->devs.size();
   uint64_t per_min = ctx->opt_host_shard_min > 0 ? (uint64_t)ctx->opt_host_shard_min : 1;
   size_t D = (size_t)std::min<uint64_t>(nd, std::max<uint64_t>(1, n / per_min));
   const uint64_t per = (n + D - 1) / D;
   plan_t p0; make_plan(ctx, ctx->devs[0], per, p0, 0, 1, 0, true);     // geometry of every slice's rows (window bits from the slice size)
   const curve_sizes sz = sizes_of(p0.curve);
-  const int K = host_pieces(ctx, per);
+  const int K = bases ? scalar_pieces(ctx, per) : host_pieces(ctx, per);
   // a work set per device that no ticket owns (tickets and lone calls may be mixed)
   std::vector<int> wsel(D, 0);
   for (size_t i = 0; i < D; i++) { wsel[i] = free_workset_index(ctx->devs[i]); if (wsel[i] < 0) return set_err(ctx, TE_MSM_ESTATE, kAllSetsOwned); }
@@ -1206,7 +1340,11 @@ int run_host_sharded(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_
     gpu_t& d = ctx->devs[i];
     if (hi == lo) return 0;
     workset_t& ws = d.ws[wsel[i]];
-    if (int rc = enqueue_host_slice(ctx, d, ws, src_points + lo * sz.point_in, src_scalars + lo * sz.scalar_in, hi - lo, p0.c, K)) return rc;
+    if (bases) {
+      if (int rc = enqueue_scalar_slice(ctx, d, ws, bases->recs[i] + lo * bases->rec_bytes, bases->rec_kind, src_scalars + lo * sz.scalar_in, hi - lo, p0.c, K)) return rc;
+    } else {
+      if (int rc = enqueue_host_slice(ctx, d, ws, src_points + lo * sz.point_in, src_scalars + lo * sz.scalar_in, hi - lo, p0.c, K)) return rc;
+    }
     HIP_TRY(ctx, hipEventSynchronize(ws.ev_result));
     return 0;
   };
@@ -1473,6 +1611,11 @@ void te_msm_destroy(te_ctx* ctx) {
     }
     free_dev(d);
   }
+  for (te_bases* b : ctx->bases) {      // bound point sets the caller did not release
+    for (size_t i = 0; i < b->recs.size() && i < ctx->devs.size(); i++)
+      if (b->recs[i]) { (void)hipSetDevice(ctx->devs[i].device); (void)hipFree(b->recs[i]); }
+    delete b;
+  }
   delete ctx;
 }
 
@@ -1676,7 +1819,10 @@ int submit_host(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars
 }
 // the enqueue of an asynchronous ticket has run (any thread); its status
 int await_job(te_ctx*, gpu_t&, workset_t& ws) { return te_sched::await_job(ws); }
-void retire_ticket(te_ctx* ctx, gpu_t& d, workset_t& ws) { te_sched::retire(*ctx, (int)(&d - ctx->devs.data()), ws); }
+void retire_ticket(te_ctx* ctx, gpu_t& d, workset_t& ws) {
+  if (ws.bound) { ws.bound->in_flight--; ws.bound = nullptr; }       // the ticket gathered from a bound point set: it may be released now
+  te_sched::retire(*ctx, (int)(&d - ctx->devs.data()), ws);
+}
 }  // namespace
 
 int te_msm_submit(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars_le, uint64_t n, uint64_t* ticket) {
@@ -1731,6 +1877,296 @@ int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]) {
   if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, kFinalCarry);
   if (ws.plan.curve == TE_MSM_CURVE_BLS12_377_G1) te377_host::horner_to_affine(ws.h_partials, ws.plan.c, (int)ws.plan.logB, ws.plan.W, out_xy_le);
   else te_host::horner_to_affine(ws.h_partials, ws.plan.c, (int)ws.plan.logB, ws.plan.W, out_xy_le);
+  return 0;
+}
+
+// ---- resident bases (include/te_msm.h): points bound once, scalars per call ---------------------------------------------------
+namespace {
+bool valid_bases(const te_ctx* ctx, const te_bases* b) { return b && std::find(ctx->bases.begin(), ctx->bases.end(), b) != ctx->bases.end(); }
+const char* const kBadBases = "not a bound point set of this context (released, or bound to another context)";
+const char* const kBasesCurve = "the point set was bound under another curve than the one selected now (option \"curve\")";
+
+void free_bases(te_ctx* ctx, te_bases* b) {
+  for (size_t i = 0; i < b->recs.size() && i < ctx->devs.size(); i++)
+    if (b->recs[i]) { (void)hipSetDevice(ctx->devs[i].device); (void)hipFree(b->recs[i]); b->recs[i] = nullptr; }
+}
+
+// The records of the set on device i: raw points -> (temporary) -> records, on a stream of its own; returns when they are there.
+// src on the host: the device's own upload (D devices: D links side by side, one host thread each); src on a device of the
+// context: read in place on its holder, pulled over the peer link elsewhere.
+int bind_on_device(te_ctx* ctx, te_bases* b, size_t i, const void* src, bool src_is_host, int src_dev) {
+  gpu_t& d = ctx->devs[i];
+  HIP_TRY(ctx, hipSetDevice(d.device));
+  const curve_sizes sz = sizes_of(b->curve);
+  const uint64_t n = b->n;
+  uint8_t* recs = nullptr; void* raw = nullptr; void* proj = nullptr; hipStream_t st = nullptr;
+  struct cleanup_t { void*& raw; void*& proj; hipStream_t& st; ~cleanup_t() { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } if (raw) (void)hipFree(raw); if (proj) (void)hipFree(proj); } } cleanup{raw, proj, st};
+  HIP_TRY(ctx, hipMalloc((void**)&recs, (size_t)n * b->rec_bytes));
+  b->recs[i] = recs;                                                       // (freed by the caller on failure: free_bases)
+  HIP_TRY(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  const void* pts = src;
+  if (src_is_host) {
+    HIP_TRY(ctx, hipMalloc(&raw, (size_t)n * sz.point_in));
+    HIP_TRY(ctx, hipMemcpyAsync(raw, src, (size_t)n * sz.point_in, hipMemcpyHostToDevice, st));
+    pts = raw;
+  } else if (src_dev != d.device || ctx->opt_stage_device_inputs) {
+    HIP_TRY(ctx, hipMalloc(&raw, (size_t)n * sz.point_in));
+    HIP_TRY(ctx, hipMemcpyPeerAsync(raw, d.device, src, src_dev, (size_t)n * sz.point_in, st));
+    { std::lock_guard<std::mutex> lk(ctx->err_mu); ctx->stat_peer_copies += 1; ctx->stat_peer_bytes += (int64_t)(n * sz.point_in); }
+    pts = raw;
+  }
+  const uint32_t n32 = (uint32_t)n;
+  te::batch_ptrs tab; te::batch_slabs row_slab; memset(&tab, 0, sizeof tab); memset(&row_slab, 0, sizeof row_slab);
+  tab.p[0] = (const uint4*)pts;
+  if (b->curve == TE_MSM_CURVE_BLS12_377_G1) {
+    te::rec_slot<14>* pr = reinterpret_cast<te::rec_slot<14>*>(recs);
+    if (b->rec_kind == 1) { HIP_TRY(ctx, hipMalloc(&proj, (size_t)n * sizeof(te::rec_slot<14>))); pr = static_cast<te::rec_slot<14>*>(proj); }
+    hipLaunchKernelGGL(te::k_prep_points377, dim3((n32 + 255) / 256, 1), dim3(256), 0, st, tab, row_slab, pr, n32);
+    if (b->rec_kind == 1) {
+      const uint32_t groups = (n32 + TE_AFF_GROUP - 1u) / TE_AFF_GROUP;
+      hipLaunchKernelGGL(te::k_affine377, dim3((groups + 255) / 256), dim3(256), 0, st, pr, reinterpret_cast<te::rec_aff377*>(recs), n32);
+    }
+  } else {
+    hipLaunchKernelGGL(te::k_prep_points, dim3((n32 + 255) / 256, 1), dim3(256), 0, st, tab, row_slab, reinterpret_cast<te::pnt_slot*>(recs), n32);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return 0;
+}
+
+int bind_common(te_ctx* ctx, const void* src, bool src_is_host, uint64_t n, te_bases** out) {
+  if (!ctx || !out) return TE_MSM_EINVAL;
+  *out = nullptr;
+  if (n >= (1ull << 31)) return set_err(ctx, TE_MSM_EINVAL, "n must be < 2^31");
+  if (n > 0 && !src) return set_err(ctx, TE_MSM_EINVAL, "null point buffer");
+  drain_workers(ctx);
+  const size_t nd = ctx->devs.size();
+  int src_dev = -1;
+  if (!src_is_host && n > 0) {
+    const int owner = nd > 1 ? device_index_of_pointer(ctx, src) : 0;
+    if (owner < 0) return set_err(ctx, TE_MSM_EINVAL, "te_msm_bind_points_device: the points must be resident on a device of the context");
+    src_dev = ctx->devs[(size_t)owner].device;
+  }
+  te_bases* b = new te_bases();
+  b->ctx = ctx; b->n = n; b->curve = ctx->opt_curve;
+  b->rec_kind = (b->curve == TE_MSM_CURVE_BLS12_377_G1 && ctx->opt_bind_affine) ? 1 : 0;
+  b->rec_bytes = rec_bytes_of(b->curve, b->rec_kind);
+  b->recs.assign(nd, nullptr);
+  int rc = 0;
+  if (n > 0) {
+    std::vector<te_sched::job_ref> jobs(nd);
+    for (size_t i = 1; i < nd; i++) jobs[i] = worker_of(ctx, i).post([=] { return bind_on_device(ctx, b, i, src, src_is_host, src_dev); });
+    rc = bind_on_device(ctx, b, 0, src, src_is_host, src_dev);
+    for (size_t i = 1; i < nd; i++) { const int r = worker_of(ctx, i).wait(jobs[i]); if (!rc) rc = r; }
+  }
+  if (rc) { free_bases(ctx, b); delete b; return rc; }
+  ctx->bases.push_back(b);
+  *out = b;
+  return 0;
+}
+
+// te_msm_run_scalars_device on a context of D > 1 devices: WINDOW shards (device i computes windows i, i + D, ...).  Every
+// device needs all n scalars: the holder reads them in place, the others pull them over their peer link (32 bytes per point:
+// a third of what run_device_window_shards moves, so one copy each instead of its scatter + all-gather); every device gathers
+// from its own copy of the bound records.  One host thread per device enqueues its copy, its share and its read-back.
+int run_bound_window_shards(te_ctx* ctx, const te_bases* bases, const void* d_scalars, uint64_t n, uint8_t* out) {
+  const size_t nd = ctx->devs.size();
+  plan_t p0; make_plan(ctx, ctx->devs[0], n, p0);
+  const curve_sizes sz = sizes_of(p0.curve);
+  const int owner = device_index_of_pointer(ctx, d_scalars);
+  if (owner < 0) return set_err(ctx, TE_MSM_EINVAL, "te_msm_run_scalars_device: the scalars must be resident on a device of the context");
+  const int src_dev = ctx->devs[(size_t)owner].device;
+  std::vector<int> wsel(nd, 0);
+  for (size_t i = 0; i < nd; i++) { wsel[i] = free_workset_index(ctx->devs[i]); if (wsel[i] < 0) return set_err(ctx, TE_MSM_ESTATE, kAllSetsOwned); }
+  std::vector<int64_t> copies(nd, 0);
+  auto share = [&](size_t i) -> int {
+    gpu_t& d = ctx->devs[i]; workset_t& ws = d.ws[wsel[i]];
+    HIP_TRY(ctx, hipSetDevice(d.device));
+    const void* ds = d_scalars;
+    if (d.device != src_dev || ctx->opt_stage_device_inputs) {
+      if (int rc = ensure_staging(ctx, ws, 0, n * sz.scalar_in)) return rc;
+      if (ws.used && ws.ev_done) HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ws.ev_done, 0));
+      HIP_TRY(ctx, hipMemcpyPeerAsync(ws.d_in_scalars, d.device, d_scalars, src_dev, n * sz.scalar_in, ws.stream));
+      copies[i] = 1; ds = ws.d_in_scalars;
+    }
+    if (int rc = enqueue_partial(ctx, d, ws, nullptr, ds, n, nullptr, ws.stream, nullptr, 0, false, 1, false, bases)) return rc;
+    return fetch_rows(ctx, ws, ws.stream);
+  };
+  std::vector<te_sched::job_ref> jobs(nd);
+  for (size_t i = 1; i < nd; i++) jobs[i] = worker_of(ctx, i).post([&share, i] { return share(i); });
+  int rc = share(0);
+  for (size_t i = 1; i < nd; i++) { const int r = worker_of(ctx, i).wait(jobs[i]); if (!rc) rc = r; }
+  for (size_t i = 0; i < nd; i++) { ctx->stat_peer_copies += copies[i]; ctx->stat_peer_bytes += copies[i] * (int64_t)(n * sz.scalar_in); }
+  std::vector<uint8_t> merged((size_t)p0.W * sz.row, 0);
+  int64_t entries = 0; bool carry = false;
+  for (size_t i = 0; i < nd; i++) {
+    gpu_t& d = ctx->devs[i]; workset_t& ws = d.ws[wsel[i]];
+    if (rc) { (void)hipSetDevice(d.device); (void)hipStreamSynchronize(ws.stream); continue; }
+    HIP_TRY(ctx, hipSetDevice(d.device));
+    HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));
+    carry = carry || *ws.h_err != 0;
+    entries += (int64_t)ws.h_err[1];
+    for (int w = d.w_first; w < p0.W; w += d.w_step) memcpy(&merged[(size_t)w * sz.row], ws.h_partials + (size_t)w * sz.row, sz.row);
+  }
+  if (rc) return rc;
+  ctx->stat_entries = entries;
+  if (carry) return set_err(ctx, TE_MSM_ESCALAR, kFinalCarry);
+  if (p0.curve == TE_MSM_CURVE_BLS12_377_G1) te377_host::horner_to_affine(merged.data(), p0.c, (int)p0.logB, p0.W, out);
+  else te_host::horner_to_affine(merged.data(), p0.c, (int)p0.logB, p0.W, out);
+  return 0;
+}
+
+int run_scalars_common(te_ctx* ctx, te_bases* bases, const void* src, bool src_is_host, uint8_t* out) {
+  if (!ctx || !out) return TE_MSM_EINVAL;
+  if (!valid_bases(ctx, bases)) return set_err(ctx, TE_MSM_EINVAL, kBadBases);
+  if (bases->curve != ctx->opt_curve) return set_err(ctx, TE_MSM_EINVAL, kBasesCurve);
+  const uint64_t n = bases->n;
+  if (n == 0) {
+    memset(out, 0, sizes_of(ctx->opt_curve).result);
+    if (ctx->opt_curve == TE_MSM_CURVE_TE_BLS12) out[32] = 1;
+    return 0;
+  }
+  if (!src) return set_err(ctx, TE_MSM_EINVAL, "null scalar buffer");
+  if (ctx->devs.size() > 1) {
+    if (src_is_host) return run_host_sharded(ctx, nullptr, static_cast<const uint8_t*>(src), n, out, bases);
+    return run_bound_window_shards(ctx, bases, src, n, out);
+  }
+  gpu_t& d = ctx->devs[0];
+  int wsel = ctx->opt_workset;
+  if (te_sched::slot_ticket(d.ws[wsel].slot)) {
+    wsel = free_workset_index(d);
+    if (wsel < 0) return set_err(ctx, TE_MSM_ESTATE, kAllSetsOwned);
+  }
+  workset_t& ws = d.ws[wsel];
+  HIP_TRY(ctx, hipSetDevice(d.device));
+  plan_t p0; make_plan(ctx, d, n, p0);
+  const curve_sizes sz = sizes_of(p0.curve);
+  if (src_is_host && !ctx->opt_profile && d.w_step == 1) {
+    // whole MSM, no stage timing: the scalars in pieces
+    if (int rc = enqueue_scalar_slice(ctx, d, ws, bases->recs[0], bases->rec_kind, static_cast<const uint8_t*>(src), n, p0.c, scalar_pieces(ctx, n))) return rc;
+  } else {
+    const void* ds = src;
+    if (src_is_host) {
+      if (int rc = ensure_staging(ctx, ws, 0, n * sz.scalar_in)) return rc;
+      if (ws.used && ws.ev_done) HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ws.ev_done, 0));
+      if (int rc = upload(ctx, ws, ws.d_in_scalars, static_cast<const uint8_t*>(src), n * sz.scalar_in, ws.stream)) return rc;
+      ds = ws.d_in_scalars;
+    }
+    if (int rc = enqueue_partial(ctx, d, ws, nullptr, ds, n, nullptr, ws.stream, nullptr, 0, false, 1, false, bases)) return rc;
+    if (int rc = fetch_rows(ctx, ws, ws.stream)) return rc;
+  }
+  HIP_TRY(ctx, hipEventSynchronize(ws.ev_result));
+  note_entries(ctx, ws);
+  if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, kFinalCarry);
+  (void)collect_stage_ms(ctx, d, ws);
+  if (p0.curve == TE_MSM_CURVE_BLS12_377_G1) te377_host::horner_to_affine(ws.h_partials, p0.c, (int)p0.logB, p0.W, out);
+  else te_host::horner_to_affine(ws.h_partials, p0.c, (int)p0.logB, p0.W, out);
+  return 0;
+}
+}  // namespace
+
+int te_msm_bind_points(te_ctx* ctx, const uint8_t* points_xy_le, uint64_t n, te_bases** out) {
+  device_guard restore_callers_device;
+  return bind_common(ctx, points_xy_le, true, n, out);
+}
+
+int te_msm_bind_points_device(te_ctx* ctx, const void* d_points_xy_le, uint64_t n, te_bases** out) {
+  device_guard restore_callers_device;
+  return bind_common(ctx, d_points_xy_le, false, n, out);
+}
+
+uint64_t te_msm_bases_count(const te_bases* bases) { return bases ? bases->n : 0; }
+
+int te_msm_release_points(te_ctx* ctx, te_bases* bases) {
+  device_guard restore_callers_device;
+  if (!ctx) return TE_MSM_EINVAL;
+  if (!valid_bases(ctx, bases)) return set_err(ctx, TE_MSM_EINVAL, kBadBases);
+  if (bases->in_flight > 0) return set_err(ctx, TE_MSM_ESTATE, "te_msm_release_points: a ticket over this point set is in flight: collect it first");
+  drain_workers(ctx);
+  for (gpu_t& d : ctx->devs) {            // lone calls are over when they return; the streams may still clear their zeroed blocks -- nothing reads the records
+    (void)hipSetDevice(d.device);
+    for (workset_t& ws : d.ws) if (ws.used && ws.ev_done) (void)hipEventSynchronize(ws.ev_done);
+  }
+  free_bases(ctx, bases);
+  ctx->bases.erase(std::find(ctx->bases.begin(), ctx->bases.end(), bases));
+  delete bases;
+  return 0;
+}
+
+int te_msm_run_scalars(te_ctx* ctx, te_bases* bases, const uint8_t* scalars_le, uint8_t out_xy_le[64]) {
+  device_guard restore_callers_device;
+  return run_scalars_common(ctx, bases, scalars_le, true, out_xy_le);
+}
+
+int te_msm_run_scalars_device(te_ctx* ctx, te_bases* bases, const void* d_scalars_le, uint8_t out_xy_le[64]) {
+  device_guard restore_callers_device;
+  return run_scalars_common(ctx, bases, d_scalars_le, false, out_xy_le);
+}
+
+int te_msm_submit_scalars(te_ctx* ctx, te_bases* bases, const uint8_t* scalars_le, uint64_t* ticket) {
+  device_guard restore_callers_device;
+  if (!ctx || !ticket) return TE_MSM_EINVAL;
+  if (!valid_bases(ctx, bases)) return set_err(ctx, TE_MSM_EINVAL, kBadBases);
+  if (bases->curve != ctx->opt_curve) return set_err(ctx, TE_MSM_EINVAL, kBasesCurve);
+  const uint64_t n = bases->n;
+  if (!scalars_le || n == 0) return set_err(ctx, TE_MSM_EINVAL, "bad arguments (an empty point set has no tickets: te_msm_run_scalars returns the identity)");
+  if (ctx->devs.size() == 1 && ctx->devs[0].w_step != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_submit_scalars computes whole MSMs: reset the window shard first");
+  const int di = pick_device(ctx, -1);
+  if (di < 0) return set_err(ctx, TE_MSM_ESTATE, "every work set has an MSM in flight: collect one first");
+  gpu_t& d = ctx->devs[(size_t)di];
+  HIP_TRY(ctx, hipSetDevice(d.device));
+  const int wi = take_free_workset(ctx, d, false);
+  if (wi < 0) return wi;
+  workset_t& ws = d.ws[wi];
+  plan_t pf; make_plan(ctx, d, n, pf, 0, 1, 0, true);
+  // pieces shorten ONE MSM's way through the device (its upload hides under its own first pieces); with other tickets in flight on
+  // the device the upload hides under THEIR device work, and one piece keeps the sort and the accumulation at full width
+  const int c = pf.c, K = (ctx->opt_scalar_chunks || d.in_flight == 0) ? scalar_pieces(ctx, n) : 1;
+  ws.job_err.clear();
+  workset_t* wsp = &ws; gpu_t* dp = &d;
+  const uint8_t* recs = bases->recs[(size_t)di]; const int kind = bases->rec_kind;
+  warm_upload_lanes(ctx);
+  te_sched::job_ref job = te_sched::next_lane_of(*ctx, (size_t)di, ctx->opt_upload_threads).post([ctx, dp, wsp, recs, kind, scalars_le, n, c, K]() -> int {
+    const int rc = enqueue_scalar_slice(ctx, *dp, *wsp, recs, kind, scalars_le, n, c, K, false);
+    if (rc) { std::lock_guard<std::mutex> lk(ctx->err_mu); wsp->job_err = ctx->err; }
+    return rc;
+  });
+  ws.bound = bases; bases->in_flight++;
+  hand_out_ticket(ctx, di, ws, ticket, std::move(job));
+  return 0;
+}
+
+int te_msm_submit_scalars_device(te_ctx* ctx, te_bases* bases, const void* d_scalars_le, uint64_t* ticket) {
+  device_guard restore_callers_device;
+  if (!ctx || !ticket) return TE_MSM_EINVAL;
+  if (!valid_bases(ctx, bases)) return set_err(ctx, TE_MSM_EINVAL, kBadBases);
+  if (bases->curve != ctx->opt_curve) return set_err(ctx, TE_MSM_EINVAL, kBasesCurve);
+  const uint64_t n = bases->n;
+  if (!d_scalars_le || n == 0) return set_err(ctx, TE_MSM_EINVAL, "bad arguments (an empty point set has no tickets: te_msm_run_scalars_device returns the identity)");
+  const bool multi = ctx->devs.size() > 1;
+  const int owner = multi ? device_index_of_pointer(ctx, d_scalars_le) : 0;
+  if (multi && owner < 0) return set_err(ctx, TE_MSM_EINVAL, "te_msm_submit_scalars_device: the scalars must be resident on a device of the context");
+  const int di = pick_device(ctx, owner);
+  if (di < 0) return set_err(ctx, TE_MSM_ESTATE, "every work set has an MSM in flight: collect one first");
+  gpu_t& d = ctx->devs[(size_t)di];
+  HIP_TRY(ctx, hipSetDevice(d.device));
+  const int wi = take_free_workset(ctx, d, true);
+  if (wi < 0) return wi;
+  workset_t& ws = d.ws[wi];
+  const int src_dev = ctx->devs[(size_t)owner].device;
+  const void* ds = d_scalars_le;
+  if (multi && (d.device != src_dev || ctx->opt_stage_device_inputs)) {
+    const curve_sizes sz = sizes_of(ctx->opt_curve);
+    if (int rc = ensure_staging(ctx, ws, 0, n * sz.scalar_in)) return rc;
+    if (ws.used) HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ws.ev_done, 0));
+    HIP_TRY(ctx, hipMemcpyPeerAsync(ws.d_in_scalars, d.device, d_scalars_le, src_dev, n * sz.scalar_in, ws.stream));
+    ctx->stat_peer_copies += 1; ctx->stat_peer_bytes += (int64_t)(n * sz.scalar_in);
+    ds = ws.d_in_scalars;
+  }
+  if (int rc = enqueue_partial(ctx, d, ws, nullptr, ds, n, nullptr, ws.stream, nullptr, 0, false, 1, multi, bases)) return rc;
+  if (int rc = fetch_rows(ctx, ws, ws.stream)) return rc;
+  ws.bound = bases; bases->in_flight++;
+  hand_out_ticket(ctx, di, ws, ticket);
   return 0;
 }
 
@@ -1793,6 +2229,8 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   if (!strcmp(key, "stage_device_inputs")) { ctx->opt_stage_device_inputs = value ? 1 : 0; return 0; }
   if (!strcmp(key, "host_staging")) { ctx->opt_host_staging = value ? 1 : 0; return 0; }
   if (!strcmp(key, "upload_threads")) { if (value < 1 || value > 16) return set_err(ctx, TE_MSM_EINVAL, "upload_threads must be in [1, 16]"); ctx->opt_upload_threads = (int)value; return 0; }
+  if (!strcmp(key, "bind_affine")) { ctx->opt_bind_affine = value ? 1 : 0; return 0; }
+  if (!strcmp(key, "scalar_chunks")) { if (value < 0 || value > 64) return set_err(ctx, TE_MSM_EINVAL, "scalar_chunks out of range"); ctx->opt_scalar_chunks = (int)value; return 0; }
   return set_err(ctx, TE_MSM_EINVAL, "unknown option");
 }
 
@@ -1822,6 +2260,10 @@ int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value) {
   if (!strcmp(key, "packed_sort")) { *value = ctx->opt_packed; return 0; }
   if (!strcmp(key, "fold_pairs")) { *value = ctx->opt_fold_pairs; return 0; }
   if (!strcmp(key, "streams_final")) { *value = ctx->devs[0].streams_final ? 1 : 0; return 0; }
+  if (!strcmp(key, "bind_affine")) { *value = ctx->opt_bind_affine; return 0; }
+  if (!strcmp(key, "scalar_chunks")) { *value = ctx->opt_scalar_chunks; return 0; }
+  if (!strcmp(key, "bases_bound")) { *value = (int64_t)ctx->bases.size(); return 0; }
+  if (!strcmp(key, "bases_bytes")) { int64_t t = 0; for (const te_bases* b : ctx->bases) for (const uint8_t* r : b->recs) if (r) t += (int64_t)(b->n * b->rec_bytes); *value = t; return 0; }
   if (!strcmp(key, "in_flight")) { int64_t t = 0; for (const gpu_t& d : ctx->devs) t += d.in_flight; *value = t; return 0; }
   if (!strcmp(key, "device_bytes")) {      drain_workers(ctx);      // device memory this context holds in work-set buffers (te_msm_trim gives it back)
     int64_t tot = 0;
@@ -1882,6 +2324,7 @@ int te_msm_workset_stream(te_ctx* ctx, int workset, void** stream, int* hw_queue
   if (!ctx || workset < 0 || workset >= TE_MSM_WORKSETS || !stream) return TE_MSM_EINVAL;
   if (ctx->devs.size() != 1) return set_err(ctx, TE_MSM_ESTATE, "te_msm_workset_stream needs a single-device context");
   const workset_t& ws = ctx->devs[0].ws[workset];
+  ctx->devs[0].streams_exported = true;       // the handle leaves the library: the device's streams are parked, not destroyed, from now on
   *stream = (void*)ws.stream;
   if (hw_queue_class) *hw_queue_class = ws.hw_queue_class;
   return 0;
@@ -2030,6 +2473,20 @@ int te_msm_synth_inputs_bls12_377(uint64_t seed, uint64_t n, uint8_t* points_xy_
   return 0;
 }
 
+int64_t te_msm_bases_read(te_ctx* ctx, const te_bases* bases, int device_index, uint64_t first, uint64_t count, void* dst, uint64_t cap, int* record_bytes) {
+  device_guard restore_callers_device;
+  if (!ctx || !dst) return TE_MSM_EINVAL;
+  if (!valid_bases(ctx, bases)) return set_err(ctx, TE_MSM_EINVAL, kBadBases);
+  if (device_index < 0 || (size_t)device_index >= ctx->devs.size() || first > bases->n || count > bases->n - first) return set_err(ctx, TE_MSM_EINVAL, "bad arguments");
+  if (record_bytes) *record_bytes = (int)bases->rec_bytes;
+  uint64_t bytes = count * bases->rec_bytes;
+  if (bytes > cap) bytes = cap;
+  if (!bytes) return 0;
+  HIP_TRY(ctx, hipSetDevice(ctx->devs[(size_t)device_index].device));
+  HIP_TRY(ctx, hipMemcpy(dst, bases->recs[(size_t)device_index] + first * bases->rec_bytes, bytes, hipMemcpyDeviceToHost));
+  return (int64_t)bytes;
+}
+
 int64_t te_msm_debug_read(te_ctx* ctx, const char* stage, void* dst, uint64_t cap) {
   device_guard restore_callers_device;
   if (!ctx || !stage || !dst) return TE_MSM_EINVAL;
@@ -2041,7 +2498,10 @@ int64_t te_msm_debug_read(te_ctx* ctx, const char* stage, void* dst, uint64_t ca
   const void* src = nullptr; uint64_t bytes = 0;
   if (ws.zero_clean_words && (!strcmp(stage, "bucket_count") || !strcmp(stage, "num_segments") || !strcmp(stage, "partials")))
     return set_err(ctx, TE_MSM_ESTATE, "this stage lives in the block that is cleared behind an MSM's read-back: set option prezero = 0 before the run to keep it");
-  if (!strcmp(stage, "records")) { src = ws.d_recs; bytes = n * sizes_of(p.curve).rec; }
+  if (!strcmp(stage, "records")) {
+    if (!ws.d_recs) return set_err(ctx, TE_MSM_ESTATE, "the last run gathered from a bound point set: the work set holds no records of its own");
+    src = ws.d_recs; bytes = n * sizes_of(p.curve).rec;
+  }
   else if (!strcmp(stage, "digits")) { src = ws.d_digits; bytes = (uint64_t)p.nw * p.nst * 2; }   // row stride nst = n rounded up to 8
   else if (!strcmp(stage, "bucket_count")) { src = ws.d_bucket_count; bytes = (uint64_t)p.nw * p.B * 4; }
   else if (!strcmp(stage, "bucket_start")) { src = ws.d_bucket_start; bytes = (uint64_t)p.nw * p.B * 4; }
