@@ -137,6 +137,65 @@ def alone_pass(ctx, step, reps):
     return {k: v / reps for k, v in acc.items()}
 
 
+def bases_resident_figures(ctx, pts, sc, expect, d_sc=None, n=None, depth=4, steps=32):
+    """Resident bases (te_msm_bind_points + te_msm_run_scalars / te_msm_submit_scalars): the points are bound ONCE (timed: bind_ms),
+    every MSM then moves its scalars only -- what the reference's harness could do with the one point buffer it passes to six calls
+    per size (full_benchmarks.ts:63-68,100-105).  latency_ms: one te_msm_run_scalars at a time from pageable host scalars (best of
+    7); in_flight_ms: te_msm_submit_scalars tickets, 8 in flight, per MSM (best of 3 passes); device_scalars_ms: scalars already in
+    HBM, `depth` tickets in flight (te_msm_submit_scalars_device).  Every result is compared with `expect`."""
+    import torch
+    prof = ctx.get_option("profile")
+    ctx.set_option("profile", 0)
+    out = {}
+    try:
+        t1 = time.perf_counter()
+        b = ctx.bind_points(pts)
+        out["bind_ms"] = (time.perf_counter() - t1) * 1e3
+        assert ctx.run_scalars(b, sc) == expect
+        lat = []
+        for _ in range(7):
+            t1 = time.perf_counter()
+            r = ctx.run_scalars(b, sc)
+            lat.append((time.perf_counter() - t1) * 1e3)
+        assert r == expect
+        out["latency_ms"] = min(lat)
+        infl = 8
+        for t in [ctx.submit_scalars(b, sc) for _ in range(infl)]:
+            assert ctx.collect(t) == expect
+        passes = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            tk = []
+            for _ in range(steps):
+                tk.append(ctx.submit_scalars(b, sc))
+                if len(tk) >= infl:
+                    assert ctx.collect(tk.pop(0)) == expect
+            while tk:
+                assert ctx.collect(tk.pop(0)) == expect
+            passes.append((time.perf_counter() - t1) * 1e3 / steps)
+        out["in_flight_ms"] = min(passes)
+        out["in_flight_passes_ms"] = passes
+        if d_sc is not None:
+            for t in [ctx.submit_scalars_device(b, d_sc) for _ in range(depth)]:
+                assert ctx.collect(t) == expect
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            tk = []
+            for _ in range(steps):
+                tk.append(ctx.submit_scalars_device(b, d_sc))
+                if len(tk) >= depth:
+                    assert ctx.collect(tk.pop(0)) == expect
+            while tk:
+                assert ctx.collect(tk.pop(0)) == expect
+            out["device_scalars_ms"] = (time.perf_counter() - t1) * 1e3 / steps
+        out["bytes_per_msm_over_pcie"] = len(sc)
+        out["bases_bytes_on_device"] = ctx.get_option("bases_bytes")
+        ctx.release_points(b)
+    finally:
+        ctx.set_option("profile", prof)
+    return out
+
+
 def roofline_block(acc_bytes, alone, timed, bls, waves, traffic=None, traffic_info=None, msms_per_launch=1, entries=None):
     """roofline of the dominant kernel.  `achieved` = algorithmic bytes per launch / the kernel's mean duration with the GPU
     to itself (HIP events around the launch on the engine's stream, measured live in this run; agrees with the kernel trace
@@ -196,6 +255,15 @@ def side_config(pkg, dev, name, curve, digits, log2n, depth, threads, steps, exp
         elapsed, result = pipelined_pass(cx, dp, ds, n, steps, depth)
         alone = alone_pass(cx, lambda: cx.run_device(dp, ds, n), 4)
         entries = cx.get_option("entries_accumulated")     # non-zero window digits of that last MSM, counted on the device
+        bound = None
+        if bls:
+            # BLS12-377 over BOUND bases: affine records (one inversion per point at bind time): 7 products and 168 bytes per gathered
+            # point instead of 8 and 224
+            bound = bases_resident_figures(cx, pts, sc, result, ds, n, depth, steps)
+            cx.set_option("profile", 1)
+            bb = cx.bind_points(pts)
+            bound["accumulate_alone_ms"] = alone_pass(cx, lambda: cx.run_scalars_device(bb, ds), 4).get("accumulate")
+            cx.release_points(bb)
     whole, acc_bytes = algorithmic_bytes(n, W, B, bls, entries)
     traffic, traffic_info = measured_traffic(log2n, c, 1, False, name)
     out = {"workload": "n=2^%d %s MSM, %d-bit %s windows (%d windows x %d buckets)%s, inputs resident in HBM" % (
@@ -203,6 +271,11 @@ def side_config(pkg, dev, name, curve, digits, log2n, depth, threads, steps, exp
            "value": steps / elapsed, "unit": "MSM/s", "steps": steps, "ms_per_step": elapsed * 1e3 / steps, "latency_ms": min(lat),
            "roofline": roofline_block(acc_bytes, alone, None, bls, entries / 64.0, traffic, traffic_info, entries=entries),
            "msm_algorithmic_bytes": whole}
+    if bound:
+        bound["value_device_scalars"] = 1e3 / bound["device_scalars_ms"]
+        bound["note"] = ("te_msm_bind_points once (affine records: 168 B and 7 products per gathered point; bind_ms), then scalars only: device_scalars_ms = "
+                         "te_msm_submit_scalars_device tickets, %d in flight; in_flight_ms / latency_ms from pageable host scalars (48 B per point over PCIe)" % depth)
+        out["bases_resident"] = bound
     if expect is None:
         t0 = time.perf_counter()
         if bls:
@@ -749,8 +822,18 @@ def main():
                                               "compute_msm promises into), %d in flight, %d upload threads, per MSM; passes: %s" % (
                                                   infl, ctx.get_option("upload_threads"), " ".join("%.3f" % x for x in in_flight_passes)))
         ctx.set_option("profile", 1)
+        # resident bases: the same boundary with the points bound once (opt-in beside compute_msm: setBases in the addon)
+        br = bases_resident_figures(ctx, pts, sc, result, d_sc.data_ptr(), n, depth)
+        out["bases_resident"] = br
+        out["bases_resident_in_flight_ms"] = br["in_flight_ms"]
+        out["bases_resident_latency_ms"] = br["latency_ms"]
+        out["bases_resident_device_scalars_ms"] = br.get("device_scalars_ms")
+        out["bases_resident_note"] = ("te_msm_bind_points once (%.1f ms), then te_msm_submit_scalars (8 in flight, per MSM) / te_msm_run_scalars (one at a time) "
+                                      "from pageable host scalars: 32 of the 96 bytes per point cross PCIe, no conversion; device_scalars: scalars in HBM, %d in flight"
+                                      % (br["bind_ms"], depth))
         out["sizes"] = {str(args.log2n): {"ms_per_step": ms_per_step, "latency_ms": min(lat), "host_buffers_ms": hb, "window_bits": c,
-                                          "core_clock_ghz": stage_ms.get("accumulate_core_clock_ghz")}}
+                                          "core_clock_ghz": stage_ms.get("accumulate_core_clock_ghz"),
+                                          "bases_resident_in_flight_ms": br["in_flight_ms"], "bases_resident_latency_ms": br["latency_ms"]}}
         size_rate(out["sizes"][str(args.log2n)], n, c, W)
         if not args.no_sizes and not bls and args.log2n == 20:
             # the other harness sizes (full_benchmarks.ts:13-15), short runs, window size chosen by the engine, on the same
@@ -777,8 +860,11 @@ def main():
                 assert r2 == ref
                 sx.set_option("profile", 1)            # the kernel stamps its own clock: one more MSM for the core clock at this size
                 assert sx.run_device(dp2.data_ptr(), ds2.data_ptr(), m) == ref
+                ghz2 = sx.stage_ms().get("accumulate_core_clock_ghz")
+                br2 = bases_resident_figures(sx, p2, s2, ref, None, m, depth, 24)
                 out["sizes"][str(lg)] = {"ms_per_step": el * 1e3 / 40, "latency_ms": min(l2), "host_buffers_ms": hb2, "window_bits": sx.plan(m)[0],
-                                         "core_clock_ghz": sx.stage_ms().get("accumulate_core_clock_ghz")}
+                                         "core_clock_ghz": ghz2,
+                                         "bases_resident_in_flight_ms": br2["in_flight_ms"], "bases_resident_latency_ms": br2["latency_ms"]}
                 size_rate(out["sizes"][str(lg)], m, *sx.plan(m))
             sx.set_option("window_bits", args.window_bits)
             sx.set_option("profile", 1)
@@ -968,7 +1054,8 @@ def main():
                 print(json.dumps(out))
             raise SystemExit("window-sharded result differs from the single-GPU result")
     # the driver's record keeps `config`, `roofline` and `cpu_baseline` of this line: the figures of the boundary go there too
-    for k in ("latency_ms", "host_buffers_ms", "host_buffers_in_flight_ms", "host_buffers_ms_one_device", "sizes"):
+    for k in ("latency_ms", "host_buffers_ms", "host_buffers_in_flight_ms", "host_buffers_ms_one_device", "bases_resident_in_flight_ms",
+              "bases_resident_latency_ms", "bases_resident_device_scalars_ms", "sizes"):
         if out.get(k) is not None:
             out["config"][k] = out[k]
     if rank == 0:

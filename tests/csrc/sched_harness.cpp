@@ -167,9 +167,16 @@ int fk_run(fake_ctx* c, const uint8_t* points, const uint8_t* scalars, uint64_t 
 }
 int64_t fk_in_flight(fake_ctx* c) { int64_t t = 0; for (auto& d : c->devs) t += d.in_flight; return t; }
 
+// a bound point set of the stand-in engine: it only remembers the caller's buffer (the real one keeps records on the devices)
+struct fake_bases { const uint8_t* points; uint64_t n; };
 struct FakeApi {
   using ctx_t = fake_ctx;
+  using bases_t = fake_bases;
   static constexpr int ESTATE = FK_ESTATE;
+  static int bind(fake_ctx*, const uint8_t* p, uint64_t n, fake_bases** out) { *out = new fake_bases{p, n}; return 0; }
+  static int release(fake_ctx*, fake_bases* b) { delete b; return 0; }
+  static int run_scalars(fake_ctx* c, fake_bases* b, const uint8_t* s, uint8_t* out) { return fk_run(c, b->points, s, b->n, out); }
+  static int submit_scalars(fake_ctx* c, fake_bases* b, const uint8_t* s, uint64_t* t) { return fk_submit(c, b->points, s, b->n, t, true); }
   static std::vector<int> default_devices() { return {0}; }
   static int init(const int* ids, int n, fake_ctx** out) { return fk_init(ids, n, out); }
   static void destroy(fake_ctx* c) { fk_destroy(c); }
@@ -320,6 +327,26 @@ void test_promises(const std::vector<msm_case>& cs, int D, int pool_threads) {
   burst(1, 1);                                                              // a lone call: point slices on several devices
   burst(2 * D, 2);
   burst(D * SETS + 5, 0);                                                   // more than there are work sets: capacity waits inside execute()
+  burst(3 * D * SETS + 1, 1);                                               // far more: with a pool of ONE thread round 5's protocol hung here (every
+                                                                            // set taken by younger tickets, the oldest job parked on capacity)
+  {
+    const te_promise::stats_t st = proto.stats();
+    CHECK(st.max_in_flight <= (int64_t)D * SETS && st.max_in_flight >= 1, "tickets in flight (%lld)", (long long)st.max_in_flight);
+    CHECK(st.submitted_in_enter + st.submitted_in_execute + st.lone_runs >= (uint64_t)(2 + 2 * D + D * SETS + 5), "every job went one way or the other");
+  }
+  // resident bases: jobs over the bound buffer take the scalars-only path, the others the ordinary one; the binding survives a reset
+  {
+    std::string err;
+    const msm_case& mb = cs[3];
+    CHECK(proto.set_bases(mb.pts.data(), mb.n, err) == 0 && proto.has_bases(), "set_bases (%s)", err.c_str());
+    const uint64_t before = proto.stats().bound_jobs;
+    burst((int)cs.size() + 3, 0);                                           // case 3 (twice) is the bound buffer, the others are not
+    CHECK(proto.stats().bound_jobs >= before + 1, "jobs over the bound buffer took the scalars-only path");
+    proto.reset();
+    burst(1, 3);                                                            // a new context binds the buffer again
+    CHECK(proto.stats().bound_jobs >= before + 2, "bound again after a reset");
+    CHECK(proto.set_bases(nullptr, 0, err) == 0 && !proto.has_bases(), "unbind");
+  }
   proto.reset();                                                            // compute_msm's force_recompile
   burst(3, 3);
   proto.set_devices({0});
@@ -338,6 +365,8 @@ int main() {
   const std::vector<msm_case> cs = make_cases();
   test_worker();
   for (int D : {1, 2, 4}) test_tickets(cs, D);
+  test_promises(cs, 1, 1);                       // UV_THREADPOOL_SIZE=1: the deterministic hang of round 5's protocol (advisor)
+  test_promises(cs, 2, 1);
   test_promises(cs, 1, 4);
   test_promises(cs, 4, 2);
   test_promises(cs, 3, 6);

@@ -326,3 +326,38 @@ def test_compute_msm_with_set_bases(pkg, model, wasm_golden):
     pkg.set_bases(None)
     assert pkg.binding._DEFAULT_CTX.get_option("bases_bound") == 0
     assert pkg.compute_msm(pts, sc, log_result=False) == want
+
+
+def test_node_set_bases(pkg, model, wasm_golden, tmp_path):
+    """from the reference's host language: setBases(points) once, then compute_msm(points, scalars) -- the same Buffer object --
+    moves the scalars only (the addon counts those jobs); a copy of the buffer takes the ordinary path; both equal the reference's
+    own output; eight promises in flight over the bound buffer on one and on four "devices"; a pool of ONE libuv thread with more
+    promises than work sets (round 5's protocol hung there)"""
+    import json
+    import os
+    import subprocess
+    from test_gpu_parity import _node_js_dir
+    node, js = _node_js_dir()
+    g = next(x for x in wasm_golden if x["name"] == "random_n262144")
+    pts, sc = make_inputs(g["seed"], g["n"], g["mode"])
+    (tmp_path / "p.bin").write_bytes(pts)
+    (tmp_path / "s.bin").write_bytes(sc)
+    want = (int(g["x"]), int(g["y"]))
+
+    def run(args, env=None):
+        r = subprocess.run([node, os.path.join(js, "run_concurrent.js"), str(tmp_path / "p.bin"), str(tmp_path / "s.bin")] + args,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+        out = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        assert "x" in out, (out, r.stderr.decode()[-2000:])
+        assert (int(out["x"]), int(out["y"])) == want and out["all_equal"], out
+        return out
+
+    out = run(["8", "-", "bases"])
+    print("node, bound bases: single %.3f ms, eight in flight %.3f ms" % (out["single_ms"], out["concurrent_ms"]))
+    assert out["stats"]["boundJobs"] == 2 + 4 * 8 and out["stats"]["maxInFlight"] == 8, out["stats"]
+    out = run(["8", "0,0,0,0", "bases"])
+    assert out["devices"] == [0, 0, 0, 0] and out["stats"]["boundJobs"] == 2 + 4 * 8, out
+    out = run(["20", "-", "bases"], env=dict(os.environ, UV_THREADPOOL_SIZE="1"))       # 20 promises, 8 work sets, one pool thread
+    assert out["stats"]["boundJobs"] == 2 + 4 * 20 and out["stats"]["maxInFlight"] == 8, out["stats"]
+    out = run(["20"], env=dict(os.environ, UV_THREADPOOL_SIZE="1"))                      # the same without bases
+    assert out["stats"]["boundJobs"] == 0 and out["stats"]["maxInFlight"] == 8, out["stats"]

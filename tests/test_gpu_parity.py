@@ -702,8 +702,9 @@ def _node_js_dir():
 
 def test_node_promises_in_flight_and_device_list(pkg, model, ora, tmp_path):
     """From the reference's host language: four compute_msm promises in flight at n = 2^18 overlap on the engine's work sets
-    (te_msm_submit / ticket_wait / collect under the addon) -- all four equal the oracle and together take less than four
-    single calls; setDevices([0, 0]) / TE_MSM_DEVICES shard one call over "two devices" with the same result"""
+    (te_msm_submit_async / ticket_wait / collect under the addon) -- all four equal the oracle and were in flight together (the
+    addon's own count; the timings are printed, not asserted); setDevices([0, 0]) / TE_MSM_DEVICES shard one call over "two devices"
+    with the same result"""
     import json
     import subprocess
     node, js = _node_js_dir()
@@ -722,9 +723,17 @@ def test_node_promises_in_flight_and_device_list(pkg, model, ora, tmp_path):
         return out
 
     out = run(["4"])
-    print("node: single %.3f ms, four in flight %.3f ms" % (out["single_ms"], out["concurrent_ms"]))
+    # the timings are RECORDED, not asserted (round-5 verdict: one slow box must not take the parity suite down -- this very line went
+    # red on a box whose copy engines were being brought up); that the four calls overlap is checked structurally: the addon saw
+    # four tickets in flight at a submit, i.e. all four were on the engine's work sets before the first one was collected
+    print("node: single %.3f ms, four in flight %.3f ms (not asserted)" % (out["single_ms"], out["concurrent_ms"]))
+    if out["concurrent_ms"] >= 4 * out["single_ms"]:
+        import warnings
+        warnings.warn("four compute_msm promises in flight took %.3f ms against %.3f ms for one call: no overlap visible in the timing on this box" % (out["concurrent_ms"], out["single_ms"]))
+    (tmp_path / "node_in_flight.json").write_text(json.dumps(out))
     assert out["devices"] == [0]
-    assert out["concurrent_ms"] < 4 * out["single_ms"], out
+    assert out["stats"]["maxInFlight"] == 4, out["stats"]
+    assert out["stats"]["boundJobs"] == 0
     out = run(["2", "0,0"])
     assert out["devices"] == [0, 0]
     out = run(["1"], env=dict(os.environ, TE_MSM_DEVICES="0,0,0"))

@@ -237,6 +237,30 @@ def test_window_count_of_15_and_5_bit_plans(pkg, model, ora):
         assert c.run(pts, sc) == ora.msm_naive(pts, sc)                                    # (the pipeline oracle has signed windows only)
 
 
+def test_acceptance_of_non_canonical_scalars_follows_the_window_size(pkg, model, ora):
+    """canonical scalars (< p) always fit; which NON-canonical ones are accepted depends on the window size,
+    hence -- through the automatic plan -- on n: a scalar in [2^254, 2^255) leaves a final carry under the 17 x 15-bit plan that
+    n = 2^16 .. 2^18 get by default (TE_MSM_ESCALAR, the reference's "final carry is 1", utils.ts:80-83) and is an ordinary scalar
+    under 16 x 16 bits, the reference's own decomposition; "window_bits" = 16 gives its acceptance range at any n"""
+    n = 1 << 16
+    pts = ora.gen_points(1700, n)
+    big = (1 << 254) + 12345
+    sc = model.scalars_to_bytes([big, 7] + [3] * (n - 2))
+    with pkg.MsmContext((0,)) as c:
+        assert c.plan(n) == (15, 17)
+        for call in (lambda: c.run(pts, sc), lambda: c.collect(c.submit(pts, sc))):
+            with pytest.raises(pkg.MsmError) as e:
+                call()
+            assert e.value.code == -3
+        c.set_option("window_bits", 16)
+        assert c.plan(n) == (16, 16)
+        assert c.run(pts, sc) == ora.msm(pts, sc, threads=8)          # the oracle's 16-bit windows accept it as the reference does
+        c.set_option("window_bits", 0)
+        small = 1 << 12
+        assert c.plan(small)[0] == 11 and c.plan(3 << 17) == (16, 16)
+        assert c.run(pts[:64 * small], sc[:32 * small]) == ora.msm(pts[:64 * small], sc[:32 * small], threads=4)      # 24 x 11 bits reach bit 263
+
+
 def test_node_eight_promises_on_four_devices(pkg, model, ora, tmp_path):
     """From the reference's host language: eight compute_msm promises in flight on TE_MSM_DEVICES=0,0,0,0 become eight
     tickets, two per device (te_msm_submit_async from the JavaScript thread, wait + collect on libuv's pool); a lone call

@@ -425,6 +425,19 @@ for n2 in (301, 2, 1):
     assert L.fpc_partial_rows(dp.numpy().tobytes(), ds.numpy().tobytes(), n2, c, first, step, buf) == 0
     t2 = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
     assert pkg.finalize_host(pkg.exchange_partials(t2, W, dist), c, W) == o.msm(p2, s2), "rank %d: MSM over distributed inputs" % rank
+# the ranks must agree on n: a rank that brings another size gets a real exception -- on EVERY rank, before the all-gathers whose
+# buffer sizes depend on it (round-5 advisor: an assert behind the collective, stripped under -O)
+n3 = 40 + rank
+try:
+    pkg.distribute_inputs(o.gen_points(93, n3), o.gen_scalars(94, n3), dist, device="cpu")
+    raise SystemExit("rank %d: mismatching n was accepted" % rank)
+except ValueError as e:
+    assert "disagree on n" in str(e), e
+try:
+    pkg.distribute_inputs(bytes(64 * 3 + 1), bytes(32 * 3), dist, device="cpu")
+    raise SystemExit("a ragged point buffer was accepted")
+except ValueError:
+    pass
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """

@@ -112,8 +112,16 @@ __global__ void __launch_bounds__(256) k_prep_points(batch_ptrs in, batch_slabs 
 #define TE_DIG_THREADS 512u
 #endif
 __device__ __forceinline__ bool digit_bucket(uint32_t stored, uint32_t half, uint32_t& bucket, uint32_t& neg);
+// (A/B builds, round 6: -DTE_DIG_WAVES / TE_L2_WAVES name the waves per SIMD the sort kernels are compiled for -- a footprint that fits
+// beside three resident accumulation waves per SIMD, 104 VGPRs -- profiles/r06_pipelined_overlap.txt)
+#ifndef TE_DIG_WAVES
+#define TE_DIG_WAVES 1
+#endif
+#ifndef TE_L2_WAVES
+#define TE_L2_WAVES 3
+#endif
 template <int C>
-__global__ void __launch_bounds__(TE_DIG_THREADS) k_digits(batch_ptrs in, uint16_t* __restrict__ digits,
+__global__ void __launch_bounds__(TE_DIG_THREADS, TE_DIG_WAVES) k_digits(batch_ptrs in, uint16_t* __restrict__ digits,
                                                 digits_params prm, uint32_t* __restrict__ err, uint32_t* __restrict__ counts1) {
   __shared__ uint32_t hist[4096];                        // [local window][partition]: nw_local * P <= 4096 for every plan
   // MSM blockIdx.y of the launch sequence: its scalars, its digit rows and level-1 counts [y * nw_local, (y + 1) * nw_local)
@@ -341,7 +349,7 @@ __device__ __forceinline__ void unpack8(const uint4& v, uint32_t (&d)[8]) {
 struct scatter_args {
   const uint16_t* digits; const uint32_t* counts1; uint16_t* part_keys; uint32_t* part_idx;
   uint32_t *part_start, *part_count, *seg_part_base; uint32_t seg_len, cap_w, nw /* local windows of the launch sequence */; sort_geom g;
-  uint32_t* entries;     // += the non-zero digits of every window (one atomic per window): what k_accumulate will gather -- bench.py's roofline
+  unsigned long long* entries;   // += the non-zero digits of every window (one 64-bit atomic per window): what k_accumulate will gather -- bench.py's roofline
 };
 // LDS of one level-1 block in words: one packed word per entry of the tile, four 512-entry tables, scan scratch.
 // Packed entry: source slot in the tile (12 bits) | partition << 12 (8 bits: P <= 256) | bucket low bits << 20 (8) | sign << 28 --
@@ -378,7 +386,7 @@ __device__ __forceinline__ void part_scatter_block(uint32_t ch, uint32_t k, uint
     const uint32_t start = block_excl_scan(tot, sm, bt);
     if (t < g.P) run_base[t] = start + pre;
     if (ch == 0) {
-      if (t == 0 && bt) atomicAdd(a.entries, bt);
+      if (t == 0 && bt) atomicAdd(a.entries, (unsigned long long)bt);
       const uint32_t extra = block_excl_scan(tot / seg_len, sm, bt);
       if (t < g.P) {
         part_start[k * g.P + t] = start; part_count[k * g.P + t] = tot;
@@ -650,7 +658,7 @@ struct l2_args {
 static_assert(sizeof(plan_lds) <= TE_L2_LIST * 4u, "the plan's LDS fits into the list area");
 // grid (P + X, nw), block 256: see "level 2" above
 template <bool PK>
-__global__ void __launch_bounds__(256, 3) k_l2_local(l2_args a) {
+__global__ void __launch_bounds__(256, TE_L2_WAVES) k_l2_local(l2_args a) {
   __shared__ uint32_t lds[TE_L2A_LDS_WORDS];
   uint32_t* const cnt_s = lds; uint32_t* const off_s = lds + 256; uint32_t* const sm = lds + 768; uint32_t* const pj = lds + 768 + 17;
   uint32_t* const list = lds + 768 + 32;
@@ -847,7 +855,7 @@ __device__ __forceinline__ void l2_place_piece(uint32_t p, uint32_t k, uint32_t 
 // more than TE_L2_CAP entries (with well-spread digits: the top window's ~115 pieces).
 struct order_args { const uint32_t* lenv; uint32_t ids; const uint32_t* size_hist; uint32_t* rel_cursor; uint32_t* order; uint32_t* num_segments; uint32_t order_cols, max_len; };
 template <bool PK>
-__global__ void __launch_bounds__(256, 3) k_l2_place_order(const uint16_t* __restrict__ part_keys, const uint32_t* __restrict__ part_idx,
+__global__ void __launch_bounds__(256, TE_L2_WAVES) k_l2_place_order(const uint16_t* __restrict__ part_keys, const uint32_t* __restrict__ part_idx,
                                                            const uint32_t* __restrict__ part_start, const uint32_t* __restrict__ part_count,
                                                            uint32_t* __restrict__ bucket_cursor, uint32_t* __restrict__ sorted, sort_geom g, order_args oa) {
   __shared__ uint32_t lds[TE_PLACE_LDS_WORDS];

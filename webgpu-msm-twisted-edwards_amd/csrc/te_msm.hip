@@ -90,8 +90,9 @@ struct workset_t {
   uint32_t *d_seg_base = nullptr, *d_seg_bucket = nullptr, *d_seg_lenv = nullptr, *d_order = nullptr;
   uint32_t *d_split_list = nullptr, *d_chunk_list = nullptr;
   uint8_t *d_seg_out = nullptr, *d_buckets = nullptr, *d_red[4] = {};   // accumulators of the plan's curve (te::ete_t<N>); d_red: ping/pong of the two fold chains
-  // ONE zeroed block per MSM (a single memset), words: [0] final-carry flag, [1] non-zero window digits (= entries accumulated;
-  // both survive the pieces of a host-buffer MSM), [2] number of segments, [3..5] split / giant
+  // ONE zeroed block per MSM (a single memset), words: [0] final-carry flag, [2..3] non-zero window digits as ONE 64-bit count (= entries
+  // accumulated; W * n passes 2^32 inside the allowed range n < 2^31: round-5 advisor; [0..3] survive the pieces of a host-buffer MSM),
+  // [4] number of segments, [5..7] split / giant
   // bucket counters, [Z_ROWS..) the partial rows of the MSM (so that flag and rows come back in ONE device-to-host copy),
   // [Z_HIST..) segment-length histogram (TE_HIST_COPIES copies), [Z_CURSOR..) reservation cursors of the schedule, [Z_END..) the level-1 histogram
   // counts1[window][chunk][partition], then bucket_count[window][bucket].  d_err .. d_bucket_count point into d_zero.
@@ -127,8 +128,10 @@ struct workset_t {
 constexpr int TE_MAX_WINDOWS = 64;    // window_bits >= 4
 // words [Z_CLOCK, Z_ROWS): k_accumulate's profiling words, 4 x TE_CLK_SLOTS 64-bit values (first wave in / last wave out on the
 // wall clock, core and wall ticks summed over the waves), see the kernel
-constexpr size_t Z_KEEP = 2;            // words [0, Z_KEEP) are kept from piece to piece of one host-buffer MSM (flag, entry count)
+constexpr size_t Z_KEEP = 4;            // words [0, Z_KEEP) are kept from piece to piece of one host-buffer MSM (flag, pad, 64-bit entry count)
+constexpr size_t Z_ENTRIES = 2;         // the 64-bit entry count (8-byte aligned)
 constexpr size_t Z_CLOCK = 8;
+static_assert(Z_KEEP + 4 <= Z_CLOCK && Z_ENTRIES % 2 == 0 && Z_ENTRIES + 2 <= Z_KEEP, "flag words");
 constexpr size_t Z_ROWS = Z_CLOCK + 4 * 2 * TE_CLK_SLOTS, Z_HIST = Z_ROWS + (size_t)TE_MAX_WINDOWS * TE_MAX_ROW_BYTES / 4, Z_CURSOR = Z_HIST + 1024 * TE_HIST_COPIES, Z_END = Z_CURSOR + 1024;
 
 struct gpu_t {
@@ -244,7 +247,11 @@ int auto_window_bits(uint64_t n) {
 
 // Windows of the decomposition.  Unsigned digits cover all 256 bits of a scalar record.  Signed digits: the scalars of this
 // boundary are below p < 2^253 (harness generator reference/webgpu/utils.ts:118-124), so the windows only have to reach bit 254
-// -- 255 bits: 17 windows of 15 bits where 256 bits take 18 (and 51 of 5 instead of 52; every other size gives the same count).
+// -- 255 bits: 17 windows of 15 bits where 256 bits take 18 (and 51 of 5 instead of 52; every other size of the allowed range
+// c in [4, 16] gives the same count).  Which scalars above p are still ACCEPTED therefore depends on c -- and through the
+// automatic window size on n: everything below 2^(cW) - sum_w 2^(cw + c - 1), i.e. about 2^255.9 for 16 x 16 bits (the reference's
+// plan, miscellaneous/utils.ts:52-95) and 2^254 - 2^240 for 17 x 15 bits (n = 2^16 .. 2^18); canonical scalars (< p < 2^253) always
+// fit.  INTEGRATION.md section 5 states the range; option "window_bits" = 16 gives a caller the reference's own acceptance at any n.
 // The 18th window of a 15-bit plan held bits 255..269 and never received a digit or a carry: 16 384 empty buckets folded and a
 // tail block run for nothing at n = 2^16 .. 2^18, where the reduction is ~40 % of the device span.  The error rule stays exact:
 // k_digits flags any bit of s + sum_w 2^(cw + c - 1) at or above c * W, the reference's "final carry is 1"
@@ -473,7 +480,7 @@ struct msm_launch {
     if (p.nw > 0) {
       te::scatter_args sa;
       sa.digits = ws.d_digits; sa.counts1 = ws.d_counts1; sa.part_keys = ws.d_part_keys; sa.part_idx = ws.d_part_idx; sa.part_start = ws.d_part_start;
-      sa.part_count = ws.d_part_count; sa.seg_part_base = ws.d_seg_part_base; sa.entries = ws.d_zero + 1; sa.seg_len = p.seg_len; sa.cap_w = cap_w; sa.nw = (uint32_t)p.nw; sa.g = sg;
+      sa.part_count = ws.d_part_count; sa.seg_part_base = ws.d_seg_part_base; sa.entries = reinterpret_cast<unsigned long long*>(ws.d_zero + Z_ENTRIES); sa.seg_len = p.seg_len; sa.cap_w = cap_w; sa.nw = (uint32_t)p.nw; sa.g = sg;
       if (with_prep) {
         te::batch_ptrs tab; te::batch_slabs row_slab;
         const uint32_t rows = (uint32_t)prep_rows(tab, row_slab), sblocks = p.CH * (uint32_t)p.nw;
@@ -1296,7 +1303,8 @@ int free_workset_index(const gpu_t& d) { return te_sched::free_set_index(d, TE_M
 const char* const kAllSetsOwned = "every work set holds a submitted MSM that has not been collected: te_msm_collect one first";
 
 // the non-zero window digits the device counted for the MSM whose flag words are in the set's pinned block (word 1)
-void note_entries(te_ctx* ctx, const workset_t& ws) { ctx->stat_entries = (int64_t)ws.h_err[1]; }
+int64_t entries_of(const workset_t& ws) { uint64_t v; memcpy(&v, ws.h_err + Z_ENTRIES, sizeof v); return (int64_t)v; }
+void note_entries(te_ctx* ctx, const workset_t& ws) { ctx->stat_entries = entries_of(ws); }
 
 // te_msm_run for a large MSM on one device: enqueue_host_slice on a free work set, wait, host tail
 int run_host_chunked(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_scalars, uint64_t n, int K, uint8_t out[64]) {
@@ -1359,7 +1367,7 @@ int run_host_sharded(te_ctx* ctx, const uint8_t* src_points, const uint8_t* src_
     if (per * i >= n) break;
     workset_t& ws = ctx->devs[i].ws[wsel[i]];
     if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, kFinalCarry);
-    entries += (int64_t)ws.h_err[1];
+    entries += entries_of(ws);
     sets.push_back(ws.h_partials);
   }
   ctx->stat_entries = entries;
@@ -1466,7 +1474,7 @@ int run_device_window_shards(te_ctx* ctx, const void* src_points, const void* sr
     HIP_TRY(ctx, hipSetDevice(d.device));
     HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));
     carry = carry || *ws.h_err != 0;
-    entries += (int64_t)ws.h_err[1];
+    entries += entries_of(ws);
     for (int w = d.w_first; w < p0.W; w += d.w_step)
       memcpy(&merged[(size_t)w * sz.row], ws.h_partials + (size_t)w * sz.row, sz.row);
   }
@@ -2005,7 +2013,7 @@ int run_bound_window_shards(te_ctx* ctx, const te_bases* bases, const void* d_sc
     HIP_TRY(ctx, hipSetDevice(d.device));
     HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));
     carry = carry || *ws.h_err != 0;
-    entries += (int64_t)ws.h_err[1];
+    entries += entries_of(ws);
     for (int w = d.w_first; w < p0.W; w += d.w_step) memcpy(&merged[(size_t)w * sz.row], ws.h_partials + (size_t)w * sz.row, sz.row);
   }
   if (rc) return rc;

@@ -33,6 +33,7 @@ namespace {
 // the engine behind te_promise::protocol (js/promise_protocol.hpp holds the lock protocol itself)
 struct EngineApi {
   using ctx_t = te_ctx;
+  using bases_t = te_bases;
   static constexpr int ESTATE = TE_MSM_ESTATE;
   static std::vector<int> default_devices() {        // TE_MSM_DEVICES="0,1,..", else device 0
     std::vector<int> ids;
@@ -53,8 +54,14 @@ struct EngineApi {
   static int collect(te_ctx* c, uint64_t t, uint8_t* out) { return te_msm_collect(c, t, out); }
   static int64_t in_flight(te_ctx* c) { int64_t v = 0; te_msm_get_option(c, "in_flight", &v); return v; }
   static int64_t num_devices(te_ctx* c) { int64_t v = 1; te_msm_get_option(c, "num_devices", &v); return v; }
+  // resident bases (include/te_msm.h): the opt-in behind setBases(buffer)
+  static int bind(te_ctx* c, const uint8_t* p, uint64_t n, te_bases** out) { return te_msm_bind_points(c, p, n, out); }
+  static int release(te_ctx* c, te_bases* b) { return te_msm_release_points(c, b); }
+  static int run_scalars(te_ctx* c, te_bases* b, const uint8_t* s, uint8_t* out) { return te_msm_run_scalars(c, b, s, out); }
+  static int submit_scalars(te_ctx* c, te_bases* b, const uint8_t* s, uint64_t* t) { return te_msm_submit_scalars(c, b, s, t); }
 };
 te_promise::protocol<EngineApi> g_proto;
+napi_ref g_bases_ref = nullptr;       // the Buffer that setBases bound: kept alive, so that its address cannot become another object's
 
 struct Job {
   napi_async_work work = nullptr;
@@ -105,8 +112,8 @@ napi_value MsmNative(napi_env env, napi_callback_info info) {
   napi_create_promise(env, &j->deferred, &promise);
   napi_create_string_utf8(env, "te_msm_run", NAPI_AUTO_LENGTH, &name);
   napi_create_async_work(env, nullptr, name, Execute, Complete, j, &j->work);
-  // other calls pending and the context exists: this one becomes a ticket right here (microseconds) and its pool thread will
-  // only wait and collect; the first call of a burst is left to its pool thread (te_promise::protocol::enter)
+  // other calls pending, the context exists and no pool thread is inside the engine: the waiting calls become tickets right here,
+  // oldest first (microseconds), and their pool threads will only wait and collect (te_promise::protocol::enter)
   g_proto.enter(&j->j);
   napi_queue_async_work(env, j->work);
   return promise;
@@ -138,6 +145,54 @@ napi_value SetDevices(napi_env env, napi_callback_info info) {
   napi_value u; napi_get_undefined(env, &u); return u;
 }
 
+// setBases(points: Buffer | null): binds this point buffer (te_msm_bind_points: uploaded and converted once, on every device);
+// compute_msm(thatBuffer, scalars) -- the same Buffer object: address and length are compared, its contents must not change --
+// then uploads and decomposes the scalars only.  Every other buffer takes the ordinary path; setBases(null) unbinds.
+// compute_msm's signature (submission.ts:73-78) is untouched; the reference's harness passes one point buffer to six calls per
+// size (submission/miscellaneous/full_benchmarks.ts:63-68,100-105).  Blocks until no promise is pending (like resetContext).
+napi_value SetBases(napi_env env, napi_callback_info info) {
+  size_t argc = 1; napi_value argv[1];
+  napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+  napi_valuetype vt = napi_undefined;
+  if (argc >= 1) napi_typeof(env, argv[0], &vt);
+  bool is_buf = false;
+  if (argc >= 1 && vt == napi_object) napi_is_buffer(env, argv[0], &is_buf);
+  if (!(is_buf || argc == 0 || vt == napi_null || vt == napi_undefined)) { napi_throw_type_error(env, nullptr, "setBases(points: Buffer | null)"); return nullptr; }
+  std::string err;
+  if (!is_buf) {
+    (void)g_proto.set_bases(nullptr, 0, err);
+    if (g_bases_ref) { napi_delete_reference(env, g_bases_ref); g_bases_ref = nullptr; }
+  } else {
+    void* p = nullptr; size_t pl = 0;
+    napi_get_buffer_info(env, argv[0], &p, &pl);
+    if (pl % 64 != 0) { napi_throw_range_error(env, nullptr, "setBases: points must be 64*n bytes"); return nullptr; }
+    napi_ref ref = nullptr;
+    napi_create_reference(env, argv[0], 1, &ref);
+    const int rc = g_proto.set_bases(static_cast<const uint8_t*>(p), pl / 64, err);
+    if (g_bases_ref) napi_delete_reference(env, g_bases_ref);         // the previous buffer is unbound either way
+    g_bases_ref = nullptr;
+    if (rc) {
+      napi_delete_reference(env, ref);
+      const std::string m = "te_msm error " + std::to_string(rc) + ": " + err;
+      napi_throw_error(env, nullptr, m.c_str());
+      return nullptr;
+    }
+    g_bases_ref = ref;
+  }
+  napi_value u; napi_get_undefined(env, &u); return u;
+}
+
+// getStats(): how the promises so far were mapped onto the engine -- tickets submitted from the JavaScript thread / from pool
+// threads, lone calls, jobs over bound bases, and the largest number of tickets seen in flight at a submit
+napi_value GetStats(napi_env env, napi_callback_info) {
+  const te_promise::stats_t st = g_proto.stats();
+  napi_value o; napi_create_object(env, &o);
+  const struct { const char* k; double v; } f[] = {{"submittedInEnter", (double)st.submitted_in_enter}, {"submittedInExecute", (double)st.submitted_in_execute},
+                                                    {"loneRuns", (double)st.lone_runs}, {"boundJobs", (double)st.bound_jobs}, {"maxInFlight", (double)st.max_in_flight}};
+  for (const auto& e : f) { napi_value v; napi_create_double(env, e.v, &v); napi_set_named_property(env, o, e.k, v); }
+  return o;
+}
+
 // getDevices(): the device list the next context is (or the current one was) created with
 napi_value GetDevices(napi_env env, napi_callback_info) {
   const std::vector<int> ids = g_proto.devices();
@@ -148,7 +203,8 @@ napi_value GetDevices(napi_env env, napi_callback_info) {
 
 napi_value Init(napi_env env, napi_value exports) {
   const struct { const char* name; napi_callback fn; } fns[] = {
-      {"msmNative", MsmNative}, {"resetContext", ResetContext}, {"setDevices", SetDevices}, {"getDevices", GetDevices}};
+      {"msmNative", MsmNative}, {"resetContext", ResetContext}, {"setDevices", SetDevices}, {"getDevices", GetDevices},
+      {"setBases", SetBases}, {"getStats", GetStats}};
   for (const auto& f : fns) {
     napi_value v;
     napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &v);

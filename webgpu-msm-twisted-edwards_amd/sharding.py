@@ -81,14 +81,23 @@ def distribute_inputs(points, scalars, dist=None, group=None, device="cuda", poi
     import torch
 
     n = len(scalars) // scalar_bytes
-    assert len(scalars) == n * scalar_bytes and len(points) == n * point_bytes
+    if len(scalars) != n * scalar_bytes or len(points) != n * point_bytes:
+        raise ValueError("distribute_inputs: points must be %d*n bytes and scalars %d*n bytes (got %d and %d)" % (point_bytes, scalar_bytes, len(points), len(scalars)))
     grouped = dist is not None and dist.is_initialized()         # (a group of one rank still runs the collective: the RCCL leg of the tests)
     world = dist.get_world_size(group) if grouped else 1
     rank = dist.get_rank(group) if grouped else 0
-    per = (n + world - 1) // world                               # equal contributions: the last slice is padded
-    lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
     gloo = grouped and dist.get_backend(group) == "gloo"
     stage = "cpu" if gloo else device
+    if grouped and world > 1:
+        # every rank must bring the same n: a rank with another size would enter the all-gathers below with another buffer size
+        # (a hang or garbage, depending on the backend) -- checked with a real exception on EVERY rank, before the collectives
+        # that depend on it (asserts are stripped under -O: round-5 advisor)
+        nn = torch.tensor([n, -n], dtype=torch.int64, device=stage)
+        dist.all_reduce(nn, op=dist.ReduceOp.MAX, group=group)
+        if int(nn[0].item()) != n or int(nn[1].item()) != -n:
+            raise ValueError("distribute_inputs: the ranks disagree on n (this rank: %d, largest: %d, smallest: %d)" % (n, int(nn[0].item()), -int(nn[1].item())))
+    per = (n + world - 1) // world                               # equal contributions: the last slice is padded
+    lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
 
     def mine(buf, unit):
         t = torch.zeros(per * unit, dtype=torch.uint8, device=stage)
@@ -157,18 +166,23 @@ class ShardedPipeline:
         self.ev = [torch.cuda.Event() for _ in range(depth)]
         self.count = [0] * depth
         self.next_ticket = self.next_collect = 0
+        self.inputs = None                                  # (d_points, d_scalars) once load_host() has distributed host buffers
 
     def load_host(self, points, scalars):
         """Distributes HOST buffers to the ranks' GPUs (distribute_inputs: rank r uploads its n / D slice, one all-gather per
         buffer over RCCL assembles the whole on every GPU) and keeps the result: (d_points, d_scalars) for submit()."""
         pb, sb = (96, 48) if self.curve == 1 else (64, 32)
+        if len(scalars) != sb * self.n or len(points) != pb * self.n:      # before the collectives: a wrong size on one rank would desynchronise them
+            raise ValueError("ShardedPipeline.load_host: the pipeline was planned for n = %d points (%d + %d bytes), got %d + %d bytes"
+                             % (self.n, pb * self.n, sb * self.n, len(points), len(scalars)))
         dp, ds, n = distribute_inputs(points, scalars, self.dist, self.group, "cuda", pb, sb)
-        assert n == self.n, "the pipeline was planned for n = %d points" % self.n
         self.inputs = (dp, ds)
         return self.inputs
 
     def submit(self, d_points=None, d_scalars=None) -> int:
         if d_points is None:
+            if self.inputs is None:
+                raise RuntimeError("ShardedPipeline.submit() without inputs: call load_host(points, scalars) first, or pass device tensors")
             d_points, d_scalars = self.inputs                   # what load_host left on this rank's GPU
         return self.submit_batch([(d_points, d_scalars)])
 
