@@ -116,7 +116,8 @@ int te_msm_submit(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scala
 /* The same with the upload itself in the background: the call picks device and work set, hands upload + enqueue to that
  * device's host thread and returns AT ONCE.  D calls in a row put D uploads on D PCIe links at the same time -- what a
  * single-threaded caller (the JavaScript event loop behind the N-API addon, a Python prover) needs to keep D devices busy
- * from host buffers: from the builder's figures 8 x (1 / 2.2 ms) MSM/s against 1 / 0.69 ms for point slices of one call.
+ * from host buffers: an EXTRAPOLATION from one device -- 8 x (1 / 2.2 ms) MSM/s, eight times the measured one-device rate, against
+ * 1 / 0.69 ms for point slices of one call (one device's rehearsed share); two physical devices have never run either.
  * The price: points_xy_le / scalars_le must stay valid and unchanged until te_msm_ticket_wait or te_msm_collect has
  * returned for the ticket.  A failure of the upload or the enqueue (TE_MSM_EDEVICE) is reported by te_msm_collect, which
  * frees the ticket.  Every device has several upload threads (option "upload_threads", default 4): while one ticket's copy is

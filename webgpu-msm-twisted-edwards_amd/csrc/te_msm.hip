@@ -185,6 +185,8 @@ struct te_ctx {
   std::vector<te_bases*> bases;  // the bound point sets of the context (te_msm_bind_points), freed by te_msm_release_points / te_msm_destroy
   int opt_bind_affine = 1;       // te_msm_bind_points, BLS12-377: affine records (one inversion per point, once) instead of the projective ones of the per-call conversion
   int opt_scalar_chunks = 0;     // te_msm_run_scalars / te_msm_submit_scalars: pieces the scalars of a bound set are uploaded and processed in (0 = from n)
+  int opt_exp_table_replicas = 1; // EXPERIMENT (profiles/r06_fixed_base_windows.txt): te_msm_bind_points keeps this many copies of the records and
+                                 // the windows of a device-scalar MSM gather from different copies -- the gather footprint of a per-window table
 };
 
 // A bound point set (include/te_msm.h, "resident bases"): the records of n points on EVERY device of its context, converted
@@ -195,6 +197,7 @@ struct te_bases {
   int curve = TE_MSM_CURVE_TE_BLS12, rec_kind = 0;
   size_t rec_bytes = 0;
   std::vector<uint8_t*> recs;    // recs[i]: n records in the memory of ctx->devs[i]
+  int replicas = 1;              // experiment "exp_table_replicas": copies of the records behind each other in recs[i]
   int in_flight = 0;             // tickets not collected that gather from it (the set cannot be released under them)
 };
 
@@ -377,6 +380,7 @@ struct msm_launch {
   bool own_rows = false;          // rows go to ws.d_partials: the caller fetches flag + rows with one copy
   bool onto = false;              // a later piece of a host-buffer MSM: keep the final-carry flag, add onto the buckets
   bool host_rows = false;         // own rows go straight to the work set's pinned host block, written by k_reduce_tail (no copy at all)
+  int table_replicas = 1;         // experiment "exp_table_replicas": window k gathers from copy k / ceil(windows / copies) of the bound records
   const uint8_t* bound = nullptr; // records of a bound point set (te_msm_bind_points), already offset to this launch's first point: no conversion,
                                   // k_accumulate gathers from here instead of ws.d_recs (p.rec_kind tells which record form)
   // Own rows of a context that computes ALL windows can be written to host memory by the tail kernel (every row slot is
@@ -412,6 +416,7 @@ struct msm_launch {
 
   // record slab of MSM m: MSMs of one call that name the same point buffer share one conversion (same pointer in one call =
   // same data; nothing is remembered across calls).  slab = index of the first MSM with that pointer.
+  te::batch_slabs replica_slabs() const { te::batch_slabs r; for (int j = 0; j < TE_BATCH_MAX; j++) r.s[j] = (uint32_t)j; return r; }
   te::batch_slabs slabs() const {
     te::batch_slabs r; memset(&r, 0, sizeof r);
     for (int m = 0; m < p.batch; m++) {
@@ -544,7 +549,7 @@ struct msm_launch {
       hipLaunchKernelGGL((te::k_accumulate<N, RK>), dim3((smax + 255) / 256), dim3(256), 0, stream, reinterpret_cast<const slot_t*>(bound ? bound : ws.d_recs), ws.d_sorted,
                          ws.d_bucket_start, ws.d_bucket_count, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv, order, ws.d_num_seg,
                          reinterpret_cast<te::ete_t<N>*>(ws.d_buckets), reinterpret_cast<te::ete_t<N>*>(ws.d_seg_out), n32, p.logB, p.seg_len, smax, onto ? 1u : 0u,
-                         (uint32_t)p.nw1, slabs(),
+                         table_replicas > 1 ? (uint32_t)((p.nw1 + table_replicas - 1) / table_replicas) : (uint32_t)p.nw1, table_replicas > 1 ? replica_slabs() : slabs(),
                          prof ? reinterpret_cast<unsigned long long*>(ws.d_zero + Z_CLOCK) : nullptr);
     }
     return 0;
@@ -832,6 +837,7 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, 
     // resident bases: the scalar-only stages, then the accumulation straight from the bound records (never captured: option "graph"
     // holds the pointers of device-resident point buffers)
     L.bound = bases->recs[(size_t)(&d - ctx->devs.data())];
+    L.table_replicas = bases->replicas;
     if (int rc = L.front_scalars()) return rc;
     L.mark(ST_PREP);
     if (int rc = L.accumulate()) return rc;
@@ -1909,7 +1915,7 @@ int bind_on_device(te_ctx* ctx, te_bases* b, size_t i, const void* src, bool src
   const uint64_t n = b->n;
   uint8_t* recs = nullptr; void* raw = nullptr; void* proj = nullptr; hipStream_t st = nullptr;
   struct cleanup_t { void*& raw; void*& proj; hipStream_t& st; ~cleanup_t() { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } if (raw) (void)hipFree(raw); if (proj) (void)hipFree(proj); } } cleanup{raw, proj, st};
-  HIP_TRY(ctx, hipMalloc((void**)&recs, (size_t)n * b->rec_bytes));
+  HIP_TRY(ctx, hipMalloc((void**)&recs, (size_t)n * b->rec_bytes * (size_t)b->replicas));
   b->recs[i] = recs;                                                       // (freed by the caller on failure: free_bases)
   HIP_TRY(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   const void* pts = src;
@@ -1937,6 +1943,8 @@ int bind_on_device(te_ctx* ctx, te_bases* b, size_t i, const void* src, bool src
   } else {
     hipLaunchKernelGGL(te::k_prep_points, dim3((n32 + 255) / 256, 1), dim3(256), 0, st, tab, row_slab, reinterpret_cast<te::pnt_slot*>(recs), n32);
   }
+  for (int r = 1; r < b->replicas; r++)
+    HIP_TRY(ctx, hipMemcpyAsync(recs + (size_t)r * n * b->rec_bytes, recs, (size_t)n * b->rec_bytes, hipMemcpyDeviceToDevice, st));
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipStreamSynchronize(st));
   return 0;
@@ -1959,6 +1967,7 @@ int bind_common(te_ctx* ctx, const void* src, bool src_is_host, uint64_t n, te_b
   b->ctx = ctx; b->n = n; b->curve = ctx->opt_curve;
   b->rec_kind = (b->curve == TE_MSM_CURVE_BLS12_377_G1 && ctx->opt_bind_affine) ? 1 : 0;
   b->rec_bytes = rec_bytes_of(b->curve, b->rec_kind);
+  b->replicas = ctx->opt_exp_table_replicas;
   b->recs.assign(nd, nullptr);
   int rc = 0;
   if (n > 0) {
@@ -2238,6 +2247,7 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   if (!strcmp(key, "host_staging")) { ctx->opt_host_staging = value ? 1 : 0; return 0; }
   if (!strcmp(key, "upload_threads")) { if (value < 1 || value > 16) return set_err(ctx, TE_MSM_EINVAL, "upload_threads must be in [1, 16]"); ctx->opt_upload_threads = (int)value; return 0; }
   if (!strcmp(key, "bind_affine")) { ctx->opt_bind_affine = value ? 1 : 0; return 0; }
+  if (!strcmp(key, "exp_table_replicas")) { if (value < 1 || value > TE_BATCH_MAX) return set_err(ctx, TE_MSM_EINVAL, "exp_table_replicas must be in [1, 8]"); ctx->opt_exp_table_replicas = (int)value; return 0; }
   if (!strcmp(key, "scalar_chunks")) { if (value < 0 || value > 64) return set_err(ctx, TE_MSM_EINVAL, "scalar_chunks out of range"); ctx->opt_scalar_chunks = (int)value; return 0; }
   return set_err(ctx, TE_MSM_EINVAL, "unknown option");
 }
@@ -2271,7 +2281,7 @@ int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value) {
   if (!strcmp(key, "bind_affine")) { *value = ctx->opt_bind_affine; return 0; }
   if (!strcmp(key, "scalar_chunks")) { *value = ctx->opt_scalar_chunks; return 0; }
   if (!strcmp(key, "bases_bound")) { *value = (int64_t)ctx->bases.size(); return 0; }
-  if (!strcmp(key, "bases_bytes")) { int64_t t = 0; for (const te_bases* b : ctx->bases) for (const uint8_t* r : b->recs) if (r) t += (int64_t)(b->n * b->rec_bytes); *value = t; return 0; }
+  if (!strcmp(key, "bases_bytes")) { int64_t t = 0; for (const te_bases* b : ctx->bases) for (const uint8_t* r : b->recs) if (r) t += (int64_t)(b->n * b->rec_bytes) * b->replicas; *value = t; return 0; }
   if (!strcmp(key, "in_flight")) { int64_t t = 0; for (const gpu_t& d : ctx->devs) t += d.in_flight; *value = t; return 0; }
   if (!strcmp(key, "device_bytes")) {      drain_workers(ctx);      // device memory this context holds in work-set buffers (te_msm_trim gives it back)
     int64_t tot = 0;
