@@ -208,6 +208,16 @@ int te_msm_submit_scalars_device(te_ctx* ctx, te_bases* bases, const void* d_sca
  *   "stage_device_inputs"  see te_msm_submit_device (default 0)
  *   "bind_affine"   1 (default) = te_msm_bind_points converts BLS12-377 points to AFFINE records (one inversion per point, once);
  *                   0 = keeps the projective records of the per-call conversion (A/B measurements).  Read at bind time.
+ *   "bind_fixed_base" c in [16, 21] (0 = off, default): te_msm_bind_points (Twisted-Edwards curve) also tabulates 2^(c w) P_i for the
+ *                   ceil(255 / c) windows w (W x 128 bytes per point: 1.7 GB for c = 20 at n = 2^20, built once).  MSMs over such a set run
+ *                   FIXED-BASE WINDOWS: every window's digit addresses the SAME set of 2^(c-1) buckets, so c can grow: 13 n + 2^20 additions
+ *                   at c = 20 where 16-bit windows need 16 n + 2^20, and no window doublings in the host tail (csrc/kernels.hip.hpp,
+ *                   "FIXED-BASE WINDOWS"; measurements: profiles/r06_fixed_base_windows.txt).  Same results.  The rows
+ *                   of such an MSM are sized for well-spread digits; badly skewed scalars (all equal, ...) overflow one, which the engine
+ *                   detects and answers by running that MSM again with the ordinary windows (read-only option "fixed_base_fallbacks"
+ *                   counts them).  A lone call on several devices runs on ONE of them (one bucket set: nothing to shard); tickets use all.
+ *                   "window_bits", "signed_digits", "segment_len" = 0 do not apply to such MSMs; a window-sharded single-device context
+ *                   keeps the ordinary windows.  Read at bind time.
  *   "scalar_chunks" te_msm_run_scalars / te_msm_submit_scalars: pieces the scalars of a bound point set are uploaded and processed
  *                   in; 0 = from n (default), 1 = whole.  The result does not depend on it.
  *   read-only:      "num_devices", "segment_len_used", "peer_copies" / "peer_bytes" (hipMemcpyPeerAsync calls a multi-device

@@ -361,3 +361,115 @@ def test_node_set_bases(pkg, model, wasm_golden, tmp_path):
     assert out["stats"]["boundJobs"] == 2 + 4 * 20 and out["stats"]["maxInFlight"] == 8, out["stats"]
     out = run(["20"], env=dict(os.environ, UV_THREADPOOL_SIZE="1"))                      # the same without bases
     assert out["stats"]["boundJobs"] == 0 and out["stats"]["maxInFlight"] == 8, out["stats"]
+
+
+# ------------------------------------------------------------------ fixed-base windows over a bound set (option "bind_fixed_base")
+def test_fixed_base_table_against_the_model(pkg, ora, model):
+    """table w of a fixed-base set holds the records of 2^(c w) P_i: ((y - x)/2, (y + x)/2, -d x y) of that multiple, by the bigint
+    model; table 0 is the ordinary conversion byte for byte"""
+    n, c = 37, 20
+    pts = ora.gen_points(4242, n)
+    P = model.P
+    rinv = pow(1 << 261, -1, P)
+    with pkg.MsmContext((0,)) as cx:
+        plain = cx.bind_points(pts)
+        ordinary = cx.bases_read(plain, 0, n)[1]
+        cx.set_option("bind_fixed_base", c)
+        b = cx.bind_points(pts)
+        W = -(-255 // c)
+        assert cx.get_option("bases_bytes") == n * 128 * (1 + W)
+        rb, tab = cx.bases_read(b, 0, n * W)
+        assert rb == 128 and len(tab) == n * W * 128 and tab[:n * 128] == ordinary
+        for w in (1, 2, W - 1):
+            for i in (0, 5, n - 1):
+                x, y = int.from_bytes(pts[64 * i:64 * i + 32], "little"), int.from_bytes(pts[64 * i + 32:64 * i + 64], "little")
+                qx, qy = model.scalar_mul(1 << (c * w), (x, y))
+                o = (w * n + i) * 128
+                hm, hp, dt = (sum(int.from_bytes(tab[o + 36 * k + 4 * j:o + 36 * k + 4 * j + 4], "little") << (29 * j) for j in range(9)) * rinv % P for k in range(3))
+                assert ((hp - hm) % P, (hp + hm) % P) == (qx, qy) and dt == (-3021 * qx * qy) % P, (w, i)
+
+
+@pytest.mark.parametrize("c", [16, 17, 18, 19, 20, 21])
+def test_fixed_base_windows_sizes_and_forms(pkg, ora, c):
+    """every table width, ragged and tiny n, host and device scalars, lone calls and tickets (also on four "devices"), against the oracle"""
+    import torch
+    for n in (1, 2, 9, 1000, 4097, 70001):
+        pts, sc = ora.gen_points(7000 + n + c, n), ora.gen_scalars(7100 + n + c, n)
+        want = ora.msm(pts, sc, threads=8)
+        ds = _dev(sc)
+        torch.cuda.synchronize()
+        for ids in ((0,), (0, 0, 0, 0)):
+            if len(ids) > 1 and n not in (9, 70001):
+                continue
+            with pkg.MsmContext(ids) as cx:
+                cx.set_option("bind_fixed_base", c)
+                b = cx.bind_points(pts)
+                assert cx.run_scalars(b, sc) == want, (c, n, ids)
+                assert cx.run_scalars_device(b, ds.data_ptr()) == want, (c, n, ids)
+                ts = [cx.submit_scalars(b, sc), cx.submit_scalars_device(b, ds.data_ptr()), cx.submit_scalars(b, sc), cx.submit_scalars_device(b, ds.data_ptr())]
+                assert [cx.collect(t) for t in reversed(ts)] == [want] * 4, (c, n, ids)
+                assert cx.get_option("fixed_base_fallbacks") == 0
+                b.release()
+
+
+def test_fixed_base_windows_against_the_reference(pkg, model, wasm_golden):
+    """the reference-generated goldens -- edge scalars (0, 1, p - 1, 2^k boundaries), witness-like skew, harness mode, random points --
+    through the c = 20 table, the headline size included; skewed scalars may overflow a row: the engine then answers with the
+    ordinary windows (counted), the result is the reference's either way"""
+    import torch
+    with pkg.MsmContext((0,)) as cx:
+        cx.set_option("bind_fixed_base", 20)
+        for g in wasm_golden:
+            if 4096 < g["n"] < (1 << 20) and g["mode"] not in ("random", "witness", "edge"):
+                continue
+            pts, sc = make_inputs(g["seed"], g["n"], g["mode"])
+            want = (int(g["x"]), int(g["y"]))
+            b = cx.bind_points(pts)
+            before = cx.get_option("fixed_base_fallbacks")
+            assert model.xy_from_bytes(cx.run_scalars(b, sc)) == want, g["name"]
+            ds = _dev(sc)
+            torch.cuda.synchronize()
+            ts = [cx.submit_scalars_device(b, ds.data_ptr()), cx.submit_scalars(b, sc)]
+            assert [model.xy_from_bytes(cx.collect(t)) for t in ts] == [want, want], g["name"]
+            if g["mode"] in ("chain", "random") and g["n"] >= 256:
+                assert cx.get_option("fixed_base_fallbacks") == before, g["name"]           # well-spread digits never overflow
+            b.release()
+            del ds
+
+
+def test_fixed_base_fallback_errors_and_mixed_sets(pkg, ora, model):
+    """all scalars equal: every window's n entries land in ONE bucket -- a row overflows, the MSM is answered by the ordinary windows;
+    a scalar out of range is the ticket's error; fixed-base and ordinary sets and unbound calls side by side on one context"""
+    n = 40000
+    pts, sc = ora.gen_points(8100, n), ora.gen_scalars(8100, n)
+    want = ora.msm(pts, sc, threads=8)
+    k = (0x1234567 << 200 | 0xabcdef << 100 | 99).to_bytes(32, "little")
+    same = k * n
+    want_same = ora.msm(pts, same, threads=8)
+    bad = bytearray(sc); bad[32 * 11:32 * 12] = b"\xff" * 32
+    with pkg.MsmContext((0,)) as cx:
+        plain = cx.bind_points(pts)
+        cx.set_option("bind_fixed_base", 19)
+        fb = cx.bind_points(pts)
+        assert cx.run_scalars(fb, sc) == want and cx.run_scalars(plain, sc) == want and cx.run(pts, sc) == want
+        assert cx.get_option("fixed_base_fallbacks") == 0
+        assert cx.run_scalars(fb, same) == want_same
+        assert cx.get_option("fixed_base_fallbacks") == 1
+        # which non-canonical scalars are accepted follows the window size here as everywhere (INTEGRATION.md section 5): 14 x 19 bits
+        # reach bit 265 -- 2^256 - 1 is an ordinary scalar --, 15 x 17 bits = 255 do not: TE_MSM_ESCALAR, in that ticket only
+        cx.set_option("bind_fixed_base", 17)
+        fb17 = cx.bind_points(pts)
+        ts = [cx.submit_scalars(fb, same), cx.submit_scalars(fb, sc), cx.submit_scalars(plain, same), cx.submit_scalars(fb17, bytes(bad)), cx.submit_scalars(fb, bytes(bad)),
+              cx.submit_scalars(fb17, sc)]
+        assert cx.collect(ts[1]) == want and cx.collect(ts[0]) == want_same and cx.collect(ts[2]) == want_same and cx.collect(ts[5]) == want
+        assert cx.get_option("fixed_base_fallbacks") == 2
+        with pytest.raises(pkg.MsmError) as e:
+            cx.collect(ts[3])
+        assert e.value.code == -3
+        assert cx.collect(ts[4]) == ora.msm_naive(pts, bytes(bad))
+        with pytest.raises(pkg.MsmError) as e:
+            cx.run_scalars(fb17, bytes(bad))
+        assert e.value.code == -3
+        # the work sets go back and forth between the two kinds of plan
+        for _ in range(2):
+            assert cx.run_scalars(plain, sc) == want and cx.run_scalars(fb, sc) == want and cx.run(pts, sc) == want

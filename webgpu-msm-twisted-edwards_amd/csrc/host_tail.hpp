@@ -333,6 +333,40 @@ static inline void horner_to_affine_points(const Pt* merged, const uint8_t* pres
 static inline void horner_to_affine(const uint8_t* partials, int c, int bucket_bits, int W, uint8_t out_xy_le[64]) {
   horner_to_affine_multi(&partials, 1, c, bucket_bits, W, out_xy_le);
 }
+// FIXED-BASE WINDOWS (kernels.hip.hpp, k_fb_digits): `rows` pseudo-windows of 2^bucket_bits buckets share one bucket set; row r
+// holds the buckets whose index is hb(r) 2^bucket_bits + lo, hb(r) = r for r < rb and 0 for the extra rows r >= rb (the top window).
+// The device rows are the usual [T | W0 | W1 | W2 | W3]; the result has no window doublings at all:
+//     sum_r ( T_r + W0_r + 2^w0 W1_r + 2^(w0+w1) W2_r + 2^(w0+w1+w2) W3_r )  +  2^bucket_bits sum_r hb(r) T_r
+// i.e. ONE window whose slots are the sums over the rows, with U = sum_r hb(r) T_r (a running sum from the top: 2 rb additions) on
+// top of it -- bucket_bits doublings in all, against c per window of Horner's rule.
+template <typename Acc> static inline void fixed_base_with(const uint8_t* partials, int rows, int rb, int bucket_bits, uint8_t out_xy_le[64]) {
+  int dw[4];
+  for (int k = 0; k < 4; k++) dw[k] = (bucket_bits + 3 - k) / 4;
+  const Fe k2d = tail_k2d();
+  auto row_of = [&](int r) { return partials + (size_t)r * TE_TAIL_ROW_BYTES; };
+  auto present = [&](int r) { return !all_zero_bytes(row_of(r), TE_TAIL_ROW_BYTES); };
+  // U = sum_{r < rb} r T_r:  S = T_{rb-1}; U = S; S += T_{rb-2}; U += S; ... down to r = 1
+  Pt S = identity(), U = identity();
+  for (int r = rb - 1; r >= 1; r--) {
+    if (present(r)) S = padd(S, load_point(row_of(r)), k2d);
+    U = padd(U, S, k2d);
+  }
+  Acc acc;
+  acc.add_point(U);
+  auto slot_sum = [&](int slot) { for (int r = 0; r < rows; r++) if (present(r)) acc.add_point(load_point(row_of(r) + (size_t)slot * TE_TAIL_POINT_BYTES)); };
+  acc.dbl_n(dw[3]); slot_sum(4);
+  acc.dbl_n(dw[2]); slot_sum(3);
+  acc.dbl_n(dw[1]); slot_sum(2);
+  acc.dbl_n(dw[0]); slot_sum(1);
+  slot_sum(0);
+  acc.to_affine(out_xy_le);
+}
+static inline void fixed_base_to_affine(const uint8_t* partials, int rows, int rb, int bucket_bits, uint8_t out_xy_le[64]) {
+#if defined(__x86_64__)
+  if (have_ifma()) { fixed_base_with<IfmaAcc>(partials, rows, rb, bucket_bits, out_xy_le); return; }
+#endif
+  fixed_base_with<ScalarAcc>(partials, rows, rb, bucket_bits, out_xy_le);
+}
 
 static inline bool tail_selftest_run() {
   if ((uint64_t)(MOD[0] * MOD_NEG_INV) != ~0ULL) return false;     // p * (-p^-1) = -1 mod 2^64

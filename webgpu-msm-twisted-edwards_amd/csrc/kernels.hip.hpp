@@ -350,6 +350,9 @@ struct scatter_args {
   const uint16_t* digits; const uint32_t* counts1; uint16_t* part_keys; uint32_t* part_idx;
   uint32_t *part_start, *part_count, *seg_part_base; uint32_t seg_len, cap_w, nw /* local windows of the launch sequence */; sort_geom g;
   unsigned long long* entries;   // += the non-zero digits of every window (one 64-bit atomic per window): what k_accumulate will gather -- bench.py's roofline
+  // fixed-base windows (k_fb_digits): the entry at position i of row k is not point i -- remap[k * nst + i] = table index | sign << 31;
+  // nullptr: the ordinary case (entry i of a window is point i).  Needs the general entry form (packed == 0).
+  const uint32_t* remap;
 };
 // LDS of one level-1 block in words: one packed word per entry of the tile, four 512-entry tables, scan scratch.
 // Packed entry: source slot in the tile (12 bits) | partition << 12 (8 bits: P <= 256) | bucket low bits << 20 (8) | sign << 28 --
@@ -439,6 +442,13 @@ __device__ __forceinline__ void part_scatter_block(uint32_t ch, uint32_t k, uint
       for (uint32_t s = t; s < tile_total; s += 512u) {
         const uint32_t w = st[s];
         oi[s + gdelta[(w >> 12) & 0xffu]] = (base + (w & 0xfffu)) | (((w >> 20) & 0xffu) << 23) | ((w >> 28) << 31);
+      }
+    } else if (a.remap) {                                 // fixed-base rows: index and sign come from the row's remap word (a 16 KB window per tile)
+      const uint32_t* __restrict__ rm = a.remap + (size_t)k * g.nst + base;
+      for (uint32_t s = t; s < tile_total; s += 512u) {
+        const uint32_t w = st[s];
+        const uint32_t gpos = s + gdelta[(w >> 12) & 0xffu], r = rm[w & 0xfffu];
+        ok[gpos] = (uint16_t)(((w >> 20) & 0xffu) | ((r >> 31) << 15)); oi[gpos] = r & 0x7fffffffu;
       }
     } else {
       for (uint32_t s = t; s < tile_total; s += 512u) {
@@ -1558,6 +1568,183 @@ __global__ void __launch_bounds__(256) k_affine377(const rec_slot<14>* __restric
       a.hm = o[0]; a.hp = o[1]; a.dt = o[2];
     }
     store_pnt_aff377(out + lo + jj, a);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FIXED-BASE WINDOWS over a bound point set (te_msm_bind_points with option "bind_fixed_base" = c; round-5 verdict item 7).
+// With the points resident, the multiples 2^(c w) P_i of every window w can be tabulated once.  Then every window's digit
+// addresses the SAME bucket set: sum_i s_i P_i = sum_w sum_i d_{w,i} (2^(c w) P_i) = sum_b (b + 1) B_b with ONE set of 2^(c-1)
+// buckets, filled by the W n table entries -- no per-window bucket sets, so c can grow: c = 20 has 13 windows and 2^19 buckets,
+// 13 n + 2^20 additions where 16 windows of 16 bits need 16 n + 2^20 (n = 2^20: -17 %), at the price of a gather table of
+// W x 128 MB that no longer fits the 256 MB Infinity Cache (profiles/r06_fixed_base_windows.txt).
+// The engine's sort, accumulation and reduction run UNCHANGED on it: the bucket index b (c - 1 bits) is cut into
+// (h_b : the top bits | lo : 15 bits) and the entries of equal h_b form a PSEUDO-WINDOW of 2^15 buckets -- a "row" of the digit
+// buffer holding codes lo + 1 (0 = no entry; unsigned geometry, half = 0) with a parallel remap row (table index w n + i |
+// sign << 31) that the level-1 scatter turns into the entry's index.  The top window of a canonical (253-bit) scalar has only
+// 13 significant bits: all its n digits have h_b = 0; they go to one EXTRA row of weight offset 0 so that the rows stay
+// balanced (12 n / RB entries in each regular row, about n in the extra one).  Weight of row r: h_b(r) 2^15 + (lo + 1); the
+// host tail adds 2^15 sum_r h_b(r) T_r to the rows' own weighted sums (te_host::fixed_base_to_affine).
+struct fb_digit_args {
+  uint32_t half[10];        // sum_w 2^(c w + c - 1) over the W windows (as digits_params.half)
+  uint32_t n, idx_base, n_table;     // scalars of this launch; table index of an entry = w * n_table + idx_base + i
+  uint32_t W;               // windows of the decomposition
+  uint32_t rows, rb;        // rows = rb + 1 pseudo-windows: rb regular ones (h_b), the extra one (index rb) for the top window's h_b = 0
+  uint32_t cap;             // entries a row can hold (= row stride nst of the digit / remap buffers)
+  uint32_t chunk_len, CH, P, logS;   // level-1 geometry of the sort (chunks per row, partitions per row)
+  uint16_t* digits; uint32_t* remap; // [rows][cap]
+  uint32_t* row_fill;       // [rows] entries reserved so far (zeroed per MSM)
+  uint32_t* counts1;        // [rows][CH][P] level-1 histogram of the sort
+  uint32_t* err;            // word 0: final carry; word 1: a row overflowed (the host falls back to the ordinary windows)
+};
+#define TE_FB_THREADS 256u
+#define TE_FB_LOBITS 15u
+// one scalar per thread; LDS: cnt[rows] | base[rows] | hist[rows][2][P] (dynamic)
+template <int C>
+__global__ void __launch_bounds__(TE_FB_THREADS) k_fb_digits(const uint4* __restrict__ scalars, fb_digit_args a) {
+  extern __shared__ uint32_t fl[];
+  uint32_t* const cnt = fl; uint32_t* const base = fl + a.rows; uint32_t* const hist = fl + 2u * a.rows;
+  const uint32_t t = threadIdx.x, i = blockIdx.x * TE_FB_THREADS + t, hn = a.rows * 2u * a.P;
+  for (uint32_t j = t; j < 2u * a.rows + hn; j += TE_FB_THREADS) fl[j] = 0u;
+  __syncthreads();
+  constexpr int WMAX = (255 + C) / C + 1;
+  const bool live = i < a.n;
+  uint32_t s[10];
+  {
+    const size_t ii = live ? i : 0u;
+    const uint4 a0 = scalars[2 * ii], a1 = scalars[2 * ii + 1];
+    const uint32_t raw[10] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, 0u, 0u};
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 10; j++) { c += (uint64_t)raw[j] + a.half[j]; s[j] = (uint32_t)c; c >>= 32; }
+  }
+  // phase A: the row of every non-zero digit and its rank among the block's entries of that row
+  uint32_t rank[WMAX]; bool bad = false;
+#pragma unroll
+  for (int w = 0; w < WMAX; w++) {
+    rank[w] = 0xffffffffu;
+    const int bit = w * C;
+    if (bit >= 320) continue;
+    const int word = bit >> 5, off = bit & 31;
+    uint32_t v = s[word] >> off;
+    if (off + C > 32 && word + 1 < 10) v |= s[word + 1] << (32 - off);
+    v &= (1u << C) - 1u;
+    if ((uint32_t)w >= a.W) { bad |= live && v != 0u; continue; }
+    const int d = (int)v - (1 << (C - 1));
+    if (!live || d == 0) continue;
+    const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u, hb = b >> TE_FB_LOBITS;
+    const uint32_t row = ((uint32_t)w + 1u == a.W && hb == 0u) ? a.rb : hb;
+    rank[w] = atomicAdd(&cnt[row], 1u);
+  }
+  if (bad) atomicOr(a.err, 1u);
+  __syncthreads();
+  if (t < a.rows) base[t] = cnt[t] ? atomicAdd(&a.row_fill[t], cnt[t]) : 0u;        // one reservation per block and row
+  __syncthreads();
+  // phase B: codes and remap words to their rows; level-1 histogram of the block's entries (a block's range of a row touches two
+  // chunks at most unless the digits are badly skewed: further chunks go straight to memory)
+#pragma unroll
+  for (int w = 0; w < WMAX; w++) {
+    if (rank[w] == 0xffffffffu) continue;
+    const int bit = w * C, word = bit >> 5, off = bit & 31;
+    uint32_t v = s[word] >> off;
+    if (off + C > 32 && word + 1 < 10) v |= s[word + 1] << (32 - off);
+    v &= (1u << C) - 1u;
+    const int d = (int)v - (1 << (C - 1));
+    const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u, hb = b >> TE_FB_LOBITS, lo = b & ((1u << TE_FB_LOBITS) - 1u);
+    const uint32_t row = ((uint32_t)w + 1u == a.W && hb == 0u) ? a.rb : hb;
+    const uint32_t pos = base[row] + rank[w];
+    if (pos >= a.cap) { atomicOr(a.err + 1, 1u); continue; }
+    a.digits[(size_t)row * a.cap + pos] = (uint16_t)(lo + 1u);
+    a.remap[(size_t)row * a.cap + pos] = ((uint32_t)w * a.n_table + a.idx_base + i) | (d < 0 ? 0x80000000u : 0u);
+    const uint32_t ch = pos / a.chunk_len, slot = ch - base[row] / a.chunk_len, part = lo >> a.logS;
+    if (slot < 2u) atomicAdd(&hist[(row * 2u + slot) * a.P + part], 1u);
+    else atomicAdd(&a.counts1[((size_t)row * a.CH + ch) * a.P + part], 1u);
+  }
+  __syncthreads();
+  for (uint32_t j = t; j < hn; j += TE_FB_THREADS) {
+    const uint32_t v = hist[j];
+    if (!v) continue;
+    const uint32_t row = j / (2u * a.P), rem = j - row * 2u * a.P, slot = rem / a.P, part = rem - slot * a.P;
+    const uint32_t ch = base[row] / a.chunk_len + slot;
+    if (ch < a.CH) atomicAdd(&a.counts1[((size_t)row * a.CH + ch) * a.P + part], v);
+  }
+}
+
+// ---- the table, once per bound set: records of window w = records of 2^(c w) P_i.  Window 0 is the ordinary conversion
+// (k_prep_points); the extended points are carried from window to window by c doublings (the unified addition with itself) and
+// every window's points go back to affine records with ONE inversion per TE_AFF_GROUP points (Montgomery's trick, Fermat chain).
+// extended point from a record: x = hp - hm, y = hp + hm, z = 1, t = x y
+__global__ void __launch_bounds__(256) k_fb_ext_from_recs(const pnt_slot* __restrict__ recs, ete* __restrict__ ext, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  store_ete<9>(ext + i, ete_from_pnt(load_pnt<9>(reinterpret_cast<const rec_slot<9>*>(recs), i)));      // (E 1, H 1, E H, 1): the point itself
+}
+__global__ void __launch_bounds__(256) k_fb_double(ete* __restrict__ ext, uint32_t n, uint32_t times) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  ete e = load_ete<9>(ext + i);
+  for (uint32_t k = 0; k < times; k++) e = ete_add<9>(e, e);
+  store_ete<9>(ext + i, e);
+}
+__device__ __forceinline__ bool fp_is_zero_mod_p(const fp& a) {           // a: product output (value < 2p): 0 or p
+  const fp t = fp_norm(mont_mul(a, fp_R1()));
+  uint32_t or0 = 0u, dp = 0u;
+#pragma unroll
+  for (int i = 0; i < NL; i++) { or0 |= t.v[i]; dp |= t.v[i] ^ p_limb(i); }
+  return or0 == 0u || dp == 0u;
+}
+__global__ void __launch_bounds__(256) k_fb_records(const ete* __restrict__ ext, pnt_slot* __restrict__ out, uint32_t n) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x, lo = t * TE_AFF_GROUP;
+  if (lo >= n) return;
+  const uint32_t cnt = min(TE_AFF_GROUP, n - lo);
+  const fp one = fp_R1();
+  fp plain1 = fp_zero(); plain1.v[0] = 1u;
+  const fp half_m = mont_mul(fp_R2_HALF(), plain1);                       // R / 2:  (a R)(R / 2) / R = (a / 2) R
+  const fp negd_m = mont_mul(mont_mul(fp_NEG_D_R3(), plain1), plain1);    // -d R
+  uint32_t* const scratch = reinterpret_cast<uint32_t*>(out);             // prefix products in the first 9 words of the (not yet written) slots
+  fp run = one;
+  for (uint32_t j = 0; j < cnt; j++) {
+    const ete e = load_ete<9>(ext + lo + j);
+    if (!fp_is_zero_mod_p(e.z)) run = mont_mul(run, e.z);
+#pragma unroll
+    for (int i = 0; i < NL; i++) scratch[(size_t)(lo + j) * 32u + i] = run.v[i];
+  }
+  // run^(p - 2): p = 1 (mod 2^32), so p - 2 ends in ... (P_W32[1] - 1) ffffffff; bit 252 of p - 2 is `run` itself
+  const uint32_t ex[8] = {0xffffffffu, P_W32[1] - 1u, P_W32[2], P_W32[3], P_W32[4], P_W32[5], P_W32[6], P_W32[7]};
+  fp inv = run;
+  for (int w = 7; w >= 0; w--) {
+    const uint32_t word = ex[w];
+    for (int b = (w == 7 ? 27 : 31); b >= 0; b--) {
+      inv = mont_mul(inv, inv);
+      if ((word >> b) & 1u) inv = mont_mul(inv, run);
+    }
+  }
+  for (uint32_t jj = cnt; jj-- > 0u;) {
+    const ete e = load_ete<9>(ext + lo + jj);
+    uint32_t w[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) w[j] = 0u;
+    if (!fp_is_zero_mod_p(e.z)) {
+      fp pre = one;
+      if (jj > 0u) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) pre.v[i] = scratch[(size_t)(lo + jj - 1u) * 32u + i];
+      }
+      const fp zi = mont_mul(inv, pre);
+      inv = mont_mul(inv, e.z);
+      const fp xy[2] = {e.x, e.y}, zz[2] = {zi, zi};
+      fp o[2];
+      mont_mul_x<2>(xy, zz, o);                                           // x, y (Montgomery form, class N)
+      const fp l[3] = {fp_sub<2>(o[1], o[0]), fp_add(o[1], o[0]), o[0]}, rr[3] = {half_m, half_m, o[1]};
+      fp q[3];
+      mont_mul_x<3>(l, rr, q);                                            // (y - x) / 2, (y + x) / 2, x y
+      const fp dt = mont_mul(q[2], negd_m);
+#pragma unroll
+      for (int j = 0; j < NL; j++) { w[j] = q[0].v[j]; w[NL + j] = q[1].v[j]; w[2 * NL + j] = dt.v[j]; }
+    }
+    uint4* dst = reinterpret_cast<uint4*>(out + lo + jj);
+#pragma unroll
+    for (int q4 = 0; q4 < 8; q4++) dst[q4] = make_uint4(w[4 * q4], w[4 * q4 + 1], w[4 * q4 + 2], w[4 * q4 + 3]);
   }
 }
 

@@ -71,6 +71,9 @@ struct plan_t {
   uint32_t S = 0, logS = 0, P = 0;   // level-1 partition: S buckets each, P = B/S partitions per window
   uint32_t packed = 0;               // level-1 entries as one 32-bit word (index | key << 23 | sign << 31): n <= 2^23
   int rec_kind = 0;                  // records k_accumulate gathers: 0 = the curve's own, 1 = affine BLS12-377 (bound point sets)
+  // fixed-base windows (bound point sets with a per-window table, kernels.hip.hpp k_fb_digits): fb_rb > 0 -- the "windows" of this
+  // plan are fb_rb + 1 pseudo-windows (rows) of 2^15 buckets over ONE bucket set; fb_c / fb_W: window bits and windows of the real decomposition
+  int fb_rb = 0, fb_c = 0, fb_W = 0;
 };
 
 struct graph_key { const void *pts, *sc, *out; uint64_t n, generation; int c, w_first, w_step, seg_len, sort; };
@@ -123,6 +126,9 @@ struct workset_t {
   // option "host_staging": the set's own pinned ring for host-buffer uploads (allocated on first use; te_msm_trim / destroy free it)
   uint8_t* h_ring = nullptr; std::vector<hipEvent_t> ring_ev; size_t ring_next = 0;
   uint64_t idle_calls = 0;            // te_msm_trim: context-level calls since the set was last used
+  uint32_t* d_fb_remap = nullptr;     // fixed-base windows: [rows][cap] table index | sign << 31 of every entry (beside d_digits' codes)
+  uint32_t* d_fb_fill = nullptr;      // ... [rows] entries reserved per row, in the zeroed block
+  const void* fb_scalars = nullptr; uint64_t fb_n = 0;   // ... the scalars (device memory) of the MSM in flight: a row overflow falls back to the ordinary windows
   te_bases* bound = nullptr;          // the bound point set the set's ticket in flight gathers from (te_msm_submit_scalars*): released only after the collect
 };
 constexpr int TE_MAX_WINDOWS = 64;    // window_bits >= 4
@@ -162,6 +168,7 @@ struct te_ctx {
   std::vector<std::unique_ptr<te_sched::worker_t>> stagers;   // the threads that fill those rings (created on first use)
   int opt_stage_device_inputs = 0;  // tickets for device-resident inputs: copy them to the chosen device even when it is the one that holds them (tests on a one-GPU box)
   int64_t stat_peer_bytes = 0;      // bytes those copies moved (get_option "peer_bytes")
+  int64_t stat_fb_fallbacks = 0;    // fixed-base MSMs whose rows overflowed (skewed scalars) and were run again with the ordinary windows
   int64_t stat_entries = 0;         // non-zero window digits (= accumulated entries) of the MSM whose result was fetched last (get_option "entries_accumulated")
   std::vector<double> host_split;   // TE_MSM_HOST_SPLIT (relative piece weights of a host-buffer upload; experiments), read once
   int opt_host_shard_min = 4096;    // multi-device te_msm_run: points per device below which fewer devices are used
@@ -185,6 +192,8 @@ struct te_ctx {
   std::vector<te_bases*> bases;  // the bound point sets of the context (te_msm_bind_points), freed by te_msm_release_points / te_msm_destroy
   int opt_bind_affine = 1;       // te_msm_bind_points, BLS12-377: affine records (one inversion per point, once) instead of the projective ones of the per-call conversion
   int opt_scalar_chunks = 0;     // te_msm_run_scalars / te_msm_submit_scalars: pieces the scalars of a bound set are uploaded and processed in (0 = from n)
+  int opt_bind_fixed_base = 0;   // te_msm_bind_points (Twisted-Edwards curve): window bits c of a per-window table 2^(c w) P_i (16..21; 0 = none): MSMs over
+                                 // the set then run fixed-base windows -- one bucket set for all windows (W x the record memory)
   int opt_exp_table_replicas = 1; // EXPERIMENT (profiles/r06_fixed_base_windows.txt): te_msm_bind_points keeps this many copies of the records and
                                  // the windows of a device-scalar MSM gather from different copies -- the gather footprint of a per-window table
 };
@@ -198,6 +207,7 @@ struct te_bases {
   size_t rec_bytes = 0;
   std::vector<uint8_t*> recs;    // recs[i]: n records in the memory of ctx->devs[i]
   int replicas = 1;              // experiment "exp_table_replicas": copies of the records behind each other in recs[i]
+  int fb_c = 0, fb_W = 0;        // fixed-base windows: recs[i] holds fb_W tables of n records, table w = records of 2^(fb_c w) P_i (table 0 = the ordinary records)
   int in_flight = 0;             // tickets not collected that gather from it (the set cannot be released under them)
 };
 
@@ -333,12 +343,14 @@ int ensure_buffers(te_ctx* ctx, gpu_t& d, workset_t& ws, uint64_t n, const plan_
   if ((rc = ensure(ctx, ws, ws.d_sorted, ws.cap[2], nd))) return rc;
   {
     const size_t c1 = (size_t)p.nw * p.CH * p.P;
-    ws.zero_words = Z_END + c1 + wb + (size_t)p.nw * p.P;
+    ws.zero_words = Z_END + c1 + wb + (size_t)p.nw * p.P + 64;            // (+ 64: the row fill counters of fixed-base windows)
     { const uint32_t* before = ws.d_zero; if ((rc = ensure(ctx, ws, ws.d_zero, ws.cap[3], ws.zero_words))) return rc; if (ws.d_zero != before) ws.zero_clean_words = 0; }
     ws.d_err = ws.d_zero; ws.d_num_seg = ws.d_zero + Z_KEEP; ws.d_size_hist = ws.d_zero + Z_HIST; ws.d_size_cursor = ws.d_zero + Z_CURSOR;
     ws.d_partials = reinterpret_cast<uint8_t*>(ws.d_zero + Z_ROWS);
     ws.d_counts1 = ws.d_zero + Z_END; ws.d_bucket_count = ws.d_counts1 + c1; ws.d_part_ticket = ws.d_bucket_count + wb;
+    ws.d_fb_fill = ws.d_part_ticket + (size_t)p.nw * p.P;
   }
+  if (p.fb_rb && (rc = ensure(ctx, ws, ws.d_fb_remap, ws.cap[27], nd))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_bucket_start, ws.cap[5], wb))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_bucket_cursor, ws.cap[16], wb))) return rc;
   if ((rc = ensure(ctx, ws, ws.d_seg_part_base, ws.cap[17], (size_t)p.nw * p.P))) return rc;
@@ -380,6 +392,7 @@ struct msm_launch {
   bool own_rows = false;          // rows go to ws.d_partials: the caller fetches flag + rows with one copy
   bool onto = false;              // a later piece of a host-buffer MSM: keep the final-carry flag, add onto the buckets
   bool host_rows = false;         // own rows go straight to the work set's pinned host block, written by k_reduce_tail (no copy at all)
+  const uint32_t* fb_remap = nullptr;   // fixed-base windows: the digit rows were filled by k_fb_digits (no k_digits launch); the level-1 scatter maps positions through it
   int table_replicas = 1;         // experiment "exp_table_replicas": window k gathers from copy k / ceil(windows / copies) of the bound records
   const uint8_t* bound = nullptr; // records of a bound point set (te_msm_bind_points), already offset to this launch's first point: no conversion,
                                   // k_accumulate gathers from here instead of ws.d_recs (p.rec_kind tells which record form)
@@ -449,10 +462,10 @@ struct msm_launch {
     if (onto || ws.zero_clean_words < ws.zero_words)
       HIP_TRY(ctx, hipMemsetAsync(ws.d_zero + (onto ? Z_KEEP : 0), 0, (ws.zero_words - (onto ? Z_KEEP : 0)) * sizeof(uint32_t), stream));
     ws.zero_clean_words = 0;
-    mark(ST_DIGITS);
+    if (!p.fb_rb) mark(ST_DIGITS);                         // (fixed-base windows: enqueue_fixed_base marked it in front of k_fb_digits)
     te::sort_geom sg;
     sg.n = n32; sg.nst = p.nst; sg.B = p.B; sg.logS = p.logS; sg.S = p.S; sg.P = p.P; sg.CH = p.CH; sg.chunk_len = p.chunk_len; sg.half = p.signed_digits ? p.B : 0u; sg.packed = p.packed;
-    if (p.nw > 0) {
+    if (p.nw > 0 && !p.fb_rb) {
       te::digits_params prm; memset(&prm, 0, sizeof prm);
       if (p.signed_digits) for (int w = 0; w < p.W; w++) { const int bit = w * p.c + p.c - 1; if (bit < 320) prm.half[bit >> 5] |= 1u << (bit & 31); }
       prm.zero_digit = p.signed_digits ? 1u << (p.c - 1) : 0u;
@@ -485,7 +498,7 @@ struct msm_launch {
     if (p.nw > 0) {
       te::scatter_args sa;
       sa.digits = ws.d_digits; sa.counts1 = ws.d_counts1; sa.part_keys = ws.d_part_keys; sa.part_idx = ws.d_part_idx; sa.part_start = ws.d_part_start;
-      sa.part_count = ws.d_part_count; sa.seg_part_base = ws.d_seg_part_base; sa.entries = reinterpret_cast<unsigned long long*>(ws.d_zero + Z_ENTRIES); sa.seg_len = p.seg_len; sa.cap_w = cap_w; sa.nw = (uint32_t)p.nw; sa.g = sg;
+      sa.part_count = ws.d_part_count; sa.seg_part_base = ws.d_seg_part_base; sa.entries = reinterpret_cast<unsigned long long*>(ws.d_zero + Z_ENTRIES); sa.seg_len = p.seg_len; sa.cap_w = cap_w; sa.nw = (uint32_t)p.nw; sa.g = sg; sa.remap = fb_remap;
       if (with_prep) {
         te::batch_ptrs tab; te::batch_slabs row_slab;
         const uint32_t rows = (uint32_t)prep_rows(tab, row_slab), sblocks = p.CH * (uint32_t)p.nw;
@@ -954,7 +967,7 @@ void free_workset_buffers(workset_t& ws) {      // the big device buffers of a w
                    (void**)&ws.d_part_idx, (void**)&ws.d_seg_part_base, (void**)&ws.d_bucket_start, (void**)&ws.d_bucket_cursor, (void**)&ws.d_sorted,
                    (void**)&ws.d_seg_base, (void**)&ws.d_seg_bucket, (void**)&ws.d_seg_lenv, (void**)&ws.d_order, (void**)&ws.d_split_list,
                    (void**)&ws.d_chunk_list, (void**)&ws.d_seg_out, (void**)&ws.d_buckets, (void**)&ws.d_red[0], (void**)&ws.d_red[1],
-                   (void**)&ws.d_red[2], (void**)&ws.d_red[3], &ws.d_in_points, &ws.d_in_scalars};
+                   (void**)&ws.d_red[2], (void**)&ws.d_red[3], &ws.d_in_points, &ws.d_in_scalars, (void**)&ws.d_fb_remap};
   for (void** q : ptrs) if (*q) { (void)hipFree(*q); *q = nullptr; }
   if (ws.h_ring) { (void)hipHostFree(ws.h_ring); ws.h_ring = nullptr; }       // the pinned ring of option "host_staging" (its events stay)
   memset(ws.cap, 0, sizeof ws.cap); ws.cap_in_points = ws.cap_in_scalars = 0;
@@ -1296,6 +1309,100 @@ int enqueue_scalar_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* re
   HIP_TRY(ctx, hipGetLastError());
   if (wait_for_pinned && !ctx->opt_host_staging && host_memory_is_pinned(src_scalars)) HIP_TRY(ctx, hipEventSynchronize(evs[(size_t)K - 1]));
   return 0;
+}
+
+// ---- fixed-base windows (kernels.hip.hpp, "FIXED-BASE WINDOWS"): the plan of an MSM over a bound set that carries a per-window table.
+// The sort / accumulation / reduction see fb_rb + 1 pseudo-windows ("rows") of 2^15 buckets and `cap` entries each: an unsigned
+// geometry (codes lo + 1, half = 0), general sort entries (the table index needs 24 bits).
+constexpr uint32_t FB_LOBITS = TE_FB_LOBITS;
+int fb_windows_for(int c) { return (255 + c - 1) / c; }
+void make_plan_fb(const te_ctx* ctx, const gpu_t& d, uint64_t n, int fb_c, plan_t& p) {
+  const int W = fb_windows_for(fb_c);
+  const uint32_t rb = 1u << ((uint32_t)fb_c - 1u - FB_LOBITS);
+  // a regular row holds (W - 1) n / rb entries for well-spread digits, the extra row the top window's n: capacity for the larger of
+  // the two plus a sixteenth (an overflow -- badly skewed scalars -- is detected on the device and falls back to the ordinary windows)
+  const uint64_t reg = ((uint64_t)(W - 1) * n + rb - 1) / rb, big = std::max<uint64_t>(reg, n);
+  const uint64_t cap = (big + big / 16 + 4096 + 7) & ~(uint64_t)7;
+  make_plan(ctx, d, cap, p, 16, 1, 0, true);           // chunk geometry, segment length and partitions for rows of `cap` entries
+  p.fb_rb = (int)rb; p.fb_c = fb_c; p.fb_W = W;
+  p.signed_digits = 0; p.c = (int)FB_LOBITS; p.W = (int)rb + 1; p.nw = p.nw1 = (int)rb + 1; p.batch = 1; p.w_first = 0; p.w_step = 1;
+  p.logB = FB_LOBITS; p.B = 1u << FB_LOBITS;
+  for (int k = 0; k < 4; k++) p.dw[k] = (p.logB + 3u - (uint32_t)k) / 4u;
+  p.S = 256u; p.P = p.B / p.S; p.logS = 8u;
+  p.packed = 0; p.rec_kind = 0;
+  // chunks per row: as make_plan, for the row count of this plan
+  uint32_t ch = TE_SCATTER_BLOCKS / (uint32_t)p.nw; if (ch < 1) ch = 1; if (ch > 256) ch = 256;
+  const uint32_t by_n = (uint32_t)((cap + TE_SCATTER_MINCHUNK - 1) / TE_SCATTER_MINCHUNK); if (ch > by_n) ch = by_n ? by_n : 1;
+  p.nst = (uint32_t)cap;
+  p.chunk_len = ((p.nst + ch - 1) / ch + 4095u) & ~4095u;
+  p.CH = (p.nst + p.chunk_len - 1) / p.chunk_len;
+  if (!ctx->opt_seg_len) {                              // twice the mean bucket size of the ONE bucket set, as a power of two in [16, 64]
+    const uint64_t a = (2ull * (uint64_t)W * n + ((uint64_t)rb << FB_LOBITS) - 1) / ((uint64_t)rb << FB_LOBITS); uint64_t s2 = 16;
+    while (s2 < a && s2 < 64) s2 <<= 1;
+    p.seg_len = (uint32_t)s2;
+  }
+}
+
+template <int C> void launch_fb_digits(const void* d_scalars, const te::fb_digit_args& a, uint32_t n, size_t lds, hipStream_t st) {
+  hipLaunchKernelGGL(te::k_fb_digits<C>, dim3((n + TE_FB_THREADS - 1u) / TE_FB_THREADS), dim3(TE_FB_THREADS), lds, st, static_cast<const uint4*>(d_scalars), a);
+}
+
+// An MSM of n scalars (device memory) over the fixed-base table of `bases` on device `d`: the scalars' digits address the table
+// entries (w, idx_base + i) -- idx_base: the first point of this launch inside the bound set (a device's slice of a lone
+// multi-device call).  Rows in the set's own block; the caller ends the sequence with fetch_rows().
+int enqueue_fixed_base(te_ctx* ctx, gpu_t& d, workset_t& ws, const te_bases* bases, const void* d_scalars, uint64_t n, uint64_t idx_base, hipStream_t stream) {
+  HIP_TRY(ctx, hipSetDevice(d.device));
+  plan_t p; make_plan_fb(ctx, d, n, bases->fb_c, p);
+  const uint64_t cap = p.nst;
+  if ((uint64_t)p.nw * cap >= (1ull << 31) || (uint64_t)bases->fb_W * bases->n >= (1ull << 31))
+    return set_err(ctx, TE_MSM_EINVAL, "fixed-base windows: windows x points must stay below 2^31");
+  if (int rc = ensure_buffers(ctx, d, ws, cap, p, false)) return rc;
+  if (ws.used && ws.last_stream != stream) HIP_TRY(ctx, hipStreamWaitEvent(stream, ws.ev_done, 0));
+  ws.plan = p; ws.n = cap; ws.used = true; ws.last_stream = stream; __atomic_store_n(&d.last_ws, (int)(&ws - d.ws), __ATOMIC_RELAXED);
+  ws.prof_level = ctx->opt_profile;
+  ws.fb_scalars = d_scalars; ws.fb_n = n;
+  msm_launch L{ctx, d, ws, p, nullptr, d_scalars, cap, ws.d_partials, ctx->opt_profile, stream, true};
+  L.host_rows = msm_launch::rows_to_host(ctx, d, p, true);
+  ws.rows_on_host = L.host_rows;
+  L.bound = bases->recs[(size_t)(&d - ctx->devs.data())];
+  L.fb_remap = ws.d_fb_remap;
+  // the zeroed block (flags, counters, level-1 histogram, row fill) and the digit rows (code 0 = no entry) -- then the digits
+  if (ws.zero_clean_words < ws.zero_words) HIP_TRY(ctx, hipMemsetAsync(ws.d_zero, 0, ws.zero_words * sizeof(uint32_t), stream));
+  ws.zero_clean_words = ws.zero_words;                                  // front_scalars below must not clear it again (it would wipe the histogram)
+  L.mark(ST_DIGITS);
+  HIP_TRY(ctx, hipMemsetAsync(ws.d_digits, 0, (size_t)p.nw * cap * sizeof(uint16_t), stream));
+  {
+    te::fb_digit_args a; memset(&a, 0, sizeof a);
+    for (int w = 0; w < p.fb_W; w++) { const int bit = w * p.fb_c + p.fb_c - 1; if (bit < 320) a.half[bit >> 5] |= 1u << (bit & 31); }
+    a.n = (uint32_t)n; a.idx_base = (uint32_t)idx_base; a.n_table = (uint32_t)bases->n; a.W = (uint32_t)p.fb_W;
+    a.rows = (uint32_t)p.nw; a.rb = (uint32_t)p.fb_rb; a.cap = (uint32_t)cap;
+    a.chunk_len = p.chunk_len; a.CH = p.CH; a.P = p.P; a.logS = p.logS;
+    a.digits = ws.d_digits; a.remap = ws.d_fb_remap; a.row_fill = ws.d_fb_fill; a.counts1 = ws.d_counts1; a.err = ws.d_err;
+    const size_t lds = (size_t)(2u * a.rows + a.rows * 2u * a.P) * sizeof(uint32_t);
+    switch (p.fb_c) {
+      case 16: launch_fb_digits<16>(d_scalars, a, a.n, lds, stream); break;
+      case 17: launch_fb_digits<17>(d_scalars, a, a.n, lds, stream); break;
+      case 18: launch_fb_digits<18>(d_scalars, a, a.n, lds, stream); break;
+      case 19: launch_fb_digits<19>(d_scalars, a, a.n, lds, stream); break;
+      case 20: launch_fb_digits<20>(d_scalars, a, a.n, lds, stream); break;
+      default: launch_fb_digits<21>(d_scalars, a, a.n, lds, stream); break;
+    }
+  }
+  // the engine's own stages from here on (front_scalars skips k_digits for a fixed-base plan)
+  if (int rc = L.front_scalars()) return rc;
+  L.mark(ST_PREP);
+  if (int rc = L.accumulate()) return rc;
+  L.mark(ST_TREE);
+  if (int rc = L.back()) return rc;
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+// the host tail of the rows a plan produced (ordinary windows: Horner; fixed-base windows: one bucket set, no window doublings)
+void fold_rows(const plan_t& p, const uint8_t* rows, uint8_t* out) {
+  if (p.fb_rb) te_host::fixed_base_to_affine(rows, p.fb_rb + 1, p.fb_rb, (int)p.logB, out);
+  else if (p.curve == TE_MSM_CURVE_BLS12_377_G1) te377_host::horner_to_affine(rows, p.c, (int)p.logB, p.W, out);
+  else te_host::horner_to_affine(rows, p.c, (int)p.logB, p.W, out);
 }
 
 // the host thread of device i of the context (host_sched.hpp), created on first use
@@ -1697,6 +1804,7 @@ int device_index_of_pointer(te_ctx* ctx, const void* p) {
   return -1;
 }
 const char* const kNoTicket = "no such ticket in flight (already collected, or never handed out)";
+int fixed_base_settle(te_ctx* ctx, gpu_t& d, workset_t& ws, const te_bases* bases);     // (resident bases, further down)
 }  // namespace
 
 int te_msm_submit_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_scalars_le, uint64_t n, uint64_t* ticket) {
@@ -1885,12 +1993,12 @@ int te_msm_collect(te_ctx* ctx, uint64_t ticket, uint8_t out_xy_le[64]) {
     return set_err(ctx, jrc, ws.job_err.empty() ? "the asynchronous submit failed" : ws.job_err.c_str());
   }
   HIP_TRY(ctx, hipEventSynchronize(ws.ev_result));   // on failure the ticket stays collectable
+  if (ws.bound) { if (int rc = fixed_base_settle(ctx, d, ws, ws.bound)) return rc; }      // (a fixed-base ticket whose rows overflowed: run again with the ordinary windows)
   (void)collect_stage_ms(ctx, d, ws);
   note_entries(ctx, ws);
   retire_ticket(ctx, d, ws);                         // the MSM is over, with a result or with a scalar-range error
   if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, kFinalCarry);
-  if (ws.plan.curve == TE_MSM_CURVE_BLS12_377_G1) te377_host::horner_to_affine(ws.h_partials, ws.plan.c, (int)ws.plan.logB, ws.plan.W, out_xy_le);
-  else te_host::horner_to_affine(ws.h_partials, ws.plan.c, (int)ws.plan.logB, ws.plan.W, out_xy_le);
+  fold_rows(ws.plan, ws.h_partials, out_xy_le);
   return 0;
 }
 
@@ -1915,7 +2023,7 @@ int bind_on_device(te_ctx* ctx, te_bases* b, size_t i, const void* src, bool src
   const uint64_t n = b->n;
   uint8_t* recs = nullptr; void* raw = nullptr; void* proj = nullptr; hipStream_t st = nullptr;
   struct cleanup_t { void*& raw; void*& proj; hipStream_t& st; ~cleanup_t() { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } if (raw) (void)hipFree(raw); if (proj) (void)hipFree(proj); } } cleanup{raw, proj, st};
-  HIP_TRY(ctx, hipMalloc((void**)&recs, (size_t)n * b->rec_bytes * (size_t)b->replicas));
+  HIP_TRY(ctx, hipMalloc((void**)&recs, (size_t)n * b->rec_bytes * (size_t)b->replicas * (size_t)(b->fb_c ? b->fb_W : 1)));
   b->recs[i] = recs;                                                       // (freed by the caller on failure: free_bases)
   HIP_TRY(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   const void* pts = src;
@@ -1945,6 +2053,17 @@ int bind_on_device(te_ctx* ctx, te_bases* b, size_t i, const void* src, bool src
   }
   for (int r = 1; r < b->replicas; r++)
     HIP_TRY(ctx, hipMemcpyAsync(recs + (size_t)r * n * b->rec_bytes, recs, (size_t)n * b->rec_bytes, hipMemcpyDeviceToDevice, st));
+  if (b->fb_c) {
+    // fixed-base windows: table w = the records of 2^(c w) P_i; the extended points travel from window to window by c doublings
+    HIP_TRY(ctx, hipMalloc(&proj, (size_t)n * sizeof(te::ete)));       // (the second temporary: unused on this curve otherwise)
+    te::ete* ext = static_cast<te::ete*>(proj);
+    const dim3 grid((n32 + 255) / 256), grid_g(((n32 + TE_AFF_GROUP - 1u) / TE_AFF_GROUP + 255) / 256);
+    hipLaunchKernelGGL(te::k_fb_ext_from_recs, grid, dim3(256), 0, st, reinterpret_cast<const te::pnt_slot*>(recs), ext, n32);
+    for (int w = 1; w < b->fb_W; w++) {
+      hipLaunchKernelGGL(te::k_fb_double, grid, dim3(256), 0, st, ext, n32, (uint32_t)b->fb_c);
+      hipLaunchKernelGGL(te::k_fb_records, grid_g, dim3(256), 0, st, ext, reinterpret_cast<te::pnt_slot*>(recs) + (size_t)w * n, n32);
+    }
+  }
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipStreamSynchronize(st));
   return 0;
@@ -1968,6 +2087,10 @@ int bind_common(te_ctx* ctx, const void* src, bool src_is_host, uint64_t n, te_b
   b->rec_kind = (b->curve == TE_MSM_CURVE_BLS12_377_G1 && ctx->opt_bind_affine) ? 1 : 0;
   b->rec_bytes = rec_bytes_of(b->curve, b->rec_kind);
   b->replicas = ctx->opt_exp_table_replicas;
+  if (ctx->opt_bind_fixed_base && b->curve == TE_MSM_CURVE_TE_BLS12 && n > 0) {
+    b->fb_c = ctx->opt_bind_fixed_base; b->fb_W = fb_windows_for(b->fb_c); b->replicas = 1;
+    if ((uint64_t)b->fb_W * n >= (1ull << 31)) { delete b; return set_err(ctx, TE_MSM_EINVAL, "bind_fixed_base: windows x points must stay below 2^31"); }
+  }
   b->recs.assign(nd, nullptr);
   int rc = 0;
   if (n > 0) {
@@ -1979,6 +2102,35 @@ int bind_common(te_ctx* ctx, const void* src, bool src_is_host, uint64_t n, te_b
   if (rc) { free_bases(ctx, b); delete b; return rc; }
   ctx->bases.push_back(b);
   *out = b;
+  return 0;
+}
+
+// A whole MSM over a fixed-base set from HOST scalars on work set `ws`: all scalars cross PCIe in one copy (the digits of every
+// window address one bucket set: there are no pieces to accumulate onto), then the fixed-base launch sequence and its read-back.
+int enqueue_fixed_base_host(te_ctx* ctx, gpu_t& d, workset_t& ws, const te_bases* bases, const uint8_t* src_scalars, uint64_t n, bool wait_for_pinned) {
+  HIP_TRY(ctx, hipSetDevice(d.device));
+  const curve_sizes sz = sizes_of(bases->curve);
+  if (int rc = ensure_staging(ctx, ws, 0, n * sz.scalar_in)) return rc;
+  if (ws.used && ws.ev_done) HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ws.ev_done, 0));      // the staging area may still be read by the set's previous MSM
+  if (int rc = upload(ctx, ws, ws.d_in_scalars, src_scalars, n * sz.scalar_in, ws.stream)) return rc;
+  if (wait_for_pinned && !ctx->opt_host_staging && host_memory_is_pinned(src_scalars)) {
+    HIP_TRY(ctx, hipEventRecord(ws.ev_copy, ws.stream));
+    HIP_TRY(ctx, hipEventSynchronize(ws.ev_copy));
+  }
+  if (int rc = enqueue_fixed_base(ctx, d, ws, bases, ws.d_in_scalars, n, 0, ws.stream)) return rc;
+  return fetch_rows(ctx, ws, ws.stream);
+}
+
+// The rows of a fixed-base MSM are on the host (ev_result passed).  A row of the pseudo-window buffers overflowed -- badly skewed
+// scalars: all equal, a few distinct values -- : the MSM runs again with the ordinary windows over table 0 of the same set (the
+// ordinary records), on the same work set; the caller then folds ws.plan's rows as usual.  0 = the rows in the pinned block are final.
+int fixed_base_settle(te_ctx* ctx, gpu_t& d, workset_t& ws, const te_bases* bases) {
+  if (!ws.plan.fb_rb || *ws.h_err || !ws.h_err[1]) return 0;
+  ctx->stat_fb_fallbacks++;
+  HIP_TRY(ctx, hipSetDevice(d.device));
+  if (int rc = enqueue_partial(ctx, d, ws, nullptr, ws.fb_scalars, ws.fb_n, nullptr, ws.stream, nullptr, 0, false, 1, true, bases)) return rc;
+  if (int rc = fetch_rows(ctx, ws, ws.stream)) return rc;
+  HIP_TRY(ctx, hipEventSynchronize(ws.ev_result));
   return 0;
 }
 
@@ -2044,12 +2196,18 @@ int run_scalars_common(te_ctx* ctx, te_bases* bases, const void* src, bool src_i
     return 0;
   }
   if (!src) return set_err(ctx, TE_MSM_EINVAL, "null scalar buffer");
+  size_t di = 0;
   if (ctx->devs.size() > 1) {
-    if (src_is_host) return run_host_sharded(ctx, nullptr, static_cast<const uint8_t*>(src), n, out, bases);
-    return run_bound_window_shards(ctx, bases, src, n, out);
+    if (!bases->fb_c) {
+      if (src_is_host) return run_host_sharded(ctx, nullptr, static_cast<const uint8_t*>(src), n, out, bases);
+      return run_bound_window_shards(ctx, bases, src, n, out);
+    }
+    // a fixed-base set has no windows or point slices to shard (one bucket set): the lone call runs on ONE device -- the holder of
+    // device-resident scalars, else the first; MSMs in flight (tickets) are how several devices work on such a set
+    if (!src_is_host) { const int owner = device_index_of_pointer(ctx, src); if (owner < 0) return set_err(ctx, TE_MSM_EINVAL, "te_msm_run_scalars_device: the scalars must be resident on a device of the context"); di = (size_t)owner; }
   }
-  gpu_t& d = ctx->devs[0];
-  int wsel = ctx->opt_workset;
+  gpu_t& d = ctx->devs[di];
+  int wsel = ctx->devs.size() > 1 ? 0 : ctx->opt_workset;
   if (te_sched::slot_ticket(d.ws[wsel].slot)) {
     wsel = free_workset_index(d);
     if (wsel < 0) return set_err(ctx, TE_MSM_ESTATE, kAllSetsOwned);
@@ -2058,9 +2216,13 @@ int run_scalars_common(te_ctx* ctx, te_bases* bases, const void* src, bool src_i
   HIP_TRY(ctx, hipSetDevice(d.device));
   plan_t p0; make_plan(ctx, d, n, p0);
   const curve_sizes sz = sizes_of(p0.curve);
-  if (src_is_host && !ctx->opt_profile && d.w_step == 1) {
+  const bool fb = bases->fb_c && (ctx->devs.size() > 1 || d.w_step == 1);      // (a window-sharded single-device context keeps the ordinary windows)
+  if (fb) {
+    if (src_is_host) { if (int rc = enqueue_fixed_base_host(ctx, d, ws, bases, static_cast<const uint8_t*>(src), n, true)) return rc; }
+    else { if (int rc = enqueue_fixed_base(ctx, d, ws, bases, src, n, 0, ws.stream)) return rc; if (int rc = fetch_rows(ctx, ws, ws.stream)) return rc; }
+  } else if (src_is_host && !ctx->opt_profile && d.w_step == 1) {
     // whole MSM, no stage timing: the scalars in pieces
-    if (int rc = enqueue_scalar_slice(ctx, d, ws, bases->recs[0], bases->rec_kind, static_cast<const uint8_t*>(src), n, p0.c, scalar_pieces(ctx, n))) return rc;
+    if (int rc = enqueue_scalar_slice(ctx, d, ws, bases->recs[di], bases->rec_kind, static_cast<const uint8_t*>(src), n, p0.c, scalar_pieces(ctx, n))) return rc;
   } else {
     const void* ds = src;
     if (src_is_host) {
@@ -2073,11 +2235,11 @@ int run_scalars_common(te_ctx* ctx, te_bases* bases, const void* src, bool src_i
     if (int rc = fetch_rows(ctx, ws, ws.stream)) return rc;
   }
   HIP_TRY(ctx, hipEventSynchronize(ws.ev_result));
+  if (int rc = fixed_base_settle(ctx, d, ws, bases)) return rc;
   note_entries(ctx, ws);
   if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, kFinalCarry);
   (void)collect_stage_ms(ctx, d, ws);
-  if (p0.curve == TE_MSM_CURVE_BLS12_377_G1) te377_host::horner_to_affine(ws.h_partials, p0.c, (int)p0.logB, p0.W, out);
-  else te_host::horner_to_affine(ws.h_partials, p0.c, (int)p0.logB, p0.W, out);
+  fold_rows(ws.plan, ws.h_partials, out);
   return 0;
 }
 }  // namespace
@@ -2143,8 +2305,9 @@ int te_msm_submit_scalars(te_ctx* ctx, te_bases* bases, const uint8_t* scalars_l
   workset_t* wsp = &ws; gpu_t* dp = &d;
   const uint8_t* recs = bases->recs[(size_t)di]; const int kind = bases->rec_kind;
   warm_upload_lanes(ctx);
-  te_sched::job_ref job = te_sched::next_lane_of(*ctx, (size_t)di, ctx->opt_upload_threads).post([ctx, dp, wsp, recs, kind, scalars_le, n, c, K]() -> int {
-    const int rc = enqueue_scalar_slice(ctx, *dp, *wsp, recs, kind, scalars_le, n, c, K, false);
+  te_sched::job_ref job = te_sched::next_lane_of(*ctx, (size_t)di, ctx->opt_upload_threads).post([ctx, dp, wsp, bases, recs, kind, scalars_le, n, c, K]() -> int {
+    const int rc = bases->fb_c ? enqueue_fixed_base_host(ctx, *dp, *wsp, bases, scalars_le, n, false)
+                               : enqueue_scalar_slice(ctx, *dp, *wsp, recs, kind, scalars_le, n, c, K, false);
     if (rc) { std::lock_guard<std::mutex> lk(ctx->err_mu); wsp->job_err = ctx->err; }
     return rc;
   });
@@ -2180,7 +2343,8 @@ int te_msm_submit_scalars_device(te_ctx* ctx, te_bases* bases, const void* d_sca
     ctx->stat_peer_copies += 1; ctx->stat_peer_bytes += (int64_t)(n * sz.scalar_in);
     ds = ws.d_in_scalars;
   }
-  if (int rc = enqueue_partial(ctx, d, ws, nullptr, ds, n, nullptr, ws.stream, nullptr, 0, false, 1, multi, bases)) return rc;
+  if (bases->fb_c && (multi || d.w_step == 1)) { if (int rc = enqueue_fixed_base(ctx, d, ws, bases, ds, n, 0, ws.stream)) return rc; }
+  else if (int rc = enqueue_partial(ctx, d, ws, nullptr, ds, n, nullptr, ws.stream, nullptr, 0, false, 1, multi, bases)) return rc;
   if (int rc = fetch_rows(ctx, ws, ws.stream)) return rc;
   ws.bound = bases; bases->in_flight++;
   hand_out_ticket(ctx, di, ws, ticket);
@@ -2247,6 +2411,7 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   if (!strcmp(key, "host_staging")) { ctx->opt_host_staging = value ? 1 : 0; return 0; }
   if (!strcmp(key, "upload_threads")) { if (value < 1 || value > 16) return set_err(ctx, TE_MSM_EINVAL, "upload_threads must be in [1, 16]"); ctx->opt_upload_threads = (int)value; return 0; }
   if (!strcmp(key, "bind_affine")) { ctx->opt_bind_affine = value ? 1 : 0; return 0; }
+  if (!strcmp(key, "bind_fixed_base")) { if (value != 0 && (value < 16 || value > 21)) return set_err(ctx, TE_MSM_EINVAL, "bind_fixed_base must be 0 or in [16, 21]"); ctx->opt_bind_fixed_base = (int)value; return 0; }
   if (!strcmp(key, "exp_table_replicas")) { if (value < 1 || value > TE_BATCH_MAX) return set_err(ctx, TE_MSM_EINVAL, "exp_table_replicas must be in [1, 8]"); ctx->opt_exp_table_replicas = (int)value; return 0; }
   if (!strcmp(key, "scalar_chunks")) { if (value < 0 || value > 64) return set_err(ctx, TE_MSM_EINVAL, "scalar_chunks out of range"); ctx->opt_scalar_chunks = (int)value; return 0; }
   return set_err(ctx, TE_MSM_EINVAL, "unknown option");
@@ -2280,8 +2445,10 @@ int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value) {
   if (!strcmp(key, "streams_final")) { *value = ctx->devs[0].streams_final ? 1 : 0; return 0; }
   if (!strcmp(key, "bind_affine")) { *value = ctx->opt_bind_affine; return 0; }
   if (!strcmp(key, "scalar_chunks")) { *value = ctx->opt_scalar_chunks; return 0; }
+  if (!strcmp(key, "bind_fixed_base")) { *value = ctx->opt_bind_fixed_base; return 0; }
+  if (!strcmp(key, "fixed_base_fallbacks")) { *value = ctx->stat_fb_fallbacks; return 0; }
   if (!strcmp(key, "bases_bound")) { *value = (int64_t)ctx->bases.size(); return 0; }
-  if (!strcmp(key, "bases_bytes")) { int64_t t = 0; for (const te_bases* b : ctx->bases) for (const uint8_t* r : b->recs) if (r) t += (int64_t)(b->n * b->rec_bytes) * b->replicas; *value = t; return 0; }
+  if (!strcmp(key, "bases_bytes")) { int64_t t = 0; for (const te_bases* b : ctx->bases) for (const uint8_t* r : b->recs) if (r) t += (int64_t)(b->n * b->rec_bytes) * b->replicas * (b->fb_c ? b->fb_W : 1); *value = t; return 0; }
   if (!strcmp(key, "in_flight")) { int64_t t = 0; for (const gpu_t& d : ctx->devs) t += d.in_flight; *value = t; return 0; }
   if (!strcmp(key, "device_bytes")) {      drain_workers(ctx);      // device memory this context holds in work-set buffers (te_msm_trim gives it back)
     int64_t tot = 0;
@@ -2495,7 +2662,8 @@ int64_t te_msm_bases_read(te_ctx* ctx, const te_bases* bases, int device_index, 
   device_guard restore_callers_device;
   if (!ctx || !dst) return TE_MSM_EINVAL;
   if (!valid_bases(ctx, bases)) return set_err(ctx, TE_MSM_EINVAL, kBadBases);
-  if (device_index < 0 || (size_t)device_index >= ctx->devs.size() || first > bases->n || count > bases->n - first) return set_err(ctx, TE_MSM_EINVAL, "bad arguments");
+  const uint64_t total = bases->n * (uint64_t)bases->replicas * (uint64_t)(bases->fb_c ? bases->fb_W : 1);      // (a fixed-base set: table w at records [w n, (w + 1) n))
+  if (device_index < 0 || (size_t)device_index >= ctx->devs.size() || first > total || count > total - first) return set_err(ctx, TE_MSM_EINVAL, "bad arguments");
   if (record_bytes) *record_bytes = (int)bases->rec_bytes;
   uint64_t bytes = count * bases->rec_bytes;
   if (bytes > cap) bytes = cap;
