@@ -79,13 +79,14 @@ def measured_traffic(log2n, c, world, default_workload=True, config=None):
     return k.get("hbm_bytes_per_launch"), info
 
 
-def isa_cycles(bls):
+def isa_cycles(bls, affine=False):
     """estimated VALU issue cycles per 64 accumulated points, from the ISA listing of the build (tools/isa_hist.py --json ->
-    profiles/isa_cycles.json, which records the hash of the sources it was taken from)"""
-    fallback = {"cycles": 15545.0 if bls else 6136.0, "note": "round-2 listing (profiles/r02_isa_hist_k_accumulate.txt)", "stale": True}
+    profiles/isa_cycles.json, which records the hash of the sources it was taken from); affine: BLS12-377 over bound bases
+    (k_accumulate<14, 1>: 7 products per gathered point)"""
+    fallback = {"cycles": (13669.0 if affine else 15545.0) if bls else 6136.0, "note": "round-2 listing (profiles/r02_isa_hist_k_accumulate.txt)", "stale": True}
     try:
         j = json.load(open(ISA_JSON))
-        k = j["k_accumulate<14>" if bls else "k_accumulate<9>"]
+        k = j[("k_accumulate<14,affine>" if affine else "k_accumulate<14>") if bls else "k_accumulate<9>"]
     except (OSError, KeyError, ValueError):
         return fallback
     return {"cycles": float(k["valu_issue_cycles"]), "note": k.get("note", ""), "stale": j.get("kernel_sources_sha") != kernel_sources_sha()}
@@ -262,7 +263,15 @@ def side_config(pkg, dev, name, curve, digits, log2n, depth, threads, steps, exp
             bound = bases_resident_figures(cx, pts, sc, result, ds, n, depth, steps)
             cx.set_option("profile", 1)
             bb = cx.bind_points(pts)
-            bound["accumulate_alone_ms"] = alone_pass(cx, lambda: cx.run_scalars_device(bb, ds), 4).get("accumulate")
+            st_b = alone_pass(cx, lambda: cx.run_scalars_device(bb, ds), 4)
+            bound["accumulate_alone_ms"] = st_b.get("accumulate")
+            isa_b = isa_cycles(True, affine=True)
+            floor_b = (cx.get_option("entries_accumulated") / 64.0) * isa_b["cycles"] / 1024.0 / 2.4e6
+            ghz_b = st_b.get("accumulate_core_clock_ghz")
+            bound["binding_roofline"] = {"bound": "valu-issue", "kernel": "k_accumulate<14, affine records>", "floor_ms_at_2.4GHz": floor_b, "kernel_ms": st_b.get("accumulate"),
+                                         "frac": floor_b / st_b["accumulate"] if st_b.get("accumulate") else None, "core_clock_ghz": ghz_b,
+                                         "frac_at_measured_clock": (floor_b * 2.4 / ghz_b) / st_b["accumulate"] if (ghz_b and st_b.get("accumulate")) else None,
+                                         "valu_issue_cycles_per_64_points": isa_b["cycles"], "isa_listing_stale": isa_b["stale"], "note": isa_b["note"]}
             cx.release_points(bb)
     whole, acc_bytes = algorithmic_bytes(n, W, B, bls, entries)
     traffic, traffic_info = measured_traffic(log2n, c, 1, False, name)

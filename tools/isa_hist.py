@@ -108,8 +108,10 @@ def main():
         import json
         path, outp = sys.argv[1], sys.argv[sys.argv.index("--json") + 1]
         j = {"listing": path, "kernel_sources_sha": sources_sha(),
-             "k_accumulate<9>": analyse(path, "k_accumulateILi9", True, quiet=True),
-             "k_accumulate<14>": analyse(path, "k_accumulateILi14", True, quiet=True)}
+             "k_accumulate<9>": analyse(path, "k_accumulateILi9ELi0", True, quiet=True),
+             "k_accumulate<14>": analyse(path, "k_accumulateILi14ELi0", True, quiet=True),
+             # round 6: BLS12-377 over BOUND bases -- affine records, 7 products per gathered point (k_accumulate<14, 1>)
+             "k_accumulate<14,affine>": analyse(path, "k_accumulateILi14ELi1", True, quiet=True)}
         json.dump(j, open(outp, "w"), indent=1)
         print(json.dumps(j, indent=1))
         return

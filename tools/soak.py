@@ -34,17 +34,21 @@ while time.time() < t_end:
                  ("host_staging", rnd.choice([0, 0, 1]))):
         ctx.set_option(k, v)
         opts[k] = v
-    mode = rnd.choice(["run", "run", "tickets", "tickets", "shards", "batch", "host_tickets", "host_tickets", "multi", "multi_tickets", "multi_tickets"])
-    if mode in ("multi", "multi_tickets"):
+    mode = rnd.choice(["run", "run", "tickets", "tickets", "shards", "batch", "host_tickets", "host_tickets", "multi", "multi_tickets", "multi_tickets",
+                       "bases", "bases", "bases", "multi_bases"])
+    if mode in ("multi", "multi_tickets", "multi_bases"):
         ctx = multi_bls if ctx is bls else multi[rnd.choice([2, 3, 4])]
         for k, v in opts.items():
             ctx.set_option(k, v)
         ctx.set_option("host_shard_min", rnd.choice([1, 1, 4096]))
     batch, n_common = [], int(2 ** rnd.uniform(0, 17.5))
+    bound_mode = mode in ("bases", "multi_bases")
     for _ in range(rnd.randint(1, pkg.WORKSETS)):
-        n = n_common if mode == "batch" else int(2 ** rnd.uniform(0, 20.2 if rnd.random() < 0.05 else 17.5))      # one launch sequence takes MSMs of one size
+        n = n_common if (mode == "batch" or bound_mode) else int(2 ** rnd.uniform(0, 20.2 if rnd.random() < 0.05 else 17.5))      # one launch sequence takes MSMs of one size
         seed = rnd.randrange(1 << 30)
-        if mode == "batch" and batch and rnd.random() < 0.4:
+        if bound_mode and batch:
+            pts = batch[0][0]                                           # resident bases: every MSM of the round runs over the ONE bound point set
+        elif mode == "batch" and batch and rnd.random() < 0.4:
             pts = batch[rnd.randrange(len(batch))][0]                  # a point buffer several MSMs of the sequence share (same object -> same device pointer below)
         else:
             pts = orc.gen_points(seed, n)
@@ -62,7 +66,49 @@ while time.time() < t_end:
             sc = bytes(a)
         batch.append((pts, sc, n))
     exp = [orc.msm(p, s, threads=8) for p, s, _ in batch]
-    if mode in ("run", "multi"):
+    if bound_mode:
+        # round 6: resident bases -- bind once (ordinary records; BLS12-377: affine or projective; Twisted-Edwards: now and then a
+        # fixed-base table), then lone calls and tickets from host and device scalars in random order, a release and a second bind in between
+        ctx.set_option("graph", 0)
+        ctx.set_option("scalar_chunks", rnd.choice([0, 0, 1, 2, 4]))
+        ctx.set_option("bind_affine", rnd.choice([1, 1, 0]))
+        ctx.set_option("bind_fixed_base", rnd.choice([0, 0, 0, 16, 17, 18, 19, 20, 21]) if ctx.curve == pkg.CURVE_TE_BLS12 else 0)
+        ctx.set_option("stage_device_inputs", rnd.choice([0, 1]))
+        n = batch[0][2]
+        b = ctx.bind_points(batch[0][0])
+        keep, tickets, got = [], [], [None] * len(batch)
+        for i, (p, s, _) in enumerate(batch):
+            kind = rnd.choice(["run", "run_dev", "submit", "submit", "submit_dev"])
+            if kind in ("run_dev", "submit_dev") and n:
+                d_s = torch.frombuffer(bytearray(s), dtype=torch.uint8).cuda()
+                torch.cuda.synchronize()
+                keep.append(d_s)
+            if n == 0 or kind == "run":
+                got[i] = ctx.run_scalars(b, s); tickets.append(None)
+            elif kind == "run_dev":
+                got[i] = ctx.run_scalars_device(b, d_s.data_ptr()); tickets.append(None)
+            elif kind == "submit":
+                tickets.append(ctx.submit_scalars(b, s))
+            else:
+                tickets.append(ctx.submit_scalars_device(b, d_s.data_ptr()))
+        for i in rnd.sample(range(len(batch)), len(batch)):
+            if tickets[i] is not None:
+                if rnd.random() < 0.5:
+                    ctx.ticket_wait(tickets[i])
+                got[i] = ctx.collect(tickets[i])
+        if rnd.random() < 0.5:                                          # released and bound again (under other bind options): the same point
+            ctx.release_points(b)
+            ctx.set_option("bind_fixed_base", 0)
+            ctx.set_option("bind_affine", rnd.choice([1, 0]))
+            b = ctx.bind_points(batch[0][0])
+            assert ctx.run_scalars(b, batch[0][1]) == exp[0], "second bind"
+        ctx.release_points(b)
+        for k in ("bind_fixed_base", "scalar_chunks"):
+            ctx.set_option(k, 0)
+        ctx.set_option("bind_affine", 1)
+        if rnd.random() < 0.3:
+            ctx.trim(rnd.choice([0, 1, 4]))
+    elif mode in ("run", "multi"):
         got = [ctx.run(p, s) for p, s, _ in batch]
     elif mode == "host_tickets":
         # te_msm_submit: host buffers, tickets collected in random order, now and then beside a synchronous call

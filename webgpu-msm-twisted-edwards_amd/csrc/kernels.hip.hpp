@@ -351,8 +351,9 @@ struct scatter_args {
   uint32_t *part_start, *part_count, *seg_part_base; uint32_t seg_len, cap_w, nw /* local windows of the launch sequence */; sort_geom g;
   unsigned long long* entries;   // += the non-zero digits of every window (one 64-bit atomic per window): what k_accumulate will gather -- bench.py's roofline
   // fixed-base windows (k_fb_digits): the entry at position i of row k is not point i -- remap[k * nst + i] = table index | sign << 31;
-  // nullptr: the ordinary case (entry i of a window is point i).  Needs the general entry form (packed == 0).
-  const uint32_t* remap;
+  // nullptr: the ordinary case (entry i of a window is point i).  Needs the general entry form (packed == 0).  row_fill[k]: the entries
+  // row k holds -- what lies behind them was never written (the rows are not cleared) and is not read
+  const uint32_t* remap; const uint32_t* row_fill;
 };
 // LDS of one level-1 block in words: one packed word per entry of the tile, four 512-entry tables, scan scratch.
 // Packed entry: source slot in the tile (12 bits) | partition << 12 (8 bits: P <= 256) | bucket low bits << 20 (8) | sign << 28 --
@@ -402,7 +403,7 @@ __device__ __forceinline__ void part_scatter_block(uint32_t ch, uint32_t k, uint
       if (t == 0) part_count[a.nw * g.P + k] = ovt;
     }
   }
-  const uint32_t lo = ch * g.chunk_len, hi = min(g.nst, lo + g.chunk_len);
+  const uint32_t lo = ch * g.chunk_len, hi = min(a.remap ? min(a.row_fill[k], g.nst) : g.nst, lo + g.chunk_len);
   const uint4* d4 = reinterpret_cast<const uint4*>(digits + (size_t)k * g.nst);
   const uint32_t last8 = (g.nst >> 3) - 1u;
   uint16_t* ok = part_keys + (size_t)k * g.nst;
@@ -1599,6 +1600,10 @@ struct fb_digit_args {
 };
 #define TE_FB_THREADS 256u
 #define TE_FB_LOBITS 15u
+// (Round 6 tried two refinements of this kernel and kept neither: staging the block's entries in LDS so that they leave as one contiguous
+// run per row -- 25 KB more LDS per block, a third of the resident blocks: 122 instead of 106 us for 13.6 M entries -- and, on top of it,
+// wave-aggregated ranks by ballots instead of one LDS atomic per entry: 140 us.  The kernel is bound by its occupancy and the latency of
+// its scattered stores, not by the atomics.)
 // one scalar per thread; LDS: cnt[rows] | base[rows] | hist[rows][2][P] (dynamic)
 template <int C>
 __global__ void __launch_bounds__(TE_FB_THREADS) k_fb_digits(const uint4* __restrict__ scalars, fb_digit_args a) {

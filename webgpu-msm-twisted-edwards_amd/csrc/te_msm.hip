@@ -498,7 +498,7 @@ struct msm_launch {
     if (p.nw > 0) {
       te::scatter_args sa;
       sa.digits = ws.d_digits; sa.counts1 = ws.d_counts1; sa.part_keys = ws.d_part_keys; sa.part_idx = ws.d_part_idx; sa.part_start = ws.d_part_start;
-      sa.part_count = ws.d_part_count; sa.seg_part_base = ws.d_seg_part_base; sa.entries = reinterpret_cast<unsigned long long*>(ws.d_zero + Z_ENTRIES); sa.seg_len = p.seg_len; sa.cap_w = cap_w; sa.nw = (uint32_t)p.nw; sa.g = sg; sa.remap = fb_remap;
+      sa.part_count = ws.d_part_count; sa.seg_part_base = ws.d_seg_part_base; sa.entries = reinterpret_cast<unsigned long long*>(ws.d_zero + Z_ENTRIES); sa.seg_len = p.seg_len; sa.cap_w = cap_w; sa.nw = (uint32_t)p.nw; sa.g = sg; sa.remap = fb_remap; sa.row_fill = ws.d_fb_fill;
       if (with_prep) {
         te::batch_ptrs tab; te::batch_slabs row_slab;
         const uint32_t rows = (uint32_t)prep_rows(tab, row_slab), sblocks = p.CH * (uint32_t)p.nw;
@@ -1366,11 +1366,11 @@ int enqueue_fixed_base(te_ctx* ctx, gpu_t& d, workset_t& ws, const te_bases* bas
   ws.rows_on_host = L.host_rows;
   L.bound = bases->recs[(size_t)(&d - ctx->devs.data())];
   L.fb_remap = ws.d_fb_remap;
-  // the zeroed block (flags, counters, level-1 histogram, row fill) and the digit rows (code 0 = no entry) -- then the digits
+  // the zeroed block (flags, counters, level-1 histogram, row fill) -- then the digits.  The digit rows are NOT cleared: the sort's
+  // first level reads every row only up to its fill (scatter_args.row_fill)
   if (ws.zero_clean_words < ws.zero_words) HIP_TRY(ctx, hipMemsetAsync(ws.d_zero, 0, ws.zero_words * sizeof(uint32_t), stream));
   ws.zero_clean_words = ws.zero_words;                                  // front_scalars below must not clear it again (it would wipe the histogram)
   L.mark(ST_DIGITS);
-  HIP_TRY(ctx, hipMemsetAsync(ws.d_digits, 0, (size_t)p.nw * cap * sizeof(uint16_t), stream));
   {
     te::fb_digit_args a; memset(&a, 0, sizeof a);
     for (int w = 0; w < p.fb_W; w++) { const int bit = w * p.fb_c + p.fb_c - 1; if (bit < 320) a.half[bit >> 5] |= 1u << (bit & 31); }
