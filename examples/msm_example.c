@@ -6,7 +6,9 @@
  * 1. compute_msm(bufferPoints, bufferScalars) of the reference (submission/submission.ts:73-78) = te_msm_run on host buffers;
  * 2. several calls in flight (concurrent compute_msm promises, ui/Benchmark.tsx:32 is an async call) = tickets:
  *    te_msm_submit_async ... te_msm_collect, on one device or -- one whole MSM per device -- on several;
- * 3. errors are negative codes with text (the reference throws: cuzk/gpu.ts:19-22, miscellaneous/utils.ts:80-83).
+ * 3. resident bases -- the harness passes ONE point buffer to six calls per size (full_benchmarks.ts:63-68,100-105): te_msm_bind_points
+ *    once, then te_msm_run_scalars / te_msm_submit_scalars move the scalars only;
+ * 4. errors are negative codes with text (the reference throws: cuzk/gpu.ts:19-22, miscellaneous/utils.ts:80-83).
  * Prints the affine result (x, y little-endian hex) and whether every path returned the same 64 bytes. */
 #define _POSIX_C_SOURCE 199309L
 #include <stdio.h>
@@ -53,6 +55,30 @@ int main(int argc, char** argv) {
     if (i == k - 1) printf("  last ticket ran on device %d (entry %d of the list)\n", dev_id, dev_index);
   }
   printf("  %d tickets in flight: %.3f ms per MSM; all results equal: %s\n", k, (now_ms() - t0) / k, same ? "yes" : "NO");
+
+  /* resident bases: the points are uploaded and converted once (on every device of the context); every MSM then moves 32 of its 96
+   * bytes per point.  The lone call, then tickets in flight over the same set; the set is released when no ticket uses it any more */
+  te_bases* bases = NULL;
+  t0 = now_ms();
+  if ((rc = te_msm_bind_points(ctx, points, n, &bases))) { fprintf(stderr, "te_msm_bind_points: %d: %s\n", rc, te_msm_last_error(ctx)); return 1; }
+  const double bind_ms = now_ms() - t0;
+  if ((rc = te_msm_run_scalars(ctx, bases, scalars, out))) { fprintf(stderr, "te_msm_run_scalars: %d: %s\n", rc, te_msm_last_error(ctx)); return 1; }
+  same = same && memcmp(out, ref, 64) == 0;
+  t0 = now_ms();
+  rc = te_msm_run_scalars(ctx, bases, scalars, out);
+  const double lone_ms = now_ms() - t0;
+  same = same && rc == 0 && memcmp(out, ref, 64) == 0;
+  t0 = now_ms();
+  for (int i = 0; i < k; i++)
+    if ((rc = te_msm_submit_scalars(ctx, bases, scalars, &ticket[i]))) { fprintf(stderr, "te_msm_submit_scalars: %d: %s\n", rc, te_msm_last_error(ctx)); return 1; }
+  same = same && te_msm_release_points(ctx, bases) == TE_MSM_ESTATE;            /* tickets over the set are in flight */
+  for (int i = 0; i < k; i++) {
+    if ((rc = te_msm_collect(ctx, ticket[i], out))) { fprintf(stderr, "te_msm_collect: %d: %s\n", rc, te_msm_last_error(ctx)); return 1; }
+    same = same && memcmp(out, ref, 64) == 0;
+  }
+  printf("  bound bases (%llu points, bind %.3f ms): te_msm_run_scalars %.3f ms, %d tickets in flight %.3f ms per MSM; all results equal: %s\n",
+         (unsigned long long)te_msm_bases_count(bases), bind_ms, lone_ms, k, (now_ms() - t0) / k, same ? "yes" : "NO");
+  same = same && te_msm_release_points(ctx, bases) == 0;
 
   /* a scalar that does not fit the signed windows is an error of ITS call */
   memset(scalars, 0xff, TE_MSM_SCALAR_BYTES);

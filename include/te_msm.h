@@ -218,6 +218,9 @@ int te_msm_submit_scalars_device(te_ctx* ctx, te_bases* bases, const void* d_sca
  *                   counts them).  A lone call on several devices runs on ONE of them (one bucket set: nothing to shard); tickets use all.
  *                   "window_bits", "signed_digits", "segment_len" = 0 do not apply to such MSMs; a window-sharded single-device context
  *                   keeps the ordinary windows.  Read at bind time.
+ *   "exp_table_replicas" 1..8 (default 1; EXPERIMENT, read at bind time): keeps that many copies of the bound records and lets the windows
+ *                   of a device-scalar MSM gather from different copies -- the gather footprint of a per-window table with the arithmetic
+ *                   unchanged (profiles/r06_fixed_base_windows.txt, step 1).  Same results.
  *   "scalar_chunks" te_msm_run_scalars / te_msm_submit_scalars: pieces the scalars of a bound point set are uploaded and processed
  *                   in; 0 = from n (default), 1 = whole.  The result does not depend on it.
  *   read-only:      "num_devices", "segment_len_used", "peer_copies" / "peer_bytes" (hipMemcpyPeerAsync calls a multi-device
@@ -225,6 +228,7 @@ int te_msm_submit_scalars_device(te_ctx* ctx, te_bases* bases, const void* d_sca
  *                   result was fetched last, counted on the device: the points k_accumulate gathered -- all windows of this
  *                   context's shard, all MSMs of a batch; bench.py prices its roofline with it),
  *                   "bases_bytes" (device memory held by bound point sets, all devices), "bases_bound" (how many sets),
+ *                   "fixed_base_fallbacks" (fixed-base MSMs answered by the ordinary windows after a row overflow),
  *                   "in_flight" (tickets not collected, all devices), "streams_final" (te_msm_workset_stream's handles will not change any
  *                   more), "device_bytes" (device memory held in work-set buffers, see te_msm_trim)
  *   "prezero"       1 (default) = a work set's block of counters is cleared BEHIND an MSM's read-back, for its next MSM
