@@ -194,6 +194,8 @@ struct te_ctx {
   int opt_scalar_chunks = 0;     // te_msm_run_scalars / te_msm_submit_scalars: pieces the scalars of a bound set are uploaded and processed in (0 = from n)
   int opt_bind_fixed_base = 0;   // te_msm_bind_points (Twisted-Edwards curve): window bits c of a per-window table 2^(c w) P_i (16..21; 0 = none): MSMs over
                                  // the set then run fixed-base windows -- one bucket set for all windows (W x the record memory)
+  int opt_lane_host_waits = 1;   // asynchronous tickets (a lane thread enqueues them): the thread WAITS for each upload before it enqueues the kernels that read
+                                 // it, instead of putting a stream wait in front of them (see lane_wait; A/B: option "lane_host_waits", env TE_MSM_LANE_HOST_WAITS)
   int opt_exp_table_replicas = 1; // EXPERIMENT (profiles/r06_fixed_base_windows.txt): te_msm_bind_points keeps this many copies of the records and
                                  // the windows of a device-scalar MSM gather from different copies -- the gather footprint of a per-window table
 };
@@ -1120,6 +1122,20 @@ int upload(te_ctx* ctx, workset_t& ws, void* dst, const uint8_t* src, size_t byt
 
 const char* const kFinalCarry = "final carry is 1: a scalar does not fit the signed window decomposition";
 
+// "The kernels behind this point read what the upload recorded in `ev` (on the copy stream) brought."  Two forms:
+//   the calling thread owns the call (te_msm_run*, te_msm_submit): a stream wait -- nothing of the host is in the MSM's critical path;
+//   a LANE thread enqueues an asynchronous ticket (wait_for_pinned == false): the thread itself waits for the upload and enqueues the
+//     kernels afterwards.  A stream wait sits in the hardware queue of the work set's stream until the upload is over (2-3 ms with four
+//     lanes sharing the link), and the runtime multiplexes the eight work-set streams onto four hardware queues, whose packets run in
+//     order: the kernels of ANOTHER ticket that shares the queue stood behind that wait -- tickets from host scalars over bound bases
+//     ran at 1.02-1.09 ms per MSM where the same tickets from device scalars take 0.89-0.92, with neither the link nor the device busy
+//     (profiles/r06_lane_host_waits.txt).  The lane thread has nothing else to do.
+int lane_wait(te_ctx* ctx, workset_t& ws, hipEvent_t ev, bool lane) {
+  if (lane && ctx->opt_lane_host_waits) HIP_TRY(ctx, hipEventSynchronize(ev));
+  else HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ev, 0));
+  return 0;
+}
+
 // pieces a host buffer of n points is uploaded and processed in on ONE device (option "host_chunks", else from n).
 // measured (tools/sweep_host_chunks.py, ms for 1 / 2 / 3 pieces): 2^17 0.672 / 0.659 / 0.773, 2^18 1.005 / 0.927 / 1.001,
 // 2^19 1.642 / 1.407 / 1.424, 2^20 2.991 / 2.464 / 2.380
@@ -1200,7 +1216,7 @@ int enqueue_host_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* src_
   if (scalars_first) {
     if (int rc = upload(ctx, ws, dscs, src_scalars, n * sz.scalar_in, ws.copy_stream)) return rc;
     HIP_TRY(ctx, hipEventRecord(evs[K], ws.copy_stream));
-    HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, evs[K], 0));
+    if (int rc = lane_wait(ctx, ws, evs[K], !wait_for_pinned)) return rc;
     stamp("scalars staged", -1);
   }
   for (int i = 0; i < K; i++) {
@@ -1215,7 +1231,7 @@ int enqueue_host_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* src_
     if (!scalars_first) {
       if (int rc = upload(ctx, ws, dscs + lo * sz.scalar_in, src_scalars + lo * sz.scalar_in, m * sz.scalar_in, ws.copy_stream)) return rc;
       HIP_TRY(ctx, hipEventRecord(evs[K], ws.copy_stream));
-      HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, evs[K], 0));
+      if (int rc = lane_wait(ctx, ws, evs[K], !wait_for_pinned)) return rc;
       stamp("scalars staged", i);
     }
     if (int rc = L.front_scalars()) return rc;                             // digits, sort and schedule run while the piece's points cross PCIe
@@ -1223,7 +1239,7 @@ int enqueue_host_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* src_
     if (int rc = upload(ctx, ws, dpts + lo * sz.point_in, src_points + lo * sz.point_in, m * sz.point_in, ws.copy_stream)) return rc;
     stamp("points staged", i);
     HIP_TRY(ctx, hipEventRecord(evs[i], ws.copy_stream));
-    HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, evs[i], 0));
+    if (int rc = lane_wait(ctx, ws, evs[i], !wait_for_pinned)) return rc;
     if (int rc = L.front_points()) return rc;
     if (int rc = L.accumulate()) return rc;
     if (int rc = L.combine()) return rc;
@@ -1289,7 +1305,7 @@ int enqueue_scalar_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* re
     if (m == 0) continue;
     if (int rc = upload(ctx, ws, dscs + lo * sz.scalar_in, src_scalars + lo * sz.scalar_in, m * sz.scalar_in, ws.copy_stream)) return rc;
     HIP_TRY(ctx, hipEventRecord(evs[(size_t)i], ws.copy_stream));
-    HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, evs[(size_t)i], 0));
+    if (int rc = lane_wait(ctx, ws, evs[(size_t)i], !wait_for_pinned)) return rc;
     make_plan(ctx, d, m, p, pf.c, 1, seg_all, true);
     p.rec_kind = rec_kind;
     if (int rc = ensure_buffers(ctx, d, ws, m, p, false)) return rc;           // no reallocation: only the pointers into the zeroed block move
@@ -1679,6 +1695,7 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
   if (const char* e = getenv("TE_MSM_HOST_STAGING")) ctx->opt_host_staging = e[0] != '0'; // option "host_staging"
   if (const char* e = getenv("TE_MSM_UPLOAD_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 16) ctx->opt_upload_threads = v; }   // option "upload_threads"
   if (const char* e = getenv("TE_MSM_FOLD_PAIRS")) ctx->opt_fold_pairs = e[0] != '0';    // option "fold_pairs"
+  if (const char* e = getenv("TE_MSM_LANE_HOST_WAITS")) ctx->opt_lane_host_waits = e[0] != '0';   // option "lane_host_waits"
   if (const char* e = getenv("TE_MSM_HOST_SPLIT")) {                                     // relative piece weights "w0,w1,..." (experiments)
     const char* q = e;
     while (*q) { char* end = nullptr; const double v = strtod(q, &end); if (end == q) break; ctx->host_split.push_back(v > 0 ? v : 1.0); q = *end == ',' ? end + 1 : end; }
@@ -2112,10 +2129,19 @@ int enqueue_fixed_base_host(te_ctx* ctx, gpu_t& d, workset_t& ws, const te_bases
   const curve_sizes sz = sizes_of(bases->curve);
   if (int rc = ensure_staging(ctx, ws, 0, n * sz.scalar_in)) return rc;
   if (ws.used && ws.ev_done) HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ws.ev_done, 0));      // the staging area may still be read by the set's previous MSM
-  if (int rc = upload(ctx, ws, ws.d_in_scalars, src_scalars, n * sz.scalar_in, ws.stream)) return rc;
-  if (wait_for_pinned && !ctx->opt_host_staging && host_memory_is_pinned(src_scalars)) {
-    HIP_TRY(ctx, hipEventRecord(ws.ev_copy, ws.stream));
+  if (!wait_for_pinned && ctx->opt_lane_host_waits) {
+    // an asynchronous ticket: the lane thread waits for the upload itself (lane_wait), no wait enters the work set's stream
+    if (ws.used && ws.ev_done) HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));
+    if (int rc = need_copy_stream(ctx, ws)) return rc;
+    if (int rc = upload(ctx, ws, ws.d_in_scalars, src_scalars, n * sz.scalar_in, ws.copy_stream)) return rc;
+    HIP_TRY(ctx, hipEventRecord(ws.ev_copy, ws.copy_stream));
     HIP_TRY(ctx, hipEventSynchronize(ws.ev_copy));
+  } else {
+    if (int rc = upload(ctx, ws, ws.d_in_scalars, src_scalars, n * sz.scalar_in, ws.stream)) return rc;
+    if (wait_for_pinned && !ctx->opt_host_staging && host_memory_is_pinned(src_scalars)) {
+      HIP_TRY(ctx, hipEventRecord(ws.ev_copy, ws.stream));
+      HIP_TRY(ctx, hipEventSynchronize(ws.ev_copy));
+    }
   }
   if (int rc = enqueue_fixed_base(ctx, d, ws, bases, ws.d_in_scalars, n, 0, ws.stream)) return rc;
   return fetch_rows(ctx, ws, ws.stream);
@@ -2411,6 +2437,7 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   if (!strcmp(key, "host_staging")) { ctx->opt_host_staging = value ? 1 : 0; return 0; }
   if (!strcmp(key, "upload_threads")) { if (value < 1 || value > 16) return set_err(ctx, TE_MSM_EINVAL, "upload_threads must be in [1, 16]"); ctx->opt_upload_threads = (int)value; return 0; }
   if (!strcmp(key, "bind_affine")) { ctx->opt_bind_affine = value ? 1 : 0; return 0; }
+  if (!strcmp(key, "lane_host_waits")) { ctx->opt_lane_host_waits = value ? 1 : 0; return 0; }
   if (!strcmp(key, "bind_fixed_base")) { if (value != 0 && (value < 16 || value > 21)) return set_err(ctx, TE_MSM_EINVAL, "bind_fixed_base must be 0 or in [16, 21]"); ctx->opt_bind_fixed_base = (int)value; return 0; }
   if (!strcmp(key, "exp_table_replicas")) { if (value < 1 || value > TE_BATCH_MAX) return set_err(ctx, TE_MSM_EINVAL, "exp_table_replicas must be in [1, 8]"); ctx->opt_exp_table_replicas = (int)value; return 0; }
   if (!strcmp(key, "scalar_chunks")) { if (value < 0 || value > 64) return set_err(ctx, TE_MSM_EINVAL, "scalar_chunks out of range"); ctx->opt_scalar_chunks = (int)value; return 0; }
@@ -2444,6 +2471,7 @@ int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value) {
   if (!strcmp(key, "fold_pairs")) { *value = ctx->opt_fold_pairs; return 0; }
   if (!strcmp(key, "streams_final")) { *value = ctx->devs[0].streams_final ? 1 : 0; return 0; }
   if (!strcmp(key, "bind_affine")) { *value = ctx->opt_bind_affine; return 0; }
+  if (!strcmp(key, "lane_host_waits")) { *value = ctx->opt_lane_host_waits; return 0; }
   if (!strcmp(key, "scalar_chunks")) { *value = ctx->opt_scalar_chunks; return 0; }
   if (!strcmp(key, "bind_fixed_base")) { *value = ctx->opt_bind_fixed_base; return 0; }
   if (!strcmp(key, "fixed_base_fallbacks")) { *value = ctx->stat_fb_fallbacks; return 0; }
