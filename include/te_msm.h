@@ -92,8 +92,14 @@ int te_msm_run_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_sca
  * tail of MSM k overlaps the device work of MSM k+1, and on the GPU the launch gaps and the latency-bound reduction tail
  * of one MSM are filled by the wide kernels of the others (the reference's full_benchmarks.ts loop awaits each call; a
  * prover calling MSMs back to back does not have to).
- * Inputs must stay valid until the ticket is collected.  Tickets may be collected in any order (until round 4: in
+ * Inputs must stay valid AND UNCHANGED until the ticket is collected.  Tickets may be collected in any order (until round 4: in
  * submission order only).
+ * Calls in flight that name the SAME point buffer (pointer, n) share one record slab (round 6, option "share_records" = 1): every call
+ * still converts its points -- nothing is remembered across calls, the buffer may hold other points for the next call once this one is
+ * collected --, but all of them convert into, and gather from, the same 128 bytes per point instead of one slab per work set: four MSMs in
+ * flight keep their gathers inside the 256 MB Infinity Cache (+4-5 % MSM/s at n = 2^20: profiles/r06_share_records_ab.txt).  This is why
+ * "unchanged" matters: overwriting a point buffer that a ticket in flight still names, and submitting it again, would rewrite the records
+ * under that ticket.
  * Contexts of several devices: the inputs may be resident on ANY device of the context (both buffers on the same one); the
  * ticket goes to the device with the fewest MSMs in flight -- ties to the device that holds the inputs -- and a device that
  * does not hold them pulls them over its peer link first (hipMemcpyPeerAsync on the work set's stream; option
@@ -221,6 +227,12 @@ int te_msm_submit_scalars_device(te_ctx* ctx, te_bases* bases, const void* d_sca
  *   "exp_table_replicas" 1..8 (default 1; EXPERIMENT, read at bind time): keeps that many copies of the bound records and lets the windows
  *                   of a device-scalar MSM gather from different copies -- the gather footprint of a per-window table with the arithmetic
  *                   unchanged (profiles/r06_fixed_base_windows.txt, step 1).  Same results.
+ *   "share_records" 1 (default) = whole-MSM calls from device-resident inputs (te_msm_submit_device, te_msm_run_device) that name the same
+ *                   point buffer while in flight share one record slab, see te_msm_submit_device; 0 = one slab per work set (A/B; env
+ *                   TE_MSM_SHARE_RECORDS).  Read-only "record_slabs": slabs allocated.
+ *   "lane_host_waits" 1 (default) = the lane thread of an asynchronous ticket (te_msm_submit_async, te_msm_submit_scalars) waits for each of
+ *                   its uploads on the host before it enqueues the kernels that read it; 0 = a stream wait in front of those kernels, which
+ *                   holds up other tickets' kernels in a shared hardware queue (A/B; env TE_MSM_LANE_HOST_WAITS; profiles/r06_lane_host_waits.txt)
  *   "scalar_chunks" te_msm_run_scalars / te_msm_submit_scalars: pieces the scalars of a bound point set are uploaded and processed
  *                   in; 0 = from n (default), 1 = whole.  The result does not depend on it.
  *   read-only:      "num_devices", "segment_len_used", "peer_copies" / "peer_bytes" (hipMemcpyPeerAsync calls a multi-device

@@ -287,3 +287,53 @@ def test_node_eight_promises_on_four_devices(pkg, model, ora, tmp_path):
         assert "x" in out, (out, r.stderr.decode()[-2000:])
         assert (int(out["x"]), int(out["y"])) == exp and out["all_equal"], (k, env)
         print("node %s: single %.3f ms, %d in flight %.3f ms" % (env, out["single_ms"], k, out["concurrent_ms"]))
+
+
+def test_shared_record_slabs(pkg, ora):
+    """round 6: calls in flight that name the same device-resident point buffer share ONE record slab -- every call still converts its
+    points: the buffer may hold other points for the next call --; different buffers, different n and the other curve get slabs of
+    their own; option "share_records" = 0 restores one slab per work set; the stage verifier's "records" come from the slab"""
+    import torch
+    n = 30000
+    pa, pb = ora.gen_points(9100, n), ora.gen_points(9101, n)
+    scs = [ora.gen_scalars(9200 + i, n) for i in range(4)]
+    want_a = [ora.msm(pa, s, threads=8) for s in scs]
+    want_b = [ora.msm(pb, s, threads=8) for s in scs]
+    da, db = _dev(pa), _dev(pb)
+    dsc = [_dev(s) for s in scs]
+    torch.cuda.synchronize()
+    with pkg.MsmContext((0,)) as c:
+        assert c.get_option("share_records") == 1 and c.get_option("record_slabs") == 0
+        ts = [c.submit_device(da.data_ptr(), d.data_ptr(), n) for d in dsc]
+        assert c.get_option("record_slabs") == 1                                             # four tickets, one point buffer, one slab
+        assert [c.collect(t) for t in ts] == want_a
+        # two point buffers in flight: a slab each; a shorter MSM over the first buffer: a third
+        ts = [c.submit_device((da if i % 2 == 0 else db).data_ptr(), dsc[i].data_ptr(), n) for i in range(4)] + [c.submit_device(da.data_ptr(), dsc[0].data_ptr(), n // 2)]
+        assert c.get_option("record_slabs") == 3
+        got = [c.collect(t) for t in ts]
+        assert got[:4] == [want_a[0], want_b[1], want_a[2], want_b[3]] and got[4] == ora.msm(pa[:64 * (n // 2)], scs[0][:32 * (n // 2)], threads=8)
+        # nothing is remembered across calls: the same buffer with OTHER points in it
+        da.copy_(db)
+        torch.cuda.synchronize()
+        ts = [c.submit_device(da.data_ptr(), d.data_ptr(), n) for d in dsc]
+        assert [c.collect(t) for t in ts] == want_b
+        assert c.run_device(da.data_ptr(), dsc[0].data_ptr(), n) == want_b[0]
+        recs = c.debug_read("records", n * 128)                                              # the shared slab's records ...
+        assert c.run(pb, scs[0]) == want_b[0]
+        assert c.debug_read("records", n * 128) == recs                                      # ... are the ones the host path converts into the set's own slab
+        held = c.get_option("device_bytes")
+        assert c.trim(0) >= 1 and c.get_option("record_slabs") == 0 and c.get_option("device_bytes") < held
+        c.set_option("share_records", 0)
+        ts = [c.submit_device(db.data_ptr(), d.data_ptr(), n) for d in dsc]
+        assert c.get_option("record_slabs") == 0
+        assert [c.collect(t) for t in ts] == want_b
+        c.set_option("share_records", 1)
+        # the second curve on the same context: slabs are keyed by the curve as well
+        from oracle import oracle377 as o
+        m = 5000
+        p3, s3 = o.gen_points(31, m), o.gen_scalars(31, m)
+        d3, ds3 = _dev(p3), _dev(s3)
+        torch.cuda.synchronize()
+        c.set_option("curve", pkg.CURVE_BLS12_377_G1)
+        ts = [c.submit_device(d3.data_ptr(), ds3.data_ptr(), m) for _ in range(3)]
+        assert [c.collect(t) for t in ts] == [o.msm(p3, s3, threads=4)] * 3

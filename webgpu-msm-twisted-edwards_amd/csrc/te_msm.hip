@@ -129,6 +129,8 @@ struct workset_t {
   uint32_t* d_fb_remap = nullptr;     // fixed-base windows: [rows][cap] table index | sign << 31 of every entry (beside d_digits' codes)
   uint32_t* d_fb_fill = nullptr;      // ... [rows] entries reserved per row, in the zeroed block
   const void* fb_scalars = nullptr; uint64_t fb_n = 0;   // ... the scalars (device memory) of the MSM in flight: a row overflow falls back to the ordinary windows
+  int slab = -1;                      // shared record slab the MSM in flight on this set uses (-1: its own d_recs, or a bound point set)
+  const uint8_t* recs_last = nullptr; // where the records of the set's last MSM are (te_msm_debug_read "records"): d_recs or a shared slab
   te_bases* bound = nullptr;          // the bound point set the set's ticket in flight gathers from (te_msm_submit_scalars*): released only after the collect
 };
 constexpr int TE_MAX_WINDOWS = 64;    // window_bits >= 4
@@ -148,6 +150,10 @@ struct gpu_t {
   int wall_clock_khz = 0;                // rate of wall_clock64() on this device
   int in_flight = 0;                     // submitted and not collected
   bool queues_probed = false;            // the hardware-queue measurement has run (spread_streams_over_queues)
+  // SHARED RECORD SLABS (round 6): whole-MSM calls from device-resident inputs that name the SAME point buffer while they are in
+  // flight convert into, and gather from, ONE record slab instead of one per work set (acquire_shared_recs).
+  struct rec_slab_t { const void* src = nullptr; uint64_t n = 0; int curve = 0; uint8_t* d = nullptr; size_t cap = 0; int users = 0; };
+  std::vector<rec_slab_t> slabs;
   bool streams_exported = false;         // te_msm_workset_stream handed a handle out: te_msm_destroy parks the streams instead of destroying them
   bool streams_final = false;            // ... and the work sets' streams will not be re-dealt any more
 };
@@ -194,6 +200,7 @@ struct te_ctx {
   int opt_scalar_chunks = 0;     // te_msm_run_scalars / te_msm_submit_scalars: pieces the scalars of a bound set are uploaded and processed in (0 = from n)
   int opt_bind_fixed_base = 0;   // te_msm_bind_points (Twisted-Edwards curve): window bits c of a per-window table 2^(c w) P_i (16..21; 0 = none): MSMs over
                                  // the set then run fixed-base windows -- one bucket set for all windows (W x the record memory)
+  int opt_share_records = 1;     // shared record slabs for calls in flight that name the same device-resident point buffer (A/B: option "share_records", env TE_MSM_SHARE_RECORDS)
   int opt_lane_host_waits = 1;   // asynchronous tickets (a lane thread enqueues them): the thread WAITS for each upload before it enqueues the kernels that read
                                  // it, instead of putting a stream wait in front of them (see lane_wait; A/B: option "lane_host_waits", env TE_MSM_LANE_HOST_WAITS)
   int opt_exp_table_replicas = 1; // EXPERIMENT (profiles/r06_fixed_base_windows.txt): te_msm_bind_points keeps this many copies of the records and
@@ -394,6 +401,8 @@ struct msm_launch {
   bool own_rows = false;          // rows go to ws.d_partials: the caller fetches flag + rows with one copy
   bool onto = false;              // a later piece of a host-buffer MSM: keep the final-carry flag, add onto the buckets
   bool host_rows = false;         // own rows go straight to the work set's pinned host block, written by k_reduce_tail (no copy at all)
+  uint8_t* recs_rw = nullptr;     // a shared record slab: the conversion writes it and k_accumulate gathers from it (instead of ws.d_recs)
+  uint8_t* recs_out() const { return recs_rw ? recs_rw : ws.d_recs; }
   const uint32_t* fb_remap = nullptr;   // fixed-base windows: the digit rows were filled by k_fb_digits (no k_digits launch); the level-1 scatter maps positions through it
   int table_replicas = 1;         // experiment "exp_table_replicas": window k gathers from copy k / ceil(windows / copies) of the bound records
   const uint8_t* bound = nullptr; // records of a bound point set (te_msm_bind_points), already offset to this launch's first point: no conversion,
@@ -449,9 +458,9 @@ struct msm_launch {
     te::batch_ptrs tab; te::batch_slabs row_slab;
     const int rows = prep_rows(tab, row_slab);
     if (p.curve == TE_MSM_CURVE_BLS12_377_G1)
-      hipLaunchKernelGGL(te::k_prep_points377, dim3((n32 + 255) / 256, rows), dim3(256), 0, stream, tab, row_slab, reinterpret_cast<te::rec_slot<14>*>(ws.d_recs), n32);
+      hipLaunchKernelGGL(te::k_prep_points377, dim3((n32 + 255) / 256, rows), dim3(256), 0, stream, tab, row_slab, reinterpret_cast<te::rec_slot<14>*>(recs_out()), n32);
     else
-      hipLaunchKernelGGL(te::k_prep_points, dim3((n32 + 255) / 256, rows), dim3(256), 0, stream, tab, row_slab, reinterpret_cast<te::pnt_slot*>(ws.d_recs), n32);
+      hipLaunchKernelGGL(te::k_prep_points, dim3((n32 + 255) / 256, rows), dim3(256), 0, stream, tab, row_slab, reinterpret_cast<te::pnt_slot*>(recs_out()), n32);
     return 0;
   }
 
@@ -507,11 +516,11 @@ struct msm_launch {
         if (bls()) {                                      // 512 points per conversion block, one per thread
           const uint32_t per_row = (n32 + 511u) / 512u;
           hipLaunchKernelGGL(te::k_part_scatter_prep377, dim3(sblocks + rows * per_row), dim3(512), 0, stream, sa, sblocks, tab, row_slab,
-                             reinterpret_cast<te::rec_slot<14>*>(ws.d_recs), n32, per_row, rows * per_row);
+                             reinterpret_cast<te::rec_slot<14>*>(recs_out()), n32, per_row, rows * per_row);
         } else {
           const uint32_t per_row = (n32 + 255u) / 256u;
           hipLaunchKernelGGL(te::k_part_scatter_prep, dim3(sblocks + rows * per_row), dim3(512), 0, stream, sa, sblocks, tab, row_slab,
-                             reinterpret_cast<te::pnt_slot*>(ws.d_recs), n32, per_row, rows * per_row);
+                             reinterpret_cast<te::pnt_slot*>(recs_out()), n32, per_row, rows * per_row);
         }
       } else {
         hipLaunchKernelGGL(te::k_part_scatter, dim3(p.CH, p.nw), dim3(512), 0, stream, sa);
@@ -561,7 +570,7 @@ struct msm_launch {
       const uint32_t n32 = this->n32(), smax = this->smax();
       const uint32_t* order = ctx->opt_sort ? ws.d_order : nullptr;
       using slot_t = typename te::rec_kind<N, RK>::slot;
-      hipLaunchKernelGGL((te::k_accumulate<N, RK>), dim3((smax + 255) / 256), dim3(256), 0, stream, reinterpret_cast<const slot_t*>(bound ? bound : ws.d_recs), ws.d_sorted,
+      hipLaunchKernelGGL((te::k_accumulate<N, RK>), dim3((smax + 255) / 256), dim3(256), 0, stream, reinterpret_cast<const slot_t*>(bound ? bound : recs_out()), ws.d_sorted,
                          ws.d_bucket_start, ws.d_bucket_count, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv, order, ws.d_num_seg,
                          reinterpret_cast<te::ete_t<N>*>(ws.d_buckets), reinterpret_cast<te::ete_t<N>*>(ws.d_seg_out), n32, p.logB, p.seg_len, smax, onto ? 1u : 0u,
                          table_replicas > 1 ? (uint32_t)((p.nw1 + table_replicas - 1) / table_replicas) : (uint32_t)p.nw1, table_replicas > 1 ? replica_slabs() : slabs(),
@@ -827,17 +836,54 @@ void spread_streams_over_queues(gpu_t& d) {
 
 int finish_sequence(te_ctx* ctx, workset_t& ws, hipStream_t stream);
 
+// SHARED RECORD SLABS.  Every work set used to own the record slab its MSM converts into: four MSMs in flight gather from
+// 4 x 128 MB of records (n = 2^20) -- twice the 256 MB Infinity Cache -- although a caller with MSMs in flight nearly always names ONE
+// point buffer (the harness: full_benchmarks.ts:63-68,100-105; a prover: its SRS).  A gather footprint beyond the cache costs clock under
+// the power ceiling (profiles/r06_fixed_base_windows.txt, step 1: 512 MB instead of 128 MB: -7 % MSMs in flight).  So whole-MSM calls
+// from device-resident inputs that name the same point buffer (pointer, n, curve) while they are in flight share one slab: EVERY call
+// still converts its points -- nothing is remembered across calls: the buffer's contents may change between calls, and a call's own
+// accumulation is ordered behind its own conversion on its stream -- but all of them write the same bytes to the same place and gather
+// from there (inputs of a call in flight must not change: include/te_msm.h).  The reference converts per call as well
+// (convert_point_coords...wgsl:37-77).  A slab serves another point buffer only when no call in flight uses it any more.
+int acquire_shared_recs(te_ctx* ctx, gpu_t& d, const void* src, uint64_t n, int curve, uint8_t** out) {
+  const size_t need = (size_t)n * sizes_of(curve).rec;
+  int pick = -1;
+  for (size_t i = 0; i < d.slabs.size(); i++) if (d.slabs[i].users > 0 && d.slabs[i].src == src && d.slabs[i].n == n && d.slabs[i].curve == curve) { pick = (int)i; break; }
+  if (pick < 0) for (size_t i = 0; i < d.slabs.size(); i++) if (d.slabs[i].users == 0 && d.slabs[i].d && d.slabs[i].cap >= need && (pick < 0 || d.slabs[i].cap < d.slabs[(size_t)pick].cap)) pick = (int)i;
+  if (pick < 0) for (size_t i = 0; i < d.slabs.size(); i++) if (d.slabs[i].users == 0) { pick = (int)i; break; }
+  if (pick < 0) { d.slabs.emplace_back(); pick = (int)d.slabs.size() - 1; }
+  gpu_t::rec_slab_t& sl = d.slabs[(size_t)pick];
+  if (!sl.d || sl.cap < need) {
+    if (sl.d) HIP_TRY(ctx, hipFree(sl.d));
+    sl.d = nullptr; sl.cap = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&sl.d, need ? need : 16));
+    sl.cap = need;
+  }
+  sl.src = src; sl.n = n; sl.curve = curve; sl.users++;
+  *out = sl.d;
+  return pick;
+}
+void release_shared_recs(gpu_t& d, workset_t& ws) {
+  if (ws.slab >= 0 && (size_t)ws.slab < d.slabs.size() && d.slabs[(size_t)ws.slab].users > 0) d.slabs[(size_t)ws.slab].users--;
+  ws.slab = -1;
+}
+
 // bases: the launch sequence gathers from a bound point set (d_points is not read: no conversion); batch must be 1
+// share_recs: a whole-MSM call whose completion the engine sees (a ticket, a synchronous call): its records may live in a shared slab
 int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, const void* d_scalars, uint64_t n,
                     void* d_partials_out, hipStream_t stream, const std::function<int(hipStream_t)>* upload_points = nullptr, int force_c = 0,
-                    bool side_stream = false, int batch = 1, bool whole = false, const te_bases* bases = nullptr) {
+                    bool side_stream = false, int batch = 1, bool whole = false, const te_bases* bases = nullptr, bool share_recs = false) {
   plan_t p; make_plan(ctx, d, n, p, force_c, batch, 0, whole);
   if (bases) p.rec_kind = bases->rec_kind;
+  share_recs = share_recs && ctx->opt_share_records && !bases && !upload_points && batch == 1 && !ctx->opt_graph && d_points != nullptr;
   if (batch > 1 && (uint64_t)p.nw * p.nst >= (1ull << 31)) return set_err(ctx, TE_MSM_EINVAL, "batch too large for this n: windows x points must stay below 2^31");
   HIP_TRY(ctx, hipSetDevice(d.device));
   if ((uint64_t)p.nw * p.B + (uint64_t)p.nw * (n / p.seg_len) + 1024u >= (1ull << 32))
     return set_err(ctx, TE_MSM_EINVAL, "segment_len is too small for this n: more than 2^32 segments");
-  if (int rc = ensure_buffers(ctx, d, ws, n, p, bases == nullptr)) return rc;
+  if (int rc = ensure_buffers(ctx, d, ws, n, p, bases == nullptr && !share_recs)) return rc;
+  release_shared_recs(d, ws);                               // (a slab the set's previous, finished MSM still named)
+  uint8_t* shared = nullptr;
+  if (share_recs) { const int si = acquire_shared_recs(ctx, d, d_points, n, p.curve, &shared); if (si < 0) return si; ws.slab = si; }
   if (ws.used && ws.last_stream != stream) HIP_TRY(ctx, hipStreamWaitEvent(stream, ws.ev_done, 0));   // the set's buffers are still the previous MSM's
   ws.plan = p; ws.n = n; ws.used = true; ws.last_stream = stream; __atomic_store_n(&d.last_ws, (int)(&ws - d.ws), __ATOMIC_RELAXED);
   ws.prof_level = ctx->opt_profile;
@@ -848,6 +894,8 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, 
   msm_launch L{ctx, d, ws, p, d_points, d_scalars, n, d_partials_out, ctx->opt_profile, stream, own_rows};
   L.host_rows = msm_launch::rows_to_host(ctx, d, p, own_rows);
   ws.rows_on_host = L.host_rows;
+  L.recs_rw = shared;
+  ws.recs_last = bases ? nullptr : (shared ? shared : ws.d_recs);
   if (bases) {
     // resident bases: the scalar-only stages, then the accumulation straight from the bound records (never captured: option "graph"
     // holds the pointers of device-resident point buffers)
@@ -982,6 +1030,8 @@ void free_workset_buffers(workset_t& ws) {      // the big device buffers of a w
 
 void free_dev(gpu_t& d) {
   (void)hipSetDevice(d.device);
+  for (auto& sl : d.slabs) if (sl.d) { (void)hipFree(sl.d); sl.d = nullptr; }
+  d.slabs.clear();
   for (workset_t& ws : d.ws) {
     free_workset_buffers(ws);
     if (ws.h_err) (void)hipHostFree(ws.h_err);
@@ -1188,6 +1238,7 @@ int enqueue_host_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* src_
     seg_all = pm.seg_len;
     if (int rc = ensure_buffers(ctx, d, ws, m_max, pm)) return rc;        // every buffer at its final size before the first piece
   }
+  release_shared_recs(d, ws); ws.recs_last = ws.d_recs;      // a host-buffer MSM converts into the set's own slab
   if (ws.used && ws.last_stream != ws.stream) HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ws.ev_done, 0));
   HIP_TRY(ctx, hipEventRecord(ws.ev_start, ws.stream));
   if (int rc = need_copy_stream(ctx, ws)) return rc;
@@ -1292,6 +1343,7 @@ int enqueue_scalar_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* re
     seg_all = pm.seg_len;
     if (int rc = ensure_buffers(ctx, d, ws, m_max, pm, false)) return rc;      // every buffer at its final size before the first piece
   }
+  release_shared_recs(d, ws); ws.recs_last = nullptr;
   if (ws.used && ws.last_stream != ws.stream) HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ws.ev_done, 0));
   HIP_TRY(ctx, hipEventRecord(ws.ev_start, ws.stream));
   if (int rc = need_copy_stream(ctx, ws)) return rc;
@@ -1373,6 +1425,7 @@ int enqueue_fixed_base(te_ctx* ctx, gpu_t& d, workset_t& ws, const te_bases* bas
   if ((uint64_t)p.nw * cap >= (1ull << 31) || (uint64_t)bases->fb_W * bases->n >= (1ull << 31))
     return set_err(ctx, TE_MSM_EINVAL, "fixed-base windows: windows x points must stay below 2^31");
   if (int rc = ensure_buffers(ctx, d, ws, cap, p, false)) return rc;
+  release_shared_recs(d, ws); ws.recs_last = nullptr;
   if (ws.used && ws.last_stream != stream) HIP_TRY(ctx, hipStreamWaitEvent(stream, ws.ev_done, 0));
   ws.plan = p; ws.n = cap; ws.used = true; ws.last_stream = stream; __atomic_store_n(&d.last_ws, (int)(&ws - d.ws), __ATOMIC_RELAXED);
   ws.prof_level = ctx->opt_profile;
@@ -1660,9 +1713,10 @@ int run_common(te_ctx* ctx, const void* src_points, const void* src_scalars, boo
     // on the side stream, beside the scalar-only kernels on ws.stream; the conversion to records follows it there
     return upload(ctx, ws, ws.d_in_points, static_cast<const uint8_t*>(src_points), n * sz.point_in, side);
   };
-  if (int rc = enqueue_partial(ctx, d, ws, dp, ds, n, nullptr, ws.stream, src_is_host ? &upload_points : nullptr)) return rc;
+  if (int rc = enqueue_partial(ctx, d, ws, dp, ds, n, nullptr, ws.stream, src_is_host ? &upload_points : nullptr, 0, false, 1, false, nullptr, !src_is_host)) return rc;
   if (int rc = fetch_rows(ctx, ws, ws.stream)) return rc;
   HIP_TRY(ctx, hipEventSynchronize(ws.ev_result));          // (pinned sources included: the call ends after its uploads)
+  release_shared_recs(d, ws);                               // the call is over: its record slab (if shared) may serve another point buffer
   note_entries(ctx, ws);
   if (*ws.h_err) return set_err(ctx, TE_MSM_ESCALAR, kFinalCarry);
   (void)collect_stage_ms(ctx, d, ws);
@@ -1695,6 +1749,7 @@ int te_msm_init(const int* device_ids, int n_dev, te_ctx** out) {
   if (const char* e = getenv("TE_MSM_HOST_STAGING")) ctx->opt_host_staging = e[0] != '0'; // option "host_staging"
   if (const char* e = getenv("TE_MSM_UPLOAD_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 16) ctx->opt_upload_threads = v; }   // option "upload_threads"
   if (const char* e = getenv("TE_MSM_FOLD_PAIRS")) ctx->opt_fold_pairs = e[0] != '0';    // option "fold_pairs"
+  if (const char* e = getenv("TE_MSM_SHARE_RECORDS")) ctx->opt_share_records = e[0] != '0';       // option "share_records"
   if (const char* e = getenv("TE_MSM_LANE_HOST_WAITS")) ctx->opt_lane_host_waits = e[0] != '0';   // option "lane_host_waits"
   if (const char* e = getenv("TE_MSM_HOST_SPLIT")) {                                     // relative piece weights "w0,w1,..." (experiments)
     const char* q = e;
@@ -1858,7 +1913,7 @@ int te_msm_submit_device(te_ctx* ctx, const void* d_points_xy_le, const void* d_
       dp = ws.d_in_points; ds = ws.d_in_scalars;
     }
     // a single-device context keeps its window shard (te_msm_set_window_shard); on several devices a ticket is a whole MSM
-    if (int rc = enqueue_partial(ctx, d, ws, dp, ds, n, nullptr, ws.stream, nullptr, 0, false, 1, multi)) return rc;
+    if (int rc = enqueue_partial(ctx, d, ws, dp, ds, n, nullptr, ws.stream, nullptr, 0, false, 1, multi, nullptr, !stage)) return rc;
     return fetch_rows(ctx, ws, ws.stream);
   };
   // (Handing this to a host thread, as te_msm_submit_async does with uploads, was measured: no gain at n = 2^16 .. 2^18, 3-7 %
@@ -1960,6 +2015,7 @@ int submit_host(te_ctx* ctx, const uint8_t* points_xy_le, const uint8_t* scalars
 int await_job(te_ctx*, gpu_t&, workset_t& ws) { return te_sched::await_job(ws); }
 void retire_ticket(te_ctx* ctx, gpu_t& d, workset_t& ws) {
   if (ws.bound) { ws.bound->in_flight--; ws.bound = nullptr; }       // the ticket gathered from a bound point set: it may be released now
+  release_shared_recs(d, ws);                                        // the ticket's MSM is over: its record slab may serve another point buffer
   te_sched::retire(*ctx, (int)(&d - ctx->devs.data()), ws);
 }
 }  // namespace
@@ -2408,6 +2464,10 @@ int te_msm_trim(te_ctx* ctx, int keep_worksets) {
       free_workset_buffers(ws);
       freed++;
     }
+    for (auto& sl : d.slabs) if (sl.users == 0 && sl.d) {                    // idle shared record slabs
+      for (workset_t& ws : d.ws) if (ws.recs_last == sl.d) ws.recs_last = nullptr;
+      HIP_TRY(ctx, hipFree(sl.d)); sl.d = nullptr; sl.cap = 0; sl.src = nullptr;
+    }
   }
   return freed;
 }
@@ -2438,6 +2498,7 @@ int te_msm_set_option(te_ctx* ctx, const char* key, int64_t value) {
   if (!strcmp(key, "upload_threads")) { if (value < 1 || value > 16) return set_err(ctx, TE_MSM_EINVAL, "upload_threads must be in [1, 16]"); ctx->opt_upload_threads = (int)value; return 0; }
   if (!strcmp(key, "bind_affine")) { ctx->opt_bind_affine = value ? 1 : 0; return 0; }
   if (!strcmp(key, "lane_host_waits")) { ctx->opt_lane_host_waits = value ? 1 : 0; return 0; }
+  if (!strcmp(key, "share_records")) { ctx->opt_share_records = value ? 1 : 0; return 0; }
   if (!strcmp(key, "bind_fixed_base")) { if (value != 0 && (value < 16 || value > 21)) return set_err(ctx, TE_MSM_EINVAL, "bind_fixed_base must be 0 or in [16, 21]"); ctx->opt_bind_fixed_base = (int)value; return 0; }
   if (!strcmp(key, "exp_table_replicas")) { if (value < 1 || value > TE_BATCH_MAX) return set_err(ctx, TE_MSM_EINVAL, "exp_table_replicas must be in [1, 8]"); ctx->opt_exp_table_replicas = (int)value; return 0; }
   if (!strcmp(key, "scalar_chunks")) { if (value < 0 || value > 64) return set_err(ctx, TE_MSM_EINVAL, "scalar_chunks out of range"); ctx->opt_scalar_chunks = (int)value; return 0; }
@@ -2472,6 +2533,8 @@ int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value) {
   if (!strcmp(key, "streams_final")) { *value = ctx->devs[0].streams_final ? 1 : 0; return 0; }
   if (!strcmp(key, "bind_affine")) { *value = ctx->opt_bind_affine; return 0; }
   if (!strcmp(key, "lane_host_waits")) { *value = ctx->opt_lane_host_waits; return 0; }
+  if (!strcmp(key, "share_records")) { *value = ctx->opt_share_records; return 0; }
+  if (!strcmp(key, "record_slabs")) { int64_t t = 0; for (const gpu_t& d : ctx->devs) for (const auto& sl : d.slabs) if (sl.d) t++; *value = t; return 0; }
   if (!strcmp(key, "scalar_chunks")) { *value = ctx->opt_scalar_chunks; return 0; }
   if (!strcmp(key, "bind_fixed_base")) { *value = ctx->opt_bind_fixed_base; return 0; }
   if (!strcmp(key, "fixed_base_fallbacks")) { *value = ctx->stat_fb_fallbacks; return 0; }
@@ -2480,7 +2543,10 @@ int te_msm_get_option(te_ctx* ctx, const char* key, int64_t* value) {
   if (!strcmp(key, "in_flight")) { int64_t t = 0; for (const gpu_t& d : ctx->devs) t += d.in_flight; *value = t; return 0; }
   if (!strcmp(key, "device_bytes")) {      drain_workers(ctx);      // device memory this context holds in work-set buffers (te_msm_trim gives it back)
     int64_t tot = 0;
-    for (const gpu_t& d : ctx->devs) for (const workset_t& ws : d.ws) { for (size_t cb : ws.cap) tot += (int64_t)cb; tot += (int64_t)(ws.cap_in_points + ws.cap_in_scalars); }
+    for (const gpu_t& d : ctx->devs) {
+      for (const workset_t& ws : d.ws) { for (size_t cb : ws.cap) tot += (int64_t)cb; tot += (int64_t)(ws.cap_in_points + ws.cap_in_scalars); }
+      for (const auto& sl : d.slabs) if (sl.d) tot += (int64_t)sl.cap;
+    }
     *value = tot; return 0;
   }
   return set_err(ctx, TE_MSM_EINVAL, "unknown option");
@@ -2713,8 +2779,8 @@ int64_t te_msm_debug_read(te_ctx* ctx, const char* stage, void* dst, uint64_t ca
   if (ws.zero_clean_words && (!strcmp(stage, "bucket_count") || !strcmp(stage, "num_segments") || !strcmp(stage, "partials")))
     return set_err(ctx, TE_MSM_ESTATE, "this stage lives in the block that is cleared behind an MSM's read-back: set option prezero = 0 before the run to keep it");
   if (!strcmp(stage, "records")) {
-    if (!ws.d_recs) return set_err(ctx, TE_MSM_ESTATE, "the last run gathered from a bound point set: the work set holds no records of its own");
-    src = ws.d_recs; bytes = n * sizes_of(p.curve).rec;
+    if (!ws.recs_last) return set_err(ctx, TE_MSM_ESTATE, "the last run gathered from a bound point set: the work set holds no records of its own");
+    src = ws.recs_last; bytes = n * sizes_of(p.curve).rec;
   }
   else if (!strcmp(stage, "digits")) { src = ws.d_digits; bytes = (uint64_t)p.nw * p.nst * 2; }   // row stride nst = n rounded up to 8
   else if (!strcmp(stage, "bucket_count")) { src = ws.d_bucket_count; bytes = (uint64_t)p.nw * p.B * 4; }
