@@ -152,7 +152,11 @@ struct gpu_t {
   bool queues_probed = false;            // the hardware-queue measurement has run (spread_streams_over_queues)
   // SHARED RECORD SLABS (round 6): whole-MSM calls from device-resident inputs that name the SAME point buffer while they are in
   // flight convert into, and gather from, ONE record slab instead of one per work set (acquire_shared_recs).
-  struct rec_slab_t { const void* src = nullptr; uint64_t n = 0; int curve = 0; uint8_t* d = nullptr; size_t cap = 0; int users = 0; };
+  // users: work sets whose latest MSM names the slab.  pending / ev[]: users that let go of it while their MSM could still be running (the
+  // building blocks te_msm_partial_device[_batch], whose completion the engine does not see): an event recorded behind that MSM; whoever
+  // takes the slab for ANOTHER point buffer waits for those events first (joining the same buffer needs no wait: the same bytes).
+  struct rec_slab_t { const void* src = nullptr; uint64_t n = 0; int curve = 0; uint8_t* d = nullptr; size_t cap = 0; int users = 0;
+                      uint32_t pending = 0; hipEvent_t ev[TE_MSM_WORKSETS] = {}; };
   std::vector<rec_slab_t> slabs;
   bool streams_exported = false;         // te_msm_workset_stream handed a handle out: te_msm_destroy parks the streams instead of destroying them
   bool streams_final = false;            // ... and the work sets' streams will not be re-dealt any more
@@ -845,26 +849,53 @@ int finish_sequence(te_ctx* ctx, workset_t& ws, hipStream_t stream);
 // accumulation is ordered behind its own conversion on its stream -- but all of them write the same bytes to the same place and gather
 // from there (inputs of a call in flight must not change: include/te_msm.h).  The reference converts per call as well
 // (convert_point_coords...wgsl:37-77).  A slab serves another point buffer only when no call in flight uses it any more.
-int acquire_shared_recs(te_ctx* ctx, gpu_t& d, const void* src, uint64_t n, int curve, uint8_t** out) {
+// (the slab's earlier users may still be running -- see rec_slab_t::pending: `stream`, on which the new user's conversion is about to be
+// enqueued, waits for them; nullptr: the host waits -- trim, destroy)
+int settle_slab(te_ctx* ctx, gpu_t::rec_slab_t& sl, hipStream_t stream, bool host) {
+  for (int wi = 0; wi < TE_MSM_WORKSETS; wi++) if ((sl.pending >> wi) & 1u) {
+    if (host) HIP_TRY(ctx, hipEventSynchronize(sl.ev[wi])); else HIP_TRY(ctx, hipStreamWaitEvent(stream, sl.ev[wi], 0));
+  }
+  sl.pending = 0;
+  return 0;
+}
+int acquire_shared_recs(te_ctx* ctx, gpu_t& d, const void* src, uint64_t n, int curve, hipStream_t stream, uint8_t** out) {
   const size_t need = (size_t)n * sizes_of(curve).rec;
   int pick = -1;
-  for (size_t i = 0; i < d.slabs.size(); i++) if (d.slabs[i].users > 0 && d.slabs[i].src == src && d.slabs[i].n == n && d.slabs[i].curve == curve) { pick = (int)i; break; }
+  // the same buffer, in use or just let go of (its records are the same bytes: no wait, and `pending` stays for whoever re-purposes the slab)
+  for (size_t i = 0; i < d.slabs.size(); i++) if ((d.slabs[i].users > 0 || d.slabs[i].pending) && d.slabs[i].d && d.slabs[i].src == src && d.slabs[i].n == n && d.slabs[i].curve == curve) {
+    d.slabs[i].users++; *out = d.slabs[i].d; return (int)i;
+  }
+  // a free slab: one nobody is waiting on first, the smallest that is large enough
+  if (pick < 0) for (size_t i = 0; i < d.slabs.size(); i++) if (d.slabs[i].users == 0 && !d.slabs[i].pending && d.slabs[i].d && d.slabs[i].cap >= need && (pick < 0 || d.slabs[i].cap < d.slabs[(size_t)pick].cap)) pick = (int)i;
   if (pick < 0) for (size_t i = 0; i < d.slabs.size(); i++) if (d.slabs[i].users == 0 && d.slabs[i].d && d.slabs[i].cap >= need && (pick < 0 || d.slabs[i].cap < d.slabs[(size_t)pick].cap)) pick = (int)i;
   if (pick < 0) for (size_t i = 0; i < d.slabs.size(); i++) if (d.slabs[i].users == 0) { pick = (int)i; break; }
   if (pick < 0) { d.slabs.emplace_back(); pick = (int)d.slabs.size() - 1; }
   gpu_t::rec_slab_t& sl = d.slabs[(size_t)pick];
   if (!sl.d || sl.cap < need) {
+    if (int rc = settle_slab(ctx, sl, nullptr, true)) return rc;
     if (sl.d) HIP_TRY(ctx, hipFree(sl.d));
     sl.d = nullptr; sl.cap = 0;
     HIP_TRY(ctx, hipMalloc((void**)&sl.d, need ? need : 16));
     sl.cap = need;
   }
+  if (int rc = settle_slab(ctx, sl, stream, false)) return rc;          // another buffer's records are about to be overwritten
   sl.src = src; sl.n = n; sl.curve = curve; sl.users++;
   *out = sl.d;
   return pick;
 }
-void release_shared_recs(gpu_t& d, workset_t& ws) {
-  if (ws.slab >= 0 && (size_t)ws.slab < d.slabs.size() && d.slabs[(size_t)ws.slab].users > 0) d.slabs[(size_t)ws.slab].users--;
+// completed: the set's MSM is known to be over (a collected ticket, a synchronous call).  Otherwise (the building blocks: the set is simply
+// used again) an event behind that MSM -- on the stream it ran on, BEFORE anything new is enqueued there -- guards the slab.
+void release_shared_recs(gpu_t& d, workset_t& ws, bool completed = true) {
+  if (ws.slab >= 0 && (size_t)ws.slab < d.slabs.size() && d.slabs[(size_t)ws.slab].users > 0) {
+    gpu_t::rec_slab_t& sl = d.slabs[(size_t)ws.slab];
+    sl.users--;
+    if (!completed && ws.last_stream) {
+      const int wi = (int)(&ws - d.ws);
+      if (!sl.ev[wi]) (void)hipEventCreateWithFlags(&sl.ev[wi], hipEventDisableTiming);
+      if (sl.ev[wi] && hipEventRecord(sl.ev[wi], ws.last_stream) == hipSuccess) sl.pending |= 1u << wi;
+      else (void)hipStreamSynchronize(ws.last_stream);                  // (no event: the host waits instead)
+    }
+  }
   ws.slab = -1;
 }
 
@@ -875,15 +906,18 @@ int enqueue_partial(te_ctx* ctx, gpu_t& d, workset_t& ws, const void* d_points, 
                     bool side_stream = false, int batch = 1, bool whole = false, const te_bases* bases = nullptr, bool share_recs = false) {
   plan_t p; make_plan(ctx, d, n, p, force_c, batch, 0, whole);
   if (bases) p.rec_kind = bases->rec_kind;
-  share_recs = share_recs && ctx->opt_share_records && !bases && !upload_points && batch == 1 && !ctx->opt_graph && d_points != nullptr;
+  // (a batch shares when all its MSMs name ONE point buffer: the batch then holds one conversion anyway -- slab 0 of msm_launch::slabs())
+  const void* share_src = d_points;
+  if (batch > 1 && d_points) { share_src = static_cast<const void* const*>(d_points)[0]; for (int m = 1; m < batch; m++) if (static_cast<const void* const*>(d_points)[m] != share_src) share_src = nullptr; }
+  share_recs = share_recs && ctx->opt_share_records && !bases && !upload_points && !ctx->opt_graph && share_src != nullptr;
   if (batch > 1 && (uint64_t)p.nw * p.nst >= (1ull << 31)) return set_err(ctx, TE_MSM_EINVAL, "batch too large for this n: windows x points must stay below 2^31");
   HIP_TRY(ctx, hipSetDevice(d.device));
   if ((uint64_t)p.nw * p.B + (uint64_t)p.nw * (n / p.seg_len) + 1024u >= (1ull << 32))
     return set_err(ctx, TE_MSM_EINVAL, "segment_len is too small for this n: more than 2^32 segments");
   if (int rc = ensure_buffers(ctx, d, ws, n, p, bases == nullptr && !share_recs)) return rc;
-  release_shared_recs(d, ws);                               // (a slab the set's previous, finished MSM still named)
+  release_shared_recs(d, ws, false);                        // (a slab the set's previous MSM still named: guarded by an event unless that MSM was seen to end)
   uint8_t* shared = nullptr;
-  if (share_recs) { const int si = acquire_shared_recs(ctx, d, d_points, n, p.curve, &shared); if (si < 0) return si; ws.slab = si; }
+  if (share_recs) { const int si = acquire_shared_recs(ctx, d, share_src, n, p.curve, stream, &shared); if (si < 0) return si; ws.slab = si; }
   if (ws.used && ws.last_stream != stream) HIP_TRY(ctx, hipStreamWaitEvent(stream, ws.ev_done, 0));   // the set's buffers are still the previous MSM's
   ws.plan = p; ws.n = n; ws.used = true; ws.last_stream = stream; __atomic_store_n(&d.last_ws, (int)(&ws - d.ws), __ATOMIC_RELAXED);
   ws.prof_level = ctx->opt_profile;
@@ -1030,7 +1064,7 @@ void free_workset_buffers(workset_t& ws) {      // the big device buffers of a w
 
 void free_dev(gpu_t& d) {
   (void)hipSetDevice(d.device);
-  for (auto& sl : d.slabs) if (sl.d) { (void)hipFree(sl.d); sl.d = nullptr; }
+  for (auto& sl : d.slabs) { if (sl.d) { (void)hipFree(sl.d); sl.d = nullptr; } for (hipEvent_t& e : sl.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; } }
   d.slabs.clear();
   for (workset_t& ws : d.ws) {
     free_workset_buffers(ws);
@@ -1238,7 +1272,7 @@ int enqueue_host_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* src_
     seg_all = pm.seg_len;
     if (int rc = ensure_buffers(ctx, d, ws, m_max, pm)) return rc;        // every buffer at its final size before the first piece
   }
-  release_shared_recs(d, ws); ws.recs_last = ws.d_recs;      // a host-buffer MSM converts into the set's own slab
+  release_shared_recs(d, ws, false); ws.recs_last = ws.d_recs;      // a host-buffer MSM converts into the set's own slab
   if (ws.used && ws.last_stream != ws.stream) HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ws.ev_done, 0));
   HIP_TRY(ctx, hipEventRecord(ws.ev_start, ws.stream));
   if (int rc = need_copy_stream(ctx, ws)) return rc;
@@ -1343,7 +1377,7 @@ int enqueue_scalar_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* re
     seg_all = pm.seg_len;
     if (int rc = ensure_buffers(ctx, d, ws, m_max, pm, false)) return rc;      // every buffer at its final size before the first piece
   }
-  release_shared_recs(d, ws); ws.recs_last = nullptr;
+  release_shared_recs(d, ws, false); ws.recs_last = nullptr;
   if (ws.used && ws.last_stream != ws.stream) HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ws.ev_done, 0));
   HIP_TRY(ctx, hipEventRecord(ws.ev_start, ws.stream));
   if (int rc = need_copy_stream(ctx, ws)) return rc;
@@ -1425,7 +1459,7 @@ int enqueue_fixed_base(te_ctx* ctx, gpu_t& d, workset_t& ws, const te_bases* bas
   if ((uint64_t)p.nw * cap >= (1ull << 31) || (uint64_t)bases->fb_W * bases->n >= (1ull << 31))
     return set_err(ctx, TE_MSM_EINVAL, "fixed-base windows: windows x points must stay below 2^31");
   if (int rc = ensure_buffers(ctx, d, ws, cap, p, false)) return rc;
-  release_shared_recs(d, ws); ws.recs_last = nullptr;
+  release_shared_recs(d, ws, false); ws.recs_last = nullptr;
   if (ws.used && ws.last_stream != stream) HIP_TRY(ctx, hipStreamWaitEvent(stream, ws.ev_done, 0));
   ws.plan = p; ws.n = cap; ws.used = true; ws.last_stream = stream; __atomic_store_n(&d.last_ws, (int)(&ws - d.ws), __ATOMIC_RELAXED);
   ws.prof_level = ctx->opt_profile;
@@ -2465,6 +2499,7 @@ int te_msm_trim(te_ctx* ctx, int keep_worksets) {
       freed++;
     }
     for (auto& sl : d.slabs) if (sl.users == 0 && sl.d) {                    // idle shared record slabs
+      if (int rc = settle_slab(ctx, sl, nullptr, true)) return rc;
       for (workset_t& ws : d.ws) if (ws.recs_last == sl.d) ws.recs_last = nullptr;
       HIP_TRY(ctx, hipFree(sl.d)); sl.d = nullptr; sl.cap = 0; sl.src = nullptr;
     }
@@ -2578,7 +2613,8 @@ int te_msm_partial_device(te_ctx* ctx, const void* d_points_xy_le, const void* d
   workset_t& ws = d.ws[ctx->opt_workset];
   if (te_sched::slot_ticket(ws.slot)) return set_err(ctx, TE_MSM_ESTATE, "the selected work set holds a submitted MSM that has not been collected");
   HIP_TRY(ctx, hipSetDevice(d.device));
-  return enqueue_partial(ctx, d, ws, d_points_xy_le, d_scalars_le, n, d_partials, stream == TE_MSM_OWN_STREAM ? ws.stream : (hipStream_t)stream);
+  return enqueue_partial(ctx, d, ws, d_points_xy_le, d_scalars_le, n, d_partials, stream == TE_MSM_OWN_STREAM ? ws.stream : (hipStream_t)stream,
+                         nullptr, 0, false, 1, false, nullptr, true);
 }
 
 int te_msm_partial_device_batch(te_ctx* ctx, const void* const* d_points_xy_le, const void* const* d_scalars_le, uint64_t n, int count,
@@ -2594,9 +2630,9 @@ int te_msm_partial_device_batch(te_ctx* ctx, const void* const* d_points_xy_le, 
   if (te_sched::slot_ticket(ws.slot)) return set_err(ctx, TE_MSM_ESTATE, "the selected work set holds a submitted MSM that has not been collected");
   HIP_TRY(ctx, hipSetDevice(d.device));
   hipStream_t st = stream == TE_MSM_OWN_STREAM ? ws.stream : (hipStream_t)stream;
-  if (count == 1) return enqueue_partial(ctx, d, ws, d_points_xy_le[0], d_scalars_le[0], n, d_partials, st);
+  if (count == 1) return enqueue_partial(ctx, d, ws, d_points_xy_le[0], d_scalars_le[0], n, d_partials, st, nullptr, 0, false, 1, false, nullptr, true);
   // the pointer arrays are only read while the launches are enqueued
-  return enqueue_partial(ctx, d, ws, d_points_xy_le, d_scalars_le, n, d_partials, st, nullptr, 0, false, count);
+  return enqueue_partial(ctx, d, ws, d_points_xy_le, d_scalars_le, n, d_partials, st, nullptr, 0, false, count, false, nullptr, true);
 }
 
 int te_msm_workset_stream(te_ctx* ctx, int workset, void** stream, int* hw_queue_class) {
