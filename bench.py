@@ -138,11 +138,12 @@ def alone_pass(ctx, step, reps):
     return {k: v / reps for k, v in acc.items()}
 
 
-def bases_resident_figures(ctx, pts, sc, expect, d_sc=None, n=None, depth=4, steps=32):
+def bases_resident_figures(ctx, pts, sc, expect, d_sc=None, n=None, depth=4, steps=96):
     """Resident bases (te_msm_bind_points + te_msm_run_scalars / te_msm_submit_scalars): the points are bound ONCE (timed: bind_ms),
     every MSM then moves its scalars only -- what the reference's harness could do with the one point buffer it passes to six calls
     per size (full_benchmarks.ts:63-68,100-105).  latency_ms: one te_msm_run_scalars at a time from pageable host scalars (best of
-    7); in_flight_ms: te_msm_submit_scalars tickets, 8 in flight, per MSM (best of 3 passes); device_scalars_ms: scalars already in
+    7); in_flight_ms: te_msm_submit_scalars tickets, 8 in flight, per MSM (best of 3 passes of `steps` MSMs: 96, so that filling and draining
+    the pipeline -- an upload plus an MSM, ~3 ms at n = 2^20 -- stay a few per cent of a pass); device_scalars_ms: scalars already in
     HBM, `depth` tickets in flight (te_msm_submit_scalars_device).  Every result is compared with `expect`."""
     import torch
     prof = ctx.get_option("profile")
@@ -260,7 +261,7 @@ def side_config(pkg, dev, name, curve, digits, log2n, depth, threads, steps, exp
         if bls:
             # BLS12-377 over BOUND bases: affine records (one inversion per point at bind time): 7 products and 168 bytes per gathered
             # point instead of 8 and 224
-            bound = bases_resident_figures(cx, pts, sc, result, ds, n, depth, steps)
+            bound = bases_resident_figures(cx, pts, sc, result, ds, n, depth, 48)
             cx.set_option("profile", 1)
             bb = cx.bind_points(pts)
             st_b = alone_pass(cx, lambda: cx.run_scalars_device(bb, ds), 4)
@@ -870,7 +871,7 @@ def main():
                 sx.set_option("profile", 1)            # the kernel stamps its own clock: one more MSM for the core clock at this size
                 assert sx.run_device(dp2.data_ptr(), ds2.data_ptr(), m) == ref
                 ghz2 = sx.stage_ms().get("accumulate_core_clock_ghz")
-                br2 = bases_resident_figures(sx, p2, s2, ref, None, m, depth, 24)
+                br2 = bases_resident_figures(sx, p2, s2, ref, None, m, depth)
                 out["sizes"][str(lg)] = {"ms_per_step": el * 1e3 / 40, "latency_ms": min(l2), "host_buffers_ms": hb2, "window_bits": sx.plan(m)[0],
                                          "core_clock_ghz": ghz2,
                                          "bases_resident_in_flight_ms": br2["in_flight_ms"], "bases_resident_latency_ms": br2["latency_ms"]}
