@@ -158,6 +158,11 @@ struct gpu_t {
   struct rec_slab_t { const void* src = nullptr; uint64_t n = 0; int curve = 0; uint8_t* d = nullptr; size_t cap = 0; int users = 0;
                       uint32_t pending = 0; hipEvent_t ev[TE_MSM_WORKSETS] = {}; };
   std::vector<rec_slab_t> slabs;
+  // asynchronous scalars-only tickets (bound bases) cross the link ONE AT A TIME per device: lanes that upload side by side share the
+  // link, every ticket reaches the device late and the tickets move in a convoy (two in flight: 1.05-1.23 ms per MSM with 2-4 lanes,
+  // 0.90-0.92 with one; tools/exp_bound_lanes_depth.py).  Host-buffer tickets (points + scalars) do not take it: their pageable copies
+  // fill each other's pin / unpin gaps (1.79 vs 1.89 ms with one lane).  TE_MSM_SCALAR_UPLOADS_SERIAL=0: off (experiments).
+  std::unique_ptr<std::mutex> scalar_link{new std::mutex};
   bool streams_exported = false;         // te_msm_workset_stream handed a handle out: te_msm_destroy parks the streams instead of destroying them
   bool streams_final = false;            // ... and the work sets' streams will not be re-dealt any more
 };
@@ -704,7 +709,17 @@ template <typename F> int capture_graph(te_ctx* ctx, workset_t& ws, hipGraphExec
 // the copy stream of a work set exists from its first host-buffer MSM on (te_msm_run): a context that only ever sees
 // device-resident inputs owns one stream per work set
 int need_copy_stream(te_ctx* ctx, workset_t& ws) {
-  if (!ws.copy_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ws.copy_stream, hipStreamNonBlocking));
+  if (ws.copy_stream) return 0;
+  // TE_MSM_COPY_PRIORITY=1 (experiment, tools/exp_bound_copy_queue.py): the runtime keeps streams of another priority on hardware
+  // queues of their own, so an upload would never stand behind a kernel of a work set that shares its queue
+  static const int prio = [] { const char* e = getenv("TE_MSM_COPY_PRIORITY"); return e ? atoi(e) : 0; }();
+  if (prio) {
+    int least = 0, greatest = 0;
+    HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_TRY(ctx, hipStreamCreateWithPriority(&ws.copy_stream, hipStreamNonBlocking, prio > 0 ? greatest : least));
+    return 0;
+  }
+  HIP_TRY(ctx, hipStreamCreateWithFlags(&ws.copy_stream, hipStreamNonBlocking));
   return 0;
 }
 
@@ -1204,6 +1219,26 @@ int upload(te_ctx* ctx, workset_t& ws, void* dst, const uint8_t* src, size_t byt
   return 0;
 }
 
+// The uploads of a host-buffer MSM on work set `ws` (side stream) must not overtake the set's previous MSM, which may still read the
+// staging area.  A marker on the set's stream and a stream wait say so -- but the marker is a packet in the hardware queue the set's
+// stream shares with other work sets, and stands there behind THEIR kernels (a k_accumulate of 1.2-1.4 ms with eight tickets in flight):
+// a third of the 32 MB scalar uploads of bound-bases tickets took 1.6-1.9 ms instead of 0.61 (TE_MSM_TRACE_HOST stamps,
+// profiles/r06_bound_host_tickets_gap.txt).  A set whose previous MSM has delivered its result -- every ticket that was collected --
+// needs no marker: everything that read the staging area precedes ev_result.  TE_MSM_COPY_MARKER=1: always (the old behaviour).
+int copy_stream_behind_previous(te_ctx* ctx, workset_t& ws) {
+  if (int rc = need_copy_stream(ctx, ws)) return rc;
+  static const bool always = [] { const char* e = getenv("TE_MSM_COPY_MARKER"); return e && e[0] == '1'; }();
+  if (!always) {
+    if (!ws.used) return 0;
+    const hipError_t q = hipEventQuery(ws.ev_result);
+    if (q == hipSuccess) return 0;
+    (void)hipGetLastError();                                                      // hipErrorNotReady is an answer, not an error
+  }
+  HIP_TRY(ctx, hipEventRecord(ws.ev_start, ws.stream));
+  HIP_TRY(ctx, hipStreamWaitEvent(ws.copy_stream, ws.ev_start, 0));
+  return 0;
+}
+
 const char* const kFinalCarry = "final carry is 1: a scalar does not fit the signed window decomposition";
 
 // "The kernels behind this point read what the upload recorded in `ev` (on the copy stream) brought."  Two forms:
@@ -1214,10 +1249,25 @@ const char* const kFinalCarry = "final carry is 1: a scalar does not fit the sig
 //     order: the kernels of ANOTHER ticket that shares the queue stood behind that wait -- tickets from host scalars over bound bases
 //     ran at 1.02-1.09 ms per MSM where the same tickets from device scalars take 0.89-0.92, with neither the link nor the device busy
 //     (profiles/r06_lane_host_waits.txt).  The lane thread has nothing else to do.
+//     It waits for the copy STREAM, not for an event recorded behind the upload: an event record is one more packet in a hardware
+//     queue the side stream shares with other work sets' streams, and stood behind their kernels for 0.5-0.7 ms in every fourth
+//     ticket (stamps: "upload awaited"); the stream's last command -- the copy -- is known to the runtime without a packet.
+//     TE_MSM_LANE_EVENT_WAITS=1: the event form (experiments).
 int lane_wait(te_ctx* ctx, workset_t& ws, hipEvent_t ev, bool lane) {
+  static const bool by_event = [] { const char* e = getenv("TE_MSM_LANE_EVENT_WAITS"); return e && e[0] == '1'; }();
+  if (lane && ctx->opt_lane_host_waits && !by_event) { HIP_TRY(ctx, hipStreamSynchronize(ws.copy_stream)); return 0; }
+  HIP_TRY(ctx, hipEventRecord(ev, ws.copy_stream));
   if (lane && ctx->opt_lane_host_waits) HIP_TRY(ctx, hipEventSynchronize(ev));
   else HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ev, 0));
   return 0;
+}
+
+// te_msm_run* / te_msm_submit (the calling thread uploads): from PAGEABLE memory hipMemcpyAsync returns when the copy is over, so
+// waiting for the copy stream on the host costs nothing and keeps the event record and the stream wait out of the hardware queues
+// as well.  EXPERIMENT, TE_MSM_CALLER_HOST_WAITS=1 (tools/exp_caller_host_waits.py); pinned sources keep the stream waits.
+bool caller_may_wait_on_host(const te_ctx* ctx, const void* a, const void* b) {
+  static const bool on = [] { const char* e = getenv("TE_MSM_CALLER_HOST_WAITS"); return e && e[0] == '1'; }();
+  return on && ctx->opt_lane_host_waits && !(a && host_memory_is_pinned(a)) && !(b && host_memory_is_pinned(b));
 }
 
 // pieces a host buffer of n points is uploaded and processed in on ONE device (option "host_chunks", else from n).
@@ -1243,6 +1293,7 @@ int enqueue_host_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* src_
   plan_t pf; make_plan(ctx, d, n, pf, c, 1, 0, true);
   const curve_sizes sz = sizes_of(pf.curve);
   if (int rc = ensure_staging(ctx, ws, n * sz.point_in, n * sz.scalar_in)) return rc;
+  const bool host_waits = !wait_for_pinned || caller_may_wait_on_host(ctx, src_points, src_scalars);
   uint8_t* dpts = static_cast<uint8_t*>(ws.d_in_points);
   uint8_t* dscs = static_cast<uint8_t*>(ws.d_in_scalars);
   // Pieces of n / K points: piece i crosses PCIe on the side stream while piece i-1 is converted and ACCUMULATED ONTO THE SAME
@@ -1274,9 +1325,7 @@ int enqueue_host_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* src_
   }
   release_shared_recs(d, ws, false); ws.recs_last = ws.d_recs;      // a host-buffer MSM converts into the set's own slab
   if (ws.used && ws.last_stream != ws.stream) HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ws.ev_done, 0));
-  HIP_TRY(ctx, hipEventRecord(ws.ev_start, ws.stream));
-  if (int rc = need_copy_stream(ctx, ws)) return rc;
-  HIP_TRY(ctx, hipStreamWaitEvent(ws.copy_stream, ws.ev_start, 0));
+  if (int rc = copy_stream_behind_previous(ctx, ws)) return rc;
   const bool tr = getenv("TE_MSM_TRACE_HOST") != nullptr;
   const auto t00 = std::chrono::steady_clock::now();
   // (index of the device in the context's list / its HIP id; the absolute time tells the threads of one call apart from the next call's)
@@ -1300,8 +1349,7 @@ int enqueue_host_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* src_
   const bool scalars_first = pf.curve == TE_MSM_CURVE_TE_BLS12;
   if (scalars_first) {
     if (int rc = upload(ctx, ws, dscs, src_scalars, n * sz.scalar_in, ws.copy_stream)) return rc;
-    HIP_TRY(ctx, hipEventRecord(evs[K], ws.copy_stream));
-    if (int rc = lane_wait(ctx, ws, evs[K], !wait_for_pinned)) return rc;
+    if (int rc = lane_wait(ctx, ws, evs[K], host_waits)) return rc;
     stamp("scalars staged", -1);
   }
   for (int i = 0; i < K; i++) {
@@ -1315,16 +1363,14 @@ int enqueue_host_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* src_
     first = false;
     if (!scalars_first) {
       if (int rc = upload(ctx, ws, dscs + lo * sz.scalar_in, src_scalars + lo * sz.scalar_in, m * sz.scalar_in, ws.copy_stream)) return rc;
-      HIP_TRY(ctx, hipEventRecord(evs[K], ws.copy_stream));
-      if (int rc = lane_wait(ctx, ws, evs[K], !wait_for_pinned)) return rc;
+      if (int rc = lane_wait(ctx, ws, evs[K], host_waits)) return rc;
       stamp("scalars staged", i);
     }
     if (int rc = L.front_scalars()) return rc;                             // digits, sort and schedule run while the piece's points cross PCIe
     stamp("scalar stages enqueued", i);
     if (int rc = upload(ctx, ws, dpts + lo * sz.point_in, src_points + lo * sz.point_in, m * sz.point_in, ws.copy_stream)) return rc;
     stamp("points staged", i);
-    HIP_TRY(ctx, hipEventRecord(evs[i], ws.copy_stream));
-    if (int rc = lane_wait(ctx, ws, evs[i], !wait_for_pinned)) return rc;
+    if (int rc = lane_wait(ctx, ws, evs[i], host_waits)) return rc;
     if (int rc = L.front_points()) return rc;
     if (int rc = L.accumulate()) return rc;
     if (int rc = L.combine()) return rc;
@@ -1379,19 +1425,29 @@ int enqueue_scalar_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* re
   }
   release_shared_recs(d, ws, false); ws.recs_last = nullptr;
   if (ws.used && ws.last_stream != ws.stream) HIP_TRY(ctx, hipStreamWaitEvent(ws.stream, ws.ev_done, 0));
-  HIP_TRY(ctx, hipEventRecord(ws.ev_start, ws.stream));
-  if (int rc = need_copy_stream(ctx, ws)) return rc;
-  HIP_TRY(ctx, hipStreamWaitEvent(ws.copy_stream, ws.ev_start, 0));            // the staging area may still be read by the set's previous MSM
+  if (int rc = copy_stream_behind_previous(ctx, ws)) return rc;                 // the staging area may still be read by the set's previous MSM
   std::vector<hipEvent_t>& evs = ws.piece_events;
   while ((int)evs.size() < K + 1) { hipEvent_t e; HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); evs.push_back(e); }
   plan_t p;
   bool first = true;
+  static const bool tr = getenv("TE_MSM_TRACE_HOST") != nullptr;          // host stamps of every piece (stderr)
+  const auto t00 = std::chrono::steady_clock::now();
+  auto stamp = [&](const char* what, int i) {
+    if (tr) fprintf(stderr, "[scalar slice ws %d] %8.1f us  %s %d\n", (int)(&ws - d.ws), std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t00).count(), what, i);
+  };
   for (int i = 0; i < K; i++) {
     const uint64_t lo = piece_lo(i), m = piece_lo(i + 1) - lo;
     if (m == 0) continue;
-    if (int rc = upload(ctx, ws, dscs + lo * sz.scalar_in, src_scalars + lo * sz.scalar_in, m * sz.scalar_in, ws.copy_stream)) return rc;
-    HIP_TRY(ctx, hipEventRecord(evs[(size_t)i], ws.copy_stream));
-    if (int rc = lane_wait(ctx, ws, evs[(size_t)i], !wait_for_pinned)) return rc;
+    {
+      static const bool serial = [] { const char* e = getenv("TE_MSM_SCALAR_UPLOADS_SERIAL"); return !(e && e[0] == '0'); }();
+      std::unique_lock<std::mutex> link(*d.scalar_link, std::defer_lock);
+      if (!wait_for_pinned && serial && ctx->opt_lane_host_waits) link.lock();       // (a lane thread: see gpu_t::scalar_link)
+      stamp("upload begins", i);
+      if (int rc = upload(ctx, ws, dscs + lo * sz.scalar_in, src_scalars + lo * sz.scalar_in, m * sz.scalar_in, ws.copy_stream)) return rc;
+      stamp("upload call returned", i);
+      if (int rc = lane_wait(ctx, ws, evs[(size_t)i], !wait_for_pinned || caller_may_wait_on_host(ctx, src_scalars, nullptr))) return rc;
+      stamp("upload awaited", i);
+    }
     make_plan(ctx, d, m, p, pf.c, 1, seg_all, true);
     p.rec_kind = rec_kind;
     if (int rc = ensure_buffers(ctx, d, ws, m, p, false)) return rc;           // no reallocation: only the pointers into the zeroed block move
@@ -1404,6 +1460,7 @@ int enqueue_scalar_slice(te_ctx* ctx, gpu_t& d, workset_t& ws, const uint8_t* re
     if (int rc = L.accumulate()) return rc;
     if (int rc = L.combine()) return rc;
     if (i == K - 1) { if (int rc = L.reduce()) return rc; }
+    stamp("piece enqueued", i);
   }
   ws.plan = p; ws.n = piece_lo(K) - piece_lo(K - 1); ws.used = true; ws.last_stream = ws.stream; ws.prof_level = 0;
   __atomic_store_n(&d.last_ws, (int)(&ws - d.ws), __ATOMIC_RELAXED);
@@ -2224,8 +2281,7 @@ int enqueue_fixed_base_host(te_ctx* ctx, gpu_t& d, workset_t& ws, const te_bases
     if (ws.used && ws.ev_done) HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));
     if (int rc = need_copy_stream(ctx, ws)) return rc;
     if (int rc = upload(ctx, ws, ws.d_in_scalars, src_scalars, n * sz.scalar_in, ws.copy_stream)) return rc;
-    HIP_TRY(ctx, hipEventRecord(ws.ev_copy, ws.copy_stream));
-    HIP_TRY(ctx, hipEventSynchronize(ws.ev_copy));
+    if (int rc = lane_wait(ctx, ws, ws.ev_copy, true)) return rc;
   } else {
     if (int rc = upload(ctx, ws, ws.d_in_scalars, src_scalars, n * sz.scalar_in, ws.stream)) return rc;
     if (wait_for_pinned && !ctx->opt_host_staging && host_memory_is_pinned(src_scalars)) {
