@@ -232,7 +232,10 @@ int te_msm_submit_scalars_device(te_ctx* ctx, te_bases* bases, const void* d_sca
  *                   TE_MSM_SHARE_RECORDS).  Read-only "record_slabs": slabs allocated.
  *   "lane_host_waits" 1 (default) = the lane thread of an asynchronous ticket (te_msm_submit_async, te_msm_submit_scalars) waits for each of
  *                   its uploads on the host before it enqueues the kernels that read it; 0 = a stream wait in front of those kernels, which
- *                   holds up other tickets' kernels in a shared hardware queue (A/B; env TE_MSM_LANE_HOST_WAITS; profiles/r06_lane_host_waits.txt)
+ *                   holds up other tickets' kernels in a shared hardware queue (A/B; env TE_MSM_LANE_HOST_WAITS; profiles/r06_lane_host_waits.txt).
+ *                   The calling thread of te_msm_run* / te_msm_submit waits the same way when its buffers are pageable (the copy call
+ *                   blocks for the copy anyway); pinned buffers keep the stream waits.  No packet of the upload path enters a hardware
+ *                   queue shared with other tickets' kernels (profiles/r06_bound_host_tickets_gap.txt, r06_caller_host_waits.txt).
  *   "scalar_chunks" te_msm_run_scalars / te_msm_submit_scalars: pieces the scalars of a bound point set are uploaded and processed
  *                   in; 0 = from n (default), 1 = whole.  The result does not depend on it.
  *   read-only:      "num_devices", "segment_len_used", "peer_copies" / "peer_bytes" (hipMemcpyPeerAsync calls a multi-device

@@ -1,5 +1,5 @@
 """te_msm_run / te_msm_submit / te_msm_run_scalars from PAGEABLE host buffers (the calling thread uploads): stream waits behind events recorded on
-the copy stream (the build) against TE_MSM_CALLER_HOST_WAITS=1 (the thread waits for the copy stream; no event, no stream wait in a hardware queue).
+the copy stream (TE_MSM_CALLER_HOST_WAITS=0) against the build (the thread waits for the copy stream; no event, no stream wait in a hardware queue).
 Child processes, alternating, three rounds; n = 2^20 and 2^18.
 python tools/exp_caller_host_waits.py            (parent)
 python tools/exp_caller_host_waits.py child"""
@@ -51,7 +51,7 @@ if __name__ == "__main__":
         child()
     else:
         for rnd in range(3):
-            for name, env in (("stream waits", {}), ("host waits", {"TE_MSM_CALLER_HOST_WAITS": "1"})):
+            for name, env in (("stream waits", {"TE_MSM_CALLER_HOST_WAITS": "0"}), ("host waits", {"TE_MSM_CALLER_HOST_WAITS": "1"})):
                 e = dict(os.environ); e.update(env)
                 r = subprocess.run([sys.executable, __file__, "child"], env=e, capture_output=True, text=True, timeout=300)
                 print("round %d %-12s %s" % (rnd, name, (r.stdout.strip().splitlines() or [r.stderr.strip()[-300:]])[-1]), flush=True)

@@ -1264,9 +1264,11 @@ int lane_wait(te_ctx* ctx, workset_t& ws, hipEvent_t ev, bool lane) {
 
 // te_msm_run* / te_msm_submit (the calling thread uploads): from PAGEABLE memory hipMemcpyAsync returns when the copy is over, so
 // waiting for the copy stream on the host costs nothing and keeps the event record and the stream wait out of the hardware queues
-// as well.  EXPERIMENT, TE_MSM_CALLER_HOST_WAITS=1 (tools/exp_caller_host_waits.py); pinned sources keep the stream waits.
+// as well: te_msm_run 2.30 vs 2.35 ms, te_msm_run_scalars 1.355 vs 1.38, te_msm_submit x8 in flight 1.90 vs 1.93-2.01 at 2^20;
+// 0.78 vs 0.81, 0.573 vs 0.595, 0.555 vs 0.56-0.63 at 2^18 (tools/exp_caller_host_waits.py, profiles/r06_caller_host_waits.txt).
+// Pinned sources keep the stream waits (their copies are asynchronous).  TE_MSM_CALLER_HOST_WAITS=0: stream waits for all.
 bool caller_may_wait_on_host(const te_ctx* ctx, const void* a, const void* b) {
-  static const bool on = [] { const char* e = getenv("TE_MSM_CALLER_HOST_WAITS"); return e && e[0] == '1'; }();
+  static const bool on = [] { const char* e = getenv("TE_MSM_CALLER_HOST_WAITS"); return !(e && e[0] == '0'); }();
   return on && ctx->opt_lane_host_waits && !(a && host_memory_is_pinned(a)) && !(b && host_memory_is_pinned(b));
 }
 
