@@ -9,8 +9,8 @@
 //
 // Jobs become tickets in the order they were entered (`waiting_` is a FIFO), by whoever holds the engine's lock at a moment
 // when a work set is free:
-//   enter    queues the job; when other promises are pending and the engine's lock is FREE, turns the waiting jobs into
-//            tickets right there, oldest first (submit_async returns at once: device and work set are picked, the upload is
+//   enter    queues the job; when the context exists and the engine's lock is FREE (and the job is not a lone one on several
+//            devices: that one is every device's), turns the waiting jobs into tickets right there, oldest first (submit_async returns at once: device and work set are picked, the upload is
 //            handed to that device's host thread) -- so the number of MSMs in flight is bounded by the engine's work sets,
 //            not by the size of the pool.  The lock is only TRIED: a pool thread may be inside te_msm_init, a lone
 //            multi-device run or a collect's host tail for milliseconds, and the JavaScript thread must not stall on it
@@ -33,6 +33,7 @@
 // one point buffer to six calls per size (submission/miscellaneous/full_benchmarks.ts:63-68,100-105).
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <condition_variable>
 #include <deque>
@@ -147,6 +148,7 @@ template <class Api> class protocol {
   bool has_bases() { std::lock_guard<std::mutex> lk(mu_); return bases_points_ != nullptr; }
 
  private:
+  static bool lone_in_enter() { static const bool on = [] { const char* e = getenv("TE_MSM_LONE_IN_ENTER"); return !(e && e[0] == '0'); }(); return on; }
   bool settled_submit(const job_t* j) const { return j->submitted || j->failed; }
   bool is_bound(const job_t* j) const { return bases_ && j->points == bases_points_ && j->n == bases_n_; }
   // with mu_ held
@@ -180,16 +182,18 @@ template <class Api> class protocol {
     j->failed = true;
     return true;
   }
-  // with mu_ held: waiting jobs become tickets, oldest first, until one does not fit.  in_enter: a job that is alone is left to
-  // its pool thread (by then it knows whether it still is: a lone call on several devices uses all of them), and an empty
-  // one always (Api::run answers it).
+  // with mu_ held: waiting jobs become tickets, oldest first, until one does not fit.  in_enter: a job that is alone on SEVERAL
+  // devices is left to its pool thread (by then it knows whether it still is: a lone call on several devices uses all of them), and
+  // an empty one always (Api::run answers it).
   void drain(bool in_enter) {
     if (!ctx_) return;                                                   // the very first call creates the context in its pool thread
     for (;;) {
       job_t* f; int pend;
       { std::lock_guard<std::mutex> q(qmu_); if (waiting_.empty()) return; f = waiting_.front(); pend = pending_; }
       if (f->n == 0) return;
-      if (in_enter && pend == 1) return;
+      // a lone job on ONE device becomes a ticket right in enter() as well: its upload starts while libuv still hands the job to a pool
+      // thread (the harness awaits every call, ui/Benchmark.tsx:32: every call is a lone one).  TE_MSM_LONE_IN_ENTER=0: left to its pool thread.
+      if (in_enter && pend == 1 && (Api::num_devices(ctx_) > 1 || !lone_in_enter())) return;
       if (!in_enter && pend == 1 && Api::num_devices(ctx_) > 1) return;  // (its own thread runs it as the lone call)
       const uint64_t before = stats_.submitted_in_enter + stats_.submitted_in_execute;
       (void)before;
