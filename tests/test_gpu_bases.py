@@ -363,6 +363,41 @@ def test_node_set_bases(pkg, model, wasm_golden, tmp_path):
     assert out["stats"]["boundJobs"] == 0 and out["stats"]["maxInFlight"] == 8, out["stats"]
 
 
+def test_node_awaited_calls_are_tickets_from_the_javascript_thread(pkg, wasm_golden, tmp_path):
+    """the reference harness's call pattern (every compute_msm awaited, ui/Benchmark.tsx:29-39) through the addon: on one device a lone
+    promise becomes a ticket in enter() -- its upload starts while libuv still hands the job to a pool thread --, with and without
+    bound bases, and on several devices it stays the lone call of its pool thread (all devices on the one MSM); results equal the
+    reference's own output either way"""
+    import json
+    import os
+    import subprocess
+    from test_gpu_parity import _node_js_dir
+    node, js = _node_js_dir()
+    g = next(x for x in wasm_golden if x["name"] == "random_n262144")
+    pts, sc = make_inputs(g["seed"], g["n"], g["mode"])
+    (tmp_path / "p.bin").write_bytes(pts)
+    (tmp_path / "s.bin").write_bytes(sc)
+    want = (int(g["x"]), int(g["y"]))
+
+    def run(args, env=None):
+        r = subprocess.run([node, os.path.join(js, "run_awaited.js"), str(tmp_path / "p.bin"), str(tmp_path / "s.bin")] + args,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+        out = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        assert "x" in out, (out, r.stderr.decode()[-2000:])
+        assert (int(out["x"]), int(out["y"])) == want, out
+        return out
+
+    out = run(["6", "bases"])                                       # 5 warm-up calls + 6 timed ones, all over the bound buffer
+    assert out["stats"]["boundJobs"] == 11 and out["stats"]["submittedInEnter"] == 11 and out["stats"]["maxInFlight"] == 1, out["stats"]
+    print("node, awaited calls over bound bases at 2^18: median %.3f ms" % out["median_ms"])
+    out = run(["6"])                                                # the very first call creates the context in its pool thread
+    assert out["stats"]["submittedInEnter"] == 10 and out["stats"]["submittedInExecute"] == 1 and out["stats"]["boundJobs"] == 0, out["stats"]
+    out = run(["6"], env=dict(os.environ, TE_MSM_LONE_IN_ENTER="0"))
+    assert out["stats"]["submittedInEnter"] == 0 and out["stats"]["submittedInExecute"] == 11, out["stats"]
+    out = run(["6"], env=dict(os.environ, TE_MSM_DEVICES="0,0"))
+    assert out["stats"]["loneRuns"] == 11 and out["stats"]["submittedInEnter"] == 0, out["stats"]
+
+
 # ------------------------------------------------------------------ fixed-base windows over a bound set (option "bind_fixed_base")
 def test_fixed_base_table_against_the_model(pkg, ora, model):
     """table w of a fixed-base set holds the records of 2^(c w) P_i: ((y - x)/2, (y + x)/2, -d x y) of that multiple, by the bigint
