@@ -198,7 +198,9 @@ int te_msm_submit_scalars_device(te_ctx* ctx, te_bases* bases, const void* d_sca
  *                   else 1), 1 = whole.  Twisted-Edwards: all scalars go first, in one copy (the link is the bottleneck);
  *                   BLS12-377: scalars piece by piece with their points (the device is).  The result does not depend on it.
  *   "host_shard_min" multi-device te_msm_run: smallest slice worth a device of its own (default 4096 points)
- *   "upload_threads" host threads per device that take te_msm_submit_async tickets (1..16, default 4; env TE_MSM_UPLOAD_THREADS)
+ *   "upload_threads" host threads per device that take te_msm_submit_async / te_msm_submit_scalars tickets (1..16, default 4; env
+ *                   TE_MSM_UPLOAD_THREADS).  Scalars-only tickets (bound bases) cross the link one at a time per device whatever the
+ *                   number of threads (side by side they only delay each other: profiles/r06_bound_host_tickets_gap.txt)
  *   "host_staging"  0 (default) = host buffers are copied straight from the caller's memory: the fastest form while the caller
  *                   REUSES its buffers (the runtime keeps pages it has copied from registered: 2.35 ms per 2^20-point call), but
  *                   the first call on a buffer costs 4.7-5.0 ms and a caller that allocates fresh buffers for every call pays
