@@ -337,3 +337,43 @@ def test_shared_record_slabs(pkg, ora):
         c.set_option("curve", pkg.CURVE_BLS12_377_G1)
         ts = [c.submit_device(d3.data_ptr(), ds3.data_ptr(), m) for _ in range(3)]
         assert [c.collect(t) for t in ts] == [o.msm(p3, s3, threads=4)] * 3
+
+
+UPLOAD_SWITCH_CHILD = r'''
+import importlib, json, sys
+sys.path.insert(0, %(root)r)
+pkg = importlib.import_module("webgpu-msm-twisted-edwards_amd")
+from oracle.gen_golden import make_inputs
+g = json.loads(sys.argv[1])
+pts, sc = make_inputs(g["seed"], g["n"], g["mode"])
+want = int(g["x"]).to_bytes(32, "little") + int(g["y"]).to_bytes(32, "little")
+for ids in ((0,), (0, 0)):
+    with pkg.MsmContext(ids) as c:
+        b = c.bind_points(pts)
+        assert c.run(pts, sc) == want and c.run_scalars(b, sc) == want
+        for rnd in range(3):                                   # work sets are reused: the second round's uploads follow a collected MSM
+            tk = [c.submit_scalars(b, sc) for _ in range(3)] + [c.submit_async(pts, sc) for _ in range(3)] + [c.submit(pts, sc)]
+            assert all(c.collect(t) == want for t in reversed(tk))
+        c.release_points(b)
+print("ok")
+'''
+
+
+def test_upload_path_switches_agree(pkg, wasm_golden):
+    """Round 6 took three marker packets out of the upload path of host-buffer MSMs (csrc/te_msm.hip: copy_stream_behind_previous,
+    lane_wait, gpu_t::scalar_link, caller_may_wait_on_host; profiles/r06_bound_host_tickets_gap.txt) and kept the old forms behind
+    environment switches for A/B runs: every combination gives the reference's own output -- tickets over bound bases, host-buffer
+    tickets (lane threads and the calling thread), lone calls, work sets reused across rounds, one and two "devices".
+    Child processes: the switches are read once per process."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = next(x for x in wasm_golden if x["name"] == "random_n65536")
+    arg = json.dumps({k: g[k] for k in ("seed", "n", "mode", "x", "y")})
+    for env in ({}, {"TE_MSM_COPY_MARKER": "1", "TE_MSM_LANE_EVENT_WAITS": "1", "TE_MSM_SCALAR_UPLOADS_SERIAL": "0", "TE_MSM_CALLER_HOST_WAITS": "0"},
+                {"TE_MSM_LANE_EVENT_WAITS": "1"}, {"TE_MSM_SCALAR_UPLOADS_SERIAL": "0"}, {"TE_MSM_CALLER_HOST_WAITS": "0", "TE_MSM_LANE_HOST_WAITS": "0"},
+                {"TE_MSM_COPY_PRIORITY": "1"}, {"TE_MSM_HOST_STAGING": "1"}):
+        r = subprocess.run([sys.executable, "-c", UPLOAD_SWITCH_CHILD % {"root": root}, arg], env=dict(os.environ, **env),
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0 and r.stdout.decode().strip().endswith("ok"), (env, r.stderr.decode()[-2000:])
