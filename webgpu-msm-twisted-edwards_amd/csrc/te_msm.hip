@@ -2266,6 +2266,10 @@ int bind_common(te_ctx* ctx, const void* src, bool src_is_host, uint64_t n, te_b
     for (size_t i = 1; i < nd; i++) { const int r = worker_of(ctx, i).wait(jobs[i]); if (!rc) rc = r; }
   }
   if (rc) { free_bases(ctx, b); delete b; return rc; }
+  // a set bound from HOST memory announces tickets from host scalars: the lanes' first concurrent copies (15-30 ms once per process,
+  // warm_upload_lanes) happen here, in the call that blocks anyway, not in the first te_msm_submit_scalars -- which the N-API addon
+  // issues on the JavaScript thread (js/promise_protocol.hpp: enter)
+  if (src_is_host && n > 0) warm_upload_lanes(ctx);
   ctx->bases.push_back(b);
   *out = b;
   return 0;
