@@ -163,6 +163,11 @@ struct gpu_t {
   // 0.90-0.92 with one; tools/exp_bound_lanes_depth.py).  Host-buffer tickets (points + scalars) do not take it: their pageable copies
   // fill each other's pin / unpin gaps (1.79 vs 1.89 ms with one lane).  TE_MSM_SCALAR_UPLOADS_SERIAL=0: off (experiments).
   std::unique_ptr<std::mutex> scalar_link{new std::mutex};
+  // EXPERIMENT TE_MSM_SERIAL_ACCUMULATE=1 (tools/exp_serial_accumulate.py): the k_accumulate launches of a device form a chain -- each waits
+  // for the one enqueued before it on another stream --, so that ONE accumulation runs at full width beside the small kernels of the other
+  // MSMs in flight instead of two at half speed
+  std::unique_ptr<std::mutex> acc_mu{new std::mutex};
+  hipEvent_t acc_ev[16] = {}; uint32_t acc_next = 0; hipEvent_t acc_prev = nullptr; hipStream_t acc_prev_stream = nullptr;
   bool streams_exported = false;         // te_msm_workset_stream handed a handle out: te_msm_destroy parks the streams instead of destroying them
   bool streams_final = false;            // ... and the work sets' streams will not be re-dealt any more
 };
@@ -579,11 +584,23 @@ struct msm_launch {
       const uint32_t n32 = this->n32(), smax = this->smax();
       const uint32_t* order = ctx->opt_sort ? ws.d_order : nullptr;
       using slot_t = typename te::rec_kind<N, RK>::slot;
+      static const bool serial = [] { const char* e = getenv("TE_MSM_SERIAL_ACCUMULATE"); return e && e[0] == '1'; }();
+      std::unique_lock<std::mutex> chain(*d.acc_mu, std::defer_lock);
+      if (serial && !ctx->opt_graph) {
+        chain.lock();
+        if (d.acc_prev && d.acc_prev_stream != stream) HIP_TRY(ctx, hipStreamWaitEvent(stream, d.acc_prev, 0));
+      }
       hipLaunchKernelGGL((te::k_accumulate<N, RK>), dim3((smax + 255) / 256), dim3(256), 0, stream, reinterpret_cast<const slot_t*>(bound ? bound : recs_out()), ws.d_sorted,
                          ws.d_bucket_start, ws.d_bucket_count, ws.d_seg_base, ws.d_seg_bucket, ws.d_seg_lenv, order, ws.d_num_seg,
                          reinterpret_cast<te::ete_t<N>*>(ws.d_buckets), reinterpret_cast<te::ete_t<N>*>(ws.d_seg_out), n32, p.logB, p.seg_len, smax, onto ? 1u : 0u,
                          table_replicas > 1 ? (uint32_t)((p.nw1 + table_replicas - 1) / table_replicas) : (uint32_t)p.nw1, table_replicas > 1 ? replica_slabs() : slabs(),
                          prof ? reinterpret_cast<unsigned long long*>(ws.d_zero + Z_CLOCK) : nullptr);
+      if (chain.owns_lock()) {
+        hipEvent_t& ev = d.acc_ev[d.acc_next++ % 16u];
+        if (!ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventRecord(ev, stream));
+        d.acc_prev = ev; d.acc_prev_stream = stream;
+      }
     }
     return 0;
   }
@@ -1081,6 +1098,8 @@ void free_dev(gpu_t& d) {
   (void)hipSetDevice(d.device);
   for (auto& sl : d.slabs) { if (sl.d) { (void)hipFree(sl.d); sl.d = nullptr; } for (hipEvent_t& e : sl.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; } }
   d.slabs.clear();
+  for (hipEvent_t& e : d.acc_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+  d.acc_prev = nullptr; d.acc_prev_stream = nullptr;
   for (workset_t& ws : d.ws) {
     free_workset_buffers(ws);
     if (ws.h_err) (void)hipHostFree(ws.h_err);
