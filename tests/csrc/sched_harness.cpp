@@ -334,6 +334,16 @@ void test_promises(const std::vector<msm_case>& cs, int D, int pool_threads) {
     CHECK(st.max_in_flight <= (int64_t)D * SETS && st.max_in_flight >= 1, "tickets in flight (%lld)", (long long)st.max_in_flight);
     CHECK(st.submitted_in_enter + st.submitted_in_execute + st.lone_runs >= (uint64_t)(2 + 2 * D + D * SETS + 5), "every job went one way or the other");
   }
+  // the harness's call pattern (every call awaited: bursts of one): on ONE device a lone job becomes a ticket in enter() -- the engine's
+  // lock is free between the calls --, on several it stays the lone call of its pool thread (round 6)
+  {
+    const te_promise::stats_t a = proto.stats();
+    for (int i = 0; i < 6; i++) burst(1, i);
+    const te_promise::stats_t b = proto.stats();
+    if (D == 1) CHECK(b.submitted_in_enter == a.submitted_in_enter + 6 && b.lone_runs == a.lone_runs, "awaited calls on one device are tickets from enter() (%llu -> %llu)",
+                      (unsigned long long)a.submitted_in_enter, (unsigned long long)b.submitted_in_enter);
+    else CHECK(b.lone_runs == a.lone_runs + 6 && b.submitted_in_enter == a.submitted_in_enter, "awaited calls on %d devices are lone calls", D);
+  }
   // resident bases: jobs over the bound buffer take the scalars-only path, the others the ordinary one; the binding survives a reset
   {
     std::string err;
