@@ -238,6 +238,10 @@ int te_msm_submit_scalars_device(te_ctx* ctx, te_bases* bases, const void* d_sca
  *                   The calling thread of te_msm_run* / te_msm_submit waits the same way when its buffers are pageable (the copy call
  *                   blocks for the copy anyway); pinned buffers keep the stream waits.  No packet of the upload path enters a hardware
  *                   queue shared with other tickets' kernels (profiles/r06_bound_host_tickets_gap.txt, r06_caller_host_waits.txt).
+ *                   The earlier forms stay behind environment switches for A/B runs, read once per process and covered by
+ *                   tests/test_gpu_tickets.py::test_upload_path_switches_agree: TE_MSM_COPY_MARKER=1, TE_MSM_LANE_EVENT_WAITS=1,
+ *                   TE_MSM_SCALAR_UPLOADS_SERIAL=0, TE_MSM_CALLER_HOST_WAITS=0, TE_MSM_COPY_PRIORITY=1|-1; TE_MSM_SERIAL_ACCUMULATE=1
+ *                   chains the accumulations of the MSMs in flight (slower: profiles/r06_serial_accumulate_experiment.txt).
  *   "scalar_chunks" te_msm_run_scalars / te_msm_submit_scalars: pieces the scalars of a bound point set are uploaded and processed
  *                   in; 0 = from n (default), 1 = whole.  The result does not depend on it.
  *   read-only:      "num_devices", "segment_len_used", "peer_copies" / "peer_bytes" (hipMemcpyPeerAsync calls a multi-device
