@@ -1261,7 +1261,8 @@ int copy_stream_behind_previous(te_ctx* ctx, workset_t& ws) {
 const char* const kFinalCarry = "final carry is 1: a scalar does not fit the signed window decomposition";
 
 // "The kernels behind this point read what the upload recorded in `ev` (on the copy stream) brought."  Two forms:
-//   the calling thread owns the call (te_msm_run*, te_msm_submit): a stream wait -- nothing of the host is in the MSM's critical path;
+//   the calling thread owns the call (te_msm_run*, te_msm_submit) and its buffers are PINNED: a stream wait -- nothing of the host is in
+//     the MSM's critical path (pageable buffers: the host form as well, see caller_may_wait_on_host below);
 //   a LANE thread enqueues an asynchronous ticket (wait_for_pinned == false): the thread itself waits for the upload and enqueues the
 //     kernels afterwards.  A stream wait sits in the hardware queue of the work set's stream until the upload is over (2-3 ms with four
 //     lanes sharing the link), and the runtime multiplexes the eight work-set streams onto four hardware queues, whose packets run in
@@ -1272,6 +1273,7 @@ const char* const kFinalCarry = "final carry is 1: a scalar does not fit the sig
 //     queue the side stream shares with other work sets' streams, and stood behind their kernels for 0.5-0.7 ms in every fourth
 //     ticket (stamps: "upload awaited"); the stream's last command -- the copy -- is known to the runtime without a packet.
 //     TE_MSM_LANE_EVENT_WAITS=1: the event form (experiments).
+// lane: the host form is wanted (a lane thread, or a calling thread whose copies have blocked anyway)
 int lane_wait(te_ctx* ctx, workset_t& ws, hipEvent_t ev, bool lane) {
   static const bool by_event = [] { const char* e = getenv("TE_MSM_LANE_EVENT_WAITS"); return e && e[0] == '1'; }();
   if (lane && ctx->opt_lane_host_waits && !by_event) { HIP_TRY(ctx, hipStreamSynchronize(ws.copy_stream)); return 0; }
