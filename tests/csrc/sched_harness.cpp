@@ -317,6 +317,8 @@ void test_promises(const std::vector<msm_case>& cs, int D, int pool_threads) {
     const int target = settled + 0;
     (void)target;
     while (proto.pending() > 0) std::this_thread::sleep_for(std::chrono::microseconds(200));
+    (void)proto.stats();        // (takes the engine's lock: the last pool thread has LEFT execute(), so the next enter() finds the lock free --
+                                //  the addon gets the same from libuv: a job's completion callback runs after its execute() has returned)
     // (pending() == 0: every execute() has left the protocol; the results below were written before that under its lock)
     for (int i = 0; i < k; i++) {
       const msm_case& m = cs[(size_t)(first + i) % cs.size()];
