@@ -18,11 +18,8 @@ const toLE32 = (v) => {
   for (let i = 0; i < 32; i++) { b[i] = Number(t & 0xffn); t >>= 8n; }
   return b;
 };
-const fromLE32 = (buf, off) => {
-  let v = 0n;
-  for (let i = 31; i >= 0; i--) v = (v << 8n) | BigInt(buf[off + i]);
-  return v;
-};
+const fromLE32 = (buf, off) =>          // four 64-bit words (a byte loop costs 64 BigInt operations per coordinate)
+  buf.readBigUInt64LE(off) | (buf.readBigUInt64LE(off + 8) << 64n) | (buf.readBigUInt64LE(off + 16) << 128n) | (buf.readBigUInt64LE(off + 24) << 192n);
 
 const asPointsBuffer = (p) => {
   if (Buffer.isBuffer(p)) return p;
